@@ -1,0 +1,232 @@
+/* smelter_hip.h — C ABI of libsmelter_hip.so: the MI355X (gfx950) execution layer that replaces what
+ * prisma-ai/Smelter delegates to Apple MetalPerformanceShaders.
+ *
+ * Two levels, both `extern "C"`, plain pointers and sizes only:
+ *
+ *  (1) KERNEL level  `sm_*`      — one entry point per MPS node class Smelter instantiates
+ *      (/root/reference/Sources/Smelter/Converters.swift; the data-source / padding-policy callbacks MPS
+ *      makes into Smelter at :140-184, :744-777 and the Padding/ policies become plain descriptor fields).  All
+ *      tensors are device pointers; activations are NHWC fp16 with an explicit pixel stride (`ld`, in
+ *      elements) so a producer can write straight into a channel slice of a concat buffer; convolution
+ *      weights are OHWI fp16 — exactly the layout Smelter's own preprocessing produces
+ *      (Extensions/Foundation/Array+Extensions.swift:78-83); bias is fp32 (Converters.swift:126-135).
+ *      Every call only ENQUEUES work on `stream` and returns; nothing blocks the host.
+ *
+ *  (2) GRAPH level   `smelter_*` — the load-and-encode surface of ONNXGraph
+ *      (/root/reference/Sources/Smelter/ONNXGraph.swift:95 init(data:configuration:), :169 metalGraph(device:),
+ *      README.md:43-44 encode(to:sourceImages:), Extensions/Foundation/MPSImage+Extensions.swift:9 toFloatArray).
+ *
+ * Return value: 0 on success, a negative SM_ERR_* otherwise; smelter_last_error_string() gives the detail
+ * (thread local).  The library never aborts the process: the reference's two fatalError sites
+ * (Onnx_TensorProto+Extensions.swift:32,60 and Converters.swift:895) are mapped to error codes.
+ */
+#ifndef SMELTER_HIP_H
+#define SMELTER_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sm_stream_t; /* hipStream_t */
+
+/* ---- error codes: 1:1 with ONNXGraph.Errors (ONNXGraph.swift:38-47) + ours ---- */
+enum {
+    SM_OK = 0,
+    SM_ERR_UNSUPPORTED_INPUT = -1,
+    SM_ERR_UNSUPPORTED_OUTPUT = -2,
+    SM_ERR_UNKNOWN_NODE_OP_TYPE = -3,
+    SM_ERR_NO_SUCH_OUTPUT = -4,
+    SM_ERR_GRAPH_INTERNAL = -5,
+    SM_ERR_INSUFFICIENT_INPUTS = -6,
+    SM_ERR_INCONSISTENT_STATE = -7,
+    SM_ERR_NOT_ENOUGH_ATTRIBUTES = -8,
+    SM_ERR_PROTO_DECODE = -9,
+    SM_ERR_UNSUPPORTED_DTYPE = -10,
+    SM_ERR_FLATTEN_AXIS = -11,
+    SM_ERR_HIP = -12,
+    SM_ERR_INVALID_ARGUMENT = -13
+};
+const char* smelter_last_error_string(void);
+const char* smelter_version(void);
+
+/* ======================================= (1) kernel level ======================================= */
+
+enum { SM_ACT_NONE = 0, SM_ACT_RELU = 1, SM_ACT_PRELU = 2 }; /* MPSCNNNeuronReLUNode(a:) Converters.swift:342-384 */
+
+/* Replaces MPSCNNConvolutionDescriptor (Converters.swift:57-79) + ONNX_ConvolutionPadding
+ * (Padding/ONNXConvolutionPadding.swift:57-89).  Shapes are resolved when the graph is compiled, not at
+ * encode time.  y[n,oy,ox,k] = act(bias[k] + sum x[n, oy*sH-pt+kh*dH, ox*sW-pl+kw*dW, g*Cg+c] * w[k,kh,kw,c] (+ res)) */
+typedef struct sm_conv_desc {
+    int32_t N, H, W, Cin;         /* input  NHWC */
+    int32_t Cout, kH, kW;         /* weight OHWI [Cout][kH][kW][Cin/groups] */
+    int32_t sH, sW, dH, dW;
+    int32_t pt, pl, pb, pr;       /* pads top,left,bottom,right (pb/pr only enter through Ho/Wo) */
+    int32_t groups;               /* 1, or == Cin == Cout (depthwise, Converters.swift:57), or general */
+    int32_t Ho, Wo;
+    int32_t act; float slope;     /* fused neuron */
+    int32_t x_ld, y_ld, res_ld;   /* pixel strides in elements; 0 = dense (Cin / Cout / Cout) */
+} sm_conv_desc;
+
+/* MPSCNNConvolutionNode / MPSCNNFullyConnectedNode (Converters.swift:253, :297).  `residual` (nullable) is an
+ * NHWC tensor of the output's shape added before the activation (fuses MPSNNAdditionNode, :440). */
+int sm_conv2d_fwd(const sm_conv_desc* d, const void* x, const void* w_ohwi, const float* bias,
+                  const void* residual, void* y, sm_stream_t stream);
+/* bytes of scratch sm_conv2d_fwd wants for this shape (split-K partials); 0 if none. */
+size_t sm_conv2d_workspace_bytes(const sm_conv_desc* d);
+int sm_conv2d_fwd_ws(const sm_conv_desc* d, const void* x, const void* w_ohwi, const float* bias,
+                     const void* residual, void* y, void* workspace, size_t workspace_bytes, sm_stream_t stream);
+/* force a tile configuration (tuning / tests); cfg < 0 restores the heuristic.  Returns the number of configs. */
+int sm_conv2d_num_configs(void);
+int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias,
+                      const void* residual, void* y, void* workspace, size_t workspace_bytes, sm_stream_t stream);
+
+/* MPSCNNBatchNormalizationNode (Converters.swift:812): y = x*scale[c] + shift[c], scale/shift fp32 folded on
+ * the host from gamma,beta,mean,var.  Unfused fallback — the compiler folds BN into the producing conv. */
+int sm_batchnorm(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld,
+                 const float* scale, const float* shift, int32_t act, float slope, sm_stream_t stream);
+/* MPSNNAdditionNode (:440) with optional fused neuron; MPSCNNNeuronReLUNode (:351,:376) */
+int sm_add(const void* a, const void* b, void* y, int64_t pixels, int32_t C, int32_t a_ld, int32_t b_ld,
+           int32_t y_ld, int32_t act, float slope, sm_stream_t stream);
+int sm_relu(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, float slope,
+            sm_stream_t stream);
+
+/* MPSCNNPoolingMaxNode / MPSCNNPoolingAverageNode + PyTorchPoolPadding (Converters.swift:607-695).
+ * y0/x0 = window start of output (0,0) (PyTorchPoolPadding.swift:56-75). */
+typedef struct sm_pool_desc {
+    int32_t N, H, W, C, kH, kW, sH, sW, y0, x0, Ho, Wo, x_ld, y_ld;
+} sm_pool_desc;
+int sm_maxpool2d(const sm_pool_desc* d, const void* x, void* y, sm_stream_t stream);
+int sm_avgpool2d(const sm_pool_desc* d, const void* x, void* y, sm_stream_t stream);
+/* GlobalAveragePoolConverter (:578-605): [N][H*W][C] -> [N][C] */
+int sm_global_avgpool(const void* x, void* y, int32_t N, int32_t HW, int32_t C, int32_t x_ld, int32_t y_ld,
+                      sm_stream_t stream);
+
+/* MPSCNNUpsamplingNearestNode / MPSCNNUpsamplingBilinearNode(alignCorners) (:522-539), integer scales */
+int sm_upsample_nearest(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t sy,
+                        int32_t sx, int32_t x_ld, int32_t y_ld, sm_stream_t stream);
+int sm_upsample_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t sy,
+                         int32_t sx, int32_t align_corners, int32_t x_ld, int32_t y_ld, sm_stream_t stream);
+/* MPSNNConcatenationNode (:564): strided channel copy; the compiler avoids it by placement when it can */
+int sm_copy_channels(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld,
+                     sm_stream_t stream);
+
+/* Layout/dtype conversion at the boundary (the MPSImage <-> texture step of README.md:33-51).
+ * NCHW fp32 -> NHWC fp16 with channels zero-padded to y_ld and a zero spatial halo. */
+int sm_nchw_f32_to_nhwc_f16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t y_ld,
+                            int32_t halo_t, int32_t halo_l, int32_t halo_b, int32_t halo_r, sm_stream_t stream);
+int sm_nhwc_f16_to_nchw_f32(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t x_ld,
+                            sm_stream_t stream);
+/* MPSImage.toFloatArray() element order (MPSImage+Extensions.swift:26-59):
+ * [image][ceil(C/4) slice][H][W][4, or C when C < 3] */
+int sm_nhwc_f16_to_float_array(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W,
+                               int32_t x_ld, sm_stream_t stream);
+size_t sm_float_array_count(int32_t N, int32_t C, int32_t H, int32_t W);
+
+/* Host-side weight preparation Smelter does on the CPU at load time */
+/* Float16.swift:17-77 (IEEE, RNE) */
+void sm_half_to_float(const uint16_t* src, float* dst, size_t n);
+void sm_float_to_half(const float* src, uint16_t* dst, size_t n);
+/* Array+Extensions.swift:52-93: OIHW -> OHWI, or (is_transpose) IOHW -> O,flipH,flipW,I; elem_size 2|4 */
+int sm_reformat_conv_weight(const void* src, void* dst, int32_t elem_size, int32_t oc, int32_t ic, int32_t kh,
+                            int32_t kw, int32_t is_transpose);
+/* ONNXConvolutionPadding.swift:91-113 / PyTorchPoolPadding.swift:94-103,56-75 */
+void sm_conv_padded_size(int32_t in_w, int32_t in_h, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t pt,
+                         int32_t pl, int32_t pb, int32_t pr, int32_t oph, int32_t opw, int32_t is_transpose,
+                         int32_t* out_w, int32_t* out_h);
+void sm_pool_padded_size(int32_t in_w, int32_t in_h, int32_t kh, int32_t kw, int32_t sh, int32_t sw, int32_t ph,
+                         int32_t pw, int32_t* out_w, int32_t* out_h);
+int32_t sm_pool_window_start(int32_t in, int32_t out, int32_t k, int32_t s);
+
+/* Device/stream plumbing for callers that do not bring their own HIP runtime binding */
+int sm_device_count(int32_t* n);
+int sm_set_device(int32_t dev);
+int sm_malloc(void** p, size_t bytes);
+int sm_free(void* p);
+int sm_memcpy_h2d(void* dst, const void* src, size_t bytes, sm_stream_t stream);
+int sm_memcpy_d2h(void* dst, const void* src, size_t bytes, sm_stream_t stream);
+int sm_memset(void* dst, int value, size_t bytes, sm_stream_t stream);
+int sm_stream_create(sm_stream_t* s);
+int sm_stream_destroy(sm_stream_t s);
+int sm_stream_synchronize(sm_stream_t s);
+/* HIP-event timer on `stream` (bench.py measures kernels on the stream they are launched on) */
+typedef struct sm_timer sm_timer;
+int sm_timer_create(sm_timer** t);
+int sm_timer_start(sm_timer* t, sm_stream_t s);
+int sm_timer_stop(sm_timer* t, sm_stream_t s);
+int sm_timer_elapsed_ms(sm_timer* t, float* ms); /* synchronises on the stop event */
+int sm_timer_destroy(sm_timer* t);
+
+/* ======================================== (2) graph level ======================================== */
+
+/* ONNXGraph.Configuration (ONNXGraph.swift:6-36) */
+enum { SM_INPUT_NONE = 0, SM_INPUT_FORCE_SCALE_LANCZOS = 1, SM_INPUT_FORCE_SCALE_BILINEAR = 2 };
+typedef struct smelter_config {
+    int32_t input_constraint;     /* Configuration.InputConstraint; only SM_INPUT_NONE is implemented */
+    int32_t align_corners;        /* billinearUpsamplingConfiguration.alignCorners, default 1 (:20) */
+    int32_t dims[4];              /* Configuration.dims: per-axis input-dim override, -1 = keep (:25,200-202) */
+    /* --- executor options (no reference counterpart) --- */
+    int32_t fuse;                 /* 1 (default): fold BN into conv, fuse Add/Relu epilogues; 0: one kernel per node */
+    int32_t use_hip_graph;        /* 1 (default): replay the launch sequence as one hipGraph */
+    int32_t autotune;             /* 1: time the conv tile configs per layer at compile; 0 (default): heuristic */
+} smelter_config;
+void smelter_config_default(smelter_config* c);
+
+typedef struct smelter_graph smelter_graph; /* ONNXGraph */
+typedef struct smelter_exec smelter_exec;   /* what metalGraph(device:) returns (MPSNNGraph) */
+typedef struct smelter_shape { int32_t channels, width, height, depth; } smelter_shape; /* TypeDefinitions.swift */
+
+enum { SM_FORMAT_ONNX = 0, SM_FORMAT_MPS_FLAVOR = 1 }; /* ONNXGraph.Format (:49-52) */
+
+/* ONNXGraph(data:configuration:) (:95-156): decodes, detects producer_name=="ONNX2MPS", indexes initializers,
+ * registers converters.  The caller may free `onnx` as soon as this returns. */
+int smelter_graph_create(const void* onnx, size_t n, const smelter_config* cfg, smelter_graph** out);
+void smelter_graph_destroy(smelter_graph* g);
+int smelter_graph_format(const smelter_graph* g);                         /* modelFormat (:58) */
+int smelter_graph_set_format(smelter_graph* g, int32_t format);           /* it is a public var in the reference */
+int smelter_graph_output_shapes(const smelter_graph* g, smelter_shape* dst, int32_t cap); /* outputShapes (:69-91) */
+int smelter_graph_num_nodes(const smelter_graph* g);
+
+/* metalGraph(device:) (:169-193): runs the converter loop, folds/casts/re-lays-out weights, plans memory,
+ * uploads weights to `hip_device`, captures the launch sequence.  `batch` = MPSImage.numberOfImages the
+ * executor is planned for (the reference drops N from the input dims, :204-215).
+ * Weight arena: if `weight_arena` is NULL the executor allocates and fills it.  Otherwise the caller owns a
+ * device buffer of smelter_exec_weight_bytes() bytes; with `upload_weights`==0 the executor leaves it
+ * untouched (batch-shard replicas: rank 0 fills, RCCL broadcasts, the others only bind). */
+int smelter_graph_weight_bytes(smelter_graph* g, int32_t batch, size_t* bytes);
+int smelter_graph_compile(smelter_graph* g, int32_t hip_device, int32_t batch, void* weight_arena,
+                          int32_t upload_weights, smelter_exec** out);
+void smelter_exec_destroy(smelter_exec* e);
+
+/* encode(to:sourceImages:) (README.md:43-44): enqueue one forward pass on `stream`; asynchronous, no host
+ * sync.  in_nchw_f32: device pointer, [batch][C][H][W] fp32.  The result stays in an executor-owned device
+ * image (NHWC fp16) until read. */
+int smelter_exec_encode(smelter_exec* e, sm_stream_t stream, const float* in_nchw_f32);
+/* toFloatArray (MPSImage+Extensions.swift:9-24): converts the result image to fp32 on `stream`, copies it to
+ * host memory and synchronises.  layout 0 = NCHW, 1 = the reference's slice-packed order. */
+int smelter_exec_output_dims(const smelter_exec* e, int32_t* n, int32_t* c, int32_t* h, int32_t* w);
+int smelter_exec_read_float(smelter_exec* e, sm_stream_t stream, float* dst, size_t cap, int32_t layout);
+/* device-side result (NHWC fp16, dense) for callers that keep going on the GPU */
+const void* smelter_exec_output_device(const smelter_exec* e);
+
+/* introspection used by tests / bench */
+int smelter_exec_num_launches(const smelter_exec* e);       /* kernels per encode after fusion */
+int smelter_exec_num_ops(const smelter_exec* e);            /* op records after fusion */
+size_t smelter_exec_weight_bytes(const smelter_exec* e);
+void* smelter_exec_weight_arena(const smelter_exec* e);
+size_t smelter_exec_activation_bytes(const smelter_exec* e);
+double smelter_exec_flops(const smelter_exec* e);           /* 2*MACs of conv+fc per encode */
+double smelter_exec_algorithmic_bytes(const smelter_exec* e); /* per-layer compulsory bytes per encode */
+/* per-op description for profiling: returns a static-lifetime string "idx kind name MxNxK cfg" */
+const char* smelter_exec_op_desc(const smelter_exec* e, int32_t idx);
+/* time one op `idx` in isolation (iters launches, HIP events); ms per launch */
+int smelter_exec_time_op(smelter_exec* e, sm_stream_t stream, int32_t idx, int32_t iters, float* ms);
+/* fetch an intermediate value by ONNX name after an encode (debug / layer parity); NCHW fp32 to host */
+int smelter_exec_read_value(smelter_exec* e, sm_stream_t stream, const char* name, float* dst, size_t cap,
+                            int32_t* c, int32_t* h, int32_t* w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,201 @@
+/* oracle/orc_ops.c — ORACLE (test infrastructure).  Per-node arithmetic in NCHW fp32.
+ *
+ * Smelter delegates these to Apple MPS node classes (closed source); the call sites are the
+ * `MPS*Node(` constructors in /root/reference/Sources/Smelter/Converters.swift (cited per function).
+ * The arithmetic restated here is the ONNX operator definition restricted to the attributes Smelter reads,
+ * accumulating in fp32 in a fixed (ic, kh, kw) order.  OpenMP over (image x output channel / row) so the
+ * same code doubles as bench.py's cpu_baseline ("port").
+ */
+#include "orc.h"
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* Converters.swift:253-264 (MPSCNNConvolutionNode) + ONNXConvolutionPadding.swift:73-79 (offset k/2 - pad,
+ * edge mode zero):  y[n,k,oy,ox] = b[k] + sum_{c,kh,kw} x[n, g*Cg+c, oy*sh-pt+kh*dh, ox*sw-pl+kw*dw] * W[k,kh,kw,c] */
+void orc_conv2d(const orc_conv_desc* d, const float* x, const float* w, const float* bias, float* y) {
+    const int Cg = d->C / d->groups, Kg = d->K / d->groups;
+    const long total = (long)d->N * d->K;
+#pragma omp parallel
+    {
+        float* acc = (float*)malloc(sizeof(float) * (size_t)d->Ho * d->Wo);
+#pragma omp for schedule(dynamic, 1)
+        for (long nk = 0; nk < total; nk++) {
+            int n = (int)(nk / d->K), k = (int)(nk % d->K), g = k / Kg;
+            float b = bias ? bias[k] : 0.f;
+            for (int i = 0; i < d->Ho * d->Wo; i++) acc[i] = 0.f;
+            for (int c = 0; c < Cg; c++) {
+                const float* xp = x + ((size_t)n * d->C + (size_t)g * Cg + c) * d->H * d->W;
+                for (int kh = 0; kh < d->kh; kh++)
+                    for (int kw = 0; kw < d->kw; kw++) {
+                        float wv = w[(((size_t)k * d->kh + kh) * d->kw + kw) * Cg + c];
+                        for (int oy = 0; oy < d->Ho; oy++) {
+                            int iy = oy * d->sh - d->pt + kh * d->dh;
+                            if (iy < 0 || iy >= d->H) continue;
+                            const float* xr = xp + (size_t)iy * d->W;
+                            float* ar = acc + (size_t)oy * d->Wo;
+                            int x0 = kw * d->dw - d->pl;
+                            for (int ox = 0; ox < d->Wo; ox++) {
+                                int ix = ox * d->sw + x0;
+                                if (ix >= 0 && ix < d->W) ar[ox] += xr[ix] * wv;
+                            }
+                        }
+                    }
+            }
+            float* yp = y + ((size_t)n * d->K + k) * d->Ho * d->Wo;
+            for (int i = 0; i < d->Ho * d->Wo; i++) yp[i] = acc[i] + b;
+        }
+        free(acc);
+    }
+}
+
+/* Converters.swift:288-302 (MPSCNNFullyConnectedNode), weight read as [out,in] :35-39 ; alpha/beta/trans ignored */
+void orc_gemm_fc(const float* x, const float* w, const float* bias, float* y, int n, int in_f, int out_f) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < n; i++)
+        for (int o = 0; o < out_f; o++) {
+            float acc = 0.f;
+            const float* xr = x + (size_t)i * in_f; const float* wr = w + (size_t)o * in_f;
+            for (int k = 0; k < in_f; k++) acc += xr[k] * wr[k];
+            y[(size_t)i * out_f + o] = acc + (bias ? bias[o] : 0.f);
+        }
+}
+
+/* Converters.swift:797-827 (MPSCNNBatchNormalizationNode): y = (x-mean)*gamma/sqrt(var+eps)+beta */
+void orc_batchnorm(const float* x, float* y, int n, int c, int hw, const float* gamma, const float* beta,
+                   const float* mean, const float* var, float eps) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < n; i++)
+        for (int ch = 0; ch < c; ch++) {
+            float s = gamma[ch] / sqrtf(var[ch] + eps), b = beta[ch], m = mean[ch];
+            const float* xp = x + ((size_t)i * c + ch) * hw; float* yp = y + ((size_t)i * c + ch) * hw;
+            for (int j = 0; j < hw; j++) yp[j] = (xp[j] - m) * s + b;
+        }
+}
+
+/* Converters.swift:342-384 (MPSCNNNeuronReLUNode(a)): x >= 0 ? x : a*x */
+void orc_relu(const float* x, float* y, size_t n, float slope) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; i++) y[i] = x[i] >= 0.f ? x[i] : slope * x[i];
+}
+
+/* Converters.swift:430-451 (MPSNNAdditionNode) */
+void orc_add(const float* a, const float* b, float* y, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; i++) y[i] = a[i] + b[i];
+}
+
+/* Converters.swift:652-695 (MPSCNNPoolingMaxNode) + PyTorchPoolPadding.swift:56-75 (window start) */
+void orc_maxpool(const float* x, float* y, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int ph,
+                 int pw, int ho, int wo) {
+    int y0, x0; (void)ph; (void)pw;
+    orc_pool_window_start(h, ho, kh, sh, &y0);
+    orc_pool_window_start(w, wo, kw, sw, &x0);
+#pragma omp parallel for schedule(static)
+    for (long nc = 0; nc < (long)n * c; nc++) {
+        const float* xp = x + (size_t)nc * h * w; float* yp = y + (size_t)nc * ho * wo;
+        for (int oy = 0; oy < ho; oy++)
+            for (int ox = 0; ox < wo; ox++) {
+                float m = -FLT_MAX; /* out-of-image taps are ignored */
+                for (int a = 0; a < kh; a++) {
+                    int iy = oy * sh + y0 + a; if (iy < 0 || iy >= h) continue;
+                    for (int b = 0; b < kw; b++) {
+                        int ix = ox * sw + x0 + b; if (ix < 0 || ix >= w) continue;
+                        float v = xp[(size_t)iy * w + ix]; if (v > m) m = v;
+                    }
+                }
+                yp[(size_t)oy * wo + ox] = m;
+            }
+    }
+}
+
+/* Converters.swift:607-650 (MPSCNNPoolingAverageNode): divisor = full window (zero padded taps count) */
+void orc_avgpool(const float* x, float* y, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int ph,
+                 int pw, int ho, int wo) {
+    int y0, x0; (void)ph; (void)pw;
+    orc_pool_window_start(h, ho, kh, sh, &y0);
+    orc_pool_window_start(w, wo, kw, sw, &x0);
+#pragma omp parallel for schedule(static)
+    for (long nc = 0; nc < (long)n * c; nc++) {
+        const float* xp = x + (size_t)nc * h * w; float* yp = y + (size_t)nc * ho * wo;
+        for (int oy = 0; oy < ho; oy++)
+            for (int ox = 0; ox < wo; ox++) {
+                float s = 0.f;
+                for (int a = 0; a < kh; a++) {
+                    int iy = oy * sh + y0 + a; if (iy < 0 || iy >= h) continue;
+                    for (int b = 0; b < kw; b++) {
+                        int ix = ox * sw + x0 + b; if (ix < 0 || ix >= w) continue;
+                        s += xp[(size_t)iy * w + ix];
+                    }
+                }
+                yp[(size_t)oy * wo + ox] = s / (float)(kh * kw);
+            }
+    }
+}
+
+/* Converters.swift:578-605 (MPSCNNPoolingAverageNode kernel = input W x H) + GlobalPoolPadding.swift:16-26 */
+void orc_global_avgpool(const float* x, float* y, int n, int c, int hw) {
+#pragma omp parallel for schedule(static)
+    for (long nc = 0; nc < (long)n * c; nc++) {
+        const float* xp = x + (size_t)nc * hw; float s = 0.f;
+        for (int j = 0; j < hw; j++) s += xp[j];
+        y[nc] = s / (float)hw;
+    }
+}
+
+/* Converters.swift:478-552: MPSCNNUpsamplingNearestNode / MPSCNNUpsamplingBilinearNode(alignCorners),
+ * integer scale factors.  nearest: src = floor(o / s).  bilinear, alignCorners: src = o*(in-1)/(out-1);
+ * otherwise half-pixel centres src = (o+0.5)/s - 0.5 clamped at 0. */
+void orc_upsample(const float* x, float* y, int n, int c, int h, int w, int sy, int sx, int bilinear,
+                  int align_corners) {
+    int ho = h * sy, wo = w * sx;
+#pragma omp parallel for schedule(static)
+    for (long nc = 0; nc < (long)n * c; nc++) {
+        const float* xp = x + (size_t)nc * h * w; float* yp = y + (size_t)nc * ho * wo;
+        for (int oy = 0; oy < ho; oy++)
+            for (int ox = 0; ox < wo; ox++) {
+                if (!bilinear) { yp[(size_t)oy * wo + ox] = xp[(size_t)(oy / sy) * w + ox / sx]; continue; }
+                float fy, fx;
+                if (align_corners) {
+                    fy = ho > 1 ? (float)oy * (float)(h - 1) / (float)(ho - 1) : 0.f;
+                    fx = wo > 1 ? (float)ox * (float)(w - 1) / (float)(wo - 1) : 0.f;
+                } else {
+                    fy = ((float)oy + 0.5f) / (float)sy - 0.5f; if (fy < 0.f) fy = 0.f;
+                    fx = ((float)ox + 0.5f) / (float)sx - 0.5f; if (fx < 0.f) fx = 0.f;
+                }
+                int y0 = (int)fy, x0 = (int)fx;
+                if (y0 > h - 1) y0 = h - 1;
+                if (x0 > w - 1) x0 = w - 1;
+                int y1 = y0 + 1 < h ? y0 + 1 : h - 1, x1 = x0 + 1 < w ? x0 + 1 : w - 1;
+                float ly = fy - (float)y0, lx = fx - (float)x0;
+                float v00 = xp[(size_t)y0 * w + x0], v01 = xp[(size_t)y0 * w + x1];
+                float v10 = xp[(size_t)y1 * w + x0], v11 = xp[(size_t)y1 * w + x1];
+                float top = v00 + (v01 - v00) * lx, bot = v10 + (v11 - v10) * lx;
+                yp[(size_t)oy * wo + ox] = top + (bot - top) * ly;
+            }
+    }
+}
+
+/* Converters.swift:554-574 (MPSNNConcatenationNode): feature-channel concatenation of k operands */
+void orc_concat_c(const float* const* xs, const int* cs, int k, float* y, int n, int hw) {
+    int ctot = 0; for (int i = 0; i < k; i++) ctot += cs[i];
+    for (int img = 0; img < n; img++) {
+        int off = 0;
+        for (int i = 0; i < k; i++) {
+            memcpy(y + ((size_t)img * ctot + off) * hw, xs[i] + (size_t)img * cs[i] * hw, sizeof(float) * (size_t)cs[i] * hw);
+            off += cs[i];
+        }
+    }
+}

@@ -1,0 +1,308 @@
+// converters.cpp — one NodeConverter class per ONNX op_type on the hot path, same class names and the same
+// attribute handling, defaults, error cases and shape rules as /root/reference/Sources/Smelter/Converters.swift
+// (line ranges cited per class).  A converter reads producers / shapes / tensors by value NAME through the
+// graph tables and publishes exactly one Op record under every node.output name.
+//
+// Reference quirks — kept / dropped (full table in DESIGN.md):
+//   kept:    conv out-size rule ignores dilation; kernel_shape+dilations+strides all required; Gemm attributes
+//            ignored, weight read as [out,in]; PRelu slope = first fp32 of raw_data; pools use pads[0],pads[1]
+//            and the Float-division size rule; Upsample scales truncated to Int; Flatten axis != 1 is an error
+//            (fatalError -> SM_ERR_FLATTEN_AXIS); unsupported tensor dtype is an error (fatalError ->
+//            SM_ERR_UNSUPPORTED_DTYPE); the reference Shape bookkeeping incl. Concat depth*=2.
+//   dropped: BN epsilon attribute IS honoured (the reference never reads it); fp32 bias is also accepted from
+//            float_data; Concat's real channel count is the sum of its operands.
+#include <string.h>
+
+#include "../kernels/common.hpp"
+#include "graph.hpp"
+
+namespace smelter {
+namespace {
+
+#define SM_FAIL(code, ...) do { sm_set_error(__VA_ARGS__); return (code); } while (0)
+#define SV(s) (int)(s).size(), (s).data()
+
+Shape mkShape(int channels, int width, int height, int depth) { Shape s; s.channels = channels; s.width = width; s.height = height; s.depth = depth; return s; }
+
+// ---- ConvolutionConverter (Converters.swift:187-338) + ConvDataSource (:12-185) ----------------------------
+struct ConvolutionConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        if (node.input.empty()) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "%.*s: no inputs", SV(node.op_type));
+        const int in = graph.output(node.input[0]);
+        if (in < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "%.*s: input '%.*s' is not a graph value", SV(node.op_type), SV(node.input[0]));   // :189-191
+        const pb::Tensor* weight = node.input.size() > 1 ? graph.tensor(node.input[1]) : nullptr;
+        if (!weight) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "%.*s: weight tensor missing", SV(node.op_type));                             // :193-194
+        const pb::Tensor* bias = node.input.size() > 2 ? graph.tensor(node.input[2]) : nullptr;                                        // :196-199
+        const Value iv = graph.value(in);
+
+        bool hasK = false, hasD = false, hasS = false;
+        int kh = 0, kw = 0, dh = 1, dw = 1, sh = 1, sw = 1, groups = 1, pt = 0, pl = 0, pb_ = 0, pr = 0, oph = 0, opw = 0;
+        for (auto& a : node.attribute) {                                                                                                // :208-225
+            if (a.name == "dilations" && a.ints.size() >= 2) { dh = (int)a.ints[0]; dw = (int)a.ints[1]; hasD = true; }
+            else if (a.name == "strides" && a.ints.size() >= 2) { sh = (int)a.ints[0]; sw = (int)a.ints[1]; hasS = true; }
+            else if (a.name == "group") groups = (int)a.i;
+            else if (a.name == "pads" && a.ints.size() >= 4) { pt = (int)a.ints[0]; pl = (int)a.ints[1]; pb_ = (int)a.ints[2]; pr = (int)a.ints[3]; }
+            else if (a.name == "kernel_shape" && a.ints.size() >= 2) { kh = (int)a.ints[0]; kw = (int)a.ints[1]; hasK = true; }
+            else if (a.name == "output_padding" && a.ints.size() >= 2) { oph = (int)a.ints[0]; opw = (int)a.ints[1]; }
+        }
+        const bool isGemm = node.op_type == "Gemm", isTranspose = node.op_type == "ConvTranspose";
+        if (isGemm) { kh = kw = dh = dw = sh = sw = 1; hasK = hasD = hasS = true; }                                                     // :228-232
+        if (!hasK || !hasD || !hasS) SM_FAIL(SM_ERR_NOT_ENOUGH_ATTRIBUTES, "%.*s: kernel_shape, dilations and strides are all required", SV(node.op_type));  // :234-237
+        if (isTranspose) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "ConvTranspose is not implemented yet (SURVEY.md §8f rank 1)");
+        if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || groups <= 0 || kh <= 0 || kw <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: non-positive attribute");
+        (void)oph; (void)opw;
+
+        // ConvDataSource.init: channel/kernel extents from the weight dims (:35-54)
+        const bool mps = graph.modelFormat == Format::mpsFlavor;
+        int OC, IC, wkh, wkw;
+        if (isGemm) { if (weight->dims.size() < 2) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "Gemm: weight rank < 2"); OC = (int)weight->dims[0]; IC = (int)weight->dims[1]; wkh = wkw = 1; }
+        else {
+            if (weight->dims.size() < 4) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "Conv: weight rank < 4");
+            if (mps) { OC = (int)weight->dims[0]; wkh = (int)weight->dims[1]; wkw = (int)weight->dims[2]; IC = (int)weight->dims[3]; }     // :40-44
+            else { OC = (int)weight->dims[0]; IC = (int)weight->dims[1]; wkh = (int)weight->dims[2]; wkw = (int)weight->dims[3]; }        // :46-54
+        }
+        if (weight->data_type != pb::FLOAT && weight->data_type != pb::FLOAT16)                                                          // :82-89 (.invalid)
+            SM_FAIL(SM_ERR_UNSUPPORTED_DTYPE, "%.*s: weight data_type %d (FLOAT or FLOAT16 expected)", SV(node.op_type), weight->data_type);
+        if (!isGemm && (wkh != kh || wkw != kw)) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: kernel_shape %dx%d disagrees with weight dims %dx%d", kh, kw, wkh, wkw);
+
+        Op op; op.kind = isGemm ? OpKind::FullyConnected : OpKind::Conv;
+        op.inputs = {in}; op.cout = OC; op.kh = kh; op.kw = kw; op.sh = sh; op.sw = sw; op.dh = dh; op.dw = dw;
+        op.pt = pt; op.pl = pl; op.pb = pb_; op.pr = pr; op.groups = groups;
+        op.weight_was_fp16 = weight->data_type == pb::FLOAT16;
+        std::vector<float> w;
+        int rc = pb::tensor_floats(*weight, &w); if (rc) SM_FAIL(rc, "Conv: weight accessor");
+        const size_t expect = (size_t)OC * IC * wkh * wkw;
+        if (w.size() != expect) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "%.*s: weight holds %zu elements, dims say %zu", SV(node.op_type), w.size(), expect);
+        if (!mps && !isGemm) {                                            // re-layout unless ONNX2MPS already did it (:91-124)
+            op.weight.resize(expect);
+            sm_reformat_conv_weight(w.data(), op.weight.data(), 4, OC, IC, wkh, wkw, 0);
+        } else op.weight = std::move(w);
+        if (bias) {                                                       // :126-135 (+ typed float_data accepted)
+            rc = pb::tensor_floats(*bias, &op.bias); if (rc) SM_FAIL(rc, "Conv: bias accessor");
+            if ((int)op.bias.size() != OC) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "%.*s: bias holds %zu elements for %d channels", SV(node.op_type), op.bias.size(), OC);
+        }
+
+        int Ho = 1, Wo = 1;
+        if (isGemm) {
+            const long feat = (long)iv.c * iv.h * iv.w;
+            if (feat != IC) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Gemm: input has %ld features, weight expects %d", feat, IC);
+            op.cin = IC;
+        } else {
+            const bool depthwise = groups != 1 && groups == OC;                                                                         // :57
+            const int cinTotal = depthwise ? OC : IC * groups;                                                                          // :59-74
+            if (cinTotal != iv.c) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: input has %d channels, weight expects %d", iv.c, cinTotal);
+            if (OC % groups) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: %d output channels not divisible by group %d", OC, groups);
+            op.cin = cinTotal;
+            sm_conv_padded_size(iv.w, iv.h, kh, kw, sh, sw, pt, pl, pb_, pr, 0, 0, 0, &Wo, &Ho);                                        // :311-322
+            if (Ho <= 0 || Wo <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: empty output %dx%d", Ho, Wo);
+        }
+        return graph.addFilter(std::move(op), OC, Ho, Wo, mkShape(1, Wo, Ho, OC), node.output);                                         // :311-336
+    }
+};
+
+// ---- ReluConverter (:342-359), PReluConverter (:361-384) ----------------------------------------------------
+struct ReluConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        if (in < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Relu: input is not a graph value");
+        const Value iv = graph.value(in);
+        Op op; op.kind = OpKind::Neuron; op.inputs = {in}; op.act = SM_ACT_RELU; op.slope = 0.f;
+        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);
+    }
+};
+struct PReluConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.size() >= 2 ? graph.output(node.input[0]) : -1;
+        const pb::Tensor* a = node.input.size() >= 2 ? graph.tensor(node.input[1]) : nullptr;
+        if (in < 0 || !a) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "PRelu: input value or slope tensor missing");
+        float alpha = 0.f;
+        if (a->raw_data.size() >= 4) memcpy(&alpha, a->raw_data.data(), 4);   // first fp32 of raw_data (:372-374)
+        const Value iv = graph.value(in);
+        Op op; op.kind = OpKind::Neuron; op.inputs = {in}; op.act = SM_ACT_PRELU; op.slope = alpha;
+        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);
+    }
+};
+
+// ---- AddConverter (:430-451): both operands must be graph values, same shape -------------------------------
+struct AddConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int a = node.input.size() >= 2 ? graph.output(node.input[0]) : -1;
+        const int b = node.input.size() >= 2 ? graph.output(node.input[1]) : -1;
+        if (a < 0 || b < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Add: an operand is not a graph value");
+        const Value va = graph.value(a), vb = graph.value(b);
+        if (va.c != vb.c || va.h != vb.h || va.w != vb.w) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Add: operand shapes differ (the reference has no broadcasting)");
+        Op op; op.kind = OpKind::Add; op.inputs = {a, b};
+        return graph.addFilter(std::move(op), va.c, va.h, va.w, va.ref, node.output);
+    }
+};
+
+// ---- UpsampleConverter (:478-552) ---------------------------------------------------------------------------
+struct UpsampleConverter : NodeConverter {
+    bool alignCorners;
+    explicit UpsampleConverter(bool ac) : alignCorners(ac) {}
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        if (in < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Upsample: input is not a graph value");
+        const pb::Attribute* mode = node.attr("mode"); const pb::Attribute* sc = node.attr("scales");
+        bool have = false; int sy = 1, sx = 1;
+        if (sc && sc->floats.size() >= 4) { sy = (int)sc->floats[2]; sx = (int)sc->floats[3]; have = true; }                           // :499
+        if (!have) {                                                                                                                    // :505-514
+            const pb::Tensor* st = node.input.size() >= 2 ? graph.tensor(node.input[1]) : nullptr;
+            if (!st || st->dims.empty() || st->dims[0] != 4) SM_FAIL(SM_ERR_NOT_ENOUGH_ATTRIBUTES, "Upsample: scales missing");
+            std::vector<int64_t> v; int rc = pb::tensor_integers(*st, &v); if (rc) SM_FAIL(rc, "Upsample: scales dtype");
+            if (v.size() < 4) SM_FAIL(SM_ERR_NOT_ENOUGH_ATTRIBUTES, "Upsample: scales tensor too short");
+            sy = (int)v[2]; sx = (int)v[3];
+        }
+        if (!mode) SM_FAIL(SM_ERR_NOT_ENOUGH_ATTRIBUTES, "Upsample: mode missing");                                                     // :517-519
+        bool bilinear;
+        if (mode->s == "nearest") bilinear = false; else if (mode->s == "bilinear" || mode->s == "linear") bilinear = true;
+        else SM_FAIL(SM_ERR_UNKNOWN_NODE_OP_TYPE, "%.*s", SV(node.op_type));                                                            // :539-540
+        if (sy <= 0 || sx <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Upsample: scale %dx%d", sy, sx);
+        const Value iv = graph.value(in);
+        Op op; op.kind = OpKind::Upsample; op.inputs = {in}; op.sy = sy; op.sx = sx; op.bilinear = bilinear; op.alignCorners = alignCorners;
+        return graph.addFilter(std::move(op), iv.c, iv.h * sy, iv.w * sx, mkShape(iv.ref.channels, sx * iv.ref.width, sy * iv.ref.height, iv.ref.depth), node.output);
+    }
+};
+
+// ---- ConcatConverter (:554-574): feature-channel concatenation, `axis` ignored ------------------------------
+struct ConcatConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        if (node.input.empty()) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Concat: no inputs");
+        Op op; op.kind = OpKind::Concat; int c = 0;
+        for (auto& name : node.input) { int id = graph.output(name); if (id < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Concat: operand '%.*s' is not a graph value", SV(name)); op.inputs.push_back(id); }
+        const Value v0 = graph.value(op.inputs[0]);
+        for (int id : op.inputs) { const Value& v = graph.value(id); if (v.h != v0.h || v.w != v0.w) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Concat: operands differ in H/W"); c += v.c; }
+        Shape ref = v0.ref; ref.depth *= 2;                                                                                             // :566-567
+        return graph.addFilter(std::move(op), c, v0.h, v0.w, ref, node.output);
+    }
+};
+
+// ---- GlobalAveragePoolConverter (:578-605) -----------------------------------------------------------------
+struct GlobalAveragePoolConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        if (in < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "GlobalAveragePool: input is not a graph value");
+        const Value iv = graph.value(in);
+        Op op; op.kind = OpKind::GlobalAvgPool; op.inputs = {in};
+        return graph.addFilter(std::move(op), iv.c, 1, 1, mkShape(iv.ref.channels, 1, 1, iv.ref.depth), node.output);
+    }
+};
+
+// ---- AveragePoolConverter (:607-650), MaxPoolConverter (:652-695) + PyTorchPoolPadding ----------------------
+struct PoolConverter : NodeConverter {
+    bool isMax;
+    explicit PoolConverter(bool m) : isMax(m) {}
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        const pb::Attribute *ks = node.attr("kernel_shape"), *pads = node.attr("pads"), *st = node.attr("strides");
+        if (in < 0 || node.attribute.size() < 3 || !ks || !pads || !st || ks->ints.size() < 2 || pads->ints.size() < 2 || st->ints.size() < 2)
+            SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "%.*s: input, kernel_shape, pads and strides are all required", SV(node.op_type));           // :654-661
+        const Value iv = graph.value(in);
+        Op op; op.kind = isMax ? OpKind::MaxPool : OpKind::AvgPool; op.inputs = {in};
+        op.kh = (int)ks->ints[0]; op.kw = (int)ks->ints[1]; op.sh = (int)st->ints[0]; op.sw = (int)st->ints[1];
+        op.pt = (int)pads->ints[0]; op.pl = (int)pads->ints[1];                                                                         // :673-674 (symmetric)
+        if (op.kh <= 0 || op.kw <= 0 || op.sh <= 0 || op.sw <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Pool: non-positive attribute");
+        int Ho, Wo; sm_pool_padded_size(iv.w, iv.h, op.kh, op.kw, op.sh, op.sw, op.pt, op.pl, &Wo, &Ho);
+        if (Ho <= 0 || Wo <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Pool: empty output");
+        op.y0 = sm_pool_window_start(iv.h, Ho, op.kh, op.sh); op.x0 = sm_pool_window_start(iv.w, Wo, op.kw, op.sw);
+        return graph.addFilter(std::move(op), iv.c, Ho, Wo, mkShape(iv.ref.channels, Wo, Ho, iv.ref.depth), node.output);
+    }
+};
+
+// ---- ConstantConverter (:716-727) --------------------------------------------------------------------------
+struct ConstantConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const pb::Attribute* v = node.attr("value");
+        if (node.output.empty() || !v) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Constant: output or value attribute missing");
+        graph.initTensor(node.output[0], &v->t);
+        return SM_OK;
+    }
+};
+
+// ---- BatchNormalizationConverter (:797-827) + BNDataSource (:730-794) --------------------------------------
+struct BatchNormalizationConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        if (in < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "BatchNormalization: input is not a graph value");
+        if (node.input.size() < 5) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "BatchNormalization: 5 inputs required");
+        const Value iv = graph.value(in);
+        std::vector<float> p[4];                                         // gamma, beta, mean, variance (:805-808)
+        for (int i = 0; i < 4; i++) {
+            const pb::Tensor* t = graph.tensor(node.input[1 + i]);
+            if (!t) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "BatchNormalization: tensor '%.*s' missing", SV(node.input[1 + i]));
+            int rc = pb::tensor_floats(*t, &p[i]); if (rc) SM_FAIL(rc, "BatchNormalization: parameter dtype");
+            if ((int)p[i].size() != iv.c) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "BatchNormalization: parameter %d holds %zu values for %d channels", i + 1, p[i].size(), iv.c);
+        }
+        const pb::Attribute* e = node.attr("epsilon"); const float eps = e ? e->f : 1e-5f;
+        Op op; op.kind = OpKind::BatchNorm; op.inputs = {in}; op.scale.resize(iv.c); op.shift.resize(iv.c);
+        for (int c = 0; c < iv.c; c++) { float s = p[0][c] / sqrtf(p[3][c] + eps); op.scale[c] = s; op.shift[c] = p[1][c] - p[2][c] * s; }
+        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);
+    }
+};
+
+// ---- ReshapeConverter (:830-876), FlattenConverter (:879-915), DropoutConverter (:918-939) ------------------
+// All three are data-order-preserving in our layout only when H == W == 1 (or when the sole consumers are
+// fully-connected layers, whose weights the executor permutes); the executor checks that and aliases.
+struct ReshapeConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.size() >= 2 ? graph.output(node.input[0]) : -1;
+        const pb::Tensor* st = node.input.size() >= 2 ? graph.tensor(node.input[1]) : nullptr;
+        if (in < 0 || !st) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Reshape: input value or shape tensor missing");
+        const Value iv = graph.value(in);
+        std::vector<int64_t> shape; int rc = pb::tensor_integers(*st, &shape); if (rc) SM_FAIL(rc, "Reshape: shape dtype");
+        const int total = iv.ref.channels * iv.ref.depth * iv.ref.height * iv.ref.width;                                               // :840-843
+        const std::vector<int> src = iv.ref.toArray(); int nd[3];
+        for (int i = 0; i < 3; i++) { int d = i < (int)shape.size() ? (int)shape[i] : 1; nd[i] = d == 0 ? src[i] : d; }                 // :844-849
+        int inferred = -1; for (int i = 0; i < 3; i++) if (nd[i] == -1) { inferred = i; break; }
+        if (inferred >= 0) { int v = total; for (int i = 0; i < 3; i++) if (i != inferred) { if (nd[i] == 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Reshape: zero dim"); v /= nd[i]; } nd[inferred] = v; }   // :851-857
+        if ((long)nd[0] * nd[1] * nd[2] != (long)iv.c * iv.h * iv.w) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Reshape: element count changes");
+        Op op; op.kind = OpKind::Alias; op.inputs = {in};
+        return graph.addFilter(std::move(op), nd[2], nd[1], nd[0], mkShape(iv.ref.channels, nd[0], nd[1], nd[2]), node.output);       // (W,H,C) = nd (:859-872)
+    }
+};
+struct FlattenConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        const pb::Attribute* ax = node.attr("axis");
+        if (in < 0 || node.attribute.empty() || !ax) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Flatten: input value or axis attribute missing");  // :881-886
+        if (ax->i != 1) SM_FAIL(SM_ERR_FLATTEN_AXIS, "Flatten: axis %lld (only 1 is supported)", (long long)ax->i);                     // :893-896
+        const Value iv = graph.value(in);
+        const int total = iv.ref.channels * iv.ref.width * iv.ref.height * iv.ref.depth;                                               // :888-889
+        Op op; op.kind = OpKind::Alias; op.inputs = {in};
+        return graph.addFilter(std::move(op), iv.c * iv.h * iv.w, 1, 1, mkShape(total, 1, 1, 1), node.output);                        // :906-911
+    }
+};
+struct DropoutConverter : NodeConverter {   // inference identity (the reference builds an MPSCNNDropoutNode, :926-929)
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        if (in < 0 || node.attribute.empty() || !node.attr("ratio")) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Dropout: input value or ratio attribute missing");
+        const Value iv = graph.value(in);
+        Op op; op.kind = OpKind::Alias; op.inputs = {in};
+        std::vector<std::string_view> outs(node.output.begin(), node.output.begin() + 1);
+        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, outs);
+    }
+};
+
+}  // namespace
+
+void registerDefaultConverters(ONNXGraph& g) {    // ONNXGraph.swift:110-155, hot-path subset (SURVEY.md §2a ★ rows)
+    auto conv = std::make_shared<ConvolutionConverter>();
+    g.registerConverter("Conv", conv)
+        .registerConverter("Gemm", conv)
+        .registerConverter("ConvTranspose", conv)
+        .registerConverter("Relu", std::make_shared<ReluConverter>())
+        .registerConverter("PRelu", std::make_shared<PReluConverter>())
+        .registerConverter("Add", std::make_shared<AddConverter>())
+        .registerConverter("Upsample", std::make_shared<UpsampleConverter>(g.configuration.alignCorners))
+        .registerConverter("Concat", std::make_shared<ConcatConverter>())
+        .registerConverter("AveragePool", std::make_shared<PoolConverter>(false))
+        .registerConverter("MaxPool", std::make_shared<PoolConverter>(true))
+        .registerConverter("Constant", std::make_shared<ConstantConverter>())
+        .registerConverter("GlobalAveragePool", std::make_shared<GlobalAveragePoolConverter>())
+        .registerConverter("BatchNormalization", std::make_shared<BatchNormalizationConverter>())
+        .registerConverter("Dropout", std::make_shared<DropoutConverter>())
+        .registerConverter("Reshape", std::make_shared<ReshapeConverter>())
+        .registerConverter("Flatten", std::make_shared<FlattenConverter>());
+}
+
+}  // namespace smelter

@@ -1,0 +1,454 @@
+// executor.cpp — compile the converted op list into a GPU launch sequence (see executor.hpp).
+//
+// Passes, in order:
+//   1. epilogue fusion   BN folded into the producing Conv/FC (the arithmetic ONNX2MPS.py:107 delegates to
+//                        onnx.optimizer `fuse_bn_into_conv`: s = gamma/sqrt(var+eps); W' = W*s[oc];
+//                        b' = (b-mean)*s+beta), residual Add and Relu/PRelu fused into conv epilogues.
+//   2. aliasing          Flatten / Reshape / Dropout never move data.
+//   3. concat placement  producers write straight into channel slices of the concat buffer (pixel stride =
+//                        total C), so MPSNNConcatenationNode (Converters.swift:564) costs no kernel.
+//   4. memory plan       liveness-based first-fit packing of activation buffers into one arena: buffers are
+//                        reused as soon as their last consumer ran, which keeps the working set inside the
+//                        256 MiB Infinity Cache for ResNet-50 bs=64.
+//   5. weight arena      fp16 OHWI weights + fp32 bias/BN vectors packed into ONE device buffer, so that a
+//                        batch-shard replica can receive it with a single RCCL broadcast.
+//   6. launch sequence   sm_* C-ABI calls only; replayed as a hipGraph when configured.
+#include "executor.hpp"
+
+#include <algorithm>
+#include <functional>
+#include <map>
+#include <memory>
+#include <numeric>
+
+#include "../kernels/common.hpp"
+#include "half.hpp"
+
+namespace smelter {
+namespace {
+
+constexpr size_t kAlign = 256;
+size_t alignUp(size_t v, size_t a = kAlign) { return (v + a - 1) / a * a; }
+bool isConvLike(OpKind k) { return k == OpKind::Conv || k == OpKind::FullyConnected; }
+const char* kindName(OpKind k) {
+    switch (k) {
+    case OpKind::Conv: return "Conv"; case OpKind::FullyConnected: return "FC"; case OpKind::BatchNorm: return "BatchNorm";
+    case OpKind::Neuron: return "Neuron"; case OpKind::Add: return "Add"; case OpKind::MaxPool: return "MaxPool";
+    case OpKind::AvgPool: return "AvgPool"; case OpKind::GlobalAvgPool: return "GlobalAvgPool"; case OpKind::Upsample: return "Upsample";
+    case OpKind::Concat: return "Concat"; case OpKind::Alias: return "Alias";
+    }
+    return "?";
+}
+
+}  // namespace
+
+Executor::~Executor() {
+    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
+    if (graph_) (void)hipGraphDestroy(graph_);
+    if (own_arena_ && arena_) (void)hipFree(arena_);
+    if (act_) (void)hipFree(act_);
+    if (ws_) (void)hipFree(ws_);
+    if (out_f32_) (void)hipFree(out_f32_);
+}
+
+void* Executor::valuePtr(int v) const {
+    const Placement& p = place_[v];
+    return act_ + root_offset_[p.root] + (size_t)p.c_off * 2;
+}
+void Executor::outputDims(int* n, int* c, int* h, int* w) const {
+    const Value& v = values_[output_value_]; *n = batch_; *c = v.c; *h = v.h; *w = v.w;
+}
+const void* Executor::outputDevice() const { return valuePtr(output_value_); }
+
+// ------------------------------------------------------------------------------------------------------------
+int Executor::plan(ONNXGraph& g, int batch) {
+    batch_ = batch; cfg_ = g.configuration;
+    values_ = g.values(); input_value_ = g.inputValue(); output_value_ = g.outputValue();
+    std::vector<Op> ops = g.ops();
+    const int nv = (int)values_.size(), no = (int)ops.size();
+    std::vector<char> dead(no, 0);
+
+    auto consumers = [&](int v) { int c = v == output_value_ ? 1 : 0; for (int i = 0; i < no; i++) if (!dead[i]) { for (int u : ops[i].inputs) c += u == v; c += ops[i].residual == v; } return c; };
+    auto producerOf = [&](int v) { for (int i = 0; i < no; i++) if (!dead[i] && ops[i].output == v) return i; return -1; };
+
+    // ---- 1. epilogue fusion --------------------------------------------------------------------------------
+    if (cfg_.fuse) {
+        for (int i = 0; i < no; i++) {
+            Op& op = ops[i];
+            if (op.kind == OpKind::BatchNorm) {
+                int v = op.inputs[0], p = producerOf(v);
+                if (p >= 0 && isConvLike(ops[p].kind) && ops[p].act == SM_ACT_NONE && ops[p].residual < 0 && consumers(v) == 1) {
+                    Op& c = ops[p];
+                    const size_t per = c.weight.size() / c.cout;
+                    if (c.bias.empty()) c.bias.assign(c.cout, 0.f);
+                    for (int o = 0; o < c.cout; o++) {
+                        const float s = op.scale[o];
+                        float* w = c.weight.data() + (size_t)o * per;
+                        for (size_t k = 0; k < per; k++) w[k] *= s;
+                        c.bias[o] = c.bias[o] * s + op.shift[o];          // (b - mean)*s + beta
+                    }
+                    c.output = op.output; dead[i] = 1;
+                }
+            } else if (op.kind == OpKind::Add) {
+                int pa = producerOf(op.inputs[0]), pb = producerOf(op.inputs[1]);
+                auto ok = [&](int p, int v) { return p >= 0 && isConvLike(ops[p].kind) && ops[p].act == SM_ACT_NONE && ops[p].residual < 0 && consumers(v) == 1; };
+                int cand = -1, other = -1;
+                bool oka = ok(pa, op.inputs[0]), okb = ok(pb, op.inputs[1]) && op.inputs[0] != op.inputs[1];
+                if (oka && okb) { if (pa > pb) { cand = pa; other = op.inputs[1]; } else { cand = pb; other = op.inputs[0]; } }
+                else if (oka) { cand = pa; other = op.inputs[1]; }
+                else if (okb) { cand = pb; other = op.inputs[0]; }
+                if (cand >= 0 && producerOf(other) < cand) {               // the other operand is ready when `cand` runs
+                    ops[cand].residual = other; ops[cand].output = op.output; dead[i] = 1;
+                }
+            } else if (op.kind == OpKind::Neuron) {
+                int v = op.inputs[0], p = producerOf(v);
+                if (p >= 0 && ops[p].act == SM_ACT_NONE && consumers(v) == 1 &&
+                    (isConvLike(ops[p].kind) || ops[p].kind == OpKind::Add || ops[p].kind == OpKind::BatchNorm)) {
+                    ops[p].act = op.act; ops[p].slope = op.slope; ops[p].output = op.output; dead[i] = 1;
+                }
+            }
+        }
+    }
+
+    // ---- 2. aliasing + 3. concat placement -----------------------------------------------------------------
+    place_.assign(nv, Placement());
+    for (int v = 0; v < nv; v++) { place_[v].root = v; place_[v].c_off = 0; place_[v].ld = values_[v].c; }
+    // first-layer image: pad channels to a multiple of 8 so the MFMA implicit-GEMM path applies (zeros written
+    // by sm_nchw_f32_to_nhwc_f16, matching zero weight columns)
+    input_ld_ = (values_[input_value_].c + 7) / 8 * 8;
+    place_[input_value_].ld = input_ld_;
+
+    std::vector<int> alias_of(nv, -1);       // value -> value it aliases
+    std::vector<int> placed_in(nv, -1);      // value -> concat value it was placed into
+    std::vector<int> fc_permute(no, 0);
+    for (int i = 0; i < no; i++) {
+        if (dead[i]) continue;
+        Op& op = ops[i];
+        if (op.kind == OpKind::Alias) {
+            int in = op.inputs[0]; const Value& iv = values_[in]; const Value& ov = values_[op.output];
+            bool reorders = (iv.h * iv.w > 1) && !(ov.c == iv.c && ov.h == iv.h && ov.w == iv.w);
+            if (reorders) {
+                // NCHW-order flatten of an NHWC buffer: fine iff every consumer is a fully-connected layer
+                // (its weight columns get permuted instead) and the source is dense.
+                bool all_fc = op.output != output_value_;
+                for (int j = 0; j < no && all_fc; j++) if (!dead[j]) for (int u : ops[j].inputs) if (u == op.output && ops[j].kind != OpKind::FullyConnected) all_fc = false;
+                if (!all_fc || in == input_value_) { sm_set_error("Flatten/Reshape of a %dx%d map feeding a non-Gemm consumer is not supported", iv.h, iv.w); return SM_ERR_INCONSISTENT_STATE; }
+                for (int j = 0; j < no; j++) if (!dead[j] && ops[j].kind == OpKind::FullyConnected && ops[j].inputs[0] == op.output) fc_permute[j] = in + 1;
+            }
+            alias_of[op.output] = in;
+        }
+    }
+    auto rootOf = [&](int v) { while (alias_of[v] >= 0) v = alias_of[v]; return v; };
+    std::vector<std::vector<std::pair<int, int>>> concat_copies(no);   // (input value, channel offset) needing a copy kernel
+    for (int i = 0; i < no; i++) {
+        if (dead[i] || ops[i].kind != OpKind::Concat) continue;
+        Op& op = ops[i]; int off = 0; const int ctot = values_[op.output].c;
+        std::vector<int> seen;
+        for (int u : op.inputs) {
+            int r = rootOf(u);
+            bool reorder_src = false; for (int j = 0; j < no; j++) if (fc_permute[j] == r + 1) reorder_src = true;
+            bool can = r == u && u != input_value_ && u != output_value_ && placed_in[u] < 0 && !reorder_src &&
+                       std::find(seen.begin(), seen.end(), u) == seen.end() && producerOf(u) >= 0 && producerOf(u) < i;
+            if (can) { placed_in[u] = op.output; place_[u].c_off = off; }
+            else concat_copies[i].push_back({u, off});
+            seen.push_back(u); off += values_[u].c;
+        }
+        (void)ctot;
+    }
+    // resolve placement chains: alias -> source; placed -> concat buffer (+offset), recursively
+    std::vector<int> state(nv, 0);
+    std::function<void(int)> resolve = [&](int v) {
+        if (state[v]) return; state[v] = 1;
+        if (alias_of[v] >= 0) { int s = alias_of[v]; resolve(s); place_[v] = place_[s]; return; }
+        if (placed_in[v] >= 0) { int b = placed_in[v]; resolve(b); int own = place_[v].c_off; place_[v].root = place_[b].root; place_[v].c_off = place_[b].c_off + own; place_[v].ld = place_[b].ld; return; }
+    };
+    for (int v = 0; v < nv; v++) resolve(v);
+
+    // ---- steps ---------------------------------------------------------------------------------------------
+    steps_.clear(); launches_ = 1 /* input conversion */; flops_ = 0; alg_bytes_ = 0;
+    for (int i = 0; i < no; i++) {
+        if (dead[i]) continue;
+        Op& op = ops[i];
+        if (op.kind == OpKind::Alias) continue;
+        if (op.kind == OpKind::Concat) {
+            for (auto& cp : concat_copies[i]) {           // fallback copies, expressed as single-input Concat steps
+                Step st; st.op.kind = OpKind::Concat; st.op.name = op.name; st.op.inputs = {cp.first}; st.op.output = op.output; st.op.pl = cp.second;
+                st.M = batch * values_[op.output].h * values_[op.output].w; st.launches = 1;
+                steps_.push_back(std::move(st));
+            }
+            continue;
+        }
+        Step st; st.M = batch * values_[op.output].h * values_[op.output].w;
+        st.real_cin = op.cin;
+        if (op.kind == OpKind::FullyConnected && fc_permute[i]) { const Value& src = values_[fc_permute[i] - 1]; st.fc_h = src.h; st.fc_w = src.w; }
+        if (isConvLike(op.kind) && op.groups == 1 && op.kind == OpKind::Conv && rootOf(op.inputs[0]) == input_value_ && input_ld_ != op.cin) {
+            // pad Cin (OHWI innermost) with zero columns up to the padded image stride
+            const int cin = op.cin, cp = input_ld_; const size_t rows = op.weight.size() / cin;
+            std::vector<float> w(rows * cp, 0.f);
+            for (size_t r = 0; r < rows; r++) std::copy(op.weight.begin() + r * cin, op.weight.begin() + (r + 1) * cin, w.begin() + r * cp);
+            op.weight.swap(w); op.cin = cp;
+        }
+        st.op = std::move(op);
+        steps_.push_back(std::move(st));
+    }
+
+    // ---- 4. memory plan ------------------------------------------------------------------------------------
+    const int ns = (int)steps_.size();
+    std::vector<int> first(nv, INT32_MAX), last(nv, -1);   // per ROOT value: live step interval
+    auto touch = [&](int v, int t) { int r = place_[v].root; first[r] = std::min(first[r], t); last[r] = std::max(last[r], t); };
+    touch(input_value_, -1);
+    for (int t = 0; t < ns; t++) {
+        const Op& op = steps_[t].op;
+        for (int u : op.inputs) touch(u, t);
+        if (op.residual >= 0) touch(op.residual, t);
+        touch(op.output, t);
+    }
+    touch(output_value_, ns);                               // result image must survive until read back
+    root_offset_.assign(nv, 0);
+    struct Blk { int v; size_t bytes; };
+    std::vector<Blk> blks;
+    for (int v = 0; v < nv; v++) if (place_[v].root == v && last[v] >= 0) {
+        size_t bytes = alignUp((size_t)batch * values_[v].h * values_[v].w * place_[v].ld * 2 + 64);
+        blks.push_back({v, bytes});
+    }
+    std::sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) { return a.bytes > b.bytes; });
+    std::vector<Blk> placed; act_bytes_ = 0;
+    for (auto& b : blks) {
+        std::vector<std::pair<size_t, size_t>> busy;        // byte ranges of already placed, time-overlapping buffers
+        for (auto& q : placed) if (!(last[q.v] < first[b.v] || last[b.v] < first[q.v])) busy.push_back({root_offset_[q.v], root_offset_[q.v] + q.bytes});
+        std::sort(busy.begin(), busy.end());
+        size_t off = 0;
+        for (auto& r : busy) { if (off + b.bytes <= r.first) break; off = std::max(off, r.second); }
+        root_offset_[b.v] = off; placed.push_back(b); act_bytes_ = std::max(act_bytes_, off + b.bytes);
+    }
+
+    // ---- 5. weight arena layout + accounting ---------------------------------------------------------------
+    size_t off = 0; ws_bytes_ = 0;
+    for (auto& st : steps_) {
+        Op& op = st.op;
+        if (isConvLike(op.kind)) {
+            st.w_off = off; off = alignUp(off + op.weight.size() * 2);
+            st.has_bias = !op.bias.empty();
+            if (st.has_bias) { st.b_off = off; off = alignUp(off + op.bias.size() * 4); }
+            const Value& ov = values_[op.output];
+            const double K = (double)op.kh * op.kw * (st.real_cin / op.groups);
+            flops_ += 2.0 * st.M * op.cout * K;
+            const Value& iv = values_[op.inputs[0]];
+            alg_bytes_ += 2.0 * ((double)batch * iv.c * iv.h * iv.w + (double)st.M * ov.c + (op.residual >= 0 ? (double)st.M * ov.c : 0.0) + (double)op.cout * K);
+            sm_conv_desc d{}; d.N = batch; d.H = op.kind == OpKind::Conv ? iv.h : 1; d.W = op.kind == OpKind::Conv ? iv.w : 1; d.Cin = op.cin; d.Cout = op.cout;
+            d.kH = op.kh; d.kW = op.kw; d.groups = op.groups; d.Ho = ov.h; d.Wo = ov.w;
+            ws_bytes_ = std::max(ws_bytes_, sm_conv2d_workspace_bytes(&d));
+        } else if (op.kind == OpKind::BatchNorm) {
+            st.s_off = off; off = alignUp(off + op.scale.size() * 4);
+            st.t_off = off; off = alignUp(off + op.shift.size() * 4);
+        }
+        if (!isConvLike(op.kind)) {
+            const Value& ov = values_[op.output]; double in_elems = 0;
+            for (int u : op.inputs) in_elems += (double)batch * values_[u].c * values_[u].h * values_[u].w;
+            alg_bytes_ += 2.0 * (in_elems + (double)batch * (op.kind == OpKind::Concat ? values_[op.inputs[0]].c : ov.c) * ov.h * ov.w);
+        }
+        launches_ += st.launches;
+        char buf[256];
+        if (isConvLike(op.kind))
+            snprintf(buf, sizeof buf, "%s %s M=%d N=%d K=%d k=%dx%d s=%d g=%d%s%s", kindName(op.kind), op.name.c_str(), st.M, op.cout, op.kh * op.kw * (op.cin / op.groups),
+                     op.kh, op.kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "");
+        else snprintf(buf, sizeof buf, "%s %s pixels=%d C=%d%s", kindName(op.kind), op.name.c_str(), st.M, values_[op.output].c, op.act ? " +act" : "");
+        st.desc = buf;
+    }
+    arena_bytes_ = std::max(off, (size_t)kAlign);
+    value_names_.resize(nv); for (int v = 0; v < nv; v++) value_names_[v] = values_[v].name;
+    return SM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+int Executor::packWeights(std::vector<uint8_t>* host) const {
+    host->assign(arena_bytes_, 0);
+    for (auto& st : steps_) {
+        const Op& op = st.op;
+        if (isConvLike(op.kind)) {
+            uint16_t* dst = (uint16_t*)(host->data() + st.w_off);
+            if (op.kind == OpKind::FullyConnected && st.fc_h * st.fc_w > 1) {
+                // columns arrive in NCHW-flatten order (c*HW + p); our buffer is NHWC (p*C + c)
+                const int hw = st.fc_h * st.fc_w, C = op.cin / hw;
+                for (int o = 0; o < op.cout; o++)
+                    for (int p = 0; p < hw; p++)
+                        for (int c = 0; c < C; c++) dst[(size_t)o * op.cin + (size_t)p * C + c] = float_to_half_bits(op.weight[(size_t)o * op.cin + (size_t)c * hw + p]);
+            } else {
+                sm_float_to_half(op.weight.data(), dst, op.weight.size());   // fp16 cast, RNE (ONNX2MPS.py:27 numpy astype(float16))
+            }
+            if (st.has_bias) memcpy(host->data() + st.b_off, op.bias.data(), op.bias.size() * 4);
+        } else if (op.kind == OpKind::BatchNorm) {
+            memcpy(host->data() + st.s_off, op.scale.data(), op.scale.size() * 4);
+            memcpy(host->data() + st.t_off, op.shift.data(), op.shift.size() * 4);
+        }
+    }
+    return SM_OK;
+}
+
+int Executor::weightBytes(ONNXGraph& g, int batch, size_t* bytes) {
+    int rc = g.build(); if (rc) return rc;
+    Executor e; rc = e.plan(g, batch); if (rc) return rc;
+    *bytes = e.arena_bytes_; return SM_OK;
+}
+
+int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool upload, Executor** out) {
+    if (batch <= 0) { sm_set_error("batch must be positive"); return SM_ERR_INVALID_ARGUMENT; }
+    int rc = g.build(); if (rc) return rc;
+    std::unique_ptr<Executor> e(new Executor());
+    e->device_ = device;
+    rc = e->plan(g, batch); if (rc) return rc;
+    SM_HIP_CHECK(hipSetDevice(device));
+    SM_HIP_CHECK(hipMalloc((void**)&e->act_, e->act_bytes_ + kAlign));
+    SM_HIP_CHECK(hipMemset(e->act_, 0, e->act_bytes_ + kAlign));
+    if (e->ws_bytes_) SM_HIP_CHECK(hipMalloc((void**)&e->ws_, e->ws_bytes_));
+    if (ext_arena) { e->arena_ = (char*)ext_arena; e->own_arena_ = false; }
+    else { SM_HIP_CHECK(hipMalloc((void**)&e->arena_, e->arena_bytes_)); e->own_arena_ = true; upload = true; }
+    if (upload) {
+        std::vector<uint8_t> host; rc = e->packWeights(&host); if (rc) return rc;
+        SM_HIP_CHECK(hipMemcpy(e->arena_, host.data(), host.size(), hipMemcpyHostToDevice));
+    }
+    const Value& ov = e->values_[e->output_value_];
+    e->out_f32_count_ = std::max(sm_float_array_count(batch, ov.c, ov.h, ov.w), (size_t)batch * ov.c * ov.h * ov.w);
+    SM_HIP_CHECK(hipMalloc((void**)&e->out_f32_, e->out_f32_count_ * 4));
+    for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit(); }   // host masters no longer needed
+    if (e->cfg_.autotune && (ext_arena == nullptr || upload)) {
+        hipStream_t s; SM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        rc = e->autotune(s);
+        (void)hipStreamDestroy(s);
+        if (rc) return rc;
+    }
+    *out = e.release();
+    return SM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+int Executor::launchStep(const Step& st, hipStream_t s) const {
+    const Op& op = st.op; const Value& ov = values_[op.output];
+    void* y = valuePtr(op.output); const int y_ld = valueLd(op.output);
+    sm_stream_t ss = (sm_stream_t)s;
+    switch (op.kind) {
+    case OpKind::Conv: case OpKind::FullyConnected: {
+        const Value& iv = values_[op.inputs[0]];
+        sm_conv_desc d{};
+        d.N = batch_; d.Cin = op.cin; d.Cout = op.cout; d.kH = op.kh; d.kW = op.kw; d.sH = op.sh; d.sW = op.sw; d.dH = op.dh; d.dW = op.dw;
+        d.pt = op.pt; d.pl = op.pl; d.pb = op.pb; d.pr = op.pr; d.groups = op.groups; d.act = op.act; d.slope = op.slope;
+        if (op.kind == OpKind::Conv) { d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.x_ld = valueLd(op.inputs[0]); }
+        else { d.H = d.W = d.Ho = d.Wo = 1; d.x_ld = st.fc_h * st.fc_w > 1 ? op.cin : valueLd(op.inputs[0]); }   // flattened map: one dense row per image
+        d.y_ld = y_ld; d.res_ld = op.residual >= 0 ? valueLd(op.residual) : 0;
+        return sm_conv2d_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
+                                 op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, ws_, ws_bytes_, ss);
+    }
+    case OpKind::BatchNorm:
+        return sm_batchnorm(valuePtr(op.inputs[0]), y, st.M, ov.c, valueLd(op.inputs[0]), y_ld, (const float*)(arena_ + st.s_off), (const float*)(arena_ + st.t_off), op.act, op.slope, ss);
+    case OpKind::Neuron:
+        return sm_batchnorm(valuePtr(op.inputs[0]), y, st.M, ov.c, valueLd(op.inputs[0]), y_ld, nullptr, nullptr, op.act, op.slope, ss);
+    case OpKind::Add:
+        return sm_add(valuePtr(op.inputs[0]), valuePtr(op.inputs[1]), y, st.M, ov.c, valueLd(op.inputs[0]), valueLd(op.inputs[1]), y_ld, op.act, op.slope, ss);
+    case OpKind::MaxPool: case OpKind::AvgPool: {
+        const Value& iv = values_[op.inputs[0]];
+        sm_pool_desc d{batch_, iv.h, iv.w, iv.c, op.kh, op.kw, op.sh, op.sw, op.y0, op.x0, ov.h, ov.w, valueLd(op.inputs[0]), y_ld};
+        return op.kind == OpKind::MaxPool ? sm_maxpool2d(&d, valuePtr(op.inputs[0]), y, ss) : sm_avgpool2d(&d, valuePtr(op.inputs[0]), y, ss);
+    }
+    case OpKind::GlobalAvgPool: {
+        const Value& iv = values_[op.inputs[0]];
+        return sm_global_avgpool(valuePtr(op.inputs[0]), y, batch_, iv.h * iv.w, iv.c, valueLd(op.inputs[0]), y_ld, ss);
+    }
+    case OpKind::Upsample: {
+        const Value& iv = values_[op.inputs[0]];
+        if (op.bilinear) return sm_upsample_bilinear(valuePtr(op.inputs[0]), y, batch_, iv.h, iv.w, iv.c, op.sy, op.sx, op.alignCorners, valueLd(op.inputs[0]), y_ld, ss);
+        return sm_upsample_nearest(valuePtr(op.inputs[0]), y, batch_, iv.h, iv.w, iv.c, op.sy, op.sx, valueLd(op.inputs[0]), y_ld, ss);
+    }
+    case OpKind::Concat: {   // copy fallback for one operand: op.pl = channel offset inside the concat buffer
+        const Value& iv = values_[op.inputs[0]];
+        return sm_copy_channels(valuePtr(op.inputs[0]), (char*)y + (size_t)op.pl * 2, st.M, iv.c, valueLd(op.inputs[0]), y_ld, ss);
+    }
+    case OpKind::Alias: return SM_OK;
+    }
+    return SM_OK;
+}
+
+int Executor::launchAll(hipStream_t s, const float* in) const {
+    const Value& iv = values_[input_value_];
+    int rc = sm_nchw_f32_to_nhwc_f16(in, valuePtr(input_value_), batch_, iv.c, iv.h, iv.w, input_ld_, 0, 0, 0, 0, (sm_stream_t)s);
+    if (rc) return rc;
+    for (auto& st : steps_) { rc = launchStep(st, s); if (rc) return rc; }
+    return SM_OK;
+}
+
+int Executor::encode(hipStream_t s, const float* in) {
+    if (!in) { sm_set_error("smelter_exec_encode: null input"); return SM_ERR_INVALID_ARGUMENT; }
+    if (!cfg_.useHipGraph) return launchAll(s, in);
+    if (!graph_exec_ || captured_in_ != in) {
+        if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
+        if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
+        hipStream_t cs; SM_HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        SM_HIP_CHECK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+        int rc = launchAll(cs, in);
+        hipError_t ee = hipStreamEndCapture(cs, &graph_);
+        (void)hipStreamDestroy(cs);
+        if (rc) return rc;
+        if (ee != hipSuccess) { sm_set_error("hipStreamEndCapture: %s", hipGetErrorString(ee)); return SM_ERR_HIP; }
+        SM_HIP_CHECK(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
+        captured_in_ = in;
+    }
+    SM_HIP_CHECK(hipGraphLaunch(graph_exec_, s));
+    return SM_OK;
+}
+
+int Executor::readFloat(hipStream_t s, float* dst, size_t cap, int layout) {
+    const Value& ov = values_[output_value_];
+    size_t count = layout == 1 ? sm_float_array_count(batch_, ov.c, ov.h, ov.w) : (size_t)batch_ * ov.c * ov.h * ov.w;
+    if (cap < count) { sm_set_error("smelter_exec_read_float: destination holds %zu floats, result has %zu", cap, count); return SM_ERR_INVALID_ARGUMENT; }
+    int rc = layout == 1 ? sm_nhwc_f16_to_float_array(valuePtr(output_value_), out_f32_, batch_, ov.c, ov.h, ov.w, valueLd(output_value_), (sm_stream_t)s)
+                         : sm_nhwc_f16_to_nchw_f32(valuePtr(output_value_), out_f32_, batch_, ov.c, ov.h, ov.w, valueLd(output_value_), (sm_stream_t)s);
+    if (rc) return rc;
+    SM_HIP_CHECK(hipMemcpyAsync(dst, out_f32_, count * 4, hipMemcpyDeviceToHost, s));
+    SM_HIP_CHECK(hipStreamSynchronize(s));
+    return SM_OK;
+}
+
+int Executor::readValue(hipStream_t s, const char* name, float* dst, size_t cap, int* c, int* h, int* w) {
+    int v = -1; for (size_t i = 0; i < value_names_.size(); i++) if (value_names_[i] == name) v = (int)i;
+    if (v < 0) { sm_set_error("no value named '%s' survives fusion", name); return SM_ERR_NO_SUCH_OUTPUT; }
+    const Value& val = values_[v]; size_t count = (size_t)batch_ * val.c * val.h * val.w;
+    *c = val.c; *h = val.h; *w = val.w;
+    if (cap < count) { sm_set_error("smelter_exec_read_value: destination too small"); return SM_ERR_INVALID_ARGUMENT; }
+    float* tmp; SM_HIP_CHECK(hipMalloc((void**)&tmp, count * 4));
+    int rc = sm_nhwc_f16_to_nchw_f32(valuePtr(v), tmp, batch_, val.c, val.h, val.w, valueLd(v), (sm_stream_t)s);
+    if (!rc) { hipError_t e1 = hipMemcpyAsync(dst, tmp, count * 4, hipMemcpyDeviceToHost, s); hipError_t e2 = hipStreamSynchronize(s); if (e1 != hipSuccess || e2 != hipSuccess) { sm_set_error("read_value copy failed"); rc = SM_ERR_HIP; } }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+int Executor::timeOp(hipStream_t s, int idx, int iters, float* ms) {
+    if (idx < 0 || idx >= (int)steps_.size() || iters <= 0) { sm_set_error("smelter_exec_time_op: bad index"); return SM_ERR_INVALID_ARGUMENT; }
+    hipEvent_t a, b; SM_HIP_CHECK(hipEventCreate(&a)); SM_HIP_CHECK(hipEventCreate(&b));
+    int rc = launchStep(steps_[idx], s);   // warm
+    SM_HIP_CHECK(hipEventRecord(a, s));
+    for (int i = 0; i < iters && !rc; i++) rc = launchStep(steps_[idx], s);
+    SM_HIP_CHECK(hipEventRecord(b, s));
+    SM_HIP_CHECK(hipEventSynchronize(b));
+    float t = 0; SM_HIP_CHECK(hipEventElapsedTime(&t, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms = t / iters;
+    return rc;
+}
+
+int Executor::autotune(hipStream_t s) {
+    const int ncfg = sm_conv2d_num_configs();
+    for (size_t i = 0; i < steps_.size(); i++) {
+        Step& st = steps_[i];
+        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8)) continue;
+        float best = 1e30f; int best_cfg = -1;
+        for (int c = 0; c < ncfg; c++) {
+            st.conv_cfg = c; float ms = 0;
+            int rc = timeOp(s, (int)i, 3, &ms); if (rc) return rc;
+            if (ms < best) { best = ms; best_cfg = c; }
+        }
+        st.conv_cfg = best_cfg;
+        st.desc += " cfg=" + std::to_string(best_cfg);
+    }
+    return SM_OK;
+}
+
+}  // namespace smelter

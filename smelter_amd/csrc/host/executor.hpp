@@ -1,0 +1,86 @@
+// executor.hpp — what `metalGraph(device:)` returns in the reference is an MPSNNGraph
+// (/root/reference/Sources/Smelter/ONNXGraph.swift:185-190); here it is an Executor: the converted op list
+// after epilogue fusion, a static memory plan, a packed weight arena on the GPU and a launch sequence of sm_*
+// kernel calls, optionally replayed as one hipGraph.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "graph.hpp"
+
+namespace smelter {
+
+struct Placement {           // where a value lives
+    int root = -1;           // value id owning the physical buffer
+    int c_off = 0;           // channel offset inside the root's pixel
+    int ld = 0;              // pixel stride in elements
+};
+
+struct Step {                // one op after fusion, with everything resolved
+    Op op;
+    int M = 0;               // output pixels (batch*Ho*Wo)
+    size_t w_off = 0, b_off = 0, s_off = 0, t_off = 0;   // arena offsets: weight fp16, bias f32, bn scale/shift f32
+    bool has_bias = false;
+    int conv_cfg = -1;       // tile configuration (-1 = heuristic)
+    int launches = 1;
+    int real_cin = 0;        // before first-layer channel padding (FLOP accounting)
+    int fc_h = 1, fc_w = 1;  // FullyConnected over a flattened HxW map: weight columns permuted NCHW->NHWC order
+    std::string desc;
+};
+
+class Executor {
+   public:
+    static int create(ONNXGraph& g, int device, int batch, void* ext_arena, bool upload, Executor** out);
+    static int weightBytes(ONNXGraph& g, int batch, size_t* bytes);
+    ~Executor();
+
+    int encode(hipStream_t s, const float* in_nchw);
+    int readFloat(hipStream_t s, float* dst, size_t cap, int layout);
+    int readValue(hipStream_t s, const char* name, float* dst, size_t cap, int* c, int* h, int* w);
+    int timeOp(hipStream_t s, int idx, int iters, float* ms);
+
+    int batch() const { return batch_; }
+    void outputDims(int* n, int* c, int* h, int* w) const;
+    const void* outputDevice() const;
+    int numLaunches() const { return launches_; }
+    int numOps() const { return (int)steps_.size(); }
+    size_t weightBytesUsed() const { return arena_bytes_; }
+    void* weightArena() const { return arena_; }
+    size_t activationBytes() const { return act_bytes_; }
+    double flops() const { return flops_; }
+    double algorithmicBytes() const { return alg_bytes_; }
+    const char* opDesc(int idx) const { return idx >= 0 && idx < (int)steps_.size() ? steps_[idx].desc.c_str() : ""; }
+
+   private:
+    Executor() = default;
+    int plan(ONNXGraph& g, int batch);                   // fusion + placement + memory plan + arena layout
+    int packWeights(std::vector<uint8_t>* host) const;   // fold/cast/pad -> arena image
+    int launchStep(const Step& st, hipStream_t s) const;
+    int launchAll(hipStream_t s, const float* in) const;
+    int autotune(hipStream_t s);
+    void* valuePtr(int v) const;
+    int valueLd(int v) const { return place_[v].ld; }
+
+    int device_ = 0, batch_ = 1;
+    Configuration cfg_;
+    std::vector<Value> values_;
+    std::vector<Placement> place_;
+    std::vector<size_t> root_offset_;    // per value id (roots only), byte offset in the activation arena
+    std::vector<Step> steps_;
+    int input_value_ = -1, output_value_ = -1, input_ld_ = 0;
+    std::vector<std::string> value_names_;
+
+    char* arena_ = nullptr; size_t arena_bytes_ = 0; bool own_arena_ = false;
+    char* act_ = nullptr; size_t act_bytes_ = 0;
+    char* ws_ = nullptr; size_t ws_bytes_ = 0;           // split-K scratch
+    float* out_f32_ = nullptr; size_t out_f32_count_ = 0; // readback staging
+    int launches_ = 0;
+    double flops_ = 0, alg_bytes_ = 0;
+
+    // hipGraph replay
+    hipGraph_t graph_ = nullptr; hipGraphExec_t graph_exec_ = nullptr; const float* captured_in_ = nullptr;
+};
+
+}  // namespace smelter

@@ -1,0 +1,56 @@
+// smelter_amd/csrc/kernels/common.hpp — shared device/host helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../../include/smelter_hip.h"
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+#define SM_WAVE 64
+#define SM_NUM_XCD 8
+#define SM_NUM_CU 256
+
+void sm_set_error(const char* fmt, ...);
+
+#define SM_HIP_CHECK(expr)                                                                            \
+    do {                                                                                              \
+        hipError_t _e = (expr);                                                                       \
+        if (_e != hipSuccess) {                                                                       \
+            sm_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);  \
+            return SM_ERR_HIP;                                                                        \
+        }                                                                                             \
+    } while (0)
+
+#define SM_LAUNCH_CHECK()                                                                             \
+    do {                                                                                              \
+        hipError_t _e = hipGetLastError();                                                            \
+        if (_e != hipSuccess) {                                                                       \
+            sm_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+            return SM_ERR_HIP;                                                                        \
+        }                                                                                             \
+    } while (0)
+
+#define SM_REQUIRE(cond, ...)                                                                         \
+    do {                                                                                              \
+        if (!(cond)) { sm_set_error(__VA_ARGS__); return SM_ERR_INVALID_ARGUMENT; }                   \
+    } while (0)
+
+__device__ __forceinline__ float sm_act(float v, int act, float slope) {
+    // MPSCNNNeuronReLUNode(a): f(x) = x >= 0 ? x : a*x   (Converters.swift:351,376)
+    return (act != SM_ACT_NONE && v < 0.f) ? v * slope : v;
+}
+
+static inline int sm_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+static inline hipStream_t sm_s(sm_stream_t s) { return (hipStream_t)s; }
+// grid for grid-stride elementwise kernels: enough blocks to fill the chip, capped (guide G11)
+static inline int sm_stream_grid(long work_items, int block) {
+    long b = (work_items + block - 1) / block;
+    long cap = (long)SM_NUM_CU * 8;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}

@@ -1,0 +1,376 @@
+// conv_igemm.hip — implicit-GEMM convolution / fully-connected on MFMA for gfx950 (CDNA4).
+//
+// Replaces MPSCNNConvolutionNode / MPSCNNFullyConnectedNode (/root/reference/Sources/Smelter/Converters.swift
+// :253, :297) together with the epilogue nodes MPS would fuse or run separately: bias (biasTerms(), :166),
+// residual MPSNNAdditionNode (:440) and MPSCNNNeuronReLUNode (:351).
+//
+// GEMM view (per group = 1):   D[cout][pixel] = sum_k W[cout][k] * X[pixel][k],   k = (kh*kW + kw)*Cin + ci
+//   * W is OHWI fp16 = [Cout][K] with K contiguous — the layout Smelter's preprocessing produces
+//     (Array+Extensions.swift:78-83), so weights are the MFMA "A" operand as stored.
+//   * X rows are gathered on the fly from the NHWC fp16 input: for Cin % 8 == 0 every 16-byte vector of a
+//     row lies inside one (kh,kw) tap, i.e. is 8 contiguous channels of one input pixel (or zero padding).
+//   * operands are swapped w.r.t. the usual "pixels = rows" so that each lane ends up holding 4 consecutive
+//     output channels of one pixel (32x32 C/D layout: col = lane&31, row = (reg&3)+8*(reg>>2)+4*(lane>>5)),
+//     which are contiguous in the NHWC output -> 8-byte stores, no LDS transpose.
+//
+// Tile: BM pixels x BN couts x BK=32, 256 threads = 4 waves arranged WGM x WGN, each wave TM x TN MFMA tiles of
+// 32x32 (v_mfma_f32_32x32x16_f16, fp32 accumulate).  Global->register->LDS staging with the next tile's loads
+// in flight during the MFMAs (one barrier per K tile, double-buffered LDS).  LDS rows are 64 B; 16-byte chunks
+// are XOR-swizzled (chunk ^ f((row>>2)&3), f = 0,2,3,1) so that every 16-lane service group of ds_read_b128
+// touches 16 distinct 16-byte bank slots (MI355X_MICROARCH.md §LDS).
+//
+// Block -> tile map is XCD aware (8 XCDs with private L2, block b runs on XCD b%8): all BN-tiles of one pixel
+// tile are issued back-to-back on the same XCD so the gathered activation tile is fetched from HBM once.
+#include "common.hpp"
+
+namespace {
+
+struct ConvParams {
+    const half_t* x; const half_t* w; const float* bias; const half_t* res; half_t* y;
+    float* ws;                       // split-K partials (fp32) or nullptr
+    int N, H, W, Cin, Cout, kH, kW, sH, sW, dH, dW, pt, pl, Ho, Wo;
+    int x_ld, y_ld, res_ld, act; float slope;
+    int M, K, mt, nt, splitk, ktiles_per_split;
+};
+
+constexpr int BK = 32;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3); }
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+    static_assert(WGM * WGN == 4, "4 waves");
+    constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
+    constexpr int A_IT = BM * 4 / 256, B_IT = BN * 4 / 256;
+    static_assert(TM >= 1 && TN >= 1 && A_IT >= 1 && B_IT >= 1, "tile too small");
+    __shared__ __attribute__((aligned(16))) half_t smem[2][(BM + BN) * BK];
+
+    // ---- block -> (pixel tile, cout tile, k split) -------------------------------------------------
+    const int bid = blockIdx.x, xcd = bid & (SM_NUM_XCD - 1), slot = bid >> 3;
+    const int per_m = p.nt * p.splitk;
+    const int mtile = xcd + SM_NUM_XCD * (slot / per_m);
+    if (mtile >= p.mt) return;
+    const int rem = slot % per_m, ntile = rem % p.nt, ksplit = rem / p.nt;
+    const int kt_begin = ksplit * p.ktiles_per_split;
+    int kt_end = kt_begin + p.ktiles_per_split;
+    const int ktiles = (p.K + BK - 1) / BK;
+    if (kt_end > ktiles) kt_end = ktiles;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int chunk = tid & 3;              // 16-byte chunk of the 64-byte K row this thread stages
+
+    // ---- per-thread gather state for the activation rows it stages ---------------------------------
+    int iy0[A_IT], ix0[A_IT]; long nb[A_IT]; bool rv[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; i++) {
+        int row = (tid >> 2) + i * 64;
+        int m = mtile * BM + row;
+        rv[i] = m < p.M;
+        int mm = rv[i] ? m : 0;
+        int n = mm / (p.Ho * p.Wo), r = mm - n * (p.Ho * p.Wo);
+        int oy = r / p.Wo, ox = r - oy * p.Wo;
+        iy0[i] = oy * p.sH - p.pt; ix0[i] = ox * p.sW - p.pl; nb[i] = (long)n * p.H * p.W;
+    }
+    // position of this thread's chunk inside K: k = kt*32 + chunk*8 -> (kh, kw, ci)
+    int k = kt_begin * BK + chunk * 8;
+    int tap = k / p.Cin, ci = k - tap * p.Cin, kh = tap / p.kW, kw = tap - kh * p.kW;
+
+    const half_t* wrow[B_IT]; bool wv[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; i++) {
+        int n = ntile * BN + (tid >> 2) + i * 64;
+        wv[i] = n < p.Cout;
+        wrow[i] = p.w + (long)(wv[i] ? n : 0) * p.K;
+    }
+
+    half8_t ra[A_IT], rb[B_IT];
+    auto load_tile = [&]() {
+        const bool kin = k < p.K;
+        const int dy = kh * p.dH, dx = kw * p.dW;
+#pragma unroll
+        for (int i = 0; i < A_IT; i++) {
+            int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            bool ok = rv[i] && kin && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (ok) v = *(const half8_t*)(p.x + (nb[i] + (long)iy * p.W + ix) * p.x_ld + ci);
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; i++) {
+            half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (wv[i] && kin) v = *(const half8_t*)(wrow[i] + k);
+            rb[i] = v;
+        }
+        // advance to the next K tile
+        k += BK; ci += BK;
+        while (ci >= p.Cin) { ci -= p.Cin; if (++kw == p.kW) { kw = 0; ++kh; } }
+    };
+    auto store_tile = [&](int buf) {
+        half_t* sa = smem[buf]; half_t* sb = smem[buf] + BM * BK;
+#pragma unroll
+        for (int i = 0; i < A_IT; i++) { int row = (tid >> 2) + i * 64; *(half8_t*)(sa + row * BK + swz(row, chunk) * 8) = ra[i]; }
+#pragma unroll
+        for (int i = 0; i < B_IT; i++) { int row = (tid >> 2) + i * 64; *(half8_t*)(sb + row * BK + swz(row, chunk) * 8) = rb[i]; }
+    };
+
+    floatx16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; a++)
+#pragma unroll
+        for (int b = 0; b < TM; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    // ---- main loop --------------------------------------------------------------------------------
+    load_tile(); store_tile(0); __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; kt++) {
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tile();
+        const half_t* sa = smem[cur]; const half_t* sb = smem[cur] + BM * BK;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const int c = ks * 2 + (lane >> 5);
+            half8_t fx[TM], fw[TN];
+#pragma unroll
+            for (int b = 0; b < TM; b++) { int row = (wm * TM + b) * 32 + (lane & 31); fx[b] = *(const half8_t*)(sa + row * BK + swz(row, c) * 8); }
+#pragma unroll
+            for (int a = 0; a < TN; a++) { int row = (wn * TN + a) * 32 + (lane & 31); fw[a] = *(const half8_t*)(sb + row * BK + swz(row, c) * 8); }
+#pragma unroll
+            for (int a = 0; a < TN; a++)
+#pragma unroll
+                for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[a], fx[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------------
+    const bool vec_ok = ((p.y_ld & 3) == 0) && ((((uintptr_t)p.y) & 7) == 0) && ((((uintptr_t)p.bias) & 15) == 0) &&
+                        (p.res == nullptr || ((p.res_ld & 3) == 0 && (((uintptr_t)p.res) & 7) == 0));
+#pragma unroll
+    for (int b = 0; b < TM; b++) {
+        const int m = mtile * BM + (wm * TM + b) * 32 + (lane & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int a = 0; a < TN; a++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int co = ntile * BN + (wn * TN + a) * 32 + 8 * q + 4 * (lane >> 5);
+                if (co >= p.Cout) continue;
+                float v[4] = {acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                if (p.splitk > 1) {   // fp32 partials, reduced by splitk_reduce_kernel
+                    float* dst = p.ws + ((long)ksplit * p.M + m) * p.Cout + co;
+                    if (co + 3 < p.Cout && (p.Cout & 3) == 0) *(floatx4*)dst = floatx4{v[0], v[1], v[2], v[3]};
+                    else for (int j = 0; j < 4 && co + j < p.Cout; j++) dst[j] = v[j];
+                    continue;
+                }
+                if (co + 3 < p.Cout && vec_ok) {
+                    if (p.bias) { floatx4 bb = *(const floatx4*)(p.bias + co); v[0] += bb[0]; v[1] += bb[1]; v[2] += bb[2]; v[3] += bb[3]; }
+                    if (p.res) { half4_t rr = *(const half4_t*)(p.res + (long)m * p.res_ld + co); v[0] += (float)rr[0]; v[1] += (float)rr[1]; v[2] += (float)rr[2]; v[3] += (float)rr[3]; }
+                    half4_t o;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) o[j] = (half_t)sm_act(v[j], p.act, p.slope);
+                    *(half4_t*)(p.y + (long)m * p.y_ld + co) = o;
+                } else {
+                    for (int j = 0; j < 4 && co + j < p.Cout; j++) {
+                        float t = v[j];
+                        if (p.bias) t += p.bias[co + j];
+                        if (p.res) t += (float)p.res[(long)m * p.res_ld + co + j];
+                        p.y[(long)m * p.y_ld + co + j] = (half_t)sm_act(t, p.act, p.slope);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// split-K second pass: sum fp32 partials, bias/residual/activation, fp16 store
+__global__ void splitk_reduce_kernel(ConvParams p) {
+    long total = (long)p.M * p.Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / p.Cout; int co = (int)(i - m * p.Cout);
+        float t = 0.f;
+        for (int s = 0; s < p.splitk; s++) t += p.ws[(long)s * total + i];
+        if (p.bias) t += p.bias[co];
+        if (p.res) t += (float)p.res[m * p.res_ld + co];
+        p.y[m * p.y_ld + co] = (half_t)sm_act(t, p.act, p.slope);
+    }
+}
+
+// Direct convolution: correctness fallback for shapes the MFMA path does not take (Cin % 8 != 0, grouped
+// non-depthwise).  One thread per output element, fp32 accumulate in (kh, kw, ci) order.
+__global__ void conv_direct_kernel(ConvParams p, int groups) {
+    const long total = (long)p.M * p.Cout;
+    const int Cg = p.Cin / groups, Kg = p.Cout / groups;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / p.Cout; int co = (int)(i - m * p.Cout);
+        int n = (int)(m / (p.Ho * p.Wo)), r = (int)(m - (long)n * p.Ho * p.Wo), oy = r / p.Wo, ox = r - oy * p.Wo;
+        int g = co / Kg;
+        float acc = 0.f;
+        for (int kh = 0; kh < p.kH; kh++) {
+            int iy = oy * p.sH - p.pt + kh * p.dH; if ((unsigned)iy >= (unsigned)p.H) continue;
+            for (int kw = 0; kw < p.kW; kw++) {
+                int ix = ox * p.sW - p.pl + kw * p.dW; if ((unsigned)ix >= (unsigned)p.W) continue;
+                const half_t* xp = p.x + (((long)n * p.H + iy) * p.W + ix) * p.x_ld + g * Cg;
+                const half_t* wp = p.w + (((long)co * p.kH + kh) * p.kW + kw) * Cg;
+                for (int c = 0; c < Cg; c++) acc += (float)xp[c] * (float)wp[c];
+            }
+        }
+        if (p.bias) acc += p.bias[co];
+        if (p.res) acc += (float)p.res[m * p.res_ld + co];
+        p.y[m * p.y_ld + co] = (half_t)sm_act(acc, p.act, p.slope);
+    }
+}
+
+// Depthwise convolution (groups == Cin == Cout, MPSCNNDepthWiseConvolutionDescriptor, Converters.swift:57-66).
+// HBM-bound VALU kernel: each thread owns 8 consecutive channels (16-byte loads/stores) of one output pixel;
+// the kH*kW per-channel taps are read from the OHWI weight [C][kH][kW][1] through L1/L2.
+__global__ __launch_bounds__(256) void dwconv_kernel(ConvParams p) {
+    const int cv = p.Cout >> 3;                       // channel vectors per pixel
+    const long total = (long)p.M * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / cv; int c0 = (int)(i - m * cv) * 8;
+        int n = (int)(m / (p.Ho * p.Wo)), r = (int)(m - (long)n * p.Ho * p.Wo), oy = r / p.Wo, ox = r - oy * p.Wo;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = p.bias ? p.bias[c0 + j] : 0.f;
+        const int taps = p.kH * p.kW;
+        for (int kh = 0; kh < p.kH; kh++) {
+            int iy = oy * p.sH - p.pt + kh * p.dH; if ((unsigned)iy >= (unsigned)p.H) continue;
+            for (int kw = 0; kw < p.kW; kw++) {
+                int ix = ox * p.sW - p.pl + kw * p.dW; if ((unsigned)ix >= (unsigned)p.W) continue;
+                half8_t xv = *(const half8_t*)(p.x + (((long)n * p.H + iy) * p.W + ix) * p.x_ld + c0);
+                const half_t* wp = p.w + (long)c0 * taps + kh * p.kW + kw;
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] += (float)xv[j] * (float)wp[j * taps];
+            }
+        }
+        half8_t o;
+        if (p.res) { half8_t rr = *(const half8_t*)(p.res + m * p.res_ld + c0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] += (float)rr[j]; }
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (half_t)sm_act(acc[j], p.act, p.slope);
+        *(half8_t*)(p.y + m * p.y_ld + c0) = o;
+    }
+}
+
+struct TileCfg { int BM, BN; void (*fn)(ConvParams); const char* name; };
+const TileCfg kCfgs[] = {
+    {128, 128, conv_igemm_kernel<128, 128, 2, 2>, "128x128"},
+    {128, 64, conv_igemm_kernel<128, 64, 2, 2>, "128x64"},
+    {64, 128, conv_igemm_kernel<64, 128, 2, 2>, "64x128"},
+    {64, 64, conv_igemm_kernel<64, 64, 2, 2>, "64x64"},
+    {256, 64, conv_igemm_kernel<256, 64, 4, 1>, "256x64"},
+    {256, 128, conv_igemm_kernel<256, 128, 2, 2>, "256x128"},
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+int pick_cfg(const ConvParams& p) {
+    // largest tile that still gives >= ~2 blocks per CU; otherwise the one with the most blocks
+    int best = 3; double best_score = -1;
+    for (int i = 0; i < kNumCfgs; i++) {
+        const TileCfg& c = kCfgs[i];
+        if (c.BN > 64 && p.Cout <= 64) continue;
+        long blocks = (long)sm_ceil_div(p.M, c.BM) * sm_ceil_div(p.Cout, c.BN);
+        double waves = (double)blocks / (SM_NUM_CU * 2);                       // 2 resident blocks per CU
+        double util = waves >= 1.0 ? waves / (double)(long)(waves + 0.999) : waves;       // tail quantisation
+        double pad = ((double)p.M * p.Cout) / ((double)sm_ceil_div(p.M, c.BM) * c.BM * sm_ceil_div(p.Cout, c.BN) * c.BN);
+        double eff = (c.BM * c.BN >= 128 * 128) ? 1.0 : (c.BM * c.BN >= 128 * 64 ? 0.8 : 0.55); // LDS-read bound small tiles
+        double score = util * pad * eff;
+        if (score > best_score) { best_score = score; best = i; }
+    }
+    return best;
+}
+
+int fill_params(const sm_conv_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y, ConvParams* p) {
+    SM_REQUIRE(d && x && w && y, "sm_conv2d_fwd: null argument");
+    SM_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->kH > 0 && d->kW > 0 && d->Ho > 0 && d->Wo > 0,
+               "sm_conv2d_fwd: non-positive dimension");
+    SM_REQUIRE(d->sH > 0 && d->sW > 0 && d->dH > 0 && d->dW > 0 && d->groups > 0, "sm_conv2d_fwd: bad stride/dilation/groups");
+    SM_REQUIRE(d->Cin % d->groups == 0 && d->Cout % d->groups == 0, "sm_conv2d_fwd: channels not divisible by groups");
+    p->x = (const half_t*)x; p->w = (const half_t*)w; p->bias = bias; p->res = (const half_t*)res; p->y = (half_t*)y; p->ws = nullptr;
+    p->N = d->N; p->H = d->H; p->W = d->W; p->Cin = d->Cin; p->Cout = d->Cout; p->kH = d->kH; p->kW = d->kW;
+    p->sH = d->sH; p->sW = d->sW; p->dH = d->dH; p->dW = d->dW; p->pt = d->pt; p->pl = d->pl; p->Ho = d->Ho; p->Wo = d->Wo;
+    p->x_ld = d->x_ld ? d->x_ld : d->Cin; p->y_ld = d->y_ld ? d->y_ld : d->Cout; p->res_ld = d->res_ld ? d->res_ld : d->Cout;
+    p->act = d->act; p->slope = d->act == SM_ACT_RELU ? 0.f : d->slope;
+    p->M = d->N * d->Ho * d->Wo; p->K = d->kH * d->kW * (d->Cin / d->groups);
+    p->splitk = 1; p->mt = p->nt = 0; p->ktiles_per_split = 0;
+    SM_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "sm_conv2d_fwd: more than 2^31 output pixels");
+    return SM_OK;
+}
+
+bool mfma_eligible(const sm_conv_desc* d, const ConvParams& p) {
+    return d->groups == 1 && (d->Cin % 8) == 0 && (p.x_ld % 8) == 0 && (((uintptr_t)p.x) & 15) == 0 && (((uintptr_t)p.w) & 15) == 0;
+}
+
+int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (d->groups > 1 && d->groups == d->Cin && d->groups == d->Cout && (d->Cout % 8) == 0 && (p.x_ld % 8) == 0 &&
+        (p.y_ld % 8) == 0 && (!p.res || (p.res_ld % 8) == 0)) {
+        long work = (long)p.M * (p.Cout / 8);
+        hipLaunchKernelGGL(dwconv_kernel, dim3(sm_stream_grid(work, 256)), dim3(256), 0, s, p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
+    if (!mfma_eligible(d, p)) {
+        long work = (long)p.M * p.Cout;
+        hipLaunchKernelGGL(conv_direct_kernel, dim3(sm_stream_grid(work, 256)), dim3(256), 0, s, p, d->groups);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
+    if (cfg < 0 || cfg >= kNumCfgs) cfg = pick_cfg(p);
+    const TileCfg& c = kCfgs[cfg];
+    p.mt = sm_ceil_div(p.M, c.BM); p.nt = sm_ceil_div(p.Cout, c.BN);
+    const int ktiles = sm_ceil_div(p.K, BK);
+    // split-K only for launches that cannot fill the chip and have a long K loop (e.g. the FC layer)
+    p.splitk = 1;
+    long blocks = (long)p.mt * p.nt;
+    if (ws && blocks < SM_NUM_CU / 2 && ktiles >= 16) {
+        int want = (int)((SM_NUM_CU + blocks - 1) / blocks);
+        int maxs = ktiles / 4; if (want > maxs) want = maxs; if (want > 32) want = 32;
+        while (want > 1 && (size_t)want * p.M * p.Cout * sizeof(float) > ws_bytes) want--;
+        if (want > 1) p.splitk = want;
+    }
+    p.ktiles_per_split = sm_ceil_div(ktiles, p.splitk);
+    p.splitk = sm_ceil_div(ktiles, p.ktiles_per_split);
+    p.ws = p.splitk > 1 ? (float*)ws : nullptr;
+    const int grid = sm_ceil_div(p.mt, SM_NUM_XCD) * SM_NUM_XCD * p.nt * p.splitk;
+    hipLaunchKernelGGL(c.fn, dim3(grid), dim3(256), 0, s, p);
+    SM_LAUNCH_CHECK();
+    if (p.splitk > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(sm_stream_grid((long)p.M * p.Cout, 256)), dim3(256), 0, s, p);
+        SM_LAUNCH_CHECK();
+    }
+    return SM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sm_conv2d_num_configs(void) { return kNumCfgs; }
+
+size_t sm_conv2d_workspace_bytes(const sm_conv_desc* d) {
+    if (!d || d->groups != 1 || (d->Cin % 8)) return 0;
+    long M = (long)d->N * d->Ho * d->Wo, K = (long)d->kH * d->kW * d->Cin;
+    long blocks = (long)sm_ceil_div(M, 64) * sm_ceil_div(d->Cout, 64);
+    if (blocks >= SM_NUM_CU / 2 || sm_ceil_div(K, BK) < 16) return 0;
+    return (size_t)32 * M * d->Cout * sizeof(float);
+}
+
+int sm_conv2d_fwd_ws(const sm_conv_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y,
+                     void* ws, size_t ws_bytes, sm_stream_t stream) {
+    ConvParams p; int rc = fill_params(d, x, w, bias, res, y, &p); if (rc) return rc;
+    return launch(d, p, -1, ws, ws_bytes, sm_s(stream));
+}
+int sm_conv2d_fwd(const sm_conv_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y, sm_stream_t stream) {
+    return sm_conv2d_fwd_ws(d, x, w, bias, res, y, nullptr, 0, stream);
+}
+int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w, const float* bias, const void* res, void* y,
+                      void* ws, size_t ws_bytes, sm_stream_t stream) {
+    ConvParams p; int rc = fill_params(d, x, w, bias, res, y, &p); if (rc) return rc;
+    return launch(d, p, cfg, ws, ws_bytes, sm_s(stream));
+}
+
+}  // extern "C"

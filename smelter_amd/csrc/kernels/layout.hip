@@ -1,0 +1,100 @@
+// layout.hip — boundary layout / dtype conversion.
+//
+// In the reference flow the application hands MPS an MPSImage made from a texture and reads the result back
+// with MPSImage.toFloatArray() (/root/reference/README.md:33-51,
+// Sources/Smelter/Extensions/Foundation/MPSImage+Extensions.swift:9-59).  Here the application hands over an
+// NCHW fp32 device tensor; internally everything is NHWC fp16.
+#include "common.hpp"
+
+namespace {
+
+// NCHW fp32 -> NHWC fp16, channels zero-padded to `ld`, zero spatial halo.  One thread per output pixel:
+// reads are coalesced along W inside each channel plane, writes are `ld` contiguous halfs per thread
+// (8 or 16 bytes for the usual C=3 -> ld=4/8 image input).
+__global__ void nchw_to_nhwc_kernel(const float* x, half_t* y, int N, int C, int H, int W, int ld, int ht, int hl, int hb, int hr) {
+    const int Hp = H + ht + hb, Wp = W + hl + hr;
+    const long total = (long)N * Hp * Wp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int n = (int)(i / ((long)Hp * Wp)), r = (int)(i - (long)n * Hp * Wp), py = r / Wp, px = r - py * Wp;
+        int iy = py - ht, ix = px - hl;
+        bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        const float* src = x + ((long)n * C * H + iy) * W + ix;
+        half_t* dst = y + i * ld;
+        for (int c0 = 0; c0 < ld; c0 += 8) {
+            half_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { int c = c0 + j; v[j] = (in && c < C) ? (half_t)src[(long)c * H * W] : (half_t)0.f; }
+            if (c0 + 8 <= ld && (ld & 7) == 0) *(half8_t*)(dst + c0) = *(half8_t*)v;
+            else if (c0 + 4 <= ld && (ld & 3) == 0) { *(half4_t*)(dst + c0) = *(half4_t*)v; if (c0 + 8 <= ld) *(half4_t*)(dst + c0 + 4) = *(half4_t*)(v + 4); }
+            else for (int j = 0; j < 8 && c0 + j < ld; j++) dst[c0 + j] = v[j];
+        }
+    }
+}
+
+// NHWC fp16 -> NCHW fp32.  32x32 (pixel x channel) tile transposed through LDS so both sides are coalesced.
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const half_t* x, float* y, int HW, int C, int ld) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
+    for (int r = ty; r < 32; r += 8) {
+        int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (p < HW && c < C) ? (float)x[((long)n * HW + p) * ld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) y[((long)n * C + c) * HW + p] = tile[tx][r];
+    }
+}
+
+// NHWC fp16 -> MPSImage.toFloatArray() order: [image][slice = c/4][H][W][comps], comps = C < 3 ? C : 4,
+// channels beyond C zero (MPSImage+Extensions.swift:27-41).
+__global__ void nhwc_to_float_array_kernel(const half_t* x, float* y, int N, int C, int HW, int ld) {
+    const int slices = (C + 3) / 4, comps = C < 3 ? C : 4;
+    const long total = (long)N * slices * HW * comps;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int k = (int)(i % comps); long t = i / comps;
+        int p = (int)(t % HW); t /= HW;
+        int sl = (int)(t % slices), n = (int)(t / slices);
+        int c = sl * 4 + k;
+        y[i] = c < C ? (float)x[((long)n * HW + p) * ld + c] : 0.f;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sm_nchw_f32_to_nhwc_f16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t y_ld, int32_t ht, int32_t hl,
+                            int32_t hb, int32_t hr, sm_stream_t st) {
+    SM_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0 && ht >= 0 && hl >= 0 && hb >= 0 && hr >= 0, "sm_nchw_f32_to_nhwc_f16: bad argument");
+    y_ld = y_ld ? y_ld : C;
+    SM_REQUIRE(y_ld >= C, "sm_nchw_f32_to_nhwc_f16: y_ld < C");
+    long pix = (long)N * (H + ht + hb) * (W + hl + hr);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(sm_stream_grid(pix, 256)), dim3(256), 0, sm_s(st), x, (half_t*)y, N, C, H, W, y_ld, ht, hl, hb, hr);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+int sm_nhwc_f16_to_nchw_f32(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t x_ld, sm_stream_t st) {
+    SM_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, "sm_nhwc_f16_to_nchw_f32: bad argument");
+    x_ld = x_ld ? x_ld : C;
+    SM_REQUIRE(N <= 65535 && (C + 31) / 32 <= 65535, "sm_nhwc_f16_to_nchw_f32: grid too large");
+    dim3 g((H * W + 31) / 32, (C + 31) / 32, N);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, g, dim3(256), 0, sm_s(st), (const half_t*)x, y, H * W, C, x_ld);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+size_t sm_float_array_count(int32_t N, int32_t C, int32_t H, int32_t W) {
+    int slices = (C + 3) / 4, cpp = C < 3 ? C : slices * 4;
+    return (size_t)W * H * cpp * N;
+}
+
+int sm_nhwc_f16_to_float_array(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t x_ld, sm_stream_t st) {
+    SM_REQUIRE(x && y && N > 0 && C > 0 && H > 0 && W > 0, "sm_nhwc_f16_to_float_array: bad argument");
+    x_ld = x_ld ? x_ld : C;
+    long total = (long)sm_float_array_count(N, C, H, W);
+    hipLaunchKernelGGL(nhwc_to_float_array_kernel, dim3(sm_stream_grid(total, 256)), dim3(256), 0, sm_s(st), (const half_t*)x, y, N, C, H * W, x_ld);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+}  // extern "C"

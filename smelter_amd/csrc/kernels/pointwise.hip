@@ -1,0 +1,228 @@
+// pointwise.hip — HBM-bound NHWC fp16 kernels: add(+neuron), relu/prelu, batch-norm (scale/shift), pooling,
+// global average pooling, upsampling, channel-slice copy.  These replace the MPS node classes Smelter
+// instantiates in /root/reference/Sources/Smelter/Converters.swift (cited per kernel).
+//
+// Common shape: the channel axis is innermost, so one thread owns 8 consecutive channels (one 16-byte
+// load/store, guide G13) of one pixel; a wave covers 512 contiguous channels-bytes -> fully coalesced.
+// Grid-stride loops over (pixel, channel-vector) with at most 8 blocks per CU.  Scalar variants cover
+// C % 8 != 0 or unaligned pixel strides.
+#include "common.hpp"
+
+namespace {
+
+__device__ __forceinline__ bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+// ---- MPSNNAdditionNode (Converters.swift:440) [+ fused MPSCNNNeuronReLUNode] --------------------------
+__global__ void add_vec_kernel(const half_t* a, const half_t* b, half_t* y, long pixels, int cv, int a_ld, int b_ld, int y_ld, int act, float slope) {
+    long total = pixels * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / cv; int c = (int)(i - m * cv) * 8;
+        half8_t va = *(const half8_t*)(a + m * a_ld + c), vb = *(const half8_t*)(b + m * b_ld + c), o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (half_t)sm_act((float)va[j] + (float)vb[j], act, slope);
+        *(half8_t*)(y + m * y_ld + c) = o;
+    }
+}
+__global__ void add_scalar_kernel(const half_t* a, const half_t* b, half_t* y, long pixels, int C, int a_ld, int b_ld, int y_ld, int act, float slope) {
+    long total = pixels * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / C; int c = (int)(i - m * C);
+        y[m * y_ld + c] = (half_t)sm_act((float)a[m * a_ld + c] + (float)b[m * b_ld + c], act, slope);
+    }
+}
+
+// ---- MPSCNNBatchNormalizationNode (:812) as y = x*scale[c]+shift[c]; scale==nullptr -> pure neuron (:351,:376)
+__global__ void affine_vec_kernel(const half_t* x, half_t* y, long pixels, int cv, int x_ld, int y_ld, const float* scale, const float* shift, int act, float slope) {
+    long total = pixels * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / cv; int c = (int)(i - m * cv) * 8;
+        half8_t v = *(const half8_t*)(x + m * x_ld + c), o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { float t = (float)v[j]; if (scale) t = t * scale[c + j] + shift[c + j]; o[j] = (half_t)sm_act(t, act, slope); }
+        *(half8_t*)(y + m * y_ld + c) = o;
+    }
+}
+__global__ void affine_scalar_kernel(const half_t* x, half_t* y, long pixels, int C, int x_ld, int y_ld, const float* scale, const float* shift, int act, float slope) {
+    long total = pixels * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / C; int c = (int)(i - m * C);
+        float t = (float)x[m * x_ld + c]; if (scale) t = t * scale[c] + shift[c];
+        y[m * y_ld + c] = (half_t)sm_act(t, act, slope);
+    }
+}
+
+// ---- MPSCNNPoolingMaxNode / MPSCNNPoolingAverageNode (:662, :617) -------------------------------------
+template <bool MAX, int V>
+__global__ void pool_kernel(sm_pool_desc d, const half_t* x, half_t* y) {
+    const int cv = (d.C + V - 1) / V;
+    const long total = (long)d.N * d.Ho * d.Wo * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / cv; int c = (int)(i - m * cv) * V;
+        int n = (int)(m / (d.Ho * d.Wo)), r = (int)(m - (long)n * d.Ho * d.Wo), oy = r / d.Wo, ox = r - oy * d.Wo;
+        float acc[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) acc[j] = MAX ? -3.0e38f : 0.f;
+        for (int a = 0; a < d.kH; a++) {
+            int iy = oy * d.sH + d.y0 + a; if ((unsigned)iy >= (unsigned)d.H) continue;
+            for (int b = 0; b < d.kW; b++) {
+                int ix = ox * d.sW + d.x0 + b; if ((unsigned)ix >= (unsigned)d.W) continue;
+                const half_t* px = x + (((long)n * d.H + iy) * d.W + ix) * d.x_ld + c;
+                if (V == 8) { half8_t v = *(const half8_t*)px;
+#pragma unroll
+                    for (int j = 0; j < V; j++) acc[j] = MAX ? fmaxf(acc[j], (float)v[j]) : acc[j] + (float)v[j];
+                } else acc[0] = MAX ? fmaxf(acc[0], (float)px[0]) : acc[0] + (float)px[0];
+            }
+        }
+        const float inv = 1.f / (float)(d.kH * d.kW);
+        half_t* py = y + m * d.y_ld + c;
+        if (V == 8) { half8_t o;
+#pragma unroll
+            for (int j = 0; j < V; j++) o[j] = (half_t)(MAX ? acc[j] : acc[j] * inv);
+            *(half8_t*)py = o;
+        } else py[0] = (half_t)(MAX ? acc[0] : acc[0] * inv);
+    }
+}
+
+// ---- GlobalAveragePoolConverter (:578-605): mean over H*W.  One block per (image, 64-channel group):
+// 4 waves stride over the pixels (lane = 8-channel vector ... C small) then combine through LDS. -----------
+__global__ __launch_bounds__(256) void gap_kernel(const half_t* x, half_t* y, int HW, int C, int x_ld, int y_ld) {
+    // block = (n, channel block of 64); thread t: channel = cb*64 + (t & 63), pixel lane = t >> 6 (0..3)
+    const int cblocks = (C + 63) / 64, n = blockIdx.x / cblocks, cb = blockIdx.x % cblocks;
+    const int c = cb * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    __shared__ float part[4][64];
+    float s = 0.f;
+    if (c < C) for (int p = pl; p < HW; p += 4) s += (float)x[((long)n * HW + p) * x_ld + c];
+    part[pl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (pl == 0 && c < C) y[(long)n * y_ld + c] = (half_t)((part[0][c & 63] + part[1][c & 63] + part[2][c & 63] + part[3][c & 63]) / (float)HW);
+}
+
+// ---- MPSCNNUpsamplingNearestNode / MPSCNNUpsamplingBilinearNode (:524, :531) ---------------------------
+template <int V>
+__global__ void upsample_kernel(const half_t* x, half_t* y, int N, int H, int W, int C, int sy, int sx, int bilinear, int align, int x_ld, int y_ld) {
+    const int Ho = H * sy, Wo = W * sx, cv = (C + V - 1) / V;
+    const long total = (long)N * Ho * Wo * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / cv; int c = (int)(i - m * cv) * V;
+        int n = (int)(m / ((long)Ho * Wo)), r = (int)(m - (long)n * Ho * Wo), oy = r / Wo, ox = r - oy * Wo;
+        half_t* py = y + m * y_ld + c;
+        const half_t* xb = x + (long)n * H * W * x_ld + c;
+        if (!bilinear) {
+            const half_t* px = xb + ((long)(oy / sy) * W + ox / sx) * x_ld;
+            if (V == 8) *(half8_t*)py = *(const half8_t*)px; else py[0] = px[0];
+            continue;
+        }
+        float fy, fx;
+        if (align) { fy = Ho > 1 ? (float)oy * (float)(H - 1) / (float)(Ho - 1) : 0.f; fx = Wo > 1 ? (float)ox * (float)(W - 1) / (float)(Wo - 1) : 0.f; }
+        else { fy = fmaxf(((float)oy + 0.5f) / (float)sy - 0.5f, 0.f); fx = fmaxf(((float)ox + 0.5f) / (float)sx - 0.5f, 0.f); }
+        int y0 = min((int)fy, H - 1), x0 = min((int)fx, W - 1), y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        float ly = fy - (float)y0, lx = fx - (float)x0;
+        const half_t *p00 = xb + ((long)y0 * W + x0) * x_ld, *p01 = xb + ((long)y0 * W + x1) * x_ld;
+        const half_t *p10 = xb + ((long)y1 * W + x0) * x_ld, *p11 = xb + ((long)y1 * W + x1) * x_ld;
+        if (V == 8) {
+            half8_t a = *(const half8_t*)p00, b = *(const half8_t*)p01, cc = *(const half8_t*)p10, dd = *(const half8_t*)p11, o;
+#pragma unroll
+            for (int j = 0; j < 8; j++) { float top = (float)a[j] + ((float)b[j] - (float)a[j]) * lx, bot = (float)cc[j] + ((float)dd[j] - (float)cc[j]) * lx; o[j] = (half_t)(top + (bot - top) * ly); }
+            *(half8_t*)py = o;
+        } else { float top = (float)p00[0] + ((float)p01[0] - (float)p00[0]) * lx, bot = (float)p10[0] + ((float)p11[0] - (float)p10[0]) * lx; py[0] = (half_t)(top + (bot - top) * ly); }
+    }
+}
+
+// ---- MPSNNConcatenationNode (:564): strided channel-slice copy -------------------------------------------
+template <int V>
+__global__ void copy_channels_kernel(const half_t* x, half_t* y, long pixels, int C, int x_ld, int y_ld) {
+    const int cv = (C + V - 1) / V; const long total = pixels * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / cv; int c = (int)(i - m * cv) * V;
+        if (V == 8) *(half8_t*)(y + m * y_ld + c) = *(const half8_t*)(x + m * x_ld + c); else y[m * y_ld + c] = x[m * x_ld + c];
+    }
+}
+
+bool vec8(int C, std::initializer_list<int> lds, std::initializer_list<const void*> ptrs) {
+    if (C % 8) return false;
+    for (int l : lds) if (l % 8) return false;
+    for (const void* p : ptrs) if (p && (((uintptr_t)p) & 15)) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sm_add(const void* a, const void* b, void* y, int64_t pixels, int32_t C, int32_t a_ld, int32_t b_ld, int32_t y_ld, int32_t act, float slope, sm_stream_t st) {
+    SM_REQUIRE(a && b && y && pixels > 0 && C > 0, "sm_add: bad argument");
+    a_ld = a_ld ? a_ld : C; b_ld = b_ld ? b_ld : C; y_ld = y_ld ? y_ld : C; if (act == SM_ACT_RELU) slope = 0.f;
+    if (vec8(C, {a_ld, b_ld, y_ld}, {a, b, y}))
+        hipLaunchKernelGGL(add_vec_kernel, dim3(sm_stream_grid(pixels * (C / 8), 256)), dim3(256), 0, sm_s(st), (const half_t*)a, (const half_t*)b, (half_t*)y, (long)pixels, C / 8, a_ld, b_ld, y_ld, act, slope);
+    else
+        hipLaunchKernelGGL(add_scalar_kernel, dim3(sm_stream_grid(pixels * C, 256)), dim3(256), 0, sm_s(st), (const half_t*)a, (const half_t*)b, (half_t*)y, (long)pixels, C, a_ld, b_ld, y_ld, act, slope);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+int sm_batchnorm(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, const float* scale, const float* shift, int32_t act, float slope, sm_stream_t st) {
+    SM_REQUIRE(x && y && pixels > 0 && C > 0 && ((scale == nullptr) == (shift == nullptr)), "sm_batchnorm: bad argument");
+    x_ld = x_ld ? x_ld : C; y_ld = y_ld ? y_ld : C; if (act == SM_ACT_RELU) slope = 0.f;
+    if (vec8(C, {x_ld, y_ld}, {x, y}))
+        hipLaunchKernelGGL(affine_vec_kernel, dim3(sm_stream_grid(pixels * (C / 8), 256)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, (long)pixels, C / 8, x_ld, y_ld, scale, shift, act, slope);
+    else
+        hipLaunchKernelGGL(affine_scalar_kernel, dim3(sm_stream_grid(pixels * C, 256)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, (long)pixels, C, x_ld, y_ld, scale, shift, act, slope);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+int sm_relu(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, float slope, sm_stream_t st) {
+    return sm_batchnorm(x, y, pixels, C, x_ld, y_ld, nullptr, nullptr, SM_ACT_PRELU, slope, st);
+}
+
+static int pool_common(const sm_pool_desc* d0, const void* x, void* y, bool is_max, sm_stream_t st) {
+    SM_REQUIRE(d0 && x && y && d0->N > 0 && d0->C > 0 && d0->Ho > 0 && d0->Wo > 0 && d0->kH > 0 && d0->kW > 0 && d0->sH > 0 && d0->sW > 0, "sm_pool: bad argument");
+    sm_pool_desc d = *d0; d.x_ld = d.x_ld ? d.x_ld : d.C; d.y_ld = d.y_ld ? d.y_ld : d.C;
+    long pix = (long)d.N * d.Ho * d.Wo;
+    if (vec8(d.C, {d.x_ld, d.y_ld}, {x, y})) {
+        dim3 g(sm_stream_grid(pix * (d.C / 8), 256));
+        if (is_max) hipLaunchKernelGGL((pool_kernel<true, 8>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
+        else hipLaunchKernelGGL((pool_kernel<false, 8>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
+    } else {
+        dim3 g(sm_stream_grid(pix * d.C, 256));
+        if (is_max) hipLaunchKernelGGL((pool_kernel<true, 1>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
+        else hipLaunchKernelGGL((pool_kernel<false, 1>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
+    }
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+int sm_maxpool2d(const sm_pool_desc* d, const void* x, void* y, sm_stream_t st) { return pool_common(d, x, y, true, st); }
+int sm_avgpool2d(const sm_pool_desc* d, const void* x, void* y, sm_stream_t st) { return pool_common(d, x, y, false, st); }
+
+int sm_global_avgpool(const void* x, void* y, int32_t N, int32_t HW, int32_t C, int32_t x_ld, int32_t y_ld, sm_stream_t st) {
+    SM_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "sm_global_avgpool: bad argument");
+    x_ld = x_ld ? x_ld : C; y_ld = y_ld ? y_ld : C;
+    hipLaunchKernelGGL(gap_kernel, dim3(N * ((C + 63) / 64)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, HW, C, x_ld, y_ld);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+static int upsample_common(const void* x, void* y, int N, int H, int W, int C, int sy, int sx, int bil, int align, int x_ld, int y_ld, sm_stream_t st) {
+    SM_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && sy > 0 && sx > 0, "sm_upsample: bad argument");
+    x_ld = x_ld ? x_ld : C; y_ld = y_ld ? y_ld : C;
+    long pix = (long)N * H * sy * W * sx;
+    if (vec8(C, {x_ld, y_ld}, {x, y}))
+        hipLaunchKernelGGL((upsample_kernel<8>), dim3(sm_stream_grid(pix * (C / 8), 256)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, N, H, W, C, sy, sx, bil, align, x_ld, y_ld);
+    else
+        hipLaunchKernelGGL((upsample_kernel<1>), dim3(sm_stream_grid(pix * C, 256)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, N, H, W, C, sy, sx, bil, align, x_ld, y_ld);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+int sm_upsample_nearest(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t sy, int32_t sx, int32_t x_ld, int32_t y_ld, sm_stream_t st) {
+    return upsample_common(x, y, N, H, W, C, sy, sx, 0, 0, x_ld, y_ld, st);
+}
+int sm_upsample_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t sy, int32_t sx, int32_t align, int32_t x_ld, int32_t y_ld, sm_stream_t st) {
+    return upsample_common(x, y, N, H, W, C, sy, sx, 1, align, x_ld, y_ld, st);
+}
+
+int sm_copy_channels(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, sm_stream_t st) {
+    SM_REQUIRE(x && y && pixels > 0 && C > 0, "sm_copy_channels: bad argument");
+    x_ld = x_ld ? x_ld : C; y_ld = y_ld ? y_ld : C;
+    if (vec8(C, {x_ld, y_ld}, {x, y}))
+        hipLaunchKernelGGL((copy_channels_kernel<8>), dim3(sm_stream_grid(pixels * (C / 8), 256)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, (long)pixels, C, x_ld, y_ld);
+    else
+        hipLaunchKernelGGL((copy_channels_kernel<1>), dim3(sm_stream_grid(pixels * C, 256)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, (long)pixels, C, x_ld, y_ld);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+}  // extern "C"

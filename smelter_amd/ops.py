@@ -1,0 +1,175 @@
+"""Kernel-level operators: thin torch-tensor wrappers over the `sm_*` C ABI (include/smelter_hip.h).
+
+torch supplies device memory and the stream only; every FLOP runs in the hand-written gfx950 kernels.
+Activations are NHWC fp16 `torch.Tensor`s on the GPU ([N,H,W,C], contiguous or with a channel-slice view
+whose pixel stride is passed as `ld`); conv weights are OHWI fp16; bias fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._native import ConvDesc, PoolDesc, check, lib
+
+ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _ld(t: torch.Tensor) -> int:
+    """pixel stride (elements) of an NHWC tensor or channel-slice view"""
+    assert t.stride(-1) == 1, "channel axis must be innermost"
+    return t.stride(-2)
+
+
+def _check_nhwc(t: torch.Tensor):
+    assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 4
+    n, h, w, c = t.shape
+    ld = _ld(t)
+    assert t.stride(1) == w * ld and t.stride(0) == h * w * ld, "only the channel axis may be sliced"
+    return n, h, w, c, ld
+
+
+def conv_out_size(h, w, kh, kw, sh, sw, pads):
+    ow, oh = C.c_int32(), C.c_int32()
+    lib().sm_conv_padded_size(w, h, kh, kw, sh, sw, pads[0], pads[1], pads[2], pads[3], 0, 0, 0, C.byref(ow), C.byref(oh))
+    return oh.value, ow.value
+
+
+def conv2d(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0), dilation=(1, 1), groups=1,
+           act=ACT_NONE, slope=0.0, out=None, cfg=None, workspace=None):
+    n, h, w, cin, x_ld = _check_nhwc(x)
+    cout, kh, kw, cg = w_ohwi.shape
+    assert w_ohwi.dtype == torch.float16 and w_ohwi.is_contiguous() and cg * groups == cin
+    ho, wo = conv_out_size(h, w, kh, kw, stride[0], stride[1], pads)
+    if out is None:
+        out = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x.device)
+    _, oh_, ow_, oc_, y_ld = _check_nhwc(out)
+    assert (oh_, ow_, oc_) == (ho, wo, cout)
+    res_ld = 0
+    if residual is not None:
+        _, rh, rw, rc, res_ld = _check_nhwc(residual)
+        assert (rh, rw, rc) == (ho, wo, cout)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == cout
+    d = ConvDesc(n, h, w, cin, cout, kh, kw, stride[0], stride[1], dilation[0], dilation[1], pads[0], pads[1], pads[2],
+                 pads[3], groups, ho, wo, act, slope, x_ld, y_ld, res_ld)
+    L = lib()
+    if cfg is not None:
+        wsb = workspace.numel() * workspace.element_size() if workspace is not None else 0
+        check(L.sm_conv2d_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(out), _ptr(workspace), wsb,
+                                  _stream()))
+    elif workspace is not None:
+        check(L.sm_conv2d_fwd_ws(C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(out), _ptr(workspace),
+                                 workspace.numel() * workspace.element_size(), _stream()))
+    else:
+        check(L.sm_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(out), _stream()))
+    return out
+
+
+def conv2d_workspace_bytes(x_shape, w_shape, stride=(1, 1), pads=(0, 0, 0, 0), groups=1) -> int:
+    n, h, w, cin = x_shape
+    cout, kh, kw, _ = w_shape
+    ho, wo = conv_out_size(h, w, kh, kw, stride[0], stride[1], pads)
+    d = ConvDesc(n, h, w, cin, cout, kh, kw, stride[0], stride[1], 1, 1, pads[0], pads[1], pads[2], pads[3], groups, ho, wo,
+                 0, 0.0, 0, 0, 0)
+    return lib().sm_conv2d_workspace_bytes(C.byref(d))
+
+
+def num_conv_configs() -> int:
+    return lib().sm_conv2d_num_configs()
+
+
+def batchnorm(x, scale, shift, act=ACT_NONE, slope=0.0, out=None):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    out = torch.empty((n, h, w, c), dtype=torch.float16, device=x.device) if out is None else out
+    check(lib().sm_batchnorm(_ptr(x), _ptr(out), n * h * w, c, x_ld, _ld(out), _ptr(scale), _ptr(shift), act, slope, _stream()))
+    return out
+
+
+def add(a, b, act=ACT_NONE, slope=0.0, out=None):
+    n, h, w, c, a_ld = _check_nhwc(a)
+    out = torch.empty((n, h, w, c), dtype=torch.float16, device=a.device) if out is None else out
+    check(lib().sm_add(_ptr(a), _ptr(b), _ptr(out), n * h * w, c, a_ld, _ld(b), _ld(out), act, slope, _stream()))
+    return out
+
+
+def relu(x, slope=0.0, out=None):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    out = torch.empty((n, h, w, c), dtype=torch.float16, device=x.device) if out is None else out
+    check(lib().sm_relu(_ptr(x), _ptr(out), n * h * w, c, x_ld, _ld(out), slope, _stream()))
+    return out
+
+
+def _pool(fn, x, k, s, p, out):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    L = lib()
+    ow, oh = C.c_int32(), C.c_int32()
+    L.sm_pool_padded_size(w, h, k[0], k[1], s[0], s[1], p[0], p[1], C.byref(ow), C.byref(oh))
+    ho, wo = oh.value, ow.value
+    out = torch.empty((n, ho, wo, c), dtype=torch.float16, device=x.device) if out is None else out
+    d = PoolDesc(n, h, w, c, k[0], k[1], s[0], s[1], L.sm_pool_window_start(h, ho, k[0], s[0]),
+                 L.sm_pool_window_start(w, wo, k[1], s[1]), ho, wo, x_ld, _ld(out))
+    check(fn(C.byref(d), _ptr(x), _ptr(out), _stream()))
+    return out
+
+
+def maxpool2d(x, k, s, p, out=None):
+    return _pool(lib().sm_maxpool2d, x, k, s, p, out)
+
+
+def avgpool2d(x, k, s, p, out=None):
+    return _pool(lib().sm_avgpool2d, x, k, s, p, out)
+
+
+def global_avgpool(x, out=None):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    out = torch.empty((n, 1, 1, c), dtype=torch.float16, device=x.device) if out is None else out
+    check(lib().sm_global_avgpool(_ptr(x), _ptr(out), n, h * w, c, x_ld, _ld(out), _stream()))
+    return out
+
+
+def upsample(x, sy, sx, bilinear=False, align_corners=True, out=None):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    out = torch.empty((n, h * sy, w * sx, c), dtype=torch.float16, device=x.device) if out is None else out
+    if bilinear:
+        check(lib().sm_upsample_bilinear(_ptr(x), _ptr(out), n, h, w, c, sy, sx, int(align_corners), x_ld, _ld(out), _stream()))
+    else:
+        check(lib().sm_upsample_nearest(_ptr(x), _ptr(out), n, h, w, c, sy, sx, x_ld, _ld(out), _stream()))
+    return out
+
+
+def copy_channels(x, out):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    check(lib().sm_copy_channels(_ptr(x), _ptr(out), n * h * w, c, x_ld, _ld(out), _stream()))
+    return out
+
+
+def nchw_f32_to_nhwc_f16(x, ld=None, halo=(0, 0, 0, 0)):
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+    n, c, h, w = x.shape
+    ld = c if ld is None else ld
+    out = torch.empty((n, h + halo[0] + halo[2], w + halo[1] + halo[3], ld), dtype=torch.float16, device=x.device)
+    check(lib().sm_nchw_f32_to_nhwc_f16(_ptr(x), _ptr(out), n, c, h, w, ld, halo[0], halo[1], halo[2], halo[3], _stream()))
+    return out
+
+
+def nhwc_f16_to_nchw_f32(x):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(lib().sm_nhwc_f16_to_nchw_f32(_ptr(x), _ptr(out), n, c, h, w, x_ld, _stream()))
+    return out
+
+
+def nhwc_f16_to_float_array(x):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    out = torch.empty((lib().sm_float_array_count(n, c, h, w),), dtype=torch.float32, device=x.device)
+    check(lib().sm_nhwc_f16_to_float_array(_ptr(x), _ptr(out), n, c, h, w, x_ld, _stream()))
+    return out
