@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""bench.py — BASELINE.json headline metric on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one pass of the hot path (smelter_exec_encode: NCHW fp32 -> NHWC fp16 conversion + all 56 fused ops of
+ResNet-50 v1.5) over one synthetic batch of 64 images per GPU that is already resident in HBM.  N > 1 = batch-shard
+replicas (one process per GPU, weights broadcast once over RCCL, no data-path collective) -> weak scaling, global batch
+64*N (N = 8 is BASELINE config 5, bs=512).  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     — the dominant kernel family (MFMA implicit-GEMM conv/FC): algorithmic FLOPs of its launches per step
+                 (2*MACs of conv+fc) / the sum of their HIP-event-timed durations on the launch stream.
+  cpu_baseline — the CPU oracle ("port" of the reference semantics; the reference has no CPU path) on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+METRIC = "images/sec (whole node) ResNet-50 ONNX 3×224×224 bs=64; %MFMA peak"
+MFMA_PEAK_TFLOPS = 2500.0        # dense fp16, /opt/skills/guides/MI355X_MICROARCH.md:42
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true", help="skip the per-op HIP-event pass (use under rocprofv3)")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    a = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from smelter_amd import dist as sd
+    from smelter_amd import zoo
+    from smelter_amd.graph import Configuration, ONNXGraph
+
+    rank, world, local = sd.init_from_env()
+    assert world == max(a.gpus, 1) or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % a.gpus
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback exists)"
+    torch.cuda.set_device(local)
+
+    t0 = time.time()
+    model, macs = zoo.resnet50(return_macs=True)                        # same seeded weights on every rank
+    g = ONNXGraph(model, Configuration(autotune=not a.no_autotune))
+    if world > 1:
+        arena = sd.broadcast_weight_arena(g, a.batch)                     # rank 0 folds/casts/packs; one RCCL broadcast
+        torch.cuda.synchronize()
+        ex = g.hipGraph(local, a.batch, weight_arena=arena, upload_weights=False)  # bind the received arena, no host weight prep
+    else:
+        ex = g.hipGraph(local, a.batch)
+    compile_s = time.time() - t0
+    x = torch.from_numpy(zoo.synthetic_images(a.batch, seed=rank)).cuda()   # resident in HBM before the timed region
+    stream = torch.cuda.current_stream()
+
+    for _ in range(a.warmup):
+        ex.encode(x, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(a.steps):
+        ex.encode(x, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = elapsed / a.steps * 1e3
+    value = a.batch * world * a.steps / elapsed
+    logits = ex.toFloatArray()
+    assert np.isfinite(logits).all()
+
+    out = None
+    if rank == 0:
+        flops_step = ex.flops                                           # per GPU per step
+        out = {"metric": METRIC, "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+               "data": "synthetic", "mfma_peak_frac": round(flops_step / (ms_per_step * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12), 4),
+               "config": {"workload": "ResNet-50 v1.5 ONNX (fp32 file, BN folded + fp16 cast at load), 3x224x224, bs=%d per GPU" % a.batch,
+                          "global_batch": a.batch * world, "parallelism": "batch-shard x%d (RCCL weight broadcast, no data-path collective)" % world,
+                          "launches_per_step": ex.numLaunches, "hip_graph": True, "compile_s": round(compile_s, 2)}}
+        # ---- roofline of the dominant kernel family, HIP events on the launch stream ----
+        if not a.no_roofline:
+            conv_ms, conv_n, other_ms, per = 0.0, 0, 0.0, []
+            for i in range(ex.numOps):
+                d = ex.opDesc(i)
+                ms = ex.timeOp(i, 20, stream)
+                per.append((ms, d))
+                if d.startswith(("Conv", "FC")):
+                    conv_ms += ms; conv_n += 1
+                else:
+                    other_ms += ms
+            achieved = flops_step / (conv_ms * 1e-3) / 1e12
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # HBM bytes/launch from rocprofv3 --pmc, if collected
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm (MFMA implicit-GEMM conv/FC, %d launches/step)" % conv_n,
+                               "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                               "traffic": traffic, "flops_per_launch": round(flops_step / conv_n), "avg_launch_us": round(conv_ms / conv_n * 1e3, 2),
+                               "sum_conv_ms": round(conv_ms, 4), "sum_other_ms": round(other_ms, 4),
+                               "algorithmic_bytes_per_step": round(ex.algorithmicBytes),
+                               "hbm_frac_of_8TBps_whole_step": round(ex.algorithmicBytes / (ms_per_step * 1e-3) / 8e12, 4)}
+            if os.environ.get("SMELTER_BENCH_VERBOSE"):
+                for ms, d in per:
+                    print("  %8.1f us  %s" % (ms * 1e3, d), file=sys.stderr)
+        # ---- CPU baseline: the oracle (a port of the reference's semantics) on the host cores, bounded sample ----
+        if world == 1 and not a.no_cpu_baseline:
+            import oracle
+            og = oracle.Graph(model)
+            xs = zoo.synthetic_images(a.cpu_batch)
+            tc = time.perf_counter()
+            ref = og.run(xs)
+            cpu_s = time.perf_counter() - tc
+            ex_small = ONNXGraph(model).hipGraph(local, a.cpu_batch)
+            ex_small.encode(torch.from_numpy(xs).cuda(), stream)
+            got = ex_small.toFloatArray()
+            err = float(np.abs(got - ref).max() / np.abs(ref).max())
+            out["cpu_baseline"] = {"value": round(a.cpu_batch / cpu_s, 3), "unit": "images/s", "cores": oracle.num_threads(), "kind": "port",
+                                   "sample": "ResNet-50 fp32 oracle (naive direct conv, OpenMP), bs=%d, 1 pass = %.1f s" % (a.cpu_batch, cpu_s),
+                                   "gpu_vs_oracle_max_err_over_max_ref": round(err, 6)}
+        print(json.dumps(out))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -195,6 +195,9 @@ int smelter_graph_num_nodes(const smelter_graph* g);
  * device buffer of smelter_exec_weight_bytes() bytes; with `upload_weights`==0 the executor leaves it
  * untouched (batch-shard replicas: rank 0 fills, RCCL broadcasts, the others only bind). */
 int smelter_graph_weight_bytes(smelter_graph* g, int32_t batch, size_t* bytes);
+/* Host-side image of the weight arena (BN fold + fp16 cast + OHWI + padding, packed); needs no GPU.  Rank 0 of
+ * a batch-shard job fills a device buffer with it and RCCL-broadcasts that buffer to the other ranks. */
+int smelter_graph_pack_weights(smelter_graph* g, int32_t batch, void* dst, size_t cap);
 int smelter_graph_compile(smelter_graph* g, int32_t hip_device, int32_t batch, void* weight_arena,
                           int32_t upload_weights, smelter_exec** out);
 void smelter_exec_destroy(smelter_exec* e);
@@ -220,6 +223,9 @@ double smelter_exec_flops(const smelter_exec* e);           /* 2*MACs of conv+fc
 double smelter_exec_algorithmic_bytes(const smelter_exec* e); /* per-layer compulsory bytes per encode */
 /* per-op description for profiling: returns a static-lifetime string "idx kind name MxNxK cfg" */
 const char* smelter_exec_op_desc(const smelter_exec* e, int32_t idx);
+/* names of the tensors materialised in fp16 storage after fusion (graph input + every kernel output) */
+int smelter_exec_num_values(const smelter_exec* e);
+const char* smelter_exec_value_name(const smelter_exec* e, int32_t idx);
 /* time one op `idx` in isolation (iters launches, HIP events); ms per launch */
 int smelter_exec_time_op(smelter_exec* e, sm_stream_t stream, int32_t idx, int32_t iters, float* ms);
 /* fetch an intermediate value by ONNX name after an encode (debug / layer parity); NCHW fp32 to host */

@@ -60,6 +60,7 @@ def lib():
         L.orc_last_error.restype = C.c_char_p
         L.orc_graph_create.argtypes = [vp, C.c_size_t, C.POINTER(Config), C.POINTER(vp)]
         L.orc_graph_destroy.argtypes = [vp]
+        L.orc_graph_set_round_list.argtypes = [vp, C.POINTER(C.c_char_p), C.c_int]
         L.orc_graph_is_mps_flavor.argtypes = [vp]
         L.orc_graph_output_shapes.argtypes = [vp, C.POINTER(Shape), C.c_int]
         L.orc_graph_input_chw.argtypes = [vp, ip, ip, ip]
@@ -266,9 +267,14 @@ class Graph:
             raise OracleError(rc, L.orc_last_error().decode())
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_graph_destroy(self._h)
-            self._h = None
+        h, self._h = getattr(self, "_h", None), None
+        if h and _LIB is not None:
+            _LIB.orc_graph_destroy(h)
+
+    def set_round_list(self, names):
+        """emulate fp16 storage for exactly these value names (an executor's materialised tensors)"""
+        arr = (C.c_char_p * len(names))(*[n.encode() for n in names])
+        lib().orc_graph_set_round_list(self._h, arr, len(names))
 
     @property
     def is_mps_flavor(self) -> bool:

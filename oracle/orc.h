@@ -147,7 +147,8 @@ void orc_round_to_half(float* x, size_t n); /* emulate fp16 image storage (MPS d
 typedef struct {
     int align_corners;         /* Configuration.billinearUpsamplingConfiguration.alignCorners, default 1 */
     int dims_override[4];      /* Configuration.dims: -1 = keep file value */
-    int act_fp16;              /* round every node output to fp16 (MPS stores intermediate images as half) */
+    int act_fp16;              /* 0: fp32 everywhere; 1: round every node output to fp16 (MPS stores intermediate
+                                * images as half); 2: round only the values given to orc_graph_set_round_list */
 } orc_config;
 
 typedef struct orc_graph orc_graph;
@@ -156,6 +157,8 @@ typedef struct { int channels, width, height, depth; } orc_shape; /* TypeDefinit
 void orc_config_default(orc_config* c);
 int  orc_graph_create(const void* bytes, size_t n, const orc_config* cfg, orc_graph** out);
 void orc_graph_destroy(orc_graph* g);
+/* act_fp16 = 2: emulate fp16 storage for exactly these value names (the tensors an executor materialises) */
+void orc_graph_set_round_list(orc_graph* g, const char* const* names, int n);
 int  orc_graph_is_mps_flavor(const orc_graph* g);
 int  orc_graph_output_shapes(const orc_graph* g, orc_shape* dst, int cap);   /* ONNXGraph.swift:69-91 */
 int  orc_graph_input_chw(const orc_graph* g, int* c, int* h, int* w);

@@ -39,6 +39,7 @@ struct orc_graph {
     /* name -> tensor (initializers + Constant outputs, ONNXGraph.swift:106-108,259) */
     struct { orc_bytes name; const orc_tensor* t; }* tens; int n_tens, cap_tens;
     int batch;
+    char** round_names; int n_round;   /* act_fp16 == 2: round exactly these values */
 };
 
 void orc_config_default(orc_config* c) { c->align_corners = 1; c->act_fp16 = 0; for (int i = 0; i < 4; i++) c->dims_override[i] = -1; }
@@ -89,8 +90,16 @@ static void clear_values(orc_graph* g) {
     for (int i = 0; i < g->n_vals; i++) if (!g->vals[i].is_input) free(g->vals[i].data); else free(g->vals[i].data);
     g->n_vals = 0; g->n_tens = g->m->n_initializer; /* drop Constant-registered tensors */
 }
+void orc_graph_set_round_list(orc_graph* g, const char* const* names, int n) {
+    for (int i = 0; i < g->n_round; i++) free(g->round_names[i]);
+    free(g->round_names); g->round_names = NULL; g->n_round = 0;
+    if (n <= 0) return;
+    g->round_names = malloc(sizeof(char*) * n);
+    for (int i = 0; i < n; i++) { g->round_names[i] = malloc(strlen(names[i]) + 1); strcpy(g->round_names[i], names[i]); }
+    g->n_round = n; g->cfg.act_fp16 = 2;
+}
 void orc_graph_destroy(orc_graph* g) {
-    if (!g) return; clear_values(g); free(g->vals); free(g->tens); orc_model_free(g->m); free(g);
+    if (!g) return; orc_graph_set_round_list(g, NULL, 0); clear_values(g); free(g->vals); free(g->tens); orc_model_free(g->m); free(g);
 }
 int orc_graph_is_mps_flavor(const orc_graph* g) { return g->mps_flavor; }
 
@@ -123,6 +132,13 @@ int orc_graph_input_chw(const orc_graph* g, int* c, int* h, int* w) {
 /* ---- converters ------------------------------------------------------------------------------------ */
 #define REF(ch, wd, ht, dp) ((orc_shape){(ch), (wd), (ht), (dp)})
 
+/* fp16 image storage emulation: mode 1 = every node output (MPS stores intermediate images as half),
+ * mode 2 = only the values named by orc_graph_set_round_list (the tensors an executor actually materialises) */
+static int wants_round(const orc_graph* g, orc_bytes name) {
+    if (g->cfg.act_fp16 == 1) return 1;
+    if (g->cfg.act_fp16 == 2) { for (int i = 0; i < g->n_round; i++) if (bis(name, g->round_names[i])) return 1; }
+    return 0;
+}
 static int conv_like(orc_graph* g, const orc_node* nd) { /* ConvolutionConverter, Converters.swift:187-338 */
     if (nd->n_input < 1) return fail(ORC_ERR_NO_SUCH_OUTPUT, "Conv: no input");
     value* in = find_value(g, nd->input[0]);
@@ -178,7 +194,7 @@ static int conv_like(orc_graph* g, const orc_node* nd) { /* ConvolutionConverter
         y = malloc(sizeof(float) * (size_t)N * OC * Ho * Wo);
         orc_conv2d(&d, in->data, w, bias, y);
     }
-    if (g->cfg.act_fp16) orc_round_to_half(y, (size_t)N * OC * Ho * Wo);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, (size_t)N * OC * Ho * Wo);
     for (int i = 0; i < nd->n_output; i++) {  /* addFilter publishes under every output name, ONNXGraph.swift:263-273 */
         float* dat = y; if (i > 0) { dat = malloc(sizeof(float) * (size_t)N * OC * Ho * Wo); memcpy(dat, y, sizeof(float) * (size_t)N * OC * Ho * Wo); }
         ov = put_value(g, nd->output[i], dat, OC, Ho, Wo, REF(1, Wo, Ho, OC));
@@ -209,7 +225,7 @@ static int unary_like(orc_graph* g, const orc_node* nd, int kind) { /* Relu :342
         orc_batchnorm(in->data, y, g->batch, in->c, in->h * in->w, p[0], p[1], p[2], p[3], eps); /* inputs 1..4 = gamma,beta,mean,var :805-808 */
         for (int i = 0; i < 4; i++) free(p[i]);
     }
-    if (g->cfg.act_fp16) orc_round_to_half(y, cnt);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
     for (int i = 0; i < nd->n_output; i++) {
         float* dat = y; if (i > 0) { dat = malloc(sizeof(float) * cnt); memcpy(dat, y, sizeof(float) * cnt); }
         put_value(g, nd->output[i], dat, in->c, in->h, in->w, in->ref);
@@ -224,7 +240,7 @@ static int add_conv(orc_graph* g, const orc_node* nd) { /* AddConverter :430-451
     if (a->c != b->c || a->h != b->h || a->w != b->w) return fail(ORC_ERR_INCONSISTENT_STATE, "Add: shape mismatch (no broadcasting in the reference)");
     size_t cnt = (size_t)g->batch * a->c * a->h * a->w; float* y = malloc(sizeof(float) * cnt);
     orc_add(a->data, b->data, y, cnt);
-    if (g->cfg.act_fp16) orc_round_to_half(y, cnt);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
     put_value(g, nd->output[0], y, a->c, a->h, a->w, a->ref);
     return ORC_OK;
 }
@@ -240,7 +256,7 @@ static int pool_conv(orc_graph* g, const orc_node* nd, int is_max) { /* MaxPool 
     size_t cnt = (size_t)g->batch * in->c * ho * wo; float* y = malloc(sizeof(float) * cnt);
     if (is_max) orc_maxpool(in->data, y, g->batch, in->c, in->h, in->w, kh, kw, sh, sw, ph, pw, ho, wo);
     else orc_avgpool(in->data, y, g->batch, in->c, in->h, in->w, kh, kw, sh, sw, ph, pw, ho, wo);
-    if (g->cfg.act_fp16) orc_round_to_half(y, cnt);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
     put_value(g, nd->output[0], y, in->c, ho, wo, REF(in->ref.channels, wo, ho, in->ref.depth));
     return ORC_OK;
 }
@@ -250,7 +266,7 @@ static int gap_conv(orc_graph* g, const orc_node* nd) { /* GlobalAveragePoolConv
     if (!in) return fail(ORC_ERR_NO_SUCH_OUTPUT, "GlobalAveragePool: input value missing");
     size_t cnt = (size_t)g->batch * in->c; float* y = malloc(sizeof(float) * cnt);
     orc_global_avgpool(in->data, y, g->batch, in->c, in->h * in->w);
-    if (g->cfg.act_fp16) orc_round_to_half(y, cnt);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
     put_value(g, nd->output[0], y, in->c, 1, 1, REF(in->ref.channels, 1, 1, in->ref.depth));
     return ORC_OK;
 }
@@ -295,7 +311,9 @@ static int upsample_conv(orc_graph* g, const orc_node* nd) { /* UpsampleConverte
     if (!have_s) {
         const orc_tensor* stn = nd->n_input >= 2 ? find_tensor(g, nd->input[1]) : NULL;          /* :505-514 */
         if (!stn || stn->ndims < 1 || stn->dims[0] != 4) return fail(ORC_ERR_NOT_ENOUGH_ATTRIBUTES, "Upsample: scales missing");
-        int64_t sv[4]; long ns = orc_tensor_integers(stn, sv, 4); if (ns < 4) return fail(ORC_ERR_NOT_ENOUGH_ATTRIBUTES, "Upsample: scales tensor");
+        int64_t sv[4]; long ns = orc_tensor_integers(stn, sv, 4);
+        if (ns < 0) return fail((int)ns, "Upsample: scales dtype");
+        if (ns < 4) return fail(ORC_ERR_NOT_ENOUGH_ATTRIBUTES, "Upsample: scales tensor");
         sy = (int)sv[2]; sx = (int)sv[3];
     }
     if (!ma) return fail(ORC_ERR_NOT_ENOUGH_ATTRIBUTES, "Upsample: mode missing");               /* :517-519 */
@@ -305,7 +323,7 @@ static int upsample_conv(orc_graph* g, const orc_node* nd) { /* UpsampleConverte
     int ho = in->h * sy, wo = in->w * sx;
     size_t cnt = (size_t)g->batch * in->c * ho * wo; float* y = malloc(sizeof(float) * cnt);
     orc_upsample(in->data, y, g->batch, in->c, in->h, in->w, sy, sx, bil, g->cfg.align_corners);
-    if (g->cfg.act_fp16) orc_round_to_half(y, cnt);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
     put_value(g, nd->output[0], y, in->c, ho, wo, REF(in->ref.channels, sx * in->ref.width, sy * in->ref.height, in->ref.depth));
     return ORC_OK;
 }
@@ -343,7 +361,7 @@ int orc_graph_run(orc_graph* g, const float* in_nchw, int batch, float** out, in
         if (n_inputs++) return fail(ORC_ERR_UNSUPPORTED_INPUT, "more than one image input");
         size_t cnt = (size_t)batch * c * h * w; float* x = malloc(sizeof(float) * cnt);
         memcpy(x, in_nchw, sizeof(float) * cnt);
-        if (g->cfg.act_fp16) orc_round_to_half(x, cnt);
+        if (g->cfg.act_fp16) orc_round_to_half(x, cnt);   /* the image itself is fp16 in every storage mode */
         value* v = put_value(g, vi->name, x, c, h, w, REF(1, w, h, c)); v->is_input = 1;          /* :243-248 */
     }
     for (int i = 0; i < g->m->n_node; i++) {                                                      /* :172-176 */

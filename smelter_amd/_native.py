@@ -99,6 +99,7 @@ SYMBOLS = {
     "smelter_graph_output_shapes": (_i32, [_vp, C.POINTER(Shape), _i32]),
     "smelter_graph_num_nodes": (_i32, [_vp]),
     "smelter_graph_weight_bytes": (_i32, [_vp, _i32, C.POINTER(_sz)]),
+    "smelter_graph_pack_weights": (_i32, [_vp, _i32, _vp, _sz]),
     "smelter_graph_compile": (_i32, [_vp, _i32, _i32, _vp, _i32, C.POINTER(_vp)]),
     "smelter_exec_destroy": (None, [_vp]),
     "smelter_exec_encode": (_i32, [_vp, _vp, _vp]),
@@ -113,6 +114,8 @@ SYMBOLS = {
     "smelter_exec_flops": (C.c_double, [_vp]),
     "smelter_exec_algorithmic_bytes": (C.c_double, [_vp]),
     "smelter_exec_op_desc": (C.c_char_p, [_vp, _i32]),
+    "smelter_exec_num_values": (_i32, [_vp]),
+    "smelter_exec_value_name": (C.c_char_p, [_vp, _i32]),
     "smelter_exec_time_op": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_f)]),
     "smelter_exec_read_value": (_i32, [_vp, _vp, C.c_char_p, _vp, _sz, _pi32, _pi32, _pi32]),
 }

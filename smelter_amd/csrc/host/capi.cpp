@@ -54,6 +54,10 @@ int smelter_graph_weight_bytes(smelter_graph* g, int32_t batch, size_t* bytes) {
     SM_REQUIRE(g && bytes && batch > 0, "smelter_graph_weight_bytes: bad argument");
     return Executor::weightBytes(*g->g, batch, bytes);
 }
+int smelter_graph_pack_weights(smelter_graph* g, int32_t batch, void* dst, size_t cap) {
+    SM_REQUIRE(g && dst && batch > 0, "smelter_graph_pack_weights: bad argument");
+    return Executor::packWeightsHost(*g->g, batch, dst, cap);
+}
 int smelter_graph_compile(smelter_graph* g, int32_t dev, int32_t batch, void* arena, int32_t upload, smelter_exec** out) {
     SM_REQUIRE(g && out, "smelter_graph_compile: null argument");
     Executor* e = nullptr;
@@ -85,6 +89,8 @@ size_t smelter_exec_activation_bytes(const smelter_exec* e) { return e ? e->e->a
 double smelter_exec_flops(const smelter_exec* e) { return e ? e->e->flops() : 0; }
 double smelter_exec_algorithmic_bytes(const smelter_exec* e) { return e ? e->e->algorithmicBytes() : 0; }
 const char* smelter_exec_op_desc(const smelter_exec* e, int32_t idx) { return e ? e->e->opDesc(idx) : ""; }
+int smelter_exec_num_values(const smelter_exec* e) { return e ? e->e->numMaterialized() : 0; }
+const char* smelter_exec_value_name(const smelter_exec* e, int32_t idx) { return e ? e->e->materializedName(idx) : ""; }
 int smelter_exec_time_op(smelter_exec* e, sm_stream_t s, int32_t idx, int32_t iters, float* ms) {
     SM_REQUIRE(e && ms, "smelter_exec_time_op: null argument");
     return e->e->timeOp((hipStream_t)s, idx, iters, ms);

@@ -257,6 +257,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
     }
     arena_bytes_ = std::max(off, (size_t)kAlign);
     value_names_.resize(nv); for (int v = 0; v < nv; v++) value_names_[v] = values_[v].name;
+    materialized_.clear(); materialized_.push_back(values_[input_value_].name);
+    for (auto& st : steps_) if (st.op.kind != OpKind::Concat) materialized_.push_back(values_[st.op.output].name);
     return SM_OK;
 }
 
@@ -291,6 +293,15 @@ int Executor::weightBytes(ONNXGraph& g, int batch, size_t* bytes) {
     *bytes = e.arena_bytes_; return SM_OK;
 }
 
+int Executor::packWeightsHost(ONNXGraph& g, int batch, void* dst, size_t cap) {
+    int rc = g.build(); if (rc) return rc;
+    Executor e; rc = e.plan(g, batch); if (rc) return rc;
+    if (cap < e.arena_bytes_) { sm_set_error("smelter_graph_pack_weights: buffer holds %zu bytes, arena needs %zu", cap, e.arena_bytes_); return SM_ERR_INVALID_ARGUMENT; }
+    std::vector<uint8_t> host; rc = e.packWeights(&host); if (rc) return rc;
+    memcpy(dst, host.data(), host.size());
+    return SM_OK;
+}
+
 int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool upload, Executor** out) {
     if (batch <= 0) { sm_set_error("batch must be positive"); return SM_ERR_INVALID_ARGUMENT; }
     int rc = g.build(); if (rc) return rc;
@@ -311,7 +322,7 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     e->out_f32_count_ = std::max(sm_float_array_count(batch, ov.c, ov.h, ov.w), (size_t)batch * ov.c * ov.h * ov.w);
     SM_HIP_CHECK(hipMalloc((void**)&e->out_f32_, e->out_f32_count_ * 4));
     for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit(); }   // host masters no longer needed
-    if (e->cfg_.autotune && (ext_arena == nullptr || upload)) {
+    if (e->cfg_.autotune) {   // with an external arena and upload == 0 the caller filled it before compiling
         hipStream_t s; SM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         rc = e->autotune(s);
         (void)hipStreamDestroy(s);

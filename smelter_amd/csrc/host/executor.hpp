@@ -34,6 +34,8 @@ class Executor {
    public:
     static int create(ONNXGraph& g, int device, int batch, void* ext_arena, bool upload, Executor** out);
     static int weightBytes(ONNXGraph& g, int batch, size_t* bytes);
+    // host-side arena image (fold + cast + pad + pack) without touching a GPU
+    static int packWeightsHost(ONNXGraph& g, int batch, void* dst, size_t cap);
     ~Executor();
 
     int encode(hipStream_t s, const float* in_nchw);
@@ -52,6 +54,9 @@ class Executor {
     double flops() const { return flops_; }
     double algorithmicBytes() const { return alg_bytes_; }
     const char* opDesc(int idx) const { return idx >= 0 && idx < (int)steps_.size() ? steps_[idx].desc.c_str() : ""; }
+    // names of the tensors that exist in fp16 storage after fusion (graph input + every step output)
+    int numMaterialized() const { return (int)materialized_.size(); }
+    const char* materializedName(int i) const { return i >= 0 && i < (int)materialized_.size() ? materialized_[i].c_str() : ""; }
 
    private:
     Executor() = default;
@@ -70,7 +75,7 @@ class Executor {
     std::vector<size_t> root_offset_;    // per value id (roots only), byte offset in the activation arena
     std::vector<Step> steps_;
     int input_value_ = -1, output_value_ = -1, input_ld_ = 0;
-    std::vector<std::string> value_names_;
+    std::vector<std::string> value_names_, materialized_;
 
     char* arena_ = nullptr; size_t arena_bytes_ = 0; bool own_arena_ = false;
     char* act_ = nullptr; size_t act_bytes_ = 0;

@@ -1,0 +1,71 @@
+"""Batch-shard data parallelism: one process per GPU, weights broadcast ONCE over RCCL/xGMI, no per-iteration
+collective (BASELINE.json north_star).  The reference has no multi-device code at all
+(/root/reference/Sources/Smelter/ONNXGraph.swift:169 takes a single MTLDevice); inference over a batch has no
+cross-sample dependency, so the batch axis shards into independent contiguous image ranges.
+
+Flow:  every rank parses the ONNX bytes (cheap, structure only) -> rank 0 alone does the weight preparation
+(BN fold, fp16 cast, OHWI, packing) into one arena -> `torch.distributed.broadcast` of that arena
+(backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests) -> every rank binds the received arena.
+"""
+from __future__ import annotations
+
+import os
+from typing import Tuple
+
+import numpy as np
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """contiguous image range [lo, hi) of `rank`; remainders go to the lowest ranks"""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend: str = None):
+    """torch.distributed init from RANK / WORLD_SIZE / MASTER_* (torchrun contract).  Returns (rank, world, local)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def broadcast_weight_arena(graph, batch: int, device=None, src: int = 0):
+    """Returns a uint8 tensor holding the packed weight arena on every rank.  Only `src` runs the CPU weight
+    preparation; the others receive the bytes through one broadcast."""
+    import torch
+    import torch.distributed as dist
+    nbytes = graph.weightBytes(batch)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    if rank == src:
+        arena = torch.from_numpy(graph.packWeights(batch)).to(device)
+    else:
+        arena = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(arena, src=src)
+    return arena
+
+
+def arena_checksum(arena) -> int:
+    """byte-exact checksum used by tests to show every rank holds identical weights"""
+    a = arena.detach().cpu().numpy().astype(np.uint64)
+    idx = np.arange(1, a.size + 1, dtype=np.uint64)
+    return int((a * idx).sum() % np.uint64(0xFFFFFFFB))
+
+
+def compile_sharded(graph, per_rank_batch: int, local_device: int = 0):
+    """rank-local executor bound to the broadcast arena (no weight upload on non-source ranks)"""
+    arena = broadcast_weight_arena(graph, per_rank_batch)
+    return graph.hipGraph(local_device, per_rank_batch, weight_arena=arena, upload_weights=False)

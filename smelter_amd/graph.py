@@ -108,6 +108,12 @@ class ONNXGraph:
         N.check(N.lib().smelter_graph_weight_bytes(self._h, batch, C.byref(b)))
         return b.value
 
+    def packWeights(self, batch: int = 1) -> np.ndarray:
+        """host image of the weight arena (BN fold + fp16 cast + OHWI + padding); needs no GPU"""
+        buf = np.zeros(self.weightBytes(batch), np.uint8)
+        N.check(N.lib().smelter_graph_pack_weights(self._h, batch, buf.ctypes.data_as(C.c_void_p), buf.size))
+        return buf
+
     def hipGraph(self, device: int = 0, batch: int = 1, weight_arena=None, upload_weights: bool = True) -> "Executor":
         """metalGraph(device:) — compile for `device`.  `weight_arena`: optional torch uint8 CUDA tensor of
         weightBytes(batch) bytes owned by the caller (used for the RCCL weight broadcast)."""
@@ -176,6 +182,12 @@ class Executor:
     activationBytes = property(lambda s: N.lib().smelter_exec_activation_bytes(s._h))
     flops = property(lambda s: N.lib().smelter_exec_flops(s._h))
     algorithmicBytes = property(lambda s: N.lib().smelter_exec_algorithmic_bytes(s._h))
+
+    @property
+    def valueNames(self):
+        """tensors that exist in fp16 storage after fusion (graph input + every kernel output)"""
+        L = N.lib()
+        return [L.smelter_exec_value_name(self._h, i).decode() for i in range(L.smelter_exec_num_values(self._h))]
 
     def opDesc(self, idx: int) -> str:
         return N.lib().smelter_exec_op_desc(self._h, idx).decode()

@@ -1,0 +1,62 @@
+"""The C oracle against the committed golden fixtures (tests/golden/*.npz, made by tools/make_golden.py with
+torch.nn.functional in fp64 in the build container).  Tolerance: the oracle accumulates in fp32, so
+|oracle - golden| <= 2e-5 * max|golden| (K <= 400 here)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from smelter_amd import zoo
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 2e-5
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def close(a, b, tol=TOL):
+    assert a.shape == b.shape
+    assert np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
+
+
+def test_fixture_inventory():
+    names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "*.npz")))
+    assert len(names) >= 17 and "toy_end_to_end" in names
+
+
+@pytest.mark.parametrize("name", ["c1x1_s1", "c1x1_s2", "c3x3_s1", "c3x3_s2", "c7x7_s2_p3", "dw3x3_s1", "dw3x3_s2"])
+def test_conv(name):
+    d = load(name)
+    k, s, p, g = (int(v) for v in d["meta"])
+    w = d["w_oihw"]
+    oc, icg = w.shape[:2]
+    w_ohwi = O.reformat_conv_weight(w, oc, icg, k, k).reshape(oc, k, k, icg)
+    close(O.conv2d(d["x"], w_ohwi, d["b"], stride=(s, s), pads=(p, p, p, p), groups=g), d["y"])
+
+
+def test_pools_and_gap():
+    d = load("maxpool_3x3_s2_p1"); close(O.maxpool(d["x"], (3, 3), (2, 2), (1, 1)), d["y"], 0)
+    d = load("maxpool_2x2_s2"); close(O.maxpool(d["x"], (2, 2), (2, 2), (0, 0)), d["y"], 0)
+    d = load("gap_7x7"); close(O.global_avgpool(d["x"]), d["y"])
+
+
+def test_upsample():
+    d = load("up_nearest_x2"); close(O.upsample(d["x"], 2, 2, False), d["y"], 0)
+    d = load("up_bilinear_x2_ac1"); close(O.upsample(d["x"], 2, 2, True, True), d["y"])
+    d = load("up_bilinear_x2_ac0"); close(O.upsample(d["x"], 2, 2, True, False), d["y"])
+    d = load("up_bilinear_3x2_ac1"); close(O.upsample(d["x"], 3, 2, True, True), d["y"])
+
+
+def test_batchnorm_and_linear():
+    d = load("batchnorm"); close(O.batchnorm(d["x"], d["gamma"], d["beta"], d["mean"], d["var"], 1e-5), d["y"])
+    d = load("linear"); close(O.gemm_fc(d["x"], d["w"], d["b"]), d["y"])
+
+
+def test_toy_network_end_to_end():
+    d = load("toy_end_to_end")
+    assert np.array_equal(d["x"], zoo.synthetic_images(1, 3, (64, 64)))       # the seeded input is reproducible
+    close(O.Graph(zoo.toy()).run(d["x"]), d["y"])

@@ -1,0 +1,60 @@
+"""BASELINE.json full sizes on the GPU: size-independent properties (the oracle cannot run bs=64 in seconds) plus an
+oracle check on a 2-image sub-batch."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from conftest import nerr
+from smelter_amd import zoo
+from smelter_amd.graph import Configuration, ONNXGraph
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def r50():
+    model, macs = zoo.resnet50(return_macs=True)
+    assert macs == 4089184256                           # 4.0892 GMAC / image
+    return model
+
+
+def test_resnet50_bs64_properties(r50):
+    x = zoo.synthetic_images(64)
+    xd = torch.from_numpy(x).cuda()
+    ex = ONNXGraph(r50, Configuration()).hipGraph(0, 64)
+    assert ex.numOps == 56
+    assert abs(ex.flops / 64 - 2 * 4089184256) < 1e3    # FLOPs per image = 2 * MACs, conv + fc only
+    assert 51.0e6 < ex.weightBytes < 51.5e6
+    ex.encode(xd)
+    a = ex.toFloatArray()
+    assert a.shape == (64, 1000, 1, 1) and np.isfinite(a).all()
+    ex.encode(xd)
+    assert np.array_equal(ex.toFloatArray(), a)         # idempotent / deterministic
+    # batch independence: permuting the images permutes the outputs bit-exactly (no cross-sample coupling)
+    perm = np.random.default_rng(0).permutation(64)
+    ex.encode(torch.from_numpy(x[perm].copy()).cuda())
+    assert np.array_equal(ex.toFloatArray(), a[perm])
+    # shard consistency: the 8-image executor reproduces rows [8,16) of the 64-image run bit-exactly
+    ex8 = ONNXGraph(r50).hipGraph(0, 8)
+    ex8.encode(torch.from_numpy(x[8:16].copy()).cuda())
+    assert np.array_equal(ex8.toFloatArray(), a[8:16])
+    # oracle on a 2-image sub-batch (fp32, unfused): fp16-storage bound
+    ref = O.Graph(r50).run(x[:2])
+    assert nerr(a[:2], ref) <= 5e-3, nerr(a[:2], ref)
+
+
+def test_mobilenet_v2_bs256_and_unet_bs16_run_and_are_deterministic():
+    for make, shape in ((lambda: zoo.mobilenet_v2(), (256, 3, 224, 224)), (lambda: zoo.unet(), (16, 3, 512, 512))):
+        model = make()
+        x = torch.from_numpy(zoo.synthetic_images(shape[0], 3, shape[2:])).cuda()
+        ex = ONNXGraph(model).hipGraph(0, shape[0])
+        ex.encode(x)
+        a = ex.toFloatArray()
+        assert np.isfinite(a).all()
+        ex.encode(x)
+        assert np.array_equal(ex.toFloatArray(), a)
+        sub = O.Graph(model).run(x[:1].cpu().numpy())
+        assert nerr(a[:1], sub) <= 5e-3
+        del ex
+        torch.cuda.empty_cache()

@@ -1,0 +1,185 @@
+"""Graph-level parity on a real MI355X: ONNX bytes -> smelter_graph_create -> compile -> encode -> toFloatArray,
+through the C ABI, against the CPU oracle.
+
+Parity metric: nerr = max|got - ref| / max|ref|.
+  * TIGHT  (the 1e-3 bar of BASELINE.json): both sides read the SAME ONNX2MPS-flavoured fp16 file (BN already folded,
+    fp16 weights) and the oracle emulates fp16 image storage at exactly the tensors the executor materialises
+    -> only accumulation order differs.  nerr <= 1e-3.
+  * LOOSE  vs. the pure-fp32 oracle on the original unfused fp32 file: bounded by fp16 storage of weights and
+    activations across the whole depth.  nerr <= 5e-3 (informational bound, stated in DESIGN.md).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from conftest import nerr
+from smelter_amd import onnx2mps, zoo
+from smelter_amd.graph import Configuration, ONNXGraph
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+MODELS = {
+    "toy": (lambda: zoo.toy(), (2, 3, 64, 64)),
+    "resnet50": (lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64)),
+    "mobilenet_v2": (lambda: zoo.mobilenet_v2(hw=(64, 64)), (3, 3, 64, 64)),
+    "unet_nearest": (lambda: zoo.unet(hw=(64, 48)), (2, 3, 64, 48)),
+    "unet_bilinear_bn": (lambda: zoo.unet(hw=(32, 32), mode="bilinear", with_bn=True, levels=3), (1, 3, 32, 32)),
+}
+
+
+def run_hip(model, x, **cfg):
+    ex = ONNXGraph(model, Configuration(**cfg)).hipGraph(0, x.shape[0])
+    ex.encode(torch.from_numpy(x).cuda())
+    return ex, ex.toFloatArray()
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+def test_tight_parity_on_mps_flavor_fp16_file(name):
+    make, shape = MODELS[name]
+    model = onnx2mps.optimize_model(make(), half=True)
+    x = zoo.synthetic_images(shape[0], 3, shape[2:])
+    ex, got = run_hip(model, x)
+    ref_g = O.Graph(model)
+    ref_g.set_round_list(ex.valueNames)
+    ref = ref_g.run(x)
+    assert got.shape == ref.shape
+    assert nerr(got, ref) <= 1e-3, nerr(got, ref)
+
+
+@pytest.mark.parametrize("name", list(MODELS))
+@pytest.mark.parametrize("fuse", [True, False])
+def test_loose_parity_vs_fp32_oracle_on_unfused_file(name, fuse):
+    make, shape = MODELS[name]
+    model = make()
+    x = zoo.synthetic_images(shape[0], 3, shape[2:])
+    ex, got = run_hip(model, x, fuse=fuse, useHipGraph=fuse)
+    ref = O.Graph(model).run(x)
+    assert nerr(got, ref) <= 5e-3, nerr(got, ref)
+    n_nodes = ONNXGraph(model).numNodes
+    assert ex.numOps < n_nodes if fuse else ex.numOps <= n_nodes
+
+
+def test_fusion_counts_resnet50():
+    ex, _ = run_hip(zoo.resnet50(hw=(64, 64)), zoo.synthetic_images(1, 3, (64, 64)))
+    # 53 convs (BN folded, Add/Relu in epilogues) + MaxPool + GlobalAveragePool + FC = 56 ops; + input conversion
+    assert ex.numOps == 56 and ex.numLaunches in (57, 58)
+    assert abs(ex.flops - 2 * 4089184256 * (64 * 64) / (224 * 224)) / ex.flops < 0.2      # scaled MAC count, FC unscaled
+
+
+def test_unet_concat_is_zero_copy():
+    ex, _ = run_hip(zoo.unet(hw=(64, 64)), zoo.synthetic_images(1, 3, (64, 64)))
+    assert not any(ex.opDesc(i).startswith("Concat") for i in range(ex.numOps))          # all 4 concats placed, no copy kernel
+
+
+def test_hipgraph_replay_equals_eager_and_is_deterministic():
+    model = zoo.resnet50(hw=(64, 64))
+    x = zoo.synthetic_images(2, 3, (64, 64))
+    ex_g, a = run_hip(model, x, useHipGraph=True)
+    _, b = run_hip(model, x, useHipGraph=False)
+    assert np.array_equal(a, b)
+    xd = torch.from_numpy(x).cuda()
+    for _ in range(3):
+        ex_g.encode(xd)
+    assert np.array_equal(ex_g.toFloatArray(), a)
+    x2 = torch.from_numpy(zoo.synthetic_images(2, 3, (64, 64), seed=9)).cuda()    # a different input pointer re-captures
+    ex_g.encode(x2)
+    assert not np.array_equal(ex_g.toFloatArray(), a)
+
+
+def test_autotuned_configs_give_the_same_numbers():
+    model = zoo.resnet50(hw=(64, 64))
+    x = zoo.synthetic_images(2, 3, (64, 64))
+    _, a = run_hip(model, x)
+    _, b = run_hip(model, x, autotune=True)
+    assert nerr(a, b) <= 1e-3      # different tiles only change the accumulation split
+
+
+def test_batch_shard_outputs_equal_the_unsharded_run():
+    # SURVEY.md §4 "multi-GPU" row on one GPU: images [lo,hi) run as their own executor == rows [lo,hi) of the full batch
+    from smelter_amd.dist import shard_range
+    model = zoo.resnet50(hw=(64, 64))
+    x = zoo.synthetic_images(8, 3, (64, 64))
+    _, full = run_hip(model, x)
+    for r in range(4):
+        lo, hi = shard_range(8, r, 4)
+        _, part = run_hip(model, x[lo:hi].copy())
+        assert np.array_equal(part, full[lo:hi])
+
+
+def test_external_weight_arena_without_upload():
+    model = zoo.resnet50(hw=(64, 64))
+    x = zoo.synthetic_images(2, 3, (64, 64))
+    _, ref = run_hip(model, x)
+    g = ONNXGraph(model)
+    arena = torch.from_numpy(g.packWeights(2)).cuda()          # what a non-source rank receives from the RCCL broadcast
+    ex = g.hipGraph(0, 2, weight_arena=arena, upload_weights=False)
+    ex.encode(torch.from_numpy(x).cuda())
+    assert np.array_equal(ex.toFloatArray(), ref)
+
+
+def test_readback_layouts():
+    model = zoo.unet(hw=(32, 32), out_ch=6)                     # C = 6: slice-packed order pads to 8 channels
+    x = zoo.synthetic_images(2, 3, (32, 32))
+    ex, nchw = run_hip(model, x)
+    packed = ex.toFloatArray(layout="mps")
+    assert np.array_equal(packed, O.pack_float_array(nchw))     # MPSImage+Extensions.swift:26-59
+
+
+def test_intermediate_values_match_layer_by_layer():
+    model = onnx2mps.optimize_model(zoo.resnet50(hw=(64, 64)), half=True)
+    x = zoo.synthetic_images(1, 3, (64, 64))
+    ex, _ = run_hip(model, x, useHipGraph=False)
+    og = O.Graph(model)
+    og.set_round_list(ex.valueNames)
+    og.run(x)
+    import ctypes as C
+    checked = 0
+    for name in ex.valueNames[1:]:
+        got = ex.readValue(name)
+        v = og.value(name)
+        assert v is not None, name
+        p, c, h, w = v
+        ref = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), (1 * c * h * w,)).reshape(1, c, h, w)
+        if got.shape != ref.shape:            # Flatten output: same data, 1x1 spatial
+            got = got.reshape(ref.shape)
+        assert nerr(got, ref) <= 1e-3, (name, nerr(got, ref))
+        checked += 1
+    assert checked >= 55
+
+
+def test_toy_network_against_committed_golden_fixture():
+    d = np.load(os.path.join(G, "toy_end_to_end.npz"))
+    _, got = run_hip(zoo.toy(), d["x"])
+    assert nerr(got, d["y"]) <= 5e-3
+
+
+def test_dims_override_and_errors_surface_through_compile():
+    from smelter_amd.graph import SmelterError
+    g = ONNXGraph(zoo.toy(), Configuration(dims={2: 32, 3: 48}))
+    ex = g.hipGraph(0, 1)
+    assert ex.outputDims == (1, 16, 32, 48)
+    b = zoo.ow.GraphBuilder("g")
+    b.add_input("input", [1, 4, 4, 4])
+    b.add_output(b.add_node("Flatten", ["input"], axis=1), [1, 64])     # Flatten of a 4x4 map feeding the graph output
+    with pytest.raises(SmelterError) as e:
+        ONNXGraph(b.to_model()).hipGraph(0, 1)
+    assert e.value.kind == "inconsistentState"
+
+
+def test_fc_after_flatten_of_spatial_map():
+    # Gemm over a flattened HxW map: weight columns are NCHW-ordered in the file, our buffer is NHWC
+    rng = np.random.default_rng(0)
+    b = zoo.ow.GraphBuilder("g")
+    b.add_input("input", [1, 8, 3, 3])
+    f = b.add_node("Flatten", ["input"], axis=1)
+    w = b.add_init("w", (rng.standard_normal((10, 72)) * 0.1).astype(np.float32))
+    bb = b.add_init("b", rng.standard_normal(10).astype(np.float32))
+    b.add_output(b.add_node("Gemm", [f, w, bb], transB=1), [1, 10])
+    model = b.to_model()
+    x = rng.standard_normal((2, 8, 3, 3)).astype(np.float32)
+    _, got = run_hip(model, x)
+    assert nerr(got, O.Graph(model).run(x)) <= 2e-3

@@ -1,0 +1,193 @@
+"""Kernel-level parity on a real MI355X: every `sm_*` entry point, called through the C ABI, against the CPU oracle
+on identical seeded inputs.  Inputs/weights are pre-rounded to fp16 so both sides see the same numbers; the oracle
+computes in fp32 and its result is rounded to fp16 once, as the kernel's store does.
+
+Tolerance (fp16 output, fp32 accumulate): |got - ref| <= 1 fp16 ulp of the value (2^-10 relative) plus an absolute
+floor of 2^-11 * max|ref| * sqrt(K)*1e-2 covering accumulation-order differences that flip a rounding.  Byte-exact
+for the pure data-movement kernels (copy, nearest upsample, max-pool, layout)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from smelter_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def h(a):
+    return O.round_to_half(np.asarray(a, np.float32))
+
+
+def to_dev(a_nchw):
+    return torch.from_numpy(np.ascontiguousarray(a_nchw.transpose(0, 2, 3, 1))).cuda().half()
+
+
+def to_host(t_nhwc):
+    torch.cuda.synchronize()
+    return t_nhwc.float().cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def assert_close(got, ref, k=1):
+    ref16 = h(ref)
+    tol = np.abs(ref16) * 2.0 ** -10 + np.abs(ref).max() * 2.0 ** -11 * max(1.0, np.sqrt(k)) * 1e-2 + 1e-7
+    bad = np.abs(got - ref16) > tol
+    assert not bad.any(), "max err %g at %d elements" % (np.abs(got - ref16).max(), bad.sum())
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, s, p, res, act            -- comments: which path / edge is exercised
+    (2, 14, 14, 64, 96, 1, 1, 0, False, 1),            # 1x1, Cout not a tile multiple
+    (2, 15, 13, 32, 72, 3, 1, 1, True, 1),             # 3x3 ragged M, residual + relu
+    (1, 17, 17, 16, 40, 3, 2, 1, False, 0),            # stride 2, no activation
+    (3, 9, 9, 8, 8, 7, 2, 3, False, 1),                # 7x7 s2 p3 (stem class), K = 392
+    (2, 28, 28, 128, 256, 1, 2, 0, True, 1),           # 1x1 s2 downsample + residual
+    (1, 7, 7, 512, 64, 3, 1, 1, False, 1),             # long K (4608)
+    (2, 5, 5, 64, 1000, 1, 1, 0, False, 0),            # Cout = 1000 (tail in N)
+    (1, 1, 1, 2048, 1000, 1, 1, 0, False, 0),          # fully connected shape, M = 1
+    (2, 6, 6, 24, 20, 3, 1, 1, True, 2),               # Cin % 8 == 0 but not 32; PRelu epilogue
+    (1, 8, 8, 3, 8, 3, 1, 1, False, 1),                # Cin = 3 -> direct kernel
+    (1, 6, 7, 12, 6, 3, 1, 1, True, 1),                # Cin % 8 != 0, odd Cout -> direct kernel, scalar stores
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("cfg", [None, 0, 1, 2, 3, 4, 5])
+def test_conv2d(case, cfg):
+    n, hh, ww, cin, cout, k, s, p, res, act = case
+    if cfg is not None and (cin % 8 or cfg >= ops.num_conv_configs()):
+        pytest.skip("tile configs only apply to the MFMA path")
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, k, k, cin)) * np.sqrt(2.0 / (cin * k * k)))
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv2d(x, w, b, stride=(s, s), pads=(p, p, p, p))
+    r = None
+    if res:
+        r = h(rng.standard_normal(ref.shape))
+        ref = ref + r
+    slope = 0.25 if act == 2 else 0.0
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), residual=to_dev(r) if res else None,
+                   stride=(s, s), pads=(p, p, p, p), act=act, slope=slope, cfg=cfg)
+    assert_close(to_host(y), ref, cin * k * k)
+
+
+def test_conv2d_split_k_workspace():
+    n, cin, cout = 64, 2048, 1000                       # the ResNet-50 FC: M = 64 cannot fill 256 CUs without split-K
+    rng = np.random.default_rng(5)
+    x = h(rng.standard_normal((n, cin, 1, 1)))
+    w = h(rng.standard_normal((cout, 1, 1, cin)) * 0.02)
+    b = rng.standard_normal(cout).astype(np.float32)
+    nbytes = ops.conv2d_workspace_bytes((n, 1, 1, cin), (cout, 1, 1, cin))
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), workspace=ws)
+    assert_close(to_host(y), O.conv2d(x, w, b), cin)
+
+
+def test_conv2d_writes_into_concat_slice_and_reads_from_one():
+    rng = np.random.default_rng(7)
+    x = h(rng.standard_normal((2, 16, 9, 9)))
+    w = h(rng.standard_normal((24, 3, 3, 16)) * 0.1)
+    big_in = torch.zeros((2, 9, 9, 48), dtype=torch.float16, device="cuda")
+    big_in[..., 16:32] = to_dev(x)
+    big_out = torch.full((2, 9, 9, 64), 7.0, dtype=torch.float16, device="cuda")
+    ops.conv2d(big_in[..., 16:32], torch.from_numpy(w).cuda().half(), None, pads=(1, 1, 1, 1), out=big_out[..., 8:32])
+    ref = O.conv2d(x, w, None, pads=(1, 1, 1, 1))
+    assert_close(to_host(big_out[..., 8:32]), ref, 144)
+    assert (big_out[..., :8] == 7).all() and (big_out[..., 32:] == 7).all()      # neighbours of the slice untouched
+
+
+@pytest.mark.parametrize("c,k,s", [(16, 3, 1), (32, 3, 2), (8, 5, 1)])
+def test_depthwise(c, k, s):
+    rng = np.random.default_rng(c)
+    x = h(rng.standard_normal((2, c, 11, 10)))
+    w = h(rng.standard_normal((c, k, k, 1)) * 0.3)
+    b = rng.standard_normal(c).astype(np.float32)
+    p = k // 2
+    ref = np.maximum(O.conv2d(x, w, b, stride=(s, s), pads=(p, p, p, p), groups=c), 0)
+    y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(s, s), pads=(p, p, p, p), groups=c, act=1)
+    assert_close(to_host(y), ref, k * k)
+
+
+@pytest.mark.parametrize("c", [8, 64, 5])
+def test_add_relu_batchnorm(c):
+    rng = np.random.default_rng(c)
+    a, b = h(rng.standard_normal((2, c, 7, 9))), h(rng.standard_normal((2, c, 7, 9)))
+    assert_close(to_host(ops.add(to_dev(a), to_dev(b))), a + b)
+    assert_close(to_host(ops.add(to_dev(a), to_dev(b), act=1)), np.maximum(a + b, 0))
+    assert np.array_equal(to_host(ops.relu(to_dev(a))), np.maximum(a, 0))
+    assert_close(to_host(ops.relu(to_dev(a), slope=0.1)), np.where(a >= 0, a, a * np.float32(0.1)))
+    g, be, m = (rng.standard_normal(c).astype(np.float32) for _ in range(3))
+    v = rng.uniform(0.5, 1.5, c).astype(np.float32)
+    s = g / np.sqrt(v + np.float32(1e-5)); t = be - m * s
+    y = ops.batchnorm(to_dev(a), torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda())
+    assert_close(to_host(y), O.batchnorm(a, g, be, m, v, 1e-5), 4)
+
+
+@pytest.mark.parametrize("c,hw,k,s,p", [(64, 112, 3, 2, 1), (16, 13, 3, 2, 1), (8, 12, 2, 2, 0), (5, 9, 3, 1, 1)])
+def test_pools(c, hw, k, s, p):
+    rng = np.random.default_rng(hw)
+    x = h(rng.standard_normal((2, c, hw, hw)))
+    assert np.array_equal(to_host(ops.maxpool2d(to_dev(x), (k, k), (s, s), (p, p))), O.maxpool(x, (k, k), (s, s), (p, p)))
+    assert_close(to_host(ops.avgpool2d(to_dev(x), (k, k), (s, s), (p, p))), O.avgpool(x, (k, k), (s, s), (p, p)), k * k)
+
+
+@pytest.mark.parametrize("c,hw", [(2048, 7), (1280, 7), (10, 5), (64, 1)])
+def test_global_avgpool(c, hw):
+    x = h(np.random.default_rng(c).standard_normal((3, c, hw, hw)))
+    assert_close(to_host(ops.global_avgpool(to_dev(x))), O.global_avgpool(x), hw * hw)
+
+
+@pytest.mark.parametrize("c", [8, 32, 3])
+def test_upsample(c):
+    x = h(np.random.default_rng(c).standard_normal((2, c, 5, 6)))
+    assert np.array_equal(to_host(ops.upsample(to_dev(x), 2, 2)), O.upsample(x, 2, 2))
+    assert np.array_equal(to_host(ops.upsample(to_dev(x), 3, 2)), O.upsample(x, 3, 2))
+    for ac in (True, False):
+        assert_close(to_host(ops.upsample(to_dev(x), 2, 2, True, ac)), O.upsample(x, 2, 2, True, ac), 4)
+
+
+def test_copy_channels_is_concat():
+    rng = np.random.default_rng(0)
+    a, b = h(rng.standard_normal((2, 16, 6, 6))), h(rng.standard_normal((2, 24, 6, 6)))
+    out = torch.empty((2, 6, 6, 40), dtype=torch.float16, device="cuda")
+    ops.copy_channels(to_dev(a), out[..., :16]); ops.copy_channels(to_dev(b), out[..., 16:])
+    assert np.array_equal(to_host(out), np.concatenate([a, b], 1))
+
+
+@pytest.mark.parametrize("c,ld", [(3, 8), (3, 4), (3, 3), (16, 16), (5, 8)])
+def test_layout_round_trip_and_float_array(c, ld):
+    x = np.random.default_rng(c).random((2, c, 9, 7), dtype=np.float32)
+    d = ops.nchw_f32_to_nhwc_f16(torch.from_numpy(x).cuda(), ld=ld)
+    torch.cuda.synchronize()
+    assert d.shape == (2, 9, 7, ld)
+    assert np.array_equal(d[..., :c].float().cpu().numpy().transpose(0, 3, 1, 2), h(x))
+    assert (d[..., c:] == 0).all()                       # channel padding is zero-filled
+    back = ops.nhwc_f16_to_nchw_f32(d[..., :c])
+    torch.cuda.synchronize()
+    assert np.array_equal(back.cpu().numpy(), h(x))
+    fa = ops.nhwc_f16_to_float_array(d[..., :c])
+    torch.cuda.synchronize()
+    assert np.array_equal(fa.cpu().numpy(), O.pack_float_array(h(x)))        # MPSImage.toFloatArray order
+
+
+def test_layout_halo():
+    x = np.random.default_rng(1).random((1, 3, 5, 6), dtype=np.float32)
+    d = ops.nchw_f32_to_nhwc_f16(torch.from_numpy(x).cuda(), ld=4, halo=(3, 3, 2, 5))
+    torch.cuda.synchronize()
+    assert d.shape == (1, 10, 14, 4)
+    inner = d[:, 3:8, 3:9, :3].float().cpu().numpy().transpose(0, 3, 1, 2)
+    assert np.array_equal(inner, h(x))
+    assert float(d.float().abs().sum().cpu()) == pytest.approx(float(np.abs(h(x)).sum()), rel=1e-3)
+
+
+def test_bad_arguments_are_errors_not_crashes():
+    from smelter_amd._native import SmelterError
+    x = torch.zeros((1, 4, 4, 8), dtype=torch.float16, device="cuda")
+    w = torch.zeros((8, 3, 3, 8), dtype=torch.float16, device="cuda")
+    with pytest.raises(SmelterError) as e:
+        ops.conv2d(x, w, dilation=(0, 1), pads=(1, 1, 1, 1))
+    assert e.value.kind == "invalidArgument"

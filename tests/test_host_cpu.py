@@ -1,0 +1,171 @@
+"""CPU tier for the product's host side: the C-ABI library loads and exports every symbol the header declares, the
+graph builder mirrors ONNXGraph's behaviour (flavour detection, shapes, every error case, same error KIND as the
+oracle), and the weight preparation (BN fold + fp16 cast + OHWI) matches an independent numpy restatement.
+No kernel is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import oracle as O
+from smelter_amd import _native as N
+from smelter_amd import onnx2mps, onnx_reader as orr, onnx_writer as ow, zoo
+from smelter_amd.graph import Configuration, Format, ONNXGraph, SmelterError
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "smelter_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b((?:sm|smelter)_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 60
+    L = C.CDLL(N.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(L, s)]
+    assert not missing, "declared in include/smelter_hip.h but not exported: %s" % missing
+    assert declared == set(N.SYMBOLS), "python binding table drifted from the header: %s" % (declared ^ set(N.SYMBOLS))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(ImportError):
+        N.lib()
+
+
+def test_product_tree_never_references_the_oracle():
+    for dp, _, fs in os.walk(os.path.join(ROOT, "smelter_amd")):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
+                src = open(os.path.join(dp, f), errors="replace").read()
+                code = re.sub(r'""".*?"""', "", src, flags=re.S)                 # prose may mention it; code may not
+                code = "\n".join(l for l in code.splitlines() if not l.strip().startswith(("#", "//", "*", "/*")))
+                assert not re.search(r"import\s+oracle|from\s+oracle|liborc|orc_[a-z]+\s*\(|oracle/", code), f
+
+
+def test_flavour_detection_and_output_shapes():
+    g = ONNXGraph(zoo.toy())
+    assert g.modelFormat == Format.onnx and g.numNodes == 9
+    s = g.outputShapes[0]                              # ONNXGraph.swift:74-80: channels=dim1, width=dim2, height=dim3
+    assert (s.channels, s.width, s.height, s.depth) == (16, 64, 64, 1)
+    mps = onnx2mps.optimize_model(zoo.toy(), half=True)
+    g2 = ONNXGraph(mps)
+    assert g2.modelFormat == Format.mpsFlavor and g2.numNodes == 6      # 3 BN folded away
+    assert O.Graph(mps).is_mps_flavor
+    g2.modelFormat = Format.onnx                       # public var in the reference (ONNXGraph.swift:58)
+    assert g2.modelFormat == Format.onnx
+    r50 = ONNXGraph(zoo.resnet50(hw=(32, 32)))
+    assert r50.numNodes == 175
+    assert r50.outputShapes == []                      # rank-2 graph output is dropped (ONNXGraph.swift:88)
+
+
+def _conv_model(attrs, wdtype=np.float32, op="Conv", extra_nodes=(), out="y", n_out=1, weight=True):
+    b = ow.GraphBuilder("g")
+    b.add_input("input", [1, 8, 6, 6])
+    if weight:
+        b.add_init("w", np.ones((8, 8, 3, 3), wdtype))
+    b.add_node_named(op, ["input", "w"], ["y"], **attrs)
+    for n in extra_nodes:
+        b.nodes.append(n)
+    for i in range(n_out):
+        b.add_output(out if i == 0 else "input", [1, 8, 6, 6])
+    return b.to_model()
+
+
+FULL = dict(dilations=[1, 1], group=1, kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[1, 1])
+ERRORS = [
+    ("notEnoughAttributes", _conv_model({k: v for k, v in FULL.items() if k != "dilations"})),   # Converters.swift:234-237
+    ("notEnoughAttributes", _conv_model({k: v for k, v in FULL.items() if k != "kernel_shape"})),
+    ("insufficientInputs", _conv_model(FULL, weight=False)),                                      # :193-194
+    ("unknownNodeOpType", _conv_model(FULL, op="LeakyRelu")),                                     # not registered: ONNXGraph.swift:173-174
+    ("noSuchOutput", _conv_model(FULL, out="nope")),                                              # :182-183
+    ("unsupportedOutput", _conv_model(FULL, n_out=2)),                                            # :178-180
+    ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("Relu", ["ghost"], ["z"])])),         # :344-348
+    ("unsupportedDtype", _conv_model(FULL, wdtype=np.float64)),                                   # ConvWeightArray.invalid :82-89
+    ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("MaxPool", ["y"], ["z"], kernel_shape=[2, 2], strides=[2, 2])])),  # pads missing :654-661
+    ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("Add", ["y", "w"], ["z"])])),         # Add with an initializer operand :436-437
+    ("notEnoughAttributes", _conv_model(FULL, extra_nodes=[ow.node("Upsample", ["y"], ["z"], mode="nearest")])),  # scales missing
+    ("unknownNodeOpType", _conv_model(FULL, extra_nodes=[ow.node("Upsample", ["y"], ["z"], mode="cubic", scales=[1.0, 1.0, 2.0, 2.0])])),
+    ("insufficientInputs", _conv_model(FULL, extra_nodes=[ow.node("BatchNormalization", ["y", "w"], ["z"])])),    # :803-809
+]
+
+
+@pytest.mark.parametrize("kind,model", ERRORS)
+def test_error_cases_match_the_reference_and_the_oracle(kind, model):
+    with pytest.raises(SmelterError) as e:
+        ONNXGraph(model).packWeights(1)
+    assert e.value.kind == kind, e.value
+    with pytest.raises(O.OracleError) as e2:
+        O.Graph(model).run(np.zeros((1, 8, 6, 6), np.float32))
+    assert e2.value.kind == kind, e2.value
+
+
+def test_unknown_op_error_carries_the_op_type():
+    with pytest.raises(SmelterError) as e:
+        ONNXGraph(_conv_model(FULL, op="LeakyRelu")).packWeights(1)
+    assert e.value.detail == "LeakyRelu"               # Errors.unknownNodeOpType(opType:)
+
+
+def test_unsupported_input_rank_and_dims_override():
+    b = ow.GraphBuilder("g")
+    b.add_input("input", [8, 6])
+    b.add_output(b.add_node("Relu", ["input"]), [8, 6])
+    with pytest.raises(SmelterError) as e:
+        ONNXGraph(b.to_model()).packWeights(1)
+    assert e.value.kind == "unsupportedInput"          # ONNXGraph.swift:213-214
+    # Configuration.dims overrides a per-axis input dim (:200-202): 64x64 toy planned at 32x48
+    g = ONNXGraph(zoo.toy(), Configuration(dims={2: 32, 3: 48}))
+    assert g.weightBytes(1) == ONNXGraph(zoo.toy()).weightBytes(1)
+    assert O.Graph(zoo.toy(), dims={2: 32, 3: 48}).run(np.zeros((1, 3, 32, 48), np.float32)).shape == (1, 16, 32, 48)
+
+
+def test_force_input_scale_is_declared_unsupported():
+    with pytest.raises(SmelterError) as e:
+        ONNXGraph(zoo.toy(), Configuration(inputConstraint="bilinear")).packWeights(1)
+    assert e.value.kind == "unsupportedInput" and "inputConstraint" in e.value.detail
+
+
+def _arena_weights(model_bytes, n_convs):
+    """first conv's fp16 OHWI weights + fp32 bias from the packed arena (layout: 256-byte aligned blocks)"""
+    return ONNXGraph(model_bytes).packWeights(1)
+
+
+def test_bn_fold_fp16_cast_and_ohwi_match_numpy_restatement():
+    # toy: conv(3->8) + BN.  Independent restatement of ONNX2MPS.py's pipeline in numpy:
+    m = orr.parse_model(zoo.toy())
+    arr = {t.name: t.to_array() for t in m.initializer}
+    conv, bn = m.node[0], m.node[1]
+    w = arr[conv.input[1]]
+    gamma, beta, mean, var = (arr[i] for i in bn.input[1:5])
+    s = gamma / np.sqrt(var + np.float32(1e-5))
+    w_f = (w * s[:, None, None, None]).astype(np.float32)
+    b_f = ((0 - mean) * s + beta).astype(np.float32)
+    ohwi = np.zeros((8, 3, 3, 8), np.float32)          # first layer: Cin padded 3 -> 8 with zero columns
+    ohwi[..., :3] = w_f.transpose(0, 2, 3, 1)
+    expect_w = ohwi.astype(np.float16).view(np.uint16).ravel()
+    arena = ONNXGraph(zoo.toy()).packWeights(1)
+    got_w = arena[:expect_w.size * 2].view(np.uint16)
+    assert np.array_equal(got_w, expect_w)
+    off = (expect_w.size * 2 + 255) // 256 * 256
+    assert np.array_equal(arena[off:off + 32].view(np.float32), b_f)
+    # the offline tool produces the same folded fp16 weights, and loading ITS output packs the identical arena
+    arena2 = ONNXGraph(onnx2mps.optimize_model(zoo.toy(), half=True)).packWeights(1)
+    assert np.array_equal(arena2[:expect_w.size * 2].view(np.uint16), expect_w)
+
+
+def test_mps_flavor_round_trip_same_function_as_unfused():
+    # ONNX2MPS-flavoured fp32 file (BN folded, weights pre-transposed) == original unfused graph, in the oracle
+    x = zoo.synthetic_images(2, 3, (32, 32))
+    model = zoo.resnet50(hw=(32, 32))
+    a = O.Graph(model).run(x)
+    b = O.Graph(onnx2mps.optimize_model(model, half=False)).run(x)
+    assert np.abs(a - b).max() <= 1e-5 * np.abs(a).max()
+
+
+def test_weight_bytes_resnet50():
+    g = ONNXGraph(zoo.resnet50(hw=(32, 32)))
+    nbytes = g.weightBytes(4)
+    assert 51.0e6 < nbytes < 51.5e6                    # 25.5 M fp16 weights + fp32 biases
+    assert nbytes == g.weightBytes(64)                 # independent of batch
