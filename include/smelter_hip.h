@@ -170,6 +170,7 @@ typedef struct smelter_config {
     int32_t fuse;                 /* 1 (default): fold BN into conv, fuse Add/Relu epilogues; 0: one kernel per node */
     int32_t use_hip_graph;        /* 1 (default): replay the launch sequence as one hipGraph */
     int32_t autotune;             /* 1: time the conv tile configs per layer at compile; 0 (default): heuristic */
+    int32_t keep_intermediates;   /* 1: no activation-buffer reuse, every tensor stays readable (debug / layer parity) */
 } smelter_config;
 void smelter_config_default(smelter_config* c);
 

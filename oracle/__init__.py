@@ -97,6 +97,7 @@ def lib():
         L.orc_model_decode.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
         L.orc_model_free.argtypes = [vp]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_acc64.argtypes = [C.c_int]
         _LIB = L
     return _LIB
 
@@ -107,6 +108,11 @@ def _f32(a):
 
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def set_acc64(on: bool):
+    """conv accumulates in fp64 instead of fp32 (noise-floor / spot-check mode)"""
+    lib().orc_set_acc64(int(on))
 
 
 def num_threads() -> int:

@@ -127,6 +127,7 @@ typedef struct {
     int Ho, Wo;
 } orc_conv_desc;
 
+void orc_set_acc64(int on); /* conv accumulates in fp64 (spot checks) */
 void orc_conv2d(const orc_conv_desc* d, const float* x, const float* w_ohwi, const float* bias, float* y);
 void orc_gemm_fc(const float* x, const float* w_oi, const float* bias, float* y, int n, int in_f, int out_f);
 void orc_batchnorm(const float* x, float* y, int n, int c, int hw, const float* gamma, const float* beta,

@@ -25,40 +25,46 @@ int orc_num_threads(void) {
 
 /* Converters.swift:253-264 (MPSCNNConvolutionNode) + ONNXConvolutionPadding.swift:73-79 (offset k/2 - pad,
  * edge mode zero):  y[n,k,oy,ox] = b[k] + sum_{c,kh,kw} x[n, g*Cg+c, oy*sh-pt+kh*dh, ox*sw-pl+kw*dw] * W[k,kh,kw,c] */
-void orc_conv2d(const orc_conv_desc* d, const float* x, const float* w, const float* bias, float* y) {
-    const int Cg = d->C / d->groups, Kg = d->K / d->groups;
-    const long total = (long)d->N * d->K;
-#pragma omp parallel
-    {
-        float* acc = (float*)malloc(sizeof(float) * (size_t)d->Ho * d->Wo);
-#pragma omp for schedule(dynamic, 1)
-        for (long nk = 0; nk < total; nk++) {
-            int n = (int)(nk / d->K), k = (int)(nk % d->K), g = k / Kg;
-            float b = bias ? bias[k] : 0.f;
-            for (int i = 0; i < d->Ho * d->Wo; i++) acc[i] = 0.f;
-            for (int c = 0; c < Cg; c++) {
-                const float* xp = x + ((size_t)n * d->C + (size_t)g * Cg + c) * d->H * d->W;
-                for (int kh = 0; kh < d->kh; kh++)
-                    for (int kw = 0; kw < d->kw; kw++) {
-                        float wv = w[(((size_t)k * d->kh + kh) * d->kw + kw) * Cg + c];
-                        for (int oy = 0; oy < d->Ho; oy++) {
-                            int iy = oy * d->sh - d->pt + kh * d->dh;
-                            if (iy < 0 || iy >= d->H) continue;
-                            const float* xr = xp + (size_t)iy * d->W;
-                            float* ar = acc + (size_t)oy * d->Wo;
-                            int x0 = kw * d->dw - d->pl;
-                            for (int ox = 0; ox < d->Wo; ox++) {
-                                int ix = ox * d->sw + x0;
-                                if (ix >= 0 && ix < d->W) ar[ox] += xr[ix] * wv;
-                            }
-                        }
-                    }
-            }
-            float* yp = y + ((size_t)n * d->K + k) * d->Ho * d->Wo;
-            for (int i = 0; i < d->Ho * d->Wo; i++) yp[i] = acc[i] + b;
-        }
-        free(acc);
+static int g_acc64 = 0;   /* fp64 accumulation: spot-check mode that separates accumulation-order effects from fp16 storage effects */
+void orc_set_acc64(int on) { g_acc64 = on; }
+
+#define ORC_CONV_BODY(ACC_T)                                                                                   \
+    const int Cg = d->C / d->groups, Kg = d->K / d->groups;                                                   \
+    const long total = (long)d->N * d->K;                                                                     \
+    _Pragma("omp parallel")                                                                                   \
+    {                                                                                                         \
+        ACC_T* acc = (ACC_T*)malloc(sizeof(ACC_T) * (size_t)d->Ho * d->Wo);                                  \
+        _Pragma("omp for schedule(dynamic, 1)")                                                               \
+        for (long nk = 0; nk < total; nk++) {                                                                 \
+            int n = (int)(nk / d->K), k = (int)(nk % d->K), g = k / Kg;                                       \
+            float b = bias ? bias[k] : 0.f;                                                                   \
+            for (int i = 0; i < d->Ho * d->Wo; i++) acc[i] = 0;                                               \
+            for (int c = 0; c < Cg; c++) {                                                                    \
+                const float* xp = x + ((size_t)n * d->C + (size_t)g * Cg + c) * d->H * d->W;                  \
+                for (int kh = 0; kh < d->kh; kh++)                                                            \
+                    for (int kw = 0; kw < d->kw; kw++) {                                                      \
+                        ACC_T wv = w[(((size_t)k * d->kh + kh) * d->kw + kw) * Cg + c];                       \
+                        for (int oy = 0; oy < d->Ho; oy++) {                                                  \
+                            int iy = oy * d->sh - d->pt + kh * d->dh;                                         \
+                            if (iy < 0 || iy >= d->H) continue;                                               \
+                            const float* xr = xp + (size_t)iy * d->W;                                         \
+                            ACC_T* ar = acc + (size_t)oy * d->Wo;                                             \
+                            int x0 = kw * d->dw - d->pl;                                                      \
+                            for (int ox = 0; ox < d->Wo; ox++) {                                              \
+                                int ix = ox * d->sw + x0;                                                     \
+                                if (ix >= 0 && ix < d->W) ar[ox] += xr[ix] * wv;                              \
+                            }                                                                                 \
+                        }                                                                                     \
+                    }                                                                                         \
+            }                                                                                                 \
+            float* yp = y + ((size_t)n * d->K + k) * d->Ho * d->Wo;                                           \
+            for (int i = 0; i < d->Ho * d->Wo; i++) yp[i] = (float)(acc[i] + b);                              \
+        }                                                                                                     \
+        free(acc);                                                                                            \
     }
+
+void orc_conv2d(const orc_conv_desc* d, const float* x, const float* w, const float* bias, float* y) {
+    if (g_acc64) { ORC_CONV_BODY(double) } else { ORC_CONV_BODY(float) }
 }
 
 /* Converters.swift:288-302 (MPSCNNFullyConnectedNode), weight read as [out,in] :35-39 ; alpha/beta/trans ignored */

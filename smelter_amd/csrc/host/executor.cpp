@@ -204,6 +204,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         touch(op.output, t);
     }
     touch(output_value_, ns);                               // result image must survive until read back
+    if (cfg_.keepIntermediates) for (int v = 0; v < nv; v++) if (last[v] >= 0) { first[v] = -1; last[v] = ns; }
     root_offset_.assign(nv, 0);
     struct Blk { int v; size_t bytes; };
     std::vector<Blk> blks;

@@ -40,6 +40,7 @@ class Configuration:  # ONNXGraph.swift:6-36 (+ executor options)
     fuse: bool = True
     useHipGraph: bool = True
     autotune: bool = False
+    keepIntermediates: bool = False
 
     def _c(self) -> N.Config:
         c = N.Config()
@@ -49,6 +50,7 @@ class Configuration:  # ONNXGraph.swift:6-36 (+ executor options)
         for k, v in self.dims.items():
             c.dims[k] = v
         c.fuse, c.use_hip_graph, c.autotune = int(self.fuse), int(self.useHipGraph), int(self.autotune)
+        c.keep_intermediates = int(self.keepIntermediates)
         return c
 
 

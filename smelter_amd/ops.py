@@ -25,15 +25,22 @@ def _ptr(t):
 
 def _ld(t: torch.Tensor) -> int:
     """pixel stride (elements) of an NHWC tensor or channel-slice view"""
-    assert t.stride(-1) == 1, "channel axis must be innermost"
-    return t.stride(-2)
+    assert t.stride(-1) == 1 or t.shape[-1] == 1, "channel axis must be innermost"
+    n, h, w, c = t.shape
+    if w > 1:                                      # size-1 axes carry arbitrary strides in torch/numpy
+        return t.stride(2)
+    if h > 1:
+        return t.stride(1)
+    if n > 1:
+        return t.stride(0)
+    return c
 
 
 def _check_nhwc(t: torch.Tensor):
     assert t.is_cuda and t.dtype == torch.float16 and t.dim() == 4
     n, h, w, c = t.shape
     ld = _ld(t)
-    assert t.stride(1) == w * ld and t.stride(0) == h * w * ld, "only the channel axis may be sliced"
+    assert (h == 1 or t.stride(1) == w * ld) and (n == 1 or t.stride(0) == h * w * ld), "only the channel axis may be sliced"
     return n, h, w, c, ld
 
 

@@ -35,10 +35,15 @@ def test_resnet50_bs64_properties(r50):
     perm = np.random.default_rng(0).permutation(64)
     ex.encode(torch.from_numpy(x[perm].copy()).cuda())
     assert np.array_equal(ex.toFloatArray(), a[perm])
-    # shard consistency: the 8-image executor reproduces rows [8,16) of the 64-image run bit-exactly
+    # shard consistency: a second executor of the same per-rank batch (what another rank builds from the broadcast
+    # arena) is bit-identical; an executor planned for a different batch may pick other tiles / split-K factors, which
+    # only changes the fp32 accumulation split -> equal to within the parity bar
+    exb = ONNXGraph(r50, Configuration()).hipGraph(0, 64)
+    exb.encode(xd)
+    assert np.array_equal(exb.toFloatArray(), a)
     ex8 = ONNXGraph(r50).hipGraph(0, 8)
     ex8.encode(torch.from_numpy(x[8:16].copy()).cuda())
-    assert np.array_equal(ex8.toFloatArray(), a[8:16])
+    assert nerr(ex8.toFloatArray(), a[8:16]) <= 1e-3
     # oracle on a 2-image sub-batch (fp32, unfused): fp16-storage bound
     ref = O.Graph(r50).run(x[:2])
     assert nerr(a[:2], ref) <= 5e-3, nerr(a[:2], ref)
