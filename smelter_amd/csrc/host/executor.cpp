@@ -454,7 +454,9 @@ int Executor::autotune(hipStream_t s) {
         float best = 1e30f; int best_cfg = -1;
         for (int c = 0; c < ncfg; c++) {
             st.conv_cfg = c; float ms = 0;
-            int rc = timeOp(s, (int)i, 3, &ms); if (rc) return rc;
+            int rc = timeOp(s, (int)i, 3, &ms);
+            if (rc == SM_ERR_INVALID_ARGUMENT) continue;   // tile config not applicable to this layer's Cin
+            if (rc) return rc;
             if (ms < best) { best = ms; best_cfg = c; }
         }
         st.conv_cfg = best_cfg;

@@ -258,22 +258,35 @@ __global__ __launch_bounds__(256) void dwconv_kernel(ConvParams p) {
     }
 }
 
-struct TileCfg { int BM, BN; void (*fn)(ConvParams); const char* name; };
+#include "conv_igemm64.hpp"
+
+// kind 0: generic (Cin % 8 == 0, BK = 32, register staging); kind 1: Cin % 64 == 0 fast path (BK = 64, LDS-DMA)
+struct TileCfg { int BM, BN, kind; void (*fn)(ConvParams); const char* name; };
 const TileCfg kCfgs[] = {
-    {128, 128, conv_igemm_kernel<128, 128, 2, 2>, "128x128"},
-    {128, 64, conv_igemm_kernel<128, 64, 2, 2>, "128x64"},
-    {64, 128, conv_igemm_kernel<64, 128, 2, 2>, "64x128"},
-    {64, 64, conv_igemm_kernel<64, 64, 2, 2>, "64x64"},
-    {256, 64, conv_igemm_kernel<256, 64, 4, 1>, "256x64"},
-    {256, 128, conv_igemm_kernel<256, 128, 2, 2>, "256x128"},
+    {128, 128, 0, conv_igemm_kernel<128, 128, 2, 2>, "128x128"},
+    {128, 64, 0, conv_igemm_kernel<128, 64, 2, 2>, "128x64"},
+    {64, 128, 0, conv_igemm_kernel<64, 128, 2, 2>, "64x128"},
+    {64, 64, 0, conv_igemm_kernel<64, 64, 2, 2>, "64x64"},
+    {256, 64, 0, conv_igemm_kernel<256, 64, 4, 1>, "256x64"},
+    {256, 128, 0, conv_igemm_kernel<256, 128, 2, 2>, "256x128"},
+    {128, 128, 1, conv_igemm64_kernel<128, 128, 2, 2>, "k64:128x128"},
+    {128, 64, 1, conv_igemm64_kernel<128, 64, 2, 2>, "k64:128x64"},
+    {64, 128, 1, conv_igemm64_kernel<64, 128, 2, 2>, "k64:64x128"},
+    {64, 64, 1, conv_igemm64_kernel<64, 64, 2, 2>, "k64:64x64"},
+    {256, 64, 1, conv_igemm64_kernel<256, 64, 4, 1>, "k64:256x64"},
+    {256, 128, 1, conv_igemm64_kernel<256, 128, 2, 2>, "k64:256x128"},
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
+bool cfg_eligible(const TileCfg& c, const ConvParams& p) { return c.kind == 0 || (p.Cin % 64) == 0; }
+
 int pick_cfg(const ConvParams& p) {
     // largest tile that still gives >= ~2 blocks per CU; otherwise the one with the most blocks
-    int best = 3; double best_score = -1;
+    const int want_kind = (p.Cin % 64) == 0 ? 1 : 0;
+    int best = want_kind ? 9 : 3; double best_score = -1;
     for (int i = 0; i < kNumCfgs; i++) {
         const TileCfg& c = kCfgs[i];
+        if (c.kind != want_kind) continue;
         if (c.BN > 64 && p.Cout <= 64) continue;
         long blocks = (long)sm_ceil_div(p.M, c.BM) * sm_ceil_div(p.Cout, c.BN);
         double waves = (double)blocks / (SM_NUM_CU * 2);                       // 2 resident blocks per CU
@@ -321,8 +334,9 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     }
     if (cfg < 0 || cfg >= kNumCfgs) cfg = pick_cfg(p);
     const TileCfg& c = kCfgs[cfg];
+    if (!cfg_eligible(c, p)) { sm_set_error("conv tile config %d (%s) does not apply to Cin=%d", cfg, c.name, p.Cin); return SM_ERR_INVALID_ARGUMENT; }
     p.mt = sm_ceil_div(p.M, c.BM); p.nt = sm_ceil_div(p.Cout, c.BN);
-    const int ktiles = sm_ceil_div(p.K, BK);
+    const int ktiles = sm_ceil_div(p.K, c.kind ? 64 : BK);
     // split-K only for launches that cannot fill the chip and have a long K loop (e.g. the FC layer)
     p.splitk = 1;
     long blocks = (long)p.mt * p.nt;

@@ -1,0 +1,175 @@
+// conv_igemm64.hpp — the fast path of the implicit-GEMM convolution: Cin % 64 == 0 (every ResNet-50 layer but the
+// stem), BK = 64, operands streamed HBM -> LDS by the LDS-DMA (`global_load_lds_dwordx4`, 16 B per lane) with no VGPR
+// round trip, epilogue transposed through LDS so that every global access is a full 16-byte lane / 128-byte line.
+// Included by conv_igemm.hip (same ConvParams, same launcher).
+//
+//  * K tiling: with Cin % 64 == 0 a 64-wide K tile lies inside ONE (kh,kw) tap, so the tap and its channel base are
+//    wave-uniform per tile; a row of the activation tile is 128 contiguous bytes of one input pixel (or zeros).
+//  * LDS-DMA writes lane-linear (wave base + lane*16 B), so the bank swizzle is applied on the SOURCE side: the lane
+//    that fills 16-byte slot c' of row r fetches chunk c = c' ^ ((r >> 1) & 7); readers apply the same XOR
+//    (cdna_hip_programming.md §5.4 rule 21).  With 128-byte rows this makes every 16-lane service group of
+//    ds_read_b128 hit 16 distinct 16-byte slots of the 256-byte bank row (MI355X_MICROARCH.md §LDS).
+//  * Zero padding / ragged tiles: out-of-image taps, rows >= M and couts >= Cout fetch from a zero page.
+//  * Pipeline: 2 LDS stages; tile t+1 is in flight while tile t feeds the MFMAs; __syncthreads() carries the
+//    vmcnt(0) that publishes the DMA'd tile (cdna_hip_programming.md §5 "step-3 structure").
+//  * Epilogue: per wave-row pass, accumulators -> LDS as fp32 [32*TM rows][BN+4] (conflict-free ds_write_b128),
+//    then 256 threads each take 8 consecutive couts of one pixel: + bias + residual (16-byte coalesced load),
+//    activation, ONE rounding to fp16, 16-byte coalesced store.
+#pragma once
+
+__device__ __attribute__((aligned(64))) unsigned int g_zero_page[64];   // zero-initialised at module load
+
+#define SM_GLDS16(gptr, ldsptr)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
+                                     (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void conv_igemm64_kernel(ConvParams p) {
+    static_assert(WGM * WGN == 4, "4 waves");
+    constexpr int BK64 = 64;
+    constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;              // 16-byte pieces per thread per tile
+    constexpr int STAGE = (BM + BN) * BK64;                     // halfs per stage
+    constexpr int EP_ROWS = 32 * TM, EP_LD = BN + 4;            // epilogue staging (floats)
+    constexpr int LDS_BYTES = (2 * STAGE * 2 > EP_ROWS * EP_LD * 4) ? 2 * STAGE * 2 : EP_ROWS * EP_LD * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem_raw[LDS_BYTES];
+    half_t* smem = (half_t*)smem_raw;
+
+    const int bid = blockIdx.x, xcd = bid & (SM_NUM_XCD - 1), slot = bid >> 3;
+    const int per_m = p.nt * p.splitk;
+    const int mtile = xcd + SM_NUM_XCD * (slot / per_m);
+    if (mtile >= p.mt) return;
+    const int rem = slot % per_m, ntile = rem % p.nt, ksplit = rem / p.nt;
+    const int ktiles = p.K / BK64;
+    const int kt_begin = ksplit * p.ktiles_per_split;
+    int kt_end = kt_begin + p.ktiles_per_split; if (kt_end > ktiles) kt_end = ktiles;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int csrc = (tid & 7) ^ ((tid >> 4) & 7);             // source chunk for this thread's LDS slot (rows j*32 + tid/8)
+    const half_t* zero = (const half_t*)g_zero_page;
+
+    // ---- per-thread row state -----------------------------------------------------------------------
+    const half_t* arow[A_IT]; int aiy[A_IT], aix[A_IT];
+#pragma unroll
+    for (int j = 0; j < A_IT; j++) {
+        const int m = mtile * BM + j * 32 + (tid >> 3);
+        if (m < p.M) {
+            int n = m / (p.Ho * p.Wo), r = m - n * (p.Ho * p.Wo), oy = r / p.Wo, ox = r - oy * p.Wo;
+            aiy[j] = oy * p.sH - p.pt; aix[j] = ox * p.sW - p.pl;
+            arow[j] = p.x + (((long)n * p.H + aiy[j]) * p.W + aix[j]) * p.x_ld + csrc * 8;
+        } else { aiy[j] = -(1 << 28); aix[j] = -(1 << 28); arow[j] = zero; }     // never valid
+    }
+    const half_t* brow[B_IT];
+#pragma unroll
+    for (int j = 0; j < B_IT; j++) {
+        const int n = ntile * BN + j * 32 + (tid >> 3);
+        brow[j] = n < p.Cout ? p.w + (long)n * p.K + csrc * 8 : nullptr;
+    }
+    const int cpt = p.Cin / BK64;                               // K tiles per tap
+    int tap = kt_begin / cpt, kh = tap / p.kW, kw = tap - kh * p.kW, cblk = kt_begin - tap * cpt;
+
+    auto issue = [&](int buf, int kt) {
+        half_t* sa = smem + buf * STAGE + (wave * 64) * 8;      // wave-uniform LDS base; lane*16 B added by the DMA
+        half_t* sb = smem + buf * STAGE + BM * BK64 + (wave * 64) * 8;
+        const int dy = kh * p.dH, dx = kw * p.dW;
+        const long toff = ((long)dy * p.W + dx) * p.x_ld + cblk * BK64;
+#pragma unroll
+        for (int j = 0; j < A_IT; j++) {
+            const bool ok = (unsigned)(aiy[j] + dy) < (unsigned)p.H && (unsigned)(aix[j] + dx) < (unsigned)p.W;
+            const half_t* src = ok ? arow[j] + toff : zero;
+            SM_GLDS16(src, sa + j * 256 * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; j++) {
+            const half_t* src = brow[j] ? brow[j] + (long)kt * BK64 : zero;
+            SM_GLDS16(src, sb + j * 256 * 8);
+        }
+        if (++cblk == cpt) { cblk = 0; if (++kw == p.kW) { kw = 0; ++kh; } }
+    };
+
+    floatx16 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; a++)
+#pragma unroll
+        for (int b = 0; b < TM; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+    issue(0, kt_begin);
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt_begin; kt < kt_end; kt++) {
+        if (kt + 1 < kt_end) issue(cur ^ 1, kt + 1);
+        const half_t* sa = smem + cur * STAGE; const half_t* sb = sa + BM * BK64;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            const int c = ks * 2 + (lane >> 5);
+            half8_t fx[TM], fw[TN];
+#pragma unroll
+            for (int b = 0; b < TM; b++) { const int row = (wm * TM + b) * 32 + (lane & 31); fx[b] = *(const half8_t*)(sa + row * BK64 + ((c ^ ((row >> 1) & 7)) << 3)); }
+#pragma unroll
+            for (int a = 0; a < TN; a++) { const int row = (wn * TN + a) * 32 + (lane & 31); fw[a] = *(const half8_t*)(sb + row * BK64 + ((c ^ ((row >> 1) & 7)) << 3)); }
+#pragma unroll
+            for (int a = 0; a < TN; a++)
+#pragma unroll
+                for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[a], fx[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: LDS transpose, coalesced 16-byte global accesses ---------------------------------------------
+    float* stg = (float*)smem_raw;
+    const bool vec_ok = ((p.y_ld & 7) == 0) && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && ((p.Cout & 7) == 0) &&
+                        (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0));
+    constexpr int CHUNKS = BN / 8, ITEMS = EP_ROWS * CHUNKS;
+#pragma unroll 1
+    for (int pw = 0; pw < WGM; pw++) {
+        if (wm == pw) {
+#pragma unroll
+            for (int b = 0; b < TM; b++)
+#pragma unroll
+                for (int a = 0; a < TN; a++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int row = b * 32 + (lane & 31), col = (wn * TN + a) * 32 + 8 * q + 4 * (lane >> 5);
+                        *(floatx4*)(stg + row * EP_LD + col) = floatx4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                    }
+        }
+        __syncthreads();
+        for (int it = tid; it < ITEMS; it += 256) {
+            const int row = it / CHUNKS, ch = it - row * CHUNKS;
+            const int m = mtile * BM + pw * EP_ROWS + row, co = ntile * BN + ch * 8;
+            if (m >= p.M || co >= p.Cout) continue;
+            floatx4 v0 = *(const floatx4*)(stg + row * EP_LD + ch * 8), v1 = *(const floatx4*)(stg + row * EP_LD + ch * 8 + 4);
+            float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            if (p.splitk > 1) {
+                float* dst = p.ws + ((long)ksplit * p.M + m) * p.Cout + co;
+                if ((p.Cout & 3) == 0 && co + 7 < p.Cout) { *(floatx4*)dst = v0; *(floatx4*)(dst + 4) = v1; }
+                else for (int j = 0; j < 8 && co + j < p.Cout; j++) dst[j] = v[j];
+                continue;
+            }
+            if (vec_ok) {
+                if (p.bias) { floatx4 b0 = *(const floatx4*)(p.bias + co), b1 = *(const floatx4*)(p.bias + co + 4);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { v[j] += b0[j]; v[4 + j] += b1[j]; } }
+                if (p.res) { half8_t rr = *(const half8_t*)(p.res + (long)m * p.res_ld + co);
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] += (float)rr[j]; }
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = (half_t)sm_act(v[j], p.act, p.slope);
+                *(half8_t*)(p.y + (long)m * p.y_ld + co) = o;
+            } else {
+                for (int j = 0; j < 8 && co + j < p.Cout; j++) {
+                    float t = v[j];
+                    if (p.bias) t += p.bias[co + j];
+                    if (p.res) t += (float)p.res[(long)m * p.res_ld + co + j];
+                    p.y[(long)m * p.y_ld + co + j] = (half_t)sm_act(t, p.act, p.slope);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}

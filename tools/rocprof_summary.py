@@ -1,0 +1,75 @@
+"""Summarise a rocprofv3 --kernel-trace run of bench.py (rocpd sqlite or kernel_trace.csv) into the text files
+committed under profiles/.  Steady-state steps are delimited by the input-conversion kernel (first launch of every
+encode); autotuning / warm-up dispatches before the last `--steps` segments are ignored.
+
+    python tools/rocprof_summary.py gpurun_out/prof_x/r_results.db --steps 20 > profiles/r01_kernel_stats.txt
+"""
+import argparse
+import collections
+import csv
+import re
+import sqlite3
+import sys
+
+
+def load(path):
+    rows = []  # (start_ns, end_ns, name)
+    if path.endswith(".db"):
+        c = sqlite3.connect(path)
+        for name, s, e in c.execute("select name, start, end from kernels order by start"):
+            rows.append((int(s), int(e), name))
+    else:
+        with open(path) as f:
+            for r in csv.DictReader(f):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+        rows.sort()
+    return rows
+
+
+def short(name):
+    m = re.search(r"conv_igemm\w*<[^>]*>", name)
+    if m:
+        return m.group(0)
+    m = re.search(r"N_1\d+(\w+?)E", name)
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"\(.*", "", name).replace("void ", "")
+    if name.startswith("_ZN"):
+        m = re.search(r"\d+([a-z_0-9]+_kernel)", name)
+        if m:
+            return m.group(1)
+    return name
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("path")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--flops-per-step", type=float, default=64 * 2 * 4089184256.0)
+    a = ap.parse_args()
+    rows = load(a.path)
+    starts = [i for i, r in enumerate(rows) if "nchw_to_nhwc" in r[2]]
+    assert len(starts) >= a.steps + 1, "found %d encode() calls" % len(starts)
+    lo = starts[-a.steps - 1]
+    hi = starts[-1]                      # the last encode may be followed by read-back kernels: use complete segments only
+    seg = rows[lo:hi]
+    span_ms = (rows[hi][0] - rows[lo][0]) / 1e6
+    per = collections.OrderedDict()
+    for s, e, n in seg:
+        k = short(n)
+        d = per.setdefault(k, [0, 0.0])
+        d[0] += 1
+        d[1] += (e - s) / 1e3
+    total_us = sum(v[1] for v in per.values())
+    print("# rocprofv3 --kernel-trace, steady state: last %d encode() steps, %d dispatches" % (a.steps, len(seg)))
+    print("# wall span %.3f ms/step ; sum of kernel durations %.3f ms/step ; %d launches/step" % (span_ms / a.steps, total_us / 1e3 / a.steps, len(seg) // a.steps))
+    print("%-46s %8s %12s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
+    for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        print("%-46s %8d %12.1f %10.2f %6.1f%%" % (k, c, t, t / c, 100 * t / total_us))
+    conv = [(c, t) for k, (c, t) in per.items() if k.startswith("conv_igemm") or "splitk" in k]
+    cc, ct = sum(c for c, _ in conv), sum(t for _, t in conv)
+    print("# conv_igemm family: %d launches/step, avg %.2f us/launch, %.3f ms/step -> %.1f TFLOP/s (%.1f%% of 2500)" % (
+        cc // a.steps, ct / cc, ct / 1e3 / a.steps, a.flops_per_step / (ct / a.steps * 1e-6) / 1e12, a.flops_per_step / (ct / a.steps * 1e-6) / 1e12 / 25))
+
+
+if __name__ == "__main__":
+    main()
