@@ -1,7 +1,7 @@
 # Top-level build: libsmelter_hip.so (product: HIP kernels + C++ host + C ABI) and oracle/liborc.so (checker).
 HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
-HIPFLAGS ?= --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result
+HIPFLAGS ?= $(EXTRA) --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-result
 CSRC     := smelter_amd/csrc
 KERNELS  := $(wildcard $(CSRC)/kernels/*.hip)
 HOSTSRC  := $(wildcard $(CSRC)/host/*.cpp)

@@ -82,6 +82,10 @@ int sm_conv2d_num_configs(void);
 int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias,
                       const void* residual, void* y, void* workspace, size_t workspace_bytes, sm_stream_t stream);
 
+/* tuning aid: average duration of `iters` back-to-back launches (HIP events on `stream`) */
+int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias, const void* residual,
+                   void* y, void* workspace, size_t workspace_bytes, int32_t iters, sm_stream_t stream, float* ms_per_launch);
+
 /* MPSCNNBatchNormalizationNode (Converters.swift:812): y = x*scale[c] + shift[c], scale/shift fp32 folded on
  * the host from gamma,beta,mean,var.  Unfused fallback — the compiler folds BN into the producing conv. */
 int sm_batchnorm(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld,

@@ -21,6 +21,8 @@
 //
 // Block -> tile map is XCD aware (8 XCDs with private L2, block b runs on XCD b%8): all BN-tiles of one pixel
 // tile are issued back-to-back on the same XCD so the gathered activation tile is fetched from HBM once.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
@@ -31,9 +33,29 @@ struct ConvParams {
     int N, H, W, Cin, Cout, kH, kW, sH, sW, dH, dW, pt, pl, Ho, Wo;
     int x_ld, y_ld, res_ld, act; float slope;
     int M, K, mt, nt, splitk, ktiles_per_split;
+    int order, mt_per_xcd, cpx;      // block -> tile map (map_block)
 };
 
 constexpr int BK = 32;
+
+// Block -> (pixel tile, cout tile, k split).  MI355X has 8 XCDs with private 4 MiB L2s and block b runs on XCD b % 8,
+// so the map decides what each L2 holds:
+//   order 0 (activations dominate): XCD x owns the CONTIGUOUS pixel-tile range [x*mt/8, (x+1)*mt/8) — neighbouring
+//            tiles share their 3x3 halo rows inside one L2 — and walks all cout tiles of a pixel tile back to back, so
+//            the gathered activation tile is fetched from HBM once.
+//   order 1 (weights dominate, e.g. 512x4608 at 7x7): XCD x owns a contiguous range of (cout tile, k split) combos and
+//            walks every pixel tile for it, so its weight slice stays L2-resident while the small activation tensor is
+//            shared by all XCDs.
+__device__ __forceinline__ bool map_block(const ConvParams& p, int& mtile, int& ntile, int& ksplit) {
+    const int bid = blockIdx.x, xcd = bid & (SM_NUM_XCD - 1), slot = bid >> 3;
+    const int per_m = p.nt * p.splitk;
+    int combo;
+    if (p.order == 0) { mtile = xcd * p.mt_per_xcd + slot / per_m; combo = slot % per_m; if (slot / per_m >= p.mt_per_xcd) return false; }
+    else { combo = xcd * p.cpx + slot / p.mt; mtile = slot % p.mt; if (slot / p.mt >= p.cpx || combo >= per_m) return false; }
+    if (mtile >= p.mt) return false;
+    ntile = combo % p.nt; ksplit = combo / p.nt;
+    return true;
+}
 
 __device__ __forceinline__ int swz(int row, int chunk) { return chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3); }
 
@@ -46,11 +68,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     __shared__ __attribute__((aligned(16))) half_t smem[2][(BM + BN) * BK];
 
     // ---- block -> (pixel tile, cout tile, k split) -------------------------------------------------
-    const int bid = blockIdx.x, xcd = bid & (SM_NUM_XCD - 1), slot = bid >> 3;
-    const int per_m = p.nt * p.splitk;
-    const int mtile = xcd + SM_NUM_XCD * (slot / per_m);
-    if (mtile >= p.mt) return;
-    const int rem = slot % per_m, ntile = rem % p.nt, ksplit = rem / p.nt;
+    int mtile, ntile, ksplit;
+    if (!map_block(p, mtile, ntile, ksplit)) return;
     const int kt_begin = ksplit * p.ktiles_per_split;
     int kt_end = kt_begin + p.ktiles_per_split;
     const int ktiles = (p.K + BK - 1) / BK;
@@ -261,20 +280,35 @@ __global__ __launch_bounds__(256) void dwconv_kernel(ConvParams p) {
 #include "conv_igemm64.hpp"
 
 // kind 0: generic (Cin % 8 == 0, BK = 32, register staging); kind 1: Cin % 64 == 0 fast path (BK = 64, LDS-DMA)
-struct TileCfg { int BM, BN, kind; void (*fn)(ConvParams); const char* name; };
+struct TileCfg { int BM, BN, kind, threads; void (*fn)(ConvParams); const char* name; };
 const TileCfg kCfgs[] = {
-    {128, 128, 0, conv_igemm_kernel<128, 128, 2, 2>, "128x128"},
-    {128, 64, 0, conv_igemm_kernel<128, 64, 2, 2>, "128x64"},
-    {64, 128, 0, conv_igemm_kernel<64, 128, 2, 2>, "64x128"},
-    {64, 64, 0, conv_igemm_kernel<64, 64, 2, 2>, "64x64"},
-    {256, 64, 0, conv_igemm_kernel<256, 64, 4, 1>, "256x64"},
-    {256, 128, 0, conv_igemm_kernel<256, 128, 2, 2>, "256x128"},
-    {128, 128, 1, conv_igemm64_kernel<128, 128, 2, 2>, "k64:128x128"},
-    {128, 64, 1, conv_igemm64_kernel<128, 64, 2, 2>, "k64:128x64"},
-    {64, 128, 1, conv_igemm64_kernel<64, 128, 2, 2>, "k64:64x128"},
-    {64, 64, 1, conv_igemm64_kernel<64, 64, 2, 2>, "k64:64x64"},
-    {256, 64, 1, conv_igemm64_kernel<256, 64, 4, 1>, "k64:256x64"},
-    {256, 128, 1, conv_igemm64_kernel<256, 128, 2, 2>, "k64:256x128"},
+    {128, 128, 0, 256, conv_igemm_kernel<128, 128, 2, 2>, "128x128"},
+    {128, 64, 0, 256, conv_igemm_kernel<128, 64, 2, 2>, "128x64"},
+    {64, 128, 0, 256, conv_igemm_kernel<64, 128, 2, 2>, "64x128"},
+    {64, 64, 0, 256, conv_igemm_kernel<64, 64, 2, 2>, "64x64"},
+    {256, 64, 0, 256, conv_igemm_kernel<256, 64, 4, 1>, "256x64"},
+    {256, 128, 0, 256, conv_igemm_kernel<256, 128, 2, 2>, "256x128"},
+    {128, 128, 1, 256, conv_igemm64_kernel<128, 128, 2, 2>, "k64:128x128"},          // 6
+    {128, 64, 1, 256, conv_igemm64_kernel<128, 64, 2, 2>, "k64:128x64"},            // 7
+    {64, 128, 1, 256, conv_igemm64_kernel<64, 128, 2, 2>, "k64:64x128"},            // 8
+    {64, 64, 1, 256, conv_igemm64_kernel<64, 64, 2, 2>, "k64:64x64"},               // 9
+    {256, 64, 1, 256, conv_igemm64_kernel<256, 64, 4, 1>, "k64:256x64"},            // 10
+    {256, 128, 1, 256, conv_igemm64_kernel<256, 128, 2, 2>, "k64:256x128"},         // 11
+    // 3-deep LDS rings with counted vmcnt
+    {128, 64, 1, 256, conv_igemm64_kernel<128, 64, 2, 2, 3>, "k64s3:128x64"},       // 12
+    {64, 64, 1, 256, conv_igemm64_kernel<64, 64, 2, 2, 3>, "k64s3:64x64"},          // 13
+    // 8 waves per block: two waves per SIMD even when the layer gives only one block per CU
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2>, "k64w8:128x128(32x64)"},  // 14
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4>, "k64w8:128x128(64x32)"},  // 15
+    {256, 128, 1, 512, conv_igemm64_kernel<256, 128, 4, 2>, "k64w8:256x128(64x64)"},  // 16
+    {256, 64, 1, 512, conv_igemm64_kernel<256, 64, 4, 2>, "k64w8:256x64(64x32)"},     // 17
+    {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 4, 2>, "k64w8:128x64(32x32)"},     // 18
+    {256, 128, 1, 512, conv_igemm64_kernel<256, 128, 4, 2, 3>, "k64w8s3:256x128"},    // 19
+#ifdef SM_ABLATION   // tools/conv_bench.py only: never built into the product library
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 1>, "abl:w8 noMFMA"},
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 2>, "abl:w8 noGlobal"},
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 3>, "abl:w8 noLdsRead"},
+#endif
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -349,8 +383,15 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     p.ktiles_per_split = sm_ceil_div(ktiles, p.splitk);
     p.splitk = sm_ceil_div(ktiles, p.ktiles_per_split);
     p.ws = p.splitk > 1 ? (float*)ws : nullptr;
-    const int grid = sm_ceil_div(p.mt, SM_NUM_XCD) * SM_NUM_XCD * p.nt * p.splitk;
-    hipLaunchKernelGGL(c.fn, dim3(grid), dim3(256), 0, s, p);
+    // block -> tile order (see map_block): weight-stationary per XCD when the weights outweigh the input tensor
+    const int combos = p.nt * p.splitk;
+    const double a_bytes = 2.0 * p.N * p.H * p.W * p.Cin, b_bytes = 2.0 * p.Cout * p.K;
+    static const int forced_order = getenv("SM_CONV_ORDER") ? atoi(getenv("SM_CONV_ORDER")) : -1;
+    p.order = (combos >= SM_NUM_XCD && b_bytes > a_bytes) ? 1 : 0;
+    if (forced_order == 0 || (forced_order == 1 && combos >= SM_NUM_XCD)) p.order = forced_order;
+    p.mt_per_xcd = sm_ceil_div(p.mt, SM_NUM_XCD); p.cpx = sm_ceil_div(combos, SM_NUM_XCD);
+    const int grid = p.order == 0 ? p.mt_per_xcd * SM_NUM_XCD * combos : p.cpx * SM_NUM_XCD * p.mt;
+    hipLaunchKernelGGL(c.fn, dim3(grid), dim3(c.threads), 0, s, p);
     SM_LAUNCH_CHECK();
     if (p.splitk > 1) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(sm_stream_grid((long)p.M * p.Cout, 256)), dim3(256), 0, s, p);
@@ -385,6 +426,23 @@ int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void*
                       void* ws, size_t ws_bytes, sm_stream_t stream) {
     ConvParams p; int rc = fill_params(d, x, w, bias, res, y, &p); if (rc) return rc;
     return launch(d, p, cfg, ws, ws_bytes, sm_s(stream));
+}
+
+// Times `iters` back-to-back launches with HIP events on `stream` (host launch cost is hidden once the queue is full).
+int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w, const float* bias, const void* res, void* y,
+                   void* ws, size_t ws_bytes, int32_t iters, sm_stream_t stream, float* ms_per_launch) {
+    SM_REQUIRE(iters > 0 && ms_per_launch, "sm_conv2d_time: bad argument");
+    ConvParams p; int rc = fill_params(d, x, w, bias, res, y, &p); if (rc) return rc;
+    hipStream_t s = sm_s(stream);
+    rc = launch(d, p, cfg, ws, ws_bytes, s); if (rc) return rc;
+    hipEvent_t a, b; SM_HIP_CHECK(hipEventCreate(&a)); SM_HIP_CHECK(hipEventCreate(&b));
+    SM_HIP_CHECK(hipEventRecord(a, s));
+    for (int i = 0; i < iters && !rc; i++) rc = launch(d, p, cfg, ws, ws_bytes, s);
+    SM_HIP_CHECK(hipEventRecord(b, s)); SM_HIP_CHECK(hipEventSynchronize(b));
+    float t = 0; SM_HIP_CHECK(hipEventElapsedTime(&t, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = t / iters;
+    return rc;
 }
 
 }  // extern "C"

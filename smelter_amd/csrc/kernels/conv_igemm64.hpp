@@ -1,5 +1,5 @@
 // conv_igemm64.hpp — the fast path of the implicit-GEMM convolution: Cin % 64 == 0 (every ResNet-50 layer but the
-// stem), BK = 64, operands streamed HBM -> LDS by the LDS-DMA (`global_load_lds_dwordx4`, 16 B per lane) with no VGPR
+// stem), BK = 64, operands streamed HBM/L2 -> LDS by the LDS-DMA (`global_load_lds_dwordx4`, 16 B per lane) with no VGPR
 // round trip, epilogue transposed through LDS so that every global access is a full 16-byte lane / 128-byte line.
 // Included by conv_igemm.hip (same ConvParams, same launcher).
 //
@@ -10,8 +10,11 @@
 //    (cdna_hip_programming.md §5.4 rule 21).  With 128-byte rows this makes every 16-lane service group of
 //    ds_read_b128 hit 16 distinct 16-byte slots of the 256-byte bank row (MI355X_MICROARCH.md §LDS).
 //  * Zero padding / ragged tiles: out-of-image taps, rows >= M and couts >= Cout fetch from a zero page.
-//  * Pipeline: 2 LDS stages; tile t+1 is in flight while tile t feeds the MFMAs; __syncthreads() carries the
-//    vmcnt(0) that publishes the DMA'd tile (cdna_hip_programming.md §5 "step-3 structure").
+//  * Pipeline: NSTAGE-deep LDS ring.  NSTAGE == 2: tile t+1 in flight while tile t feeds the MFMAs, __syncthreads()
+//    carries the vmcnt(0) that publishes the DMA'd tile.  NSTAGE >= 3: the layers here are short, latency-bound GEMMs
+//    (M = 3k..200k pixels, 1..72 K tiles per block), so NSTAGE-1 tiles are kept in flight across raw s_barriers with a
+//    COUNTED s_waitcnt vmcnt(N) (cdna_hip_programming.md §5 "Pipelining across barriers", T3+T4): the only wait is for
+//    the oldest tile.
 //  * Epilogue: per wave-row pass, accumulators -> LDS as fp32 [32*TM rows][BN+4] (conflict-free ds_write_b128),
 //    then 256 threads each take 8 consecutive couts of one pixel: + bias + residual (16-byte coalesced load),
 //    activation, ONE rounding to fp16, 16-byte coalesced store.
@@ -23,23 +26,30 @@ __device__ __attribute__((aligned(64))) unsigned int g_zero_page[64];   // zero-
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
                                      (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
-template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void conv_igemm64_kernel(ConvParams p) {
-    static_assert(WGM * WGN == 4, "4 waves");
+template <int N> __device__ __forceinline__ void sm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ABL: ablation switch for tools/conv_bench.py (0 = product; 1 = no MFMA; 2 = no global->LDS traffic after the prologue;
+// 3 = no LDS fragment reads)
+template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams p) {
+    static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
+    constexpr int NT = WGM * WGN * 64;                          // threads per block
+    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 stages");
     constexpr int BK64 = 64;
     constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
-    constexpr int A_IT = BM / 32, B_IT = BN / 32;              // 16-byte pieces per thread per tile
+    constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;      // 16-byte pieces per thread per tile
+    constexpr int RPI = NT / 8;                                 // tile rows covered by one DMA instruction of the whole block
+    static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
+    constexpr int LOADS = A_IT + B_IT;                          // LDS-DMA instructions per wave per tile
     constexpr int STAGE = (BM + BN) * BK64;                     // halfs per stage
     constexpr int EP_ROWS = 32 * TM, EP_LD = BN + 4;            // epilogue staging (floats)
-    constexpr int LDS_BYTES = (2 * STAGE * 2 > EP_ROWS * EP_LD * 4) ? 2 * STAGE * 2 : EP_ROWS * EP_LD * 4;
+    constexpr int LDS_BYTES = (NSTAGE * STAGE * 2 > EP_ROWS * EP_LD * 4) ? NSTAGE * STAGE * 2 : EP_ROWS * EP_LD * 4;
+    static_assert((NSTAGE - 2) * LOADS <= 63, "vmcnt range");
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[LDS_BYTES];
     half_t* smem = (half_t*)smem_raw;
 
-    const int bid = blockIdx.x, xcd = bid & (SM_NUM_XCD - 1), slot = bid >> 3;
-    const int per_m = p.nt * p.splitk;
-    const int mtile = xcd + SM_NUM_XCD * (slot / per_m);
-    if (mtile >= p.mt) return;
-    const int rem = slot % per_m, ntile = rem % p.nt, ksplit = rem / p.nt;
+    int mtile, ntile, ksplit;
+    if (!map_block(p, mtile, ntile, ksplit)) return;
     const int ktiles = p.K / BK64;
     const int kt_begin = ksplit * p.ktiles_per_split;
     int kt_end = kt_begin + p.ktiles_per_split; if (kt_end > ktiles) kt_end = ktiles;
@@ -53,7 +63,7 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(ConvParams p) {
     const half_t* arow[A_IT]; int aiy[A_IT], aix[A_IT];
 #pragma unroll
     for (int j = 0; j < A_IT; j++) {
-        const int m = mtile * BM + j * 32 + (tid >> 3);
+        const int m = mtile * BM + j * RPI + (tid >> 3);
         if (m < p.M) {
             int n = m / (p.Ho * p.Wo), r = m - n * (p.Ho * p.Wo), oy = r / p.Wo, ox = r - oy * p.Wo;
             aiy[j] = oy * p.sH - p.pt; aix[j] = ox * p.sW - p.pl;
@@ -63,7 +73,7 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(ConvParams p) {
     const half_t* brow[B_IT];
 #pragma unroll
     for (int j = 0; j < B_IT; j++) {
-        const int n = ntile * BN + j * 32 + (tid >> 3);
+        const int n = ntile * BN + j * RPI + (tid >> 3);
         brow[j] = n < p.Cout ? p.w + (long)n * p.K + csrc * 8 : nullptr;
     }
     const int cpt = p.Cin / BK64;                               // K tiles per tap
@@ -78,12 +88,12 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(ConvParams p) {
         for (int j = 0; j < A_IT; j++) {
             const bool ok = (unsigned)(aiy[j] + dy) < (unsigned)p.H && (unsigned)(aix[j] + dx) < (unsigned)p.W;
             const half_t* src = ok ? arow[j] + toff : zero;
-            SM_GLDS16(src, sa + j * 256 * 8);
+            SM_GLDS16(src, sa + j * NT * 8);
         }
 #pragma unroll
         for (int j = 0; j < B_IT; j++) {
             const half_t* src = brow[j] ? brow[j] + (long)kt * BK64 : zero;
-            SM_GLDS16(src, sb + j * 256 * 8);
+            SM_GLDS16(src, sb + j * NT * 8);
         }
         if (++cblk == cpt) { cblk = 0; if (++kw == p.kW) { kw = 0; ++kh; } }
     };
@@ -96,27 +106,56 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    issue(0, kt_begin);
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt_begin; kt < kt_end; kt++) {
-        if (kt + 1 < kt_end) issue(cur ^ 1, kt + 1);
-        const half_t* sa = smem + cur * STAGE; const half_t* sb = sa + BM * BK64;
+    auto compute = [&](int buf, bool first) {
+        const half_t* sa = smem + buf * STAGE; const half_t* sb = sa + BM * BK64;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             const int c = ks * 2 + (lane >> 5);
             half8_t fx[TM], fw[TN];
 #pragma unroll
-            for (int b = 0; b < TM; b++) { const int row = (wm * TM + b) * 32 + (lane & 31); fx[b] = *(const half8_t*)(sa + row * BK64 + ((c ^ ((row >> 1) & 7)) << 3)); }
+            for (int b = 0; b < TM; b++) { const int row = (wm * TM + b) * 32 + (lane & 31); if (ABL != 3 || first) fx[b] = *(const half8_t*)(sa + row * BK64 + ((c ^ ((row >> 1) & 7)) << 3)); }
 #pragma unroll
-            for (int a = 0; a < TN; a++) { const int row = (wn * TN + a) * 32 + (lane & 31); fw[a] = *(const half8_t*)(sb + row * BK64 + ((c ^ ((row >> 1) & 7)) << 3)); }
+            for (int a = 0; a < TN; a++) { const int row = (wn * TN + a) * 32 + (lane & 31); if (ABL != 3 || first) fw[a] = *(const half8_t*)(sb + row * BK64 + ((c ^ ((row >> 1) & 7)) << 3)); }
 #pragma unroll
             for (int a = 0; a < TN; a++)
 #pragma unroll
-                for (int b = 0; b < TM; b++) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[a], fx[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TM; b++) {
+                    if (ABL != 1) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[a], fx[b], acc[a][b], 0, 0, 0);
+                    else { asm volatile("" ::"v"(fw[a]), "v"(fx[b])); }
+                }
         }
+    };
+
+    if constexpr (NSTAGE == 2) {
+        issue(0, kt_begin);
         __syncthreads();
-        cur ^= 1;
+        int cur = 0;
+        for (int kt = kt_begin; kt < kt_end; kt++) {
+            if (kt + 1 < kt_end && ABL != 2) issue(cur ^ 1, kt + 1);
+            compute(cur, kt == kt_begin);
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        // tile t lives in ring slot (t - kt_begin) % NSTAGE
+        int issued = kt_begin;
+#pragma unroll
+        for (int s = 0; s < NSTAGE - 1; s++) if (issued < kt_end) { issue(s, issued); ++issued; }
+        int slot = 0, islot = NSTAGE - 1;
+        for (int kt = kt_begin; kt < kt_end; kt++) {
+            const int newer = issued - kt - 1;                  // tiles issued after tile kt, allowed to stay in flight
+            if (newer >= 2) sm_wait_vmcnt<(NSTAGE >= 4 ? 2 : 0) * LOADS>();
+            else if (newer == 1) sm_wait_vmcnt<(NSTAGE >= 3 ? 1 : 0) * LOADS>();
+            else sm_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();                       // everybody's share of tile kt landed; slot of tile kt-1 is free
+            __builtin_amdgcn_sched_barrier(0);
+            if (issued < kt_end && ABL != 2) { issue(islot, issued); ++issued; }
+            if (++islot == NSTAGE) islot = 0;
+            compute(slot, kt == kt_begin);
+            if (++slot == NSTAGE) slot = 0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragment reads are done before it passes the next barrier
+        }
+        __builtin_amdgcn_s_barrier();
     }
 
     // ---- epilogue: LDS transpose, coalesced 16-byte global accesses ---------------------------------------------
@@ -138,7 +177,7 @@ __global__ __launch_bounds__(256) void conv_igemm64_kernel(ConvParams p) {
                     }
         }
         __syncthreads();
-        for (int it = tid; it < ITEMS; it += 256) {
+        for (int it = tid; it < ITEMS; it += NT) {
             const int row = it / CHUNKS, ch = it - row * CHUNKS;
             const int m = mtile * BM + pw * EP_ROWS + row, co = ntile * BN + ch * 8;
             if (m >= p.M || co >= p.Cout) continue;

@@ -1,0 +1,31 @@
+"""Single-layer convolution micro-benchmark (tile config sweep / ablations / rocprofv3 --pmc target).
+    python tools/conv_bench.py --shape 64,56,56,64,64,3,1,1 [--cfg 7] [--iters 50]      shape = N,H,W,Cin,Cout,k,s,p
+"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from smelter_amd import ops
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--shape", default="64,56,56,64,64,3,1,1")
+ap.add_argument("--cfg", default="all")
+ap.add_argument("--iters", type=int, default=30)
+ap.add_argument("--res", action="store_true")
+a = ap.parse_args()
+n, h, w, cin, cout, k, s, p = map(int, a.shape.split(","))
+x = torch.randn((n, h, w, cin), device="cuda").half()
+wt = (torch.randn((cout, k, k, cin), device="cuda") * (2.0 / (cin * k * k)) ** 0.5).half()
+b = torch.randn(cout, device="cuda")
+ho, wo = ops.conv_out_size(h, w, k, k, s, s, (p, p, p, p))
+y = torch.empty((n, ho, wo, cout), device="cuda", dtype=torch.float16)
+r = torch.randn((n, ho, wo, cout), device="cuda").half() if a.res else None
+flops = 2.0 * n * ho * wo * cout * cin * k * k
+byts = 2.0 * (x.numel() + y.numel() * (2 if a.res else 1) + wt.numel())
+cfgs = range(ops.num_conv_configs()) if a.cfg == "all" else [int(c) for c in a.cfg.split(",")]
+for cfg in cfgs:
+    try:
+        ms = ops.conv2d_time(x, wt, b, residual=r, stride=(s, s), pads=(p, p, p, p), act=1, cfg=cfg, iters=a.iters, out=y)
+    except Exception as e:
+        continue
+    us = ms * 1e3
+    print("cfg %2d  %8.1f us  %7.1f TFLOP/s  %6.2f TB/s (compulsory)" % (cfg, us, flops / us / 1e6, byts / us / 1e6))
