@@ -233,6 +233,10 @@ int smelter_exec_num_values(const smelter_exec* e);
 const char* smelter_exec_value_name(const smelter_exec* e, int32_t idx);
 /* time one op `idx` in isolation (iters launches, HIP events); ms per launch */
 int smelter_exec_time_op(smelter_exec* e, sm_stream_t stream, int32_t idx, int32_t iters, float* ms);
+/* in-situ per-launch timing: `iters` eager passes over the whole sequence with HIP events on `stream` between
+ * consecutive launches.  ms[0] = input conversion, ms[1 + i] = op i; cap >= num_ops + 1. */
+int smelter_exec_profile(smelter_exec* e, sm_stream_t stream, const float* in_nchw_f32, int32_t iters, float* ms,
+                         int32_t cap);
 /* fetch an intermediate value by ONNX name after an encode (debug / layer parity); NCHW fp32 to host */
 int smelter_exec_read_value(smelter_exec* e, sm_stream_t stream, const char* name, float* dst, size_t cap,
                             int32_t* c, int32_t* h, int32_t* w);

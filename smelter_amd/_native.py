@@ -118,6 +118,7 @@ SYMBOLS = {
     "smelter_exec_num_values": (_i32, [_vp]),
     "smelter_exec_value_name": (C.c_char_p, [_vp, _i32]),
     "smelter_exec_time_op": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_f)]),
+    "smelter_exec_profile": (_i32, [_vp, _vp, _vp, _i32, C.POINTER(_f), _i32]),
     "smelter_exec_read_value": (_i32, [_vp, _vp, C.c_char_p, _vp, _sz, _pi32, _pi32, _pi32]),
 }
 

@@ -95,6 +95,10 @@ int smelter_exec_time_op(smelter_exec* e, sm_stream_t s, int32_t idx, int32_t it
     SM_REQUIRE(e && ms, "smelter_exec_time_op: null argument");
     return e->e->timeOp((hipStream_t)s, idx, iters, ms);
 }
+int smelter_exec_profile(smelter_exec* e, sm_stream_t s, const float* in, int32_t iters, float* ms, int32_t cap) {
+    SM_REQUIRE(e, "smelter_exec_profile: null executor");
+    return e->e->profile((hipStream_t)s, in, iters, ms, cap);
+}
 int smelter_exec_read_value(smelter_exec* e, sm_stream_t s, const char* name, float* dst, size_t cap, int32_t* c, int32_t* h, int32_t* w) {
     SM_REQUIRE(e && name && dst && c && h && w, "smelter_exec_read_value: null argument");
     return e->e->readValue((hipStream_t)s, name, dst, cap, c, h, w);

@@ -446,6 +446,27 @@ int Executor::timeOp(hipStream_t s, int idx, int iters, float* ms) {
     return rc;
 }
 
+int Executor::profile(hipStream_t s, const float* in, int iters, float* ms, int cap) {
+    const int n = (int)steps_.size() + 1;
+    if (!in || !ms || cap < n || iters <= 0) { sm_set_error("smelter_exec_profile: bad argument"); return SM_ERR_INVALID_ARGUMENT; }
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev) SM_HIP_CHECK(hipEventCreate(&e));
+    std::vector<double> acc(n, 0.0);
+    const Value& iv = values_[input_value_];
+    int rc = SM_OK;
+    for (int it = 0; it < iters + 1 && !rc; it++) {          // pass 0 = warm-up, not accumulated
+        SM_HIP_CHECK(hipEventRecord(ev[0], s));
+        rc = sm_nchw_f32_to_nhwc_f16(in, valuePtr(input_value_), batch_, iv.c, iv.h, iv.w, input_ld_, 0, 0, 0, 0, (sm_stream_t)s);
+        SM_HIP_CHECK(hipEventRecord(ev[1], s));
+        for (int i = 0; i < n - 1 && !rc; i++) { rc = launchStep(steps_[i], s); SM_HIP_CHECK(hipEventRecord(ev[i + 2], s)); }
+        SM_HIP_CHECK(hipStreamSynchronize(s));
+        if (it > 0) for (int i = 0; i < n; i++) { float t = 0; SM_HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1])); acc[i] += t; }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < n; i++) ms[i] = (float)(acc[i] / iters);
+    return rc;
+}
+
 int Executor::autotune(hipStream_t s) {
     const int ncfg = sm_conv2d_num_configs();
     for (size_t i = 0; i < steps_.size(); i++) {

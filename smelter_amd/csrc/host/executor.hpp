@@ -42,6 +42,9 @@ class Executor {
     int readFloat(hipStream_t s, float* dst, size_t cap, int layout);
     int readValue(hipStream_t s, const char* name, float* dst, size_t cap, int* c, int* h, int* w);
     int timeOp(hipStream_t s, int idx, int iters, float* ms);
+    // in-situ timing: `iters` full eager passes with HIP events between consecutive launches on `s`;
+    // ms[0] = input conversion, ms[1 + i] = op i (averages).  cap >= numOps() + 1.
+    int profile(hipStream_t s, const float* in, int iters, float* ms, int cap);
 
     int batch() const { return batch_; }
     void outputDims(int* n, int* c, int* h, int* w) const;

@@ -307,7 +307,6 @@ const TileCfg kCfgs[] = {
 #ifdef SM_ABLATION   // tools/conv_bench.py only: never built into the product library
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 1>, "abl:w8 noMFMA"},
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 2>, "abl:w8 noGlobal"},
-    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 3>, "abl:w8 noLdsRead"},
 #endif
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);

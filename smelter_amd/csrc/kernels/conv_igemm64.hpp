@@ -19,6 +19,7 @@
 //    then 256 threads each take 8 consecutive couts of one pixel: + bias + residual (16-byte coalesced load),
 //    activation, ONE rounding to fp16, 16-byte coalesced store.
 #pragma once
+#include <type_traits>
 
 __device__ __attribute__((aligned(64))) unsigned int g_zero_page[64];   // zero-initialised at module load
 
@@ -30,7 +31,7 @@ template <int N> __device__ __forceinline__ void sm_wait_vmcnt() { asm volatile(
 
 // ABL: ablation switch for tools/conv_bench.py (0 = product; 1 = no MFMA; 2 = no global->LDS traffic after the prologue;
 // 3 = no LDS fragment reads)
-template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams p) {
     static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
     constexpr int NT = WGM * WGN * 64;                          // threads per block
@@ -79,23 +80,35 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
     const int cpt = p.Cin / BK64;                               // K tiles per tap
     int tap = kt_begin / cpt, kh = tap / p.kW, kw = tap - kh * p.kW, cblk = kt_begin - tap * cpt;
 
+    // LDS-DMA of one K tile = LOADS instructions per wave.  ILV = 1 spreads them behind the MFMAs of each k-step of the
+    // tile being computed; measured on MI355X this is SLOWER than issuing the whole burst first (14x14 3x3 256->256:
+    // 35.3 vs 28.8 us; the tile then lands later and the barrier wait grows), so ILV = 0 is the default.
+    struct TileSrc { half_t* sa; half_t* sb; int dy, dx; long toff; long koff; };
+    auto tile_src = [&](int buf, int kt) {
+        TileSrc t;
+        t.sa = smem + buf * STAGE + (wave * 64) * 8;            // wave-uniform LDS base; lane*16 B added by the DMA
+        t.sb = smem + buf * STAGE + BM * BK64 + (wave * 64) * 8;
+        t.dy = kh * p.dH; t.dx = kw * p.dW;
+        t.toff = ((long)t.dy * p.W + t.dx) * p.x_ld + cblk * BK64;
+        t.koff = (long)kt * BK64;
+        if (++cblk == cpt) { cblk = 0; if (++kw == p.kW) { kw = 0; ++kh; } }   // advance to the following tile
+        return t;
+    };
+    auto piece = [&](const TileSrc& t, int i) {                 // i-th DMA instruction of the tile, 0 <= i < LOADS
+        if (i < A_IT) {
+            const bool ok = (unsigned)(aiy[i] + t.dy) < (unsigned)p.H && (unsigned)(aix[i] + t.dx) < (unsigned)p.W;
+            const half_t* src = ok ? arow[i] + t.toff : zero;
+            SM_GLDS16(src, t.sa + i * NT * 8);
+        } else {
+            const int j = i - A_IT;
+            const half_t* src = brow[j] ? brow[j] + t.koff : zero;
+            SM_GLDS16(src, t.sb + j * NT * 8);
+        }
+    };
     auto issue = [&](int buf, int kt) {
-        half_t* sa = smem + buf * STAGE + (wave * 64) * 8;      // wave-uniform LDS base; lane*16 B added by the DMA
-        half_t* sb = smem + buf * STAGE + BM * BK64 + (wave * 64) * 8;
-        const int dy = kh * p.dH, dx = kw * p.dW;
-        const long toff = ((long)dy * p.W + dx) * p.x_ld + cblk * BK64;
+        const TileSrc t = tile_src(buf, kt);
 #pragma unroll
-        for (int j = 0; j < A_IT; j++) {
-            const bool ok = (unsigned)(aiy[j] + dy) < (unsigned)p.H && (unsigned)(aix[j] + dx) < (unsigned)p.W;
-            const half_t* src = ok ? arow[j] + toff : zero;
-            SM_GLDS16(src, sa + j * NT * 8);
-        }
-#pragma unroll
-        for (int j = 0; j < B_IT; j++) {
-            const half_t* src = brow[j] ? brow[j] + (long)kt * BK64 : zero;
-            SM_GLDS16(src, sb + j * NT * 8);
-        }
-        if (++cblk == cpt) { cblk = 0; if (++kw == p.kW) { kw = 0; ++kh; } }
+        for (int i = 0; i < LOADS; i++) piece(t, i);
     };
 
     floatx16 acc[TN][TM];
@@ -106,8 +119,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
-    auto compute = [&](int buf, bool first) {
+    // MFMAs of the tile in `buf`; when `nxt >= 0` the DMA of tile `kt_next` into slot `nxt` is interleaved
+    auto compute = [&](int buf, bool first, int nxt, int kt_next) {
         const half_t* sa = smem + buf * STAGE; const half_t* sb = sa + BM * BK64;
+        TileSrc t{};
+        const bool dma = nxt >= 0 && ABL != 2;
+        if (dma) { t = tile_src(nxt, kt_next); if (!ILV) {
+#pragma unroll
+            for (int i = 0; i < LOADS; i++) piece(t, i); } }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
             const int c = ks * 2 + (lane >> 5);
@@ -123,6 +142,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
                     if (ABL != 1) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[a], fx[b], acc[a][b], 0, 0, 0);
                     else { asm volatile("" ::"v"(fw[a]), "v"(fx[b])); }
                 }
+            if (ILV && dma) {
+#pragma unroll
+                for (int i = (ks * LOADS) / 4; i < ((ks + 1) * LOADS) / 4; i++) piece(t, i);
+            }
         }
     };
 
@@ -131,13 +154,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
         __syncthreads();
         int cur = 0;
         for (int kt = kt_begin; kt < kt_end; kt++) {
-            if (kt + 1 < kt_end && ABL != 2) issue(cur ^ 1, kt + 1);
-            compute(cur, kt == kt_begin);
+            compute(cur, kt == kt_begin, kt + 1 < kt_end ? (cur ^ 1) : -1, kt + 1);
             __syncthreads();
             cur ^= 1;
         }
     } else {
-        // tile t lives in ring slot (t - kt_begin) % NSTAGE
+        // tile t lives in ring slot (t - kt_begin) % NSTAGE; NSTAGE-1 tiles in flight across raw barriers, counted vmcnt
         int issued = kt_begin;
 #pragma unroll
         for (int s = 0; s < NSTAGE - 1; s++) if (issued < kt_end) { issue(s, issued); ++issued; }
@@ -149,9 +171,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
             else sm_wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                       // everybody's share of tile kt landed; slot of tile kt-1 is free
             __builtin_amdgcn_sched_barrier(0);
-            if (issued < kt_end && ABL != 2) { issue(islot, issued); ++issued; }
+            const bool more = issued < kt_end;
+            compute(slot, kt == kt_begin, more ? islot : -1, issued);
+            if (more) ++issued;
             if (++islot == NSTAGE) islot = 0;
-            compute(slot, kt == kt_begin);
             if (++slot == NSTAGE) slot = 0;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragment reads are done before it passes the next barrier
         }

@@ -194,6 +194,13 @@ class Executor:
     def opDesc(self, idx: int) -> str:
         return N.lib().smelter_exec_op_desc(self._h, idx).decode()
 
+    def profile(self, images, iters: int = 10, stream=None):
+        """in-situ per-launch times (ms): [input conversion, op 0, op 1, ...], HIP events between launches"""
+        n = self.numOps + 1
+        arr = (C.c_float * n)()
+        N.check(N.lib().smelter_exec_profile(self._h, _stream_ptr(stream), C.c_void_p(images.data_ptr()), iters, arr, n))
+        return list(arr)
+
     def timeOp(self, idx: int, iters: int = 10, stream=None) -> float:
         ms = C.c_float()
         N.check(N.lib().smelter_exec_time_op(self._h, _stream_ptr(stream), idx, iters, C.byref(ms)))
