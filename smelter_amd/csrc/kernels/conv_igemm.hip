@@ -34,6 +34,7 @@ struct ConvParams {
     int x_ld, y_ld, res_ld, act; float slope;
     int M, K, mt, nt, splitk, ktiles_per_split;
     int order, mt_per_xcd, cpx;      // block -> tile map (map_block)
+    int krot;                        // rotate the K loop start per block (conv_igemm64.hpp)
 };
 
 constexpr int BK = 32;
@@ -304,6 +305,18 @@ const TileCfg kCfgs[] = {
     {256, 64, 1, 512, conv_igemm64_kernel<256, 64, 4, 2>, "k64w8:256x64(64x32)"},     // 17
     {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 4, 2>, "k64w8:128x64(32x32)"},     // 18
     {256, 128, 1, 512, conv_igemm64_kernel<256, 128, 4, 2, 3>, "k64w8s3:256x128"},    // 19
+    // 4-deep rings: every K tile of a K <= 256 layer in flight at once
+    {128, 64, 1, 256, conv_igemm64_kernel<128, 64, 2, 2, 4>, "k64s4:128x64"},         // 20
+    {64, 64, 1, 256, conv_igemm64_kernel<64, 64, 2, 2, 4>, "k64s4:64x64"},            // 21
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 4>, "k64w8s4:128x128"},    // 22
+    {64, 128, 1, 256, conv_igemm64_kernel<64, 128, 2, 2, 4>, "k64s4:64x128"},         // 23
+    // single LDS stage for K == 64: half the LDS, twice the resident blocks (memory-level parallelism)
+    {128, 128, 2, 256, conv_igemm64_kernel<128, 128, 2, 2, 1>, "k64s1:128x128"},      // 24
+    {128, 128, 2, 512, conv_igemm64_kernel<128, 128, 4, 2, 1>, "k64w8s1:128x128"},    // 25
+    {128, 64, 2, 256, conv_igemm64_kernel<128, 64, 2, 2, 1>, "k64s1:128x64"},         // 26
+    {64, 64, 2, 256, conv_igemm64_kernel<64, 64, 2, 2, 1>, "k64s1:64x64"},            // 27
+    {256, 64, 2, 512, conv_igemm64_kernel<256, 64, 4, 2, 1>, "k64w8s1:256x64"},       // 28
+    {64, 128, 2, 256, conv_igemm64_kernel<64, 128, 2, 2, 1>, "k64s1:64x128"},         // 29
 #ifdef SM_ABLATION   // tools/conv_bench.py only: never built into the product library
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 1>, "abl:w8 noMFMA"},
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 2>, "abl:w8 noGlobal"},
@@ -311,7 +324,8 @@ const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-bool cfg_eligible(const TileCfg& c, const ConvParams& p) { return c.kind == 0 || (p.Cin % 64) == 0; }
+// kind 2 = single LDS stage: only for K == 64 (one K tile)
+bool cfg_eligible(const TileCfg& c, const ConvParams& p) { return c.kind == 0 || ((p.Cin % 64) == 0 && (c.kind == 1 || p.K == 64)); }
 
 int pick_cfg(const ConvParams& p) {
     // largest tile that still gives >= ~2 blocks per CU; otherwise the one with the most blocks
@@ -389,6 +403,10 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     p.order = (combos >= SM_NUM_XCD && b_bytes > a_bytes) ? 1 : 0;
     if (forced_order == 0 || (forced_order == 1 && combos >= SM_NUM_XCD)) p.order = forced_order;
     p.mt_per_xcd = sm_ceil_div(p.mt, SM_NUM_XCD); p.cpx = sm_ceil_div(combos, SM_NUM_XCD);
+    // off by default: it makes an image's fp32 accumulation order depend on its position in the batch (results stay
+    // deterministic, but the bit-exact batch-permutation invariance is lost) and bought < 1 % on the whole network
+    static const int krot = getenv("SM_CONV_KROT") ? atoi(getenv("SM_CONV_KROT")) : 0;
+    p.krot = krot;
     const int grid = p.order == 0 ? p.mt_per_xcd * SM_NUM_XCD * combos : p.cpx * SM_NUM_XCD * p.mt;
     hipLaunchKernelGGL(c.fn, dim3(grid), dim3(c.threads), 0, s, p);
     SM_LAUNCH_CHECK();
@@ -435,10 +453,25 @@ int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w,
     hipStream_t s = sm_s(stream);
     rc = launch(d, p, cfg, ws, ws_bytes, s); if (rc) return rc;
     hipEvent_t a, b; SM_HIP_CHECK(hipEventCreate(&a)); SM_HIP_CHECK(hipEventCreate(&b));
-    SM_HIP_CHECK(hipEventRecord(a, s));
-    for (int i = 0; i < iters && !rc; i++) rc = launch(d, p, cfg, ws, ws_bytes, s);
-    SM_HIP_CHECK(hipEventRecord(b, s)); SM_HIP_CHECK(hipEventSynchronize(b));
-    float t = 0; SM_HIP_CHECK(hipEventElapsedTime(&t, a, b));
+    float t = 0;
+    if (getenv("SM_TIME_COLD")) {
+        // cold-cache timing: in a network every layer finds its weights in HBM and its input in HBM / Infinity Cache,
+        // not in a cache warmed by the previous launch of the same kernel -> evict (768 MB memset) before each launch
+        static char* scratch = nullptr; const size_t sbytes = (size_t)768 << 20;
+        if (!scratch) SM_HIP_CHECK(hipMalloc((void**)&scratch, sbytes));
+        for (int i = 0; i < iters && !rc; i++) {
+            SM_HIP_CHECK(hipMemsetAsync(scratch, i & 0xff, sbytes, s));
+            SM_HIP_CHECK(hipEventRecord(a, s));
+            rc = launch(d, p, cfg, ws, ws_bytes, s);
+            SM_HIP_CHECK(hipEventRecord(b, s)); SM_HIP_CHECK(hipEventSynchronize(b));
+            float ti = 0; SM_HIP_CHECK(hipEventElapsedTime(&ti, a, b)); t += ti;
+        }
+    } else {
+        SM_HIP_CHECK(hipEventRecord(a, s));
+        for (int i = 0; i < iters && !rc; i++) rc = launch(d, p, cfg, ws, ws_bytes, s);
+        SM_HIP_CHECK(hipEventRecord(b, s)); SM_HIP_CHECK(hipEventSynchronize(b));
+        SM_HIP_CHECK(hipEventElapsedTime(&t, a, b));
+    }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *ms_per_launch = t / iters;
     return rc;

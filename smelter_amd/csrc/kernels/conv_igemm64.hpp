@@ -35,7 +35,7 @@ template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams p) {
     static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
     constexpr int NT = WGM * WGN * 64;                          // threads per block
-    static_assert(NSTAGE >= 2 && NSTAGE <= 4, "2..4 stages");
+    static_assert(NSTAGE >= 1 && NSTAGE <= 4, "1..4 stages");
     constexpr int BK64 = 64;
     constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
     constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;      // 16-byte pieces per thread per tile
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
     constexpr int STAGE = (BM + BN) * BK64;                     // halfs per stage
     constexpr int EP_ROWS = 32 * TM, EP_LD = BN + 4;            // epilogue staging (floats)
     constexpr int LDS_BYTES = (NSTAGE * STAGE * 2 > EP_ROWS * EP_LD * 4) ? NSTAGE * STAGE * 2 : EP_ROWS * EP_LD * 4;
-    static_assert((NSTAGE - 2) * LOADS <= 63, "vmcnt range");
+    static_assert(NSTAGE < 3 || (NSTAGE - 2) * LOADS <= 63, "vmcnt range");
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[LDS_BYTES];
     half_t* smem = (half_t*)smem_raw;
 
@@ -77,8 +77,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
         const int n = ntile * BN + j * RPI + (tid >> 3);
         brow[j] = n < p.Cout ? p.w + (long)n * p.K + csrc * 8 : nullptr;
     }
+    // Residual operand (fused MPSNNAdditionNode): its loads do not depend on the GEMM, so they are put in flight FIRST
+    // (16-byte coalesced, same (row, chunk) ownership as the epilogue stores) and consumed ~a whole K loop later.
+    constexpr int CHUNKS = BN / 8, ITEMS = EP_ROWS * CHUNKS, IPT = (ITEMS + NT - 1) / NT;
+    const bool vec_ok = ((p.y_ld & 7) == 0) && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && ((p.Cout & 7) == 0) &&
+                        (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0));
+    half8_t rres[WGM][IPT];
+    if (p.res && vec_ok && p.splitk == 1) {
+#pragma unroll
+        for (int pw = 0; pw < WGM; pw++)
+#pragma unroll
+            for (int k2 = 0; k2 < IPT; k2++) {
+                const int it = tid + k2 * NT, row = it / CHUNKS, ch = it - row * CHUNKS;
+                const int m = mtile * BM + pw * EP_ROWS + row, co = ntile * BN + ch * 8;
+                half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (it < ITEMS && m < p.M && co < p.Cout) v = *(const half8_t*)(p.res + (long)m * p.res_ld + co);
+                rres[pw][k2] = v;
+            }
+    }
     const int cpt = p.Cin / BK64;                               // K tiles per tap
-    int tap = kt_begin / cpt, kh = tap / p.kW, kw = tap - kh * p.kW, cblk = kt_begin - tap * cpt;
+    // K rotation: the blocks that run concurrently on one XCD share weight tiles.  If they all walk K in the same order,
+    // every weight tile is a first touch (HBM latency) for all of them at once, once per K tile; starting each block at a
+    // different K tile makes a tile a miss for ONE block and an L2 hit for the others.
+    const int nk = kt_end - kt_begin;
+    const int rot = p.krot ? (mtile * 5 + ntile * 3) % nk : 0;
+    auto kt_of = [&](int i) { int r = i + rot; if (r >= nk) r -= nk; return kt_begin + r; };   // i-th tile this block processes
 
     // LDS-DMA of one K tile = LOADS instructions per wave.  ILV = 1 spreads them behind the MFMAs of each k-step of the
     // tile being computed; measured on MI355X this is SLOWER than issuing the whole burst first (14x14 3x3 256->256:
@@ -88,10 +111,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
         TileSrc t;
         t.sa = smem + buf * STAGE + (wave * 64) * 8;            // wave-uniform LDS base; lane*16 B added by the DMA
         t.sb = smem + buf * STAGE + BM * BK64 + (wave * 64) * 8;
+        const int tap = kt / cpt, cblk = kt - tap * cpt, kh = tap / p.kW, kw = tap - kh * p.kW;     // wave-uniform (SALU)
         t.dy = kh * p.dH; t.dx = kw * p.dW;
         t.toff = ((long)t.dy * p.W + t.dx) * p.x_ld + cblk * BK64;
         t.koff = (long)kt * BK64;
-        if (++cblk == cpt) { cblk = 0; if (++kw == p.kW) { kw = 0; ++kh; } }   // advance to the following tile
         return t;
     };
     auto piece = [&](const TileSrc& t, int i) {                 // i-th DMA instruction of the tile, 0 <= i < LOADS
@@ -149,30 +172,41 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
         }
     };
 
-    if constexpr (NSTAGE == 2) {
-        issue(0, kt_begin);
+    if (nk <= NSTAGE) {
+        // short K (the 1x1 convs with Cin <= 64*NSTAGE are HBM-streaming layers): everything this block will ever read
+        // is put in flight at once — no serialised round trips, maximum bytes in flight per CU — then one barrier.
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) if (i < nk) issue(i, kt_of(i));
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NSTAGE; i++) if (i < nk) compute(i, i == 0, -1, 0);
+        __syncthreads();
+    } else if constexpr (NSTAGE == 1) {
+        return;                                                   // the launcher never selects a 1-stage config for K > 64
+    } else if constexpr (NSTAGE == 2) {
+        issue(0, kt_of(0));
         __syncthreads();
         int cur = 0;
-        for (int kt = kt_begin; kt < kt_end; kt++) {
-            compute(cur, kt == kt_begin, kt + 1 < kt_end ? (cur ^ 1) : -1, kt + 1);
+        for (int i = 0; i < nk; i++) {
+            compute(cur, i == 0, i + 1 < nk ? (cur ^ 1) : -1, kt_of(i + 1 < nk ? i + 1 : i));
             __syncthreads();
             cur ^= 1;
         }
     } else {
         // tile t lives in ring slot (t - kt_begin) % NSTAGE; NSTAGE-1 tiles in flight across raw barriers, counted vmcnt
-        int issued = kt_begin;
+        int issued = 0;
 #pragma unroll
-        for (int s = 0; s < NSTAGE - 1; s++) if (issued < kt_end) { issue(s, issued); ++issued; }
+        for (int s = 0; s < NSTAGE - 1; s++) if (issued < nk) { issue(s, kt_of(issued)); ++issued; }
         int slot = 0, islot = NSTAGE - 1;
-        for (int kt = kt_begin; kt < kt_end; kt++) {
-            const int newer = issued - kt - 1;                  // tiles issued after tile kt, allowed to stay in flight
+        for (int i = 0; i < nk; i++) {
+            const int newer = issued - i - 1;                   // tiles issued after tile i, allowed to stay in flight
             if (newer >= 2) sm_wait_vmcnt<(NSTAGE >= 4 ? 2 : 0) * LOADS>();
             else if (newer == 1) sm_wait_vmcnt<(NSTAGE >= 3 ? 1 : 0) * LOADS>();
             else sm_wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();                       // everybody's share of tile kt landed; slot of tile kt-1 is free
             __builtin_amdgcn_sched_barrier(0);
-            const bool more = issued < kt_end;
-            compute(slot, kt == kt_begin, more ? islot : -1, issued);
+            const bool more = issued < nk;
+            compute(slot, i == 0, more ? islot : -1, kt_of(more ? issued : i));
             if (more) ++issued;
             if (++islot == NSTAGE) islot = 0;
             if (++slot == NSTAGE) slot = 0;
@@ -183,10 +217,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
 
     // ---- epilogue: LDS transpose, coalesced 16-byte global accesses ---------------------------------------------
     float* stg = (float*)smem_raw;
-    const bool vec_ok = ((p.y_ld & 7) == 0) && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && ((p.Cout & 7) == 0) &&
-                        (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0));
-    constexpr int CHUNKS = BN / 8, ITEMS = EP_ROWS * CHUNKS;
-#pragma unroll 1
+#pragma unroll
     for (int pw = 0; pw < WGM; pw++) {
         if (wm == pw) {
 #pragma unroll
@@ -200,7 +231,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
                     }
         }
         __syncthreads();
-        for (int it = tid; it < ITEMS; it += NT) {
+#pragma unroll
+        for (int k2 = 0; k2 < IPT; k2++) {
+            const int it = tid + k2 * NT;
+            if (it >= ITEMS) continue;
             const int row = it / CHUNKS, ch = it - row * CHUNKS;
             const int m = mtile * BM + pw * EP_ROWS + row, co = ntile * BN + ch * 8;
             if (m >= p.M || co >= p.Cout) continue;
@@ -216,7 +250,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
                 if (p.bias) { floatx4 b0 = *(const floatx4*)(p.bias + co), b1 = *(const floatx4*)(p.bias + co + 4);
 #pragma unroll
                     for (int j = 0; j < 4; j++) { v[j] += b0[j]; v[4 + j] += b1[j]; } }
-                if (p.res) { half8_t rr = *(const half8_t*)(p.res + (long)m * p.res_ld + co);
+                if (p.res) { const half8_t rr = rres[pw][k2];     // prefetched before the main loop
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[j] += (float)rr[j]; }
                 half8_t o;

@@ -52,7 +52,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg", [None] + list(range(20)))
+@pytest.mark.parametrize("cfg", [None] + list(range(30)))
 def test_conv2d(case, cfg):
     n, hh, ww, cin, cout, k, s, p, res, act = case
     if cfg is not None and (cin % 8 or cfg >= ops.num_conv_configs() or (cfg >= 6 and cin % 64)):
@@ -69,8 +69,14 @@ def test_conv2d(case, cfg):
     slope = 0.25 if act == 2 else 0.0
     if act:
         ref = np.where(ref >= 0, ref, ref * slope)
-    y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), residual=to_dev(r) if res else None,
-                   stride=(s, s), pads=(p, p, p, p), act=act, slope=slope, cfg=cfg)
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), residual=to_dev(r) if res else None,
+                       stride=(s, s), pads=(p, p, p, p), act=act, slope=slope, cfg=cfg)
+    except SmelterError as e:
+        if cfg is not None and "does not apply" in e.detail:      # e.g. the single-stage configs need K == 64
+            pytest.skip(e.detail)
+        raise
     assert_close(to_host(y), ref, cin * k * k)
 
 

@@ -73,3 +73,14 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def last_step_listing(path, steps):
+    """per-dispatch durations of the last complete encode() step, in launch order"""
+    rows = load(path)
+    starts = [i for i, r in enumerate(rows) if "nchw_to_nhwc" in r[2]]
+    lo, hi = starts[-2], starts[-1]
+    out = []
+    for s, e, n in rows[lo:hi]:
+        out.append(((e - s) / 1e3, short(n)))
+    return out
