@@ -278,6 +278,69 @@ __global__ __launch_bounds__(256) void dwconv_kernel(ConvParams p) {
     }
 }
 
+// 3x3 depthwise, stride S (MobileNet-v2: 17 layers, all HBM-bound: 2 bytes in + 2 bytes out per 18 FLOPs).
+// One thread = 8 consecutive channels x a strip of PX output pixels of one row.  The 72 weights of its 8 channels are
+// 144 CONTIGUOUS bytes of the OHWI tensor [C][3][3][1] -> nine 16-byte loads (the generic kernel issued 72 scalar ones);
+// the (PX-1)*S+3 input columns of each of the 3 rows are loaded once (16 B each, zero outside the image) and shared by
+// the PX outputs; consecutive threads take consecutive channel vectors of the same strip -> fully coalesced.
+template <int S, int PX>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
+    constexpr int IW = (PX - 1) * S + 3;
+    const int cv = p.Cout >> 3, strips = (p.Wo + PX - 1) / PX;
+    const long total = (long)p.N * p.Ho * strips * cv;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cv) * 8; long t = i / cv;
+        const int st = (int)(t % strips); t /= strips;
+        const int oy = (int)(t % p.Ho), n = (int)(t / p.Ho);
+        const int ox0 = st * PX, iy0 = oy * S - p.pt, ix0 = ox0 * S - p.pl;
+        half8_t wv[9];
+        const half8_t* wp = (const half8_t*)(p.w + (long)c0 * 9);
+#pragma unroll
+        for (int q = 0; q < 9; q++) wv[q] = wp[q];
+        float acc[PX][8];
+#pragma unroll
+        for (int o = 0; o < PX; o++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[o][j] = p.bias ? p.bias[c0 + j] : 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++) {
+            const int iy = iy0 + kh;
+            const bool rowok = (unsigned)iy < (unsigned)p.H;
+            half8_t xin[IW];
+#pragma unroll
+            for (int c = 0; c < IW; c++) {
+                const int ix = ix0 + c;
+                half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (rowok && (unsigned)ix < (unsigned)p.W) v = *(const half8_t*)(p.x + (((long)n * p.H + iy) * p.W + ix) * p.x_ld + c0);
+                xin[c] = v;
+            }
+#pragma unroll
+            for (int o = 0; o < PX; o++)
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int widx = j * 9 + kh * 3 + kw;                 // flat index into the 72 weights of this thread
+                        acc[o][j] += (float)xin[o * S + kw][j] * (float)wv[widx >> 3][widx & 7];
+                    }
+        }
+#pragma unroll
+        for (int o = 0; o < PX; o++) {
+            const int ox = ox0 + o;
+            if (ox >= p.Wo) break;
+            const long m = ((long)n * p.Ho + oy) * p.Wo + ox;
+            if (p.res) { half8_t rr = *(const half8_t*)(p.res + m * p.res_ld + c0);
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[o][j] += (float)rr[j]; }
+            half8_t ov;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ov[j] = (half_t)sm_act(acc[o][j], p.act, p.slope);
+            *(half8_t*)(p.y + m * p.y_ld + c0) = ov;
+        }
+    }
+}
+
 #include "conv_igemm64.hpp"
 
 // kind 0: generic (Cin % 8 == 0, BK = 32, register staging); kind 1: Cin % 64 == 0 fast path (BK = 64, LDS-DMA)
@@ -317,6 +380,9 @@ const TileCfg kCfgs[] = {
     {64, 64, 2, 256, conv_igemm64_kernel<64, 64, 2, 2, 1>, "k64s1:64x64"},            // 27
     {256, 64, 2, 512, conv_igemm64_kernel<256, 64, 4, 2, 1>, "k64w8s1:256x64"},       // 28
     {64, 128, 2, 256, conv_igemm64_kernel<64, 128, 2, 2, 1>, "k64s1:64x128"},         // 29
+    // narrow outputs (Cout <= 32: U-Net full-resolution layers): no MFMA work wasted on zero cout columns
+    {128, 32, 1, 256, conv_igemm64_kernel<128, 32, 4, 1>, "k64:128x32"},              // 30
+    {256, 32, 1, 256, conv_igemm64_kernel<256, 32, 4, 1>, "k64:256x32"},              // 31
 #ifdef SM_ABLATION   // tools/conv_bench.py only: never built into the product library
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 1>, "abl:w8 noMFMA"},
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 2>, "abl:w8 noGlobal"},
@@ -371,7 +437,16 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     if (d->groups > 1 && d->groups == d->Cin && d->groups == d->Cout && (d->Cout % 8) == 0 && (p.x_ld % 8) == 0 &&
         (p.y_ld % 8) == 0 && (!p.res || (p.res_ld % 8) == 0)) {
         long work = (long)p.M * (p.Cout / 8);
-        hipLaunchKernelGGL(dwconv_kernel, dim3(sm_stream_grid(work, 256)), dim3(256), 0, s, p);
+        const bool k3 = p.kH == 3 && p.kW == 3 && p.dH == 1 && p.dW == 1 && p.sH == p.sW && (((uintptr_t)p.w) & 15) == 0;
+        if (k3 && p.sH == 1) {
+            long w4 = (long)p.N * p.Ho * sm_ceil_div(p.Wo, 4) * (p.Cout / 8);
+            hipLaunchKernelGGL((dwconv3x3_kernel<1, 4>), dim3(sm_stream_grid(w4, 256)), dim3(256), 0, s, p);
+        } else if (k3 && p.sH == 2) {
+            long w2 = (long)p.N * p.Ho * sm_ceil_div(p.Wo, 2) * (p.Cout / 8);
+            hipLaunchKernelGGL((dwconv3x3_kernel<2, 2>), dim3(sm_stream_grid(w2, 256)), dim3(256), 0, s, p);
+        } else {
+            hipLaunchKernelGGL(dwconv_kernel, dim3(sm_stream_grid(work, 256)), dim3(256), 0, s, p);
+        }
         SM_LAUNCH_CHECK(); return SM_OK;
     }
     if (!mfma_eligible(d, p)) {
