@@ -11,10 +11,16 @@ LIB      := smelter_amd/libsmelter_hip.so
 
 all: $(LIB) oracle
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/kernels/*.hpp) include/smelter_hip.h
+# objects are rebuilt when the flags change (e.g. make EXTRA=-DSM_ABLATION and then a plain make)
+FLAGSTAMP := build/.flags
+$(FLAGSTAMP): FORCE
+	@mkdir -p build; echo '$(HIPCC) $(HIPFLAGS)' | cmp -s - $@ || echo '$(HIPCC) $(HIPFLAGS)' > $@
+FORCE:
+
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/kernels/*.hpp) include/smelter_hip.h $(FLAGSTAMP)
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(OBJDIR)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/host/*.hpp) $(wildcard $(CSRC)/kernels/*.hpp) include/smelter_hip.h
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/host/*.hpp) $(wildcard $(CSRC)/kernels/*.hpp) include/smelter_hip.h $(FLAGSTAMP)
 	@mkdir -p $(dir $@)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 $(LIB): $(OBJS)
@@ -25,4 +31,4 @@ oracle:
 
 clean:
 	rm -rf build $(LIB); $(MAKE) -C oracle clean
-.PHONY: all oracle clean
+.PHONY: all oracle clean FORCE

@@ -22,6 +22,7 @@
 // Block -> tile map is XCD aware (8 XCDs with private L2, block b runs on XCD b%8): all BN-tiles of one pixel
 // tile are issued back-to-back on the same XCD so the gathered activation tile is fetched from HBM once.
 #include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 
@@ -34,8 +35,19 @@ struct ConvParams {
     int x_ld, y_ld, res_ld, act; float slope;
     int M, K, mt, nt, splitk, ktiles_per_split;
     int order, mt_per_xcd, cpx;      // block -> tile map (map_block)
-    int krot;                        // rotate the K loop start per block (conv_igemm64.hpp)
+    unsigned dhw_mul, dhw_sh, dw_mul, dw_sh;   // sm_fastdiv constants for / (Ho*Wo) and / Wo
+    unsigned pm_mul, pm_sh, mt_mul, mt_sh, nt_mul, nt_sh;   // ... for / (nt*splitk), / mt, / nt (map_block)
+    unsigned rowpat;                 // sum over kh < kH of 1 << (kh*kW): tap-mask pattern (conv_igemm64.hpp)
 };
+
+// Division of n < 2^31 by a launch-time constant d: q = (n * mul) >> sh with s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1
+// (< 2^32), sh = 31 + s.  Exact: mul*d - 2^(31+s) = e in (0, d], so n*mul / 2^(31+s) = n/d + n*e / (d * 2^(31+s)) and the
+// excess is < 2^-s <= 1/d, too small to carry the fraction of n/d (<= (d-1)/d) over the next integer.
+inline void sm_fastdiv_make(unsigned d, unsigned* mul, unsigned* sh) {
+    unsigned s = 0; while ((1ull << s) < d) s++;
+    *mul = (unsigned)(((1ull << (31 + s)) / d) + 1); *sh = 31 + s;
+}
+__device__ __forceinline__ unsigned sm_fastdiv(unsigned n, unsigned mul, unsigned sh) { return (unsigned)(((unsigned long long)n * mul) >> sh); }
 
 constexpr int BK = 32;
 
@@ -51,10 +63,15 @@ __device__ __forceinline__ bool map_block(const ConvParams& p, int& mtile, int& 
     const int bid = blockIdx.x, xcd = bid & (SM_NUM_XCD - 1), slot = bid >> 3;
     const int per_m = p.nt * p.splitk;
     int combo;
-    if (p.order == 0) { mtile = xcd * p.mt_per_xcd + slot / per_m; combo = slot % per_m; if (slot / per_m >= p.mt_per_xcd) return false; }
-    else { combo = xcd * p.cpx + slot / p.mt; mtile = slot % p.mt; if (slot / p.mt >= p.cpx || combo >= per_m) return false; }
+    if (p.order == 0) {
+        const int q = (int)sm_fastdiv((unsigned)slot, p.pm_mul, p.pm_sh);
+        mtile = xcd * p.mt_per_xcd + q; combo = slot - q * per_m; if (q >= p.mt_per_xcd) return false;
+    } else {
+        const int q = (int)sm_fastdiv((unsigned)slot, p.mt_mul, p.mt_sh);
+        combo = xcd * p.cpx + q; mtile = slot - q * p.mt; if (q >= p.cpx || combo >= per_m) return false;
+    }
     if (mtile >= p.mt) return false;
-    ntile = combo % p.nt; ksplit = combo / p.nt;
+    ksplit = (int)sm_fastdiv((unsigned)combo, p.nt_mul, p.nt_sh); ntile = combo - ksplit * p.nt;
     return true;
 }
 
@@ -391,11 +408,12 @@ const TileCfg kCfgs[] = {
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 // kind 2 = single LDS stage: only for K == 64 (one K tile)
-bool cfg_eligible(const TileCfg& c, const ConvParams& p) { return c.kind == 0 || ((p.Cin % 64) == 0 && (c.kind == 1 || p.K == 64)); }
+// kinds 1/2 (conv_igemm64.hpp): Cin % 64 == 0 and a tap mask of <= 32 bits
+bool cfg_eligible(const TileCfg& c, const ConvParams& p) { return c.kind == 0 || ((p.Cin % 64) == 0 && p.kH * p.kW <= 32 && (c.kind == 1 || p.K == 64)); }
 
 int pick_cfg(const ConvParams& p) {
     // largest tile that still gives >= ~2 blocks per CU; otherwise the one with the most blocks
-    const int want_kind = (p.Cin % 64) == 0 ? 1 : 0;
+    const int want_kind = ((p.Cin % 64) == 0 && p.kH * p.kW <= 32) ? 1 : 0;
     int best = want_kind ? 9 : 3; double best_score = -1;
     for (int i = 0; i < kNumCfgs; i++) {
         const TileCfg& c = kCfgs[i];
@@ -426,6 +444,9 @@ int fill_params(const sm_conv_desc* d, const void* x, const void* w, const float
     p->M = d->N * d->Ho * d->Wo; p->K = d->kH * d->kW * (d->Cin / d->groups);
     p->splitk = 1; p->mt = p->nt = 0; p->ktiles_per_split = 0;
     SM_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "sm_conv2d_fwd: more than 2^31 output pixels");
+    SM_REQUIRE((long)d->N * d->H * d->W < (1L << 31) - (1L << 24), "sm_conv2d_fwd: more than 2^31 input pixels");
+    sm_fastdiv_make((unsigned)(d->Ho * d->Wo), &p->dhw_mul, &p->dhw_sh); sm_fastdiv_make((unsigned)d->Wo, &p->dw_mul, &p->dw_sh);
+    p->rowpat = 0; if (d->kH * d->kW <= 32) for (int kh = 0; kh < d->kH; kh++) p->rowpat |= 1u << (kh * d->kW);
     return SM_OK;
 }
 
@@ -478,10 +499,8 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     p.order = (combos >= SM_NUM_XCD && b_bytes > a_bytes) ? 1 : 0;
     if (forced_order == 0 || (forced_order == 1 && combos >= SM_NUM_XCD)) p.order = forced_order;
     p.mt_per_xcd = sm_ceil_div(p.mt, SM_NUM_XCD); p.cpx = sm_ceil_div(combos, SM_NUM_XCD);
-    // off by default: it makes an image's fp32 accumulation order depend on its position in the batch (results stay
-    // deterministic, but the bit-exact batch-permutation invariance is lost) and bought < 1 % on the whole network
-    static const int krot = getenv("SM_CONV_KROT") ? atoi(getenv("SM_CONV_KROT")) : 0;
-    p.krot = krot;
+    sm_fastdiv_make((unsigned)combos, &p.pm_mul, &p.pm_sh); sm_fastdiv_make((unsigned)p.mt, &p.mt_mul, &p.mt_sh);
+    sm_fastdiv_make((unsigned)p.nt, &p.nt_mul, &p.nt_sh);
     const int grid = p.order == 0 ? p.mt_per_xcd * SM_NUM_XCD * combos : p.cpx * SM_NUM_XCD * p.mt;
     hipLaunchKernelGGL(c.fn, dim3(grid), dim3(c.threads), 0, s, p);
     SM_LAUNCH_CHECK();
@@ -548,6 +567,28 @@ int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w,
         SM_HIP_CHECK(hipEventElapsedTime(&t, a, b));
     }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+#ifdef SM_TIMELINE
+    {   // one more launch with the per-block timeline recorded (conv_igemm64 kernels only)
+        static unsigned long long h[8192 * 16];
+        memset(h, 0, sizeof h);
+        SM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl), h, sizeof h));
+        rc = launch(d, p, cfg, ws, ws_bytes, s); SM_HIP_CHECK(hipStreamSynchronize(s));
+        SM_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tl), sizeof h));
+        static const char* names[8] = {"map_block", "rows", "brow+cursor", "prologue issue", "res+bias+init", "first tile", "main loop", "epilogue"};
+        double ph[8] = {0}, wall = 0; unsigned long long w0 = ~0ull, w1 = 0; int nb = 0;
+        for (int b2 = 0; b2 < 8192; b2++) {
+            const unsigned long long* e = h + b2 * 16;
+            if (!e[0] || !e[15]) continue;                       // unused slot or a block that map_block() retired
+            nb++; for (int q = 0; q < 8; q++) ph[q] += (double)(e[2 + q] - e[1 + q]);
+            wall += (double)(e[15] - e[0]); if (e[0] < w0) w0 = e[0]; if (e[15] > w1) w1 = e[15];
+        }
+        if (nb) {
+            fprintf(stderr, "[timeline cfg %d] %d blocks:", cfg, nb);
+            for (int q = 0; q < 8; q++) fprintf(stderr, " %s %.0f |", names[q], ph[q] / nb);
+            fprintf(stderr, " block wall avg %.2f us ; first start -> last end %.2f us ; event %.2f us\n", wall / nb / 100.0, (double)(w1 - w0) / 100.0, t / iters * 1e3);
+        }
+    }
+#endif
     *ms_per_launch = t / iters;
     return rc;
 }

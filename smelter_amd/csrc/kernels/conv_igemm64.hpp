@@ -5,19 +5,22 @@
 //
 //  * K tiling: with Cin % 64 == 0 a 64-wide K tile lies inside ONE (kh,kw) tap, so the tap and its channel base are
 //    wave-uniform per tile; a row of the activation tile is 128 contiguous bytes of one input pixel (or zeros).
+//    The per-tile bookkeeping is a handful of SALU adds (tap / channel-block counters advanced incrementally); whether a
+//    row's tap lies inside the image is ONE bit of a per-row tap mask built once in the prologue (kH*kW <= 32).
 //  * LDS-DMA writes lane-linear (wave base + lane*16 B), so the bank swizzle is applied on the SOURCE side: the lane
 //    that fills 16-byte slot c' of row r fetches chunk c = c' ^ ((r >> 1) & 7); readers apply the same XOR
 //    (cdna_hip_programming.md §5.4 rule 21).  With 128-byte rows this makes every 16-lane service group of
 //    ds_read_b128 hit 16 distinct 16-byte slots of the 256-byte bank row (MI355X_MICROARCH.md §LDS).
-//  * Zero padding / ragged tiles: out-of-image taps, rows >= M and couts >= Cout fetch from a zero page.
-//  * Pipeline: NSTAGE-deep LDS ring.  NSTAGE == 2: tile t+1 in flight while tile t feeds the MFMAs, __syncthreads()
-//    carries the vmcnt(0) that publishes the DMA'd tile.  NSTAGE >= 3: the layers here are short, latency-bound GEMMs
-//    (M = 3k..200k pixels, 1..72 K tiles per block), so NSTAGE-1 tiles are kept in flight across raw s_barriers with a
-//    COUNTED s_waitcnt vmcnt(N) (cdna_hip_programming.md §5 "Pipelining across barriers", T3+T4): the only wait is for
-//    the oldest tile.
-//  * Epilogue: per wave-row pass, accumulators -> LDS as fp32 [32*TM rows][BN+4] (conflict-free ds_write_b128),
-//    then 256 threads each take 8 consecutive couts of one pixel: + bias + residual (16-byte coalesced load),
-//    activation, ONE rounding to fp16, 16-byte coalesced store.
+//  * Zero padding: out-of-image taps fetch from a zero page.  Ragged tiles (rows >= M, couts >= Cout) are CLAMPED to the
+//    last valid row instead: a GEMM row/column only feeds its own outputs, and those are never stored.
+//  * Pipeline: NSTAGE-deep LDS ring, ONE raw s_barrier per K tile, counted `s_waitcnt vmcnt(N)` so that NSTAGE-1 tiles
+//    stay in flight across the barrier (cdna_hip_programming.md §5 "Pipelining across barriers").  Inside a tile the
+//    fragment reads of k-step s+1 are requested before the MFMAs of k-step s.
+//  * Epilogue: the accumulators start at the bias (one value per accumulator register: registers <-> couts), so the
+//    epilogue is accumulators -> LDS as fp32 [rows][BN+4] (conflict-free ds_write_b128), then every thread takes 8
+//    consecutive couts of one pixel: + residual (16-byte load issued BEFORE the main loop), activation, ONE rounding to
+//    fp16, 16-byte coalesced store.  All waves stage at once when the tile fits 68 KB of LDS (two blocks per CU stay
+//    resident); 256-row tiles take two passes.
 #pragma once
 #include <type_traits>
 
@@ -27,206 +30,263 @@ __device__ __attribute__((aligned(64))) unsigned int g_zero_page[64];   // zero-
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
                                      (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
+#ifdef SM_TIMELINE   // diagnostic build (make EXTRA="-DSM_ABLATION -DSM_TIMELINE"): per-block phase timestamps
+// slot 0: wall clock at start, slots 1..13: clock64() at SM_TL(0..12), slot 15: wall clock at the end (SM_TL_END)
+__device__ unsigned long long g_tl[8192 * 16];
+#define SM_TL(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) { if ((i) == 0) g_tl[blockIdx.x * 16] = wall_clock64(); \
+    g_tl[blockIdx.x * 16 + 1 + (i)] = clock64(); } } while (0)
+#define SM_TL_END() do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_tl[blockIdx.x * 16 + 15] = wall_clock64(); } while (0)
+#else
+#define SM_TL(i)
+#define SM_TL_END()
+#endif
+
 template <int N> __device__ __forceinline__ void sm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// ABL: ablation switch for tools/conv_bench.py (0 = product; 1 = no MFMA; 2 = no global->LDS traffic after the prologue;
-// 3 = no LDS fragment reads)
-template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0>
+constexpr int sm_pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; return r; }
+
+// ABL: ablation switch for tools/conv_bench.py (0 = product; 1 = no MFMA; 2 = no global->LDS traffic after the prologue)
+template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams p) {
     static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
-    constexpr int NT = WGM * WGN * 64;                          // threads per block
     static_assert(NSTAGE >= 1 && NSTAGE <= 4, "1..4 stages");
-    constexpr int BK64 = 64;
+    constexpr int NT = WGM * WGN * 64;                          // threads per block
     constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
     constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;      // 16-byte pieces per thread per tile
     constexpr int RPI = NT / 8;                                 // tile rows covered by one DMA instruction of the whole block
     static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
     constexpr int LOADS = A_IT + B_IT;                          // LDS-DMA instructions per wave per tile
-    constexpr int STAGE = (BM + BN) * BK64;                     // halfs per stage
-    constexpr int EP_ROWS = 32 * TM, EP_LD = BN + 4;            // epilogue staging (floats)
-    constexpr int LDS_BYTES = (NSTAGE * STAGE * 2 > EP_ROWS * EP_LD * 4) ? NSTAGE * STAGE * 2 : EP_ROWS * EP_LD * 4;
-    static_assert(NSTAGE < 3 || (NSTAGE - 2) * LOADS <= 63, "vmcnt range");
+    constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128, PIPE_BYTES = NSTAGE * STAGE_BYTES;
+    // epilogue staging (fp32): WPP wave-rows of 32*TM pixels per pass
+    constexpr int EP_LD = BN + 4, WROWS = 32 * TM;
+    constexpr int EP_BUDGET = PIPE_BYTES > 69632 ? PIPE_BYTES : 69632;
+    constexpr int WPP_MAX = EP_BUDGET / (WROWS * EP_LD * 4);
+    constexpr int WPP = WPP_MAX >= WGM ? WGM : sm_pow2_floor(WPP_MAX < 1 ? 1 : WPP_MAX);
+    constexpr int EP_ROWS = WROWS * WPP, EP_PASSES = WGM / WPP;
+    static_assert(WGM % WPP == 0, "epilogue passes");
+    // + 8 bytes per tile row at the very end: the row table of the prologue (never touched by the ring or the staging)
+    constexpr int LDS_BYTES = (PIPE_BYTES > EP_ROWS * EP_LD * 4 ? PIPE_BYTES : EP_ROWS * EP_LD * 4) + BM * 8;
+    static_assert((NSTAGE - 1) * LOADS <= 63, "vmcnt range");
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[LDS_BYTES];
-    half_t* smem = (half_t*)smem_raw;
 
+    SM_TL(0);
     int mtile, ntile, ksplit;
     if (!map_block(p, mtile, ntile, ksplit)) return;
-    const int ktiles = p.K / BK64;
+    SM_TL(1);
     const int kt_begin = ksplit * p.ktiles_per_split;
+    const int ktiles = p.K >> 6;
     int kt_end = kt_begin + p.ktiles_per_split; if (kt_end > ktiles) kt_end = ktiles;
+    const int nk = kt_end - kt_begin;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> LDS bases live in SGPRs
     const int wm = wave / WGN, wn = wave % WGN;
-    const int csrc = (tid & 7) ^ ((tid >> 4) & 7);             // source chunk for this thread's LDS slot (rows j*32 + tid/8)
+    const int csrc = (tid & 7) ^ ((tid >> 4) & 7);             // source chunk for this thread's LDS slot (rows j*RPI + tid/8)
     const half_t* zero = (const half_t*)g_zero_page;
 
     // ---- per-thread row state -----------------------------------------------------------------------
-    const half_t* arow[A_IT]; int aiy[A_IT], aix[A_IT];
+    // Setup runs once per block with one wave per SIMD, i.e. every instruction is exposed: no loops, no branches, and
+    // each tile row (input pixel index + tap mask, shared by the 8 lanes that fetch its 8 chunks) is derived by ONE thread
+    // and handed over through LDS.
+    {
+        const int HoWo = p.Ho * p.Wo;
+        const bool unit_dil = p.dH == 1 && p.dW == 1;
+        int2* rowinfo = (int2*)(smem_raw + LDS_BYTES - BM * 8);
+        if (BM >= NT || tid < BM) {
+#pragma unroll
+            for (int rr = 0; rr < (BM + NT - 1) / NT; rr++) {
+                const int row = tid + rr * NT;
+                int m = mtile * BM + row; if (m >= p.M) m = p.M - 1;
+                const int n = (int)sm_fastdiv((unsigned)m, p.dhw_mul, p.dhw_sh), r = m - n * HoWo;
+                const int oy = (int)sm_fastdiv((unsigned)r, p.dw_mul, p.dw_sh), ox = r - oy * p.Wo;
+                const int iy = oy * p.sH - p.pt, ix = ox * p.sW - p.pl;
+                const int pix = (n * p.H + iy) * p.W + ix;          // |pix| < 2^31 (fill_params)
+                unsigned msk = 0;
+                if (unit_dil) {
+                    // taps kw in [lo_w, hi_w] and kh in [lo_h, hi_h] are inside the image: bits kh*kW + kw of the mask
+                    const int lo_w = ix < 0 ? -ix : 0, hi_w = min(p.kW - 1, p.W - 1 - ix);
+                    const int lo_h = iy < 0 ? -iy : 0, hi_h = min(p.kH - 1, p.H - 1 - iy);
+                    const unsigned colm = (0xFFFFFFFFu >> (31 - max(hi_w, 0))) & (0xFFFFFFFFu << min(lo_w, 31));
+                    const unsigned rowm = (0xFFFFFFFFu >> (32 - (max(hi_h, 0) + 1) * p.kW)) & (0xFFFFFFFFu << (min(lo_h, p.kH - 1) * p.kW));
+                    if (lo_w <= hi_w && lo_h <= hi_h) msk = colm * (p.rowpat & rowm);
+                } else {
+                    unsigned colm = 0;
+                    for (int kw = 0; kw < p.kW; kw++) colm |= ((unsigned)(ix + kw * p.dW) < (unsigned)p.W ? 1u : 0u) << kw;
+                    for (int kh = 0; kh < p.kH; kh++) if ((unsigned)(iy + kh * p.dH) < (unsigned)p.H) msk |= colm << (kh * p.kW);
+                }
+                rowinfo[row] = int2{pix, (int)msk};
+            }
+        }
+        __syncthreads();
+    }
+    const half_t* arow[A_IT]; unsigned amask[A_IT];
 #pragma unroll
     for (int j = 0; j < A_IT; j++) {
-        const int m = mtile * BM + j * RPI + (tid >> 3);
-        if (m < p.M) {
-            int n = m / (p.Ho * p.Wo), r = m - n * (p.Ho * p.Wo), oy = r / p.Wo, ox = r - oy * p.Wo;
-            aiy[j] = oy * p.sH - p.pt; aix[j] = ox * p.sW - p.pl;
-            arow[j] = p.x + (((long)n * p.H + aiy[j]) * p.W + aix[j]) * p.x_ld + csrc * 8;
-        } else { aiy[j] = -(1 << 28); aix[j] = -(1 << 28); arow[j] = zero; }     // never valid
+        const int2 ri = ((const int2*)(smem_raw + LDS_BYTES - BM * 8))[j * RPI + (tid >> 3)];
+        arow[j] = p.x + (long)ri.x * p.x_ld + csrc * 8; amask[j] = (unsigned)ri.y;
     }
+    SM_TL(2);
     const half_t* brow[B_IT];
 #pragma unroll
     for (int j = 0; j < B_IT; j++) {
-        const int n = ntile * BN + j * RPI + (tid >> 3);
-        brow[j] = n < p.Cout ? p.w + (long)n * p.K + csrc * 8 : nullptr;
+        int n = ntile * BN + j * RPI + (tid >> 3); if (n >= p.Cout) n = p.Cout - 1;
+        brow[j] = p.w + (long)n * p.K + csrc * 8;
     }
-    // Residual operand (fused MPSNNAdditionNode): its loads do not depend on the GEMM, so they are put in flight FIRST
-    // (16-byte coalesced, same (row, chunk) ownership as the epilogue stores) and consumed ~a whole K loop later.
+    // ---- K-tile cursor of the NEXT tile to issue: all wave-uniform, advanced with a few SALU ops per tile -------------
+    const int cpt = p.Cin >> 6;                                 // K tiles per tap
+    int cblk, kw_i;
+    long a_off, b_off;                                          // element offsets of the tile inside a pixel row / weight row
+    unsigned tapbit;
+    if (kt_begin == 0) { cblk = 0; kw_i = 0; a_off = 0; b_off = 0; tapbit = 1u; }
+    else {                                                      // split-K blocks start in the middle of the K range
+        const int tap = kt_begin / cpt; cblk = kt_begin - tap * cpt;
+        const int kh = tap / p.kW; kw_i = tap - kh * p.kW;
+        a_off = ((long)(kh * p.dH) * p.W + kw_i * p.dW) * p.x_ld + cblk * 64;
+        b_off = (long)kt_begin * 64;
+        tapbit = 1u << tap;
+    }
+    const long a_wrap_c = (long)p.dW * p.x_ld - (long)(cpt - 1) * 64;      // next tap, same kernel row
+    const long a_wrap_w = ((long)p.dH * p.W - (long)p.kW * p.dW) * p.x_ld;  // ... and on to the next kernel row
+
+    auto issue = [&](int slot) {
+        unsigned char* sa = smem_raw + slot * STAGE_BYTES + wave * 1024;   // wave-uniform LDS base; lane*16 B added by the DMA
+#pragma unroll
+        for (int i = 0; i < A_IT; i++) {
+            const half_t* src = (amask[i] & tapbit) ? arow[i] + a_off : zero;
+            SM_GLDS16(src, sa + i * NT * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < B_IT; j++) SM_GLDS16(brow[j] + b_off, sa + A_BYTES + j * NT * 16);
+        b_off += 64;
+        if (++cblk == cpt) {
+            cblk = 0; a_off += a_wrap_c; tapbit <<= 1;
+            if (++kw_i == p.kW) { kw_i = 0; a_off += a_wrap_w; }
+        } else a_off += 64;
+    };
+
+    SM_TL(3);
+    // ---- first tiles in flight as early as possible; everything else of the prologue hides behind their latency --------
+    // Tile i lives in ring slot i % NSTAGE.  Short K (nk <= NSTAGE, the HBM-streaming 1x1 layers): everything the block
+    // will ever read is in flight at once.
+    int issued = 0;
+    const int pre = nk <= NSTAGE ? nk : NSTAGE - 1;
+#pragma unroll
+    for (int s = 0; s < NSTAGE; s++) if (s < pre) { issue(s); ++issued; }
+    int slot = 0, islot = pre == NSTAGE ? 0 : pre;
+    __builtin_amdgcn_sched_barrier(0);
+    SM_TL(4);
+
+    // Residual operand (fused MPSNNAdditionNode): its loads do not depend on the GEMM, so they are put in flight right behind
+    // the first tiles (16-byte coalesced, same (row, chunk) ownership as the epilogue stores) and consumed ~a whole K loop later.
+    // Unconditional loads from clamped (always valid) addresses: what a ragged tile reads extra is never stored.
     constexpr int CHUNKS = BN / 8, ITEMS = EP_ROWS * CHUNKS, IPT = (ITEMS + NT - 1) / NT;
-    const bool vec_ok = ((p.y_ld & 7) == 0) && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && ((p.Cout & 7) == 0) &&
+    const bool vec_ok = ((p.y_ld & 7) == 0) && ((((uintptr_t)p.y) & 15) == 0) && ((p.Cout & 7) == 0) &&
                         (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0));
-    half8_t rres[WGM][IPT];
+    half8_t rres[EP_PASSES][IPT];
     if (p.res && vec_ok && p.splitk == 1) {
 #pragma unroll
-        for (int pw = 0; pw < WGM; pw++)
+        for (int pw = 0; pw < EP_PASSES; pw++)
 #pragma unroll
             for (int k2 = 0; k2 < IPT; k2++) {
-                const int it = tid + k2 * NT, row = it / CHUNKS, ch = it - row * CHUNKS;
-                const int m = mtile * BM + pw * EP_ROWS + row, co = ntile * BN + ch * 8;
-                half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (it < ITEMS && m < p.M && co < p.Cout) v = *(const half8_t*)(p.res + (long)m * p.res_ld + co);
-                rres[pw][k2] = v;
+                int it = tid + k2 * NT; if (ITEMS % NT != 0 && it >= ITEMS) it = ITEMS - 1;
+                const int row = it / CHUNKS, ch = it - row * CHUNKS;
+                const int m = min(mtile * BM + pw * EP_ROWS + row, p.M - 1), co = min(ntile * BN + ch * 8, p.Cout - 8);
+                rres[pw][k2] = *(const half8_t*)(p.res + (long)m * p.res_ld + co);
             }
     }
-    const int cpt = p.Cin / BK64;                               // K tiles per tap
-    // K rotation: the blocks that run concurrently on one XCD share weight tiles.  If they all walk K in the same order,
-    // every weight tile is a first touch (HBM latency) for all of them at once, once per K tile; starting each block at a
-    // different K tile makes a tile a miss for ONE block and an L2 hit for the others.
-    const int nk = kt_end - kt_begin;
-    const int rot = p.krot ? (mtile * 5 + ntile * 3) % nk : 0;
-    auto kt_of = [&](int i) { int r = i + rot; if (r >= nk) r -= nk; return kt_begin + r; };   // i-th tile this block processes
 
-    // LDS-DMA of one K tile = LOADS instructions per wave.  ILV = 1 spreads them behind the MFMAs of each k-step of the
-    // tile being computed; measured on MI355X this is SLOWER than issuing the whole burst first (14x14 3x3 256->256:
-    // 35.3 vs 28.8 us; the tile then lands later and the barrier wait grows), so ILV = 0 is the default.
-    struct TileSrc { half_t* sa; half_t* sb; int dy, dx; long toff; long koff; };
-    auto tile_src = [&](int buf, int kt) {
-        TileSrc t;
-        t.sa = smem + buf * STAGE + (wave * 64) * 8;            // wave-uniform LDS base; lane*16 B added by the DMA
-        t.sb = smem + buf * STAGE + BM * BK64 + (wave * 64) * 8;
-        const int tap = kt / cpt, cblk = kt - tap * cpt, kh = tap / p.kW, kw = tap - kh * p.kW;     // wave-uniform (SALU)
-        t.dy = kh * p.dH; t.dx = kw * p.dW;
-        t.toff = ((long)t.dy * p.W + t.dx) * p.x_ld + cblk * BK64;
-        t.koff = (long)kt * BK64;
-        return t;
-    };
-    auto piece = [&](const TileSrc& t, int i) {                 // i-th DMA instruction of the tile, 0 <= i < LOADS
-        if (i < A_IT) {
-            const bool ok = (unsigned)(aiy[i] + t.dy) < (unsigned)p.H && (unsigned)(aix[i] + t.dx) < (unsigned)p.W;
-            const half_t* src = ok ? arow[i] + t.toff : zero;
-            SM_GLDS16(src, t.sa + i * NT * 8);
-        } else {
-            const int j = i - A_IT;
-            const half_t* src = brow[j] ? brow[j] + t.koff : zero;
-            SM_GLDS16(src, t.sb + j * NT * 8);
+    // ---- accumulators start at the bias: register 4q+r of acc[a][*] <-> cout (wn*TN+a)*32 + 8q + 4*(lane>>5) + r ------
+    // (requested behind the first tiles, consumed just before the main loop)
+    floatx4 bv[TN][4];
+    floatx16 acc[TN][TM];
+    {
+        const bool bias_vec = (p.Cout & 3) == 0 && ((((uintptr_t)p.bias) & 15) == 0);
+#pragma unroll
+        for (int a = 0; a < TN; a++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int co = ntile * BN + (wn * TN + a) * 32 + 8 * q + 4 * (lane >> 5);
+                floatx4 v = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias && p.splitk == 1) {
+                    if (bias_vec) v = *(const floatx4*)(p.bias + min(co, p.Cout - 4));   // couts >= Cout are never stored
+                    else for (int r = 0; r < 4; r++) if (co + r < p.Cout) v[r] = p.bias[co + r];
+                }
+                bv[a][q] = v;
+            }
+    }
+
+    // fragment addresses: row (lane & 31) of a 32-row block, 16-byte chunk (2*ks + (lane >> 5)) ^ swizzle(row)
+    unsigned voff[4];
+    {
+        const unsigned sw = ((lane & 31) >> 1) & 7;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) voff[ks] = (lane & 31) * 128 + (((ks * 2 + (lane >> 5)) ^ sw) << 4);
+    }
+    auto compute = [&](int slot) {
+        const unsigned sA = slot * STAGE_BYTES + wm * (TM * 4096), sB = slot * STAGE_BYTES + A_BYTES + wn * (TN * 4096);
+        half8_t fx[2][TM], fw[2][TN];
+#pragma unroll
+        for (int b = 0; b < TM; b++) fx[0][b] = *(const half8_t*)(smem_raw + sA + voff[0] + b * 4096);
+#pragma unroll
+        for (int a = 0; a < TN; a++) fw[0][a] = *(const half8_t*)(smem_raw + sB + voff[0] + a * 4096);
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            if (ks + 1 < 4) {
+#pragma unroll
+                for (int b = 0; b < TM; b++) fx[(ks + 1) & 1][b] = *(const half8_t*)(smem_raw + sA + voff[ks + 1] + b * 4096);
+#pragma unroll
+                for (int a = 0; a < TN; a++) fw[(ks + 1) & 1][a] = *(const half8_t*)(smem_raw + sB + voff[ks + 1] + a * 4096);
+            }
+#pragma unroll
+            for (int a = 0; a < TN; a++)
+#pragma unroll
+                for (int b = 0; b < TM; b++) {
+                    if (ABL != 1) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks & 1][a], fx[ks & 1][b], acc[a][b], 0, 0, 0);
+                    else { asm volatile("" ::"v"(fw[ks & 1][a]), "v"(fx[ks & 1][b])); }
+                }
         }
     };
-    auto issue = [&](int buf, int kt) {
-        const TileSrc t = tile_src(buf, kt);
-#pragma unroll
-        for (int i = 0; i < LOADS; i++) piece(t, i);
-    };
-
-    floatx16 acc[TN][TM];
 #pragma unroll
     for (int a = 0; a < TN; a++)
 #pragma unroll
         for (int b = 0; b < TM; b++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+            for (int r = 0; r < 16; r++) acc[a][b][r] = bv[a][r >> 2][r & 3];
+    SM_TL(5);
 
-    // MFMAs of the tile in `buf`; when `nxt >= 0` the DMA of tile `kt_next` into slot `nxt` is interleaved
-    auto compute = [&](int buf, bool first, int nxt, int kt_next) {
-        const half_t* sa = smem + buf * STAGE; const half_t* sb = sa + BM * BK64;
-        TileSrc t{};
-        const bool dma = nxt >= 0 && ABL != 2;
-        if (dma) { t = tile_src(nxt, kt_next); if (!ILV) {
-#pragma unroll
-            for (int i = 0; i < LOADS; i++) piece(t, i); } }
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
-            const int c = ks * 2 + (lane >> 5);
-            half8_t fx[TM], fw[TN];
-#pragma unroll
-            for (int b = 0; b < TM; b++) { const int row = (wm * TM + b) * 32 + (lane & 31); if (ABL != 3 || first) fx[b] = *(const half8_t*)(sa + row * BK64 + ((c ^ ((row >> 1) & 7)) << 3)); }
-#pragma unroll
-            for (int a = 0; a < TN; a++) { const int row = (wn * TN + a) * 32 + (lane & 31); if (ABL != 3 || first) fw[a] = *(const half8_t*)(sb + row * BK64 + ((c ^ ((row >> 1) & 7)) << 3)); }
-#pragma unroll
-            for (int a = 0; a < TN; a++)
-#pragma unroll
-                for (int b = 0; b < TM; b++) {
-                    if (ABL != 1) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[a], fx[b], acc[a][b], 0, 0, 0);
-                    else { asm volatile("" ::"v"(fw[a]), "v"(fx[b])); }
-                }
-            if (ILV && dma) {
-#pragma unroll
-                for (int i = (ks * LOADS) / 4; i < ((ks + 1) * LOADS) / 4; i++) piece(t, i);
-            }
-        }
-    };
-
-    if (nk <= NSTAGE) {
-        // short K (the 1x1 convs with Cin <= 64*NSTAGE are HBM-streaming layers): everything this block will ever read
-        // is put in flight at once — no serialised round trips, maximum bytes in flight per CU — then one barrier.
-#pragma unroll
-        for (int i = 0; i < NSTAGE; i++) if (i < nk) issue(i, kt_of(i));
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NSTAGE; i++) if (i < nk) compute(i, i == 0, -1, 0);
-        __syncthreads();
-    } else if constexpr (NSTAGE == 1) {
-        return;                                                   // the launcher never selects a 1-stage config for K > 64
-    } else if constexpr (NSTAGE == 2) {
-        issue(0, kt_of(0));
-        __syncthreads();
-        int cur = 0;
-        for (int i = 0; i < nk; i++) {
-            compute(cur, i == 0, i + 1 < nk ? (cur ^ 1) : -1, kt_of(i + 1 < nk ? i + 1 : i));
-            __syncthreads();
-            cur ^= 1;
-        }
-    } else {
-        // tile t lives in ring slot (t - kt_begin) % NSTAGE; NSTAGE-1 tiles in flight across raw barriers, counted vmcnt
-        int issued = 0;
-#pragma unroll
-        for (int s = 0; s < NSTAGE - 1; s++) if (issued < nk) { issue(s, kt_of(issued)); ++issued; }
-        int slot = 0, islot = NSTAGE - 1;
-        for (int i = 0; i < nk; i++) {
-            const int newer = issued - i - 1;                   // tiles issued after tile i, allowed to stay in flight
-            if (newer >= 2) sm_wait_vmcnt<(NSTAGE >= 4 ? 2 : 0) * LOADS>();
-            else if (newer == 1) sm_wait_vmcnt<(NSTAGE >= 3 ? 1 : 0) * LOADS>();
-            else sm_wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();                       // everybody's share of tile kt landed; slot of tile kt-1 is free
-            __builtin_amdgcn_sched_barrier(0);
-            const bool more = issued < nk;
-            compute(slot, i == 0, more ? islot : -1, kt_of(more ? issued : i));
-            if (more) ++issued;
-            if (++islot == NSTAGE) islot = 0;
-            if (++slot == NSTAGE) slot = 0;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // this wave's fragment reads are done before it passes the next barrier
-        }
-        __builtin_amdgcn_s_barrier();
+    // ---- main loop: ONE barrier per K tile; the counted vmcnt leaves the newer tiles (and nothing older) in flight -------
+    for (int i = 0; i < nk; i++) {
+        const int newer = issued - i - 1;                       // tiles issued after tile i, allowed to stay in flight
+        if (NSTAGE >= 4 && newer >= 3) sm_wait_vmcnt<(NSTAGE >= 4 ? 3 : 0) * LOADS>();
+        else if (NSTAGE >= 3 && newer == 2) sm_wait_vmcnt<(NSTAGE >= 3 ? 2 : 0) * LOADS>();
+        else if (NSTAGE >= 2 && newer == 1) sm_wait_vmcnt<(NSTAGE >= 2 ? 1 : 0) * LOADS>();
+        else sm_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                           // everybody's share of tile i landed; the slot of tile i-1 is free
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef SM_TIMELINE
+        if (i == 0) SM_TL(6);
+#endif
+        if (issued < nk && ABL != 2) { issue(islot); ++issued; if (++islot == NSTAGE) islot = 0; }
+        compute(slot);
+        if (++slot == NSTAGE) slot = 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's fragment reads are done before it passes the next barrier
     }
+    __syncthreads();
+    SM_TL(7);
 
     // ---- epilogue: LDS transpose, coalesced 16-byte global accesses ---------------------------------------------
     float* stg = (float*)smem_raw;
 #pragma unroll
-    for (int pw = 0; pw < WGM; pw++) {
-        if (wm == pw) {
+    for (int pw = 0; pw < EP_PASSES; pw++) {
+        if (wm / WPP == pw) {
+            const int wrow = (wm % WPP) * WROWS;
 #pragma unroll
             for (int b = 0; b < TM; b++)
 #pragma unroll
                 for (int a = 0; a < TN; a++)
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        const int row = b * 32 + (lane & 31), col = (wn * TN + a) * 32 + 8 * q + 4 * (lane >> 5);
+                        const int row = wrow + b * 32 + (lane & 31), col = (wn * TN + a) * 32 + 8 * q + 4 * (lane >> 5);
                         *(floatx4*)(stg + row * EP_LD + col) = floatx4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
                     }
         }
@@ -247,9 +307,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
                 continue;
             }
             if (vec_ok) {
-                if (p.bias) { floatx4 b0 = *(const floatx4*)(p.bias + co), b1 = *(const floatx4*)(p.bias + co + 4);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { v[j] += b0[j]; v[4 + j] += b1[j]; } }
                 if (p.res) { const half8_t rr = rres[pw][k2];     // prefetched before the main loop
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[j] += (float)rr[j]; }
@@ -260,12 +317,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
             } else {
                 for (int j = 0; j < 8 && co + j < p.Cout; j++) {
                     float t = v[j];
-                    if (p.bias) t += p.bias[co + j];
                     if (p.res) t += (float)p.res[(long)m * p.res_ld + co + j];
                     p.y[(long)m * p.y_ld + co + j] = (half_t)sm_act(t, p.act, p.slope);
                 }
             }
         }
-        __syncthreads();
+        if (pw + 1 < EP_PASSES) __syncthreads();
     }
+    SM_TL(8);
+    SM_TL_END();
 }

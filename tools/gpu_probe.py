@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--ops", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--insitu", action="store_true")
     a = ap.parse_args()
     make, hw, bs = {"r50": (zoo.resnet50, (224, 224), 64), "mbv2": (zoo.mobilenet_v2, (224, 224), 256), "unet": (zoo.unet, (512, 512), 16)}[a.model]
     bs = a.batch or bs
@@ -46,6 +47,25 @@ def main():
         got = ex.toFloatArray()[:1]
         ref = O.Graph(m).run(x[:1].cpu().numpy())
         print("parity (first image) nerr %.2e" % (np.abs(got - ref).max() / np.abs(ref).max()))
+    if a.insitu:
+        import re
+        prof = ex.profile(x, 20)
+        print("  in-graph (cold) per-op: us | roofline-bound us (max of bytes/6.5TB/s, flops/1.6PF) | ratio")
+        tot = tb = 0
+        for i in range(ex.numOps):
+            d = ex.opDesc(i); us = prof[i + 1] * 1e3; tot += us
+            mm = re.search(r"M=(\d+) N=(\d+) K=(\d+) k=(\d+)x\d+ s=(\d+) g=(\d+)", d)
+            if mm:
+                M, Nn, K, k, s, gr = map(int, mm.groups())
+                cin = K // (k * k) * gr
+                by = 2 * (M * s * s * cin + M * Nn * (2 if "+res" in d else 1) + K * Nn)
+                fl = 2.0 * M * Nn * K
+                bound = max(by / 6.5e12, fl / 1.6e15) * 1e6
+                tb += bound
+                print("  %7.1f %7.1f %5.2fx  %6.0f TF/s %5.2f TB/s  %s" % (us, bound, us / bound, fl / us / 1e6, by / us / 1e6, d))
+            else:
+                print("  %7.1f                 %s" % (us, d))
+        print("  sum %.1f us, conv bound sum %.1f us; input conversion %.1f us" % (tot, tb, prof[0] * 1e3))
     if a.ops:
         tot = 0
         for i in range(ex.numOps):
