@@ -482,8 +482,8 @@ int Executor::autotune(hipStream_t s) {
         float best = 1e30f; int best_cfg = -1;
         for (int c = 0; c < ncfg && !rc; c++) {
             st.conv_cfg = c;
-            float tot = 0; bool ok = true;
-            for (int it = 0; it < 3 && ok && !rc; it++) {
+            float tot = 1e30f; bool ok = true;                           // best of 4 timed launches: robust against stragglers
+            for (int it = 0; it < 5 && ok && !rc; it++) {
                 if (flush) SM_HIP_CHECK(hipMemsetAsync(flush, it, flush_bytes, s));
                 SM_HIP_CHECK(hipEventRecord(a, s));
                 int r = launchStep(st, s);
@@ -492,7 +492,7 @@ int Executor::autotune(hipStream_t s) {
                 if (r) { rc = r; break; }
                 SM_HIP_CHECK(hipEventSynchronize(b));
                 float t = 0; SM_HIP_CHECK(hipEventElapsedTime(&t, a, b));
-                if (it > 0) tot += t;                                      // first launch of a config also pays code fetch
+                if (it > 0 && t < tot) tot = t;                            // first launch of a config also pays code fetch
             }
             if (ok && !rc && tot < best) { best = tot; best_cfg = c; }
         }

@@ -400,6 +400,14 @@ const TileCfg kCfgs[] = {
     // narrow outputs (Cout <= 32: U-Net full-resolution layers): no MFMA work wasted on zero cout columns
     {128, 32, 1, 256, conv_igemm64_kernel<128, 32, 4, 1>, "k64:128x32"},              // 30
     {256, 32, 1, 256, conv_igemm64_kernel<256, 32, 4, 1>, "k64:256x32"},              // 31
+    // DMA issue interleaved with the MFMAs (8-wave tiles)
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 3, 0, 1>, "k64w8s3i:128x128(64x32)"},  // 32
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 3, 0, 1>, "k64w8s3i:128x128(32x64)"},  // 33
+    {256, 128, 1, 512, conv_igemm64_kernel<256, 128, 4, 2, 2, 0, 1>, "k64w8i:256x128"},           // 34
+    {256, 128, 1, 512, conv_igemm64_kernel<256, 128, 4, 2, 3, 0, 1>, "k64w8s3i:256x128"},         // 35
+    {256, 64, 1, 512, conv_igemm64_kernel<256, 64, 4, 2, 3, 0, 1>, "k64w8s3i:256x64"},            // 36
+    {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 4, 2, 3, 0, 1>, "k64w8s3i:128x64"},            // 37
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 1>, "k64w8i:128x128(64x32)"},    // 38
 #ifdef SM_ABLATION   // tools/conv_bench.py only: never built into the product library
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 1>, "abl:w8 noMFMA"},
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 2>, "abl:w8 noGlobal"},

@@ -46,7 +46,7 @@ template <int N> __device__ __forceinline__ void sm_wait_vmcnt() { asm volatile(
 constexpr int sm_pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; return r; }
 
 // ABL: ablation switch for tools/conv_bench.py (0 = product; 1 = no MFMA; 2 = no global->LDS traffic after the prologue)
-template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0>
+template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams p) {
     static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
     static_assert(NSTAGE >= 1 && NSTAGE <= 4, "1..4 stages");
@@ -148,20 +148,24 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
     const long a_wrap_c = (long)p.dW * p.x_ld - (long)(cpt - 1) * 64;      // next tap, same kernel row
     const long a_wrap_w = ((long)p.dH * p.W - (long)p.kW * p.dW) * p.x_ld;  // ... and on to the next kernel row
 
-    auto issue = [&](int slot) {
+    auto piece = [&](int slot, int i) {                         // i-th LDS-DMA instruction of the tile under the cursor
         unsigned char* sa = smem_raw + slot * STAGE_BYTES + wave * 1024;   // wave-uniform LDS base; lane*16 B added by the DMA
-#pragma unroll
-        for (int i = 0; i < A_IT; i++) {
+        if (i < A_IT) {
             const half_t* src = (amask[i] & tapbit) ? arow[i] + a_off : zero;
             SM_GLDS16(src, sa + i * NT * 16);
-        }
-#pragma unroll
-        for (int j = 0; j < B_IT; j++) SM_GLDS16(brow[j] + b_off, sa + A_BYTES + j * NT * 16);
+        } else SM_GLDS16(brow[i - A_IT] + b_off, sa + A_BYTES + (i - A_IT) * NT * 16);
+    };
+    auto advance = [&]() {
         b_off += 64;
         if (++cblk == cpt) {
             cblk = 0; a_off += a_wrap_c; tapbit <<= 1;
             if (++kw_i == p.kW) { kw_i = 0; a_off += a_wrap_w; }
         } else a_off += 64;
+    };
+    auto issue = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < LOADS; i++) piece(slot, i);
+        advance();
     };
 
     SM_TL(3);
@@ -222,7 +226,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) voff[ks] = (lane & 31) * 128 + (((ks * 2 + (lane >> 5)) ^ sw) << 4);
     }
-    auto compute = [&](int slot) {
+    // ILV = 1: a VMEM instruction stalls its wave while the address queue is full, so the LOADS DMA instructions of the
+    // next tile are spread between the MFMAs of this one instead of being issued as one burst (mainloop.hip: +5 % for the
+    // 8-wave 128x128 tile, +26 % for 256x128; no gain for 4-wave tiles)
+    auto compute = [&](int slot, int dslot, bool dma) {
         const unsigned sA = slot * STAGE_BYTES + wm * (TM * 4096), sB = slot * STAGE_BYTES + A_BYTES + wn * (TN * 4096);
         half8_t fx[2][TM], fw[2][TN];
 #pragma unroll
@@ -243,7 +250,18 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
                 for (int b = 0; b < TM; b++) {
                     if (ABL != 1) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks & 1][a], fx[ks & 1][b], acc[a][b], 0, 0, 0);
                     else { asm volatile("" ::"v"(fw[ks & 1][a]), "v"(fx[ks & 1][b])); }
+                    if (ILV) {
+                        constexpr int NM = 4 * TM * TN, MPL = NM / LOADS > 0 ? NM / LOADS : 1;   // MFMAs per DMA instruction
+                        const int cnt = (ks * TN + a) * TM + b + 1;
+                        if (cnt % MPL == 0 && cnt / MPL - 1 < LOADS && dma) piece(dslot, cnt / MPL - 1);
+                    }
                 }
+        }
+        if (ILV) {
+            constexpr int NM = 4 * TM * TN, MPL = NM / LOADS > 0 ? NM / LOADS : 1;
+#pragma unroll
+            for (int i = NM / MPL; i < LOADS; i++) if (dma) piece(dslot, i);
+            if (dma) advance();
         }
     };
 #pragma unroll
@@ -266,8 +284,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
 #ifdef SM_TIMELINE
         if (i == 0) SM_TL(6);
 #endif
-        if (issued < nk && ABL != 2) { issue(islot); ++issued; if (++islot == NSTAGE) islot = 0; }
-        compute(slot);
+        const bool more = issued < nk && ABL != 2;
+        if (!ILV && more) issue(islot);
+        compute(slot, islot, more);
+        if (more) { ++issued; if (++islot == NSTAGE) islot = 0; }
         if (++slot == NSTAGE) slot = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's fragment reads are done before it passes the next barrier
     }
