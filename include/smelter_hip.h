@@ -122,6 +122,11 @@ int sm_nchw_f32_to_nhwc_f16(const float* x, void* y, int32_t N, int32_t C, int32
                             int32_t halo_t, int32_t halo_l, int32_t halo_b, int32_t halo_r, sm_stream_t stream);
 int sm_nhwc_f16_to_nchw_f32(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t x_ld,
                             sm_stream_t stream);
+/* First-layer image (C <= 4), NCHW fp32 -> "row-pair image" fp16 [N][Hs][Ws][8]: pixel (y, x) = image pixel
+ * (y - pad_t, x - pad_l) in halfs 0..3 and the pixel below it in halfs 4..7, zeros outside the image.  The compiled
+ * graph runs the first convolution (ConvolutionConverter, kernel width <= 8) on this layout as a Cin = 64, kW = 1 GEMM. */
+int sm_nchw_f32_to_rowpair_f16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Hs,
+                               int32_t Ws, int32_t pad_t, int32_t pad_l, sm_stream_t stream);
 /* MPSImage.toFloatArray() element order (MPSImage+Extensions.swift:26-59):
  * [image][ceil(C/4) slice][H][W][4, or C when C < 3] */
 int sm_nhwc_f16_to_float_array(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W,

@@ -68,6 +68,7 @@ SYMBOLS = {
     "sm_upsample_bilinear": (_i32, [_vp, _vp] + [_i32] * 9 + [_vp]),
     "sm_copy_channels": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "sm_nchw_f32_to_nhwc_f16": (_i32, [_vp, _vp] + [_i32] * 9 + [_vp]),
+    "sm_nchw_f32_to_rowpair_f16": (_i32, [_vp, _vp] + [_i32] * 8 + [_vp]),
     "sm_nhwc_f16_to_nchw_f32": (_i32, [_vp, _vp] + [_i32] * 5 + [_vp]),
     "sm_nhwc_f16_to_float_array": (_i32, [_vp, _vp] + [_i32] * 5 + [_vp]),
     "sm_float_array_count": (_sz, [_i32] * 4),

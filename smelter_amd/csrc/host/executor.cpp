@@ -117,6 +117,24 @@ int Executor::plan(ONNXGraph& g, int batch) {
     // by sm_nchw_f32_to_nhwc_f16, matching zero weight columns)
     input_ld_ = (values_[input_value_].c + 7) / 8 * 8;
     place_[input_value_].ld = input_ld_;
+    // "image stem": an RGB(A) image feeding ONE ordinary convolution.  With C <= 4 the im2col row of a pixel is kH runs of
+    // kW*C <= 32 contiguous halfs; stored as a row-pair image (sm_nchw_f32_to_rowpair_f16: pixel = [row y | row y+1] x 4
+    // channels, zero halo instead of padding) two kernel rows of 8 pixels are 64 contiguous halfs, so the layer runs on
+    // the BK = 64 LDS-DMA kernel as a Cin = 64, kH' = ceil(kH/2), kW' = 1, dilation-2 convolution with K' = 64 kH' instead
+    // of the generic BK = 32 kernel with K = kH*kW*8 (ResNet-50 7x7/2: K' = 256 vs 392).
+    int stem_op = -1;
+    if (!cfg_.keepIntermediates && input_value_ != output_value_ && values_[input_value_].c <= 4) {
+        int users = 0;
+        for (int j = 0; j < no; j++) if (!dead[j]) {
+            for (int u : ops[j].inputs) if (u == input_value_) { users++; stem_op = j; }
+            if (ops[j].residual == input_value_) users += 2;
+        }
+        if (users != 1) stem_op = -1;
+        if (stem_op >= 0) {
+            const Op& o = ops[stem_op];
+            if (o.kind != OpKind::Conv || o.groups != 1 || o.kw > 8 || o.dh != 1 || o.dw != 1 || o.cin != values_[input_value_].c) stem_op = -1;
+        }
+    }
 
     std::vector<int> alias_of(nv, -1);       // value -> value it aliases
     std::vector<int> placed_in(nv, -1);      // value -> concat value it was placed into
@@ -181,7 +199,22 @@ int Executor::plan(ONNXGraph& g, int batch) {
         Step st; st.M = batch * values_[op.output].h * values_[op.output].w;
         st.real_cin = op.cin;
         if (op.kind == OpKind::FullyConnected && fc_permute[i]) { const Value& src = values_[fc_permute[i] - 1]; st.fc_h = src.h; st.fc_w = src.w; }
-        if (isConvLike(op.kind) && op.groups == 1 && op.kind == OpKind::Conv && rootOf(op.inputs[0]) == input_value_ && input_ld_ != op.cin) {
+        st.real_k = isConvLike(op.kind) ? op.kh * op.kw * (op.cin / op.groups) : 0; st.real_kh = op.kh; st.real_kw = op.kw;
+        if (i == stem_op) {
+            // weights [Cout][kH][kW][C] -> [Cout][P][8 pixels][row 2j | row 2j+1][4 channels], zero where kh >= kH, kw >= kW, c >= C
+            const Value& ov = values_[op.output];
+            const int C = op.cin, P = (op.kh + 1) / 2;
+            std::vector<float> w((size_t)op.cout * P * 64, 0.f);
+            for (int co = 0; co < op.cout; co++)
+                for (int kh = 0; kh < op.kh; kh++)
+                    for (int kw = 0; kw < op.kw; kw++)
+                        for (int c = 0; c < C; c++)
+                            w[((size_t)co * P + kh / 2) * 64 + kw * 8 + (kh & 1) * 4 + c] = op.weight[(((size_t)co * op.kh + kh) * op.kw + kw) * C + c];
+            stem_ = true; stem_pt_ = op.pt; stem_pl_ = op.pl;
+            stem_h_ = (ov.h - 1) * op.sh + 2 * (P - 1) + 1; stem_w_ = (ov.w - 1) * op.sw + 8;
+            op.weight.swap(w); op.cin = 64; op.kh = P; op.kw = 1; op.dh = 2; op.dw = 1; op.pt = op.pl = op.pb = op.pr = 0;
+            st.stem = true; input_ld_ = 8; place_[input_value_].ld = 8;
+        } else if (isConvLike(op.kind) && op.groups == 1 && op.kind == OpKind::Conv && rootOf(op.inputs[0]) == input_value_ && input_ld_ != op.cin) {
             // pad Cin (OHWI innermost) with zero columns up to the padded image stride
             const int cin = op.cin, cp = input_ld_; const size_t rows = op.weight.size() / cin;
             std::vector<float> w(rows * cp, 0.f);
@@ -210,6 +243,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     std::vector<Blk> blks;
     for (int v = 0; v < nv; v++) if (place_[v].root == v && last[v] >= 0) {
         size_t bytes = alignUp((size_t)batch * values_[v].h * values_[v].w * place_[v].ld * 2 + 64);
+        if (stem_ && v == input_value_) bytes = alignUp((size_t)batch * stem_h_ * stem_w_ * 16 + 64);
         blks.push_back({v, bytes});
     }
     std::sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) { return a.bytes > b.bytes; });
@@ -232,7 +266,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             st.has_bias = !op.bias.empty();
             if (st.has_bias) { st.b_off = off; off = alignUp(off + op.bias.size() * 4); }
             const Value& ov = values_[op.output];
-            const double K = (double)op.kh * op.kw * (st.real_cin / op.groups);
+            const double K = (double)st.real_k;
             flops_ += 2.0 * st.M * op.cout * K;
             const Value& iv = values_[op.inputs[0]];
             alg_bytes_ += 2.0 * ((double)batch * iv.c * iv.h * iv.w + (double)st.M * ov.c + (op.residual >= 0 ? (double)st.M * ov.c : 0.0) + (double)op.cout * K);
@@ -251,8 +285,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
         launches_ += st.launches;
         char buf[256];
         if (isConvLike(op.kind))
-            snprintf(buf, sizeof buf, "%s %s M=%d N=%d K=%d k=%dx%d s=%d g=%d%s%s", kindName(op.kind), op.name.c_str(), st.M, op.cout, op.kh * op.kw * (op.cin / op.groups),
-                     op.kh, op.kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "");
+            snprintf(buf, sizeof buf, "%s %s M=%d N=%d K=%d k=%dx%d s=%d g=%d%s%s%s", kindName(op.kind), op.name.c_str(), st.M, op.cout, op.kh * op.kw * (op.cin / op.groups),
+                     st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem ? " stem" : "");
         else snprintf(buf, sizeof buf, "%s %s pixels=%d C=%d%s", kindName(op.kind), op.name.c_str(), st.M, values_[op.output].c, op.act ? " +act" : "");
         st.desc = buf;
     }
@@ -346,6 +380,7 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
         d.pt = op.pt; d.pl = op.pl; d.pb = op.pb; d.pr = op.pr; d.groups = op.groups; d.act = op.act; d.slope = op.slope;
         if (op.kind == OpKind::Conv) { d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.x_ld = valueLd(op.inputs[0]); }
         else { d.H = d.W = d.Ho = d.Wo = 1; d.x_ld = st.fc_h * st.fc_w > 1 ? op.cin : valueLd(op.inputs[0]); }   // flattened map: one dense row per image
+        if (st.stem) { d.H = stem_h_; d.W = stem_w_; d.x_ld = 8; }                                             // row-pair image
         d.y_ld = y_ld; d.res_ld = op.residual >= 0 ? valueLd(op.residual) : 0;
         return sm_conv2d_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
                                  op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, ws_, ws_bytes_, ss);
@@ -379,9 +414,15 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
     return SM_OK;
 }
 
-int Executor::launchAll(hipStream_t s, const float* in) const {
+// application image (NCHW fp32) -> the layout the first layer reads
+int Executor::convertInput(hipStream_t s, const float* in) const {
     const Value& iv = values_[input_value_];
-    int rc = sm_nchw_f32_to_nhwc_f16(in, valuePtr(input_value_), batch_, iv.c, iv.h, iv.w, input_ld_, 0, 0, 0, 0, (sm_stream_t)s);
+    if (stem_) return sm_nchw_f32_to_rowpair_f16(in, valuePtr(input_value_), batch_, iv.c, iv.h, iv.w, stem_h_, stem_w_, stem_pt_, stem_pl_, (sm_stream_t)s);
+    return sm_nchw_f32_to_nhwc_f16(in, valuePtr(input_value_), batch_, iv.c, iv.h, iv.w, input_ld_, 0, 0, 0, 0, (sm_stream_t)s);
+}
+
+int Executor::launchAll(hipStream_t s, const float* in) const {
+    int rc = convertInput(s, in);
     if (rc) return rc;
     for (auto& st : steps_) { rc = launchStep(st, s); if (rc) return rc; }
     return SM_OK;
@@ -452,11 +493,10 @@ int Executor::profile(hipStream_t s, const float* in, int iters, float* ms, int 
     std::vector<hipEvent_t> ev(n + 1);
     for (auto& e : ev) SM_HIP_CHECK(hipEventCreate(&e));
     std::vector<double> acc(n, 0.0);
-    const Value& iv = values_[input_value_];
     int rc = SM_OK;
     for (int it = 0; it < iters + 1 && !rc; it++) {          // pass 0 = warm-up, not accumulated
         SM_HIP_CHECK(hipEventRecord(ev[0], s));
-        rc = sm_nchw_f32_to_nhwc_f16(in, valuePtr(input_value_), batch_, iv.c, iv.h, iv.w, input_ld_, 0, 0, 0, 0, (sm_stream_t)s);
+        rc = convertInput(s, in);
         SM_HIP_CHECK(hipEventRecord(ev[1], s));
         for (int i = 0; i < n - 1 && !rc; i++) { rc = launchStep(steps_[i], s); SM_HIP_CHECK(hipEventRecord(ev[i + 2], s)); }
         SM_HIP_CHECK(hipStreamSynchronize(s));

@@ -27,6 +27,9 @@ struct Step {                // one op after fusion, with everything resolved
     int launches = 1;
     int real_cin = 0;        // before first-layer channel padding (FLOP accounting)
     int fc_h = 1, fc_w = 1;  // FullyConnected over a flattened HxW map: weight columns permuted NCHW->NHWC order
+    bool stem = false;       // first-layer conv running on the row-pair image (executor.cpp "image stem")
+    int real_k = 0;          // kH*kW*Cin/groups of the model (FLOP / byte accounting, description)
+    int real_kh = 0, real_kw = 0;
     std::string desc;
 };
 
@@ -66,6 +69,7 @@ class Executor {
     int plan(ONNXGraph& g, int batch);                   // fusion + placement + memory plan + arena layout
     int packWeights(std::vector<uint8_t>* host) const;   // fold/cast/pad -> arena image
     int launchStep(const Step& st, hipStream_t s) const;
+    int convertInput(hipStream_t s, const float* in) const;
     int launchAll(hipStream_t s, const float* in) const;
     int autotune(hipStream_t s);
     void* valuePtr(int v) const;
@@ -78,6 +82,7 @@ class Executor {
     std::vector<size_t> root_offset_;    // per value id (roots only), byte offset in the activation arena
     std::vector<Step> steps_;
     int input_value_ = -1, output_value_ = -1, input_ld_ = 0;
+    bool stem_ = false; int stem_h_ = 0, stem_w_ = 0, stem_pt_ = 0, stem_pl_ = 0;   // row-pair image geometry
     std::vector<std::string> value_names_, materialized_;
 
     char* arena_ = nullptr; size_t arena_bytes_ = 0; bool own_arena_ = false;

@@ -31,6 +31,31 @@ __global__ void nchw_to_nhwc_kernel(const float* x, half_t* y, int N, int C, int
     }
 }
 
+// NCHW fp32 (C <= 4) -> "row-pair image" fp16 [N][Hs][Ws][8]: pixel (y, x) holds image pixel (y - pt, x - pl) in halfs 0..3
+// and the pixel BELOW it, (y + 1 - pt, x - pl), in halfs 4..7 (zeros outside the image / beyond C).  64 consecutive halfs
+// starting at (y, x) are then 8 pixels of kernel row kh and 8 pixels of kernel row kh + 1: one BK = 64 tile of the
+// first-layer convolution (executor.cpp "image stem").  One thread per pixel, one 16-byte store.
+__global__ void nchw_to_rowpair_kernel(const float* x, half_t* y, int N, int C, int H, int W, int Hs, int Ws, int pt, int pl) {
+    const long total = (long)N * Hs * Ws;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / ((long)Hs * Ws)), r = (int)(i - (long)n * Hs * Ws), py = r / Ws, px = r - py * Ws;
+        const int ix = px - pl;
+        half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if ((unsigned)ix < (unsigned)W) {
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int iy = py - pt + half;
+                if ((unsigned)iy < (unsigned)H) {
+                    const float* src = x + ((long)n * C * H + iy) * W + ix;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) if (c < C) v[half * 4 + c] = (half_t)src[(long)c * H * W];
+                }
+            }
+        }
+        *(half8_t*)(y + i * 8) = v;
+    }
+}
+
 // NHWC fp16 -> NCHW fp32.  32x32 (pixel x channel) tile transposed through LDS so both sides are coalesced.
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const half_t* x, float* y, int HW, int C, int ld) {
     __shared__ float tile[32][33];
@@ -72,6 +97,15 @@ int sm_nchw_f32_to_nhwc_f16(const float* x, void* y, int32_t N, int32_t C, int32
     SM_REQUIRE(y_ld >= C, "sm_nchw_f32_to_nhwc_f16: y_ld < C");
     long pix = (long)N * (H + ht + hb) * (W + hl + hr);
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(sm_stream_grid(pix, 256)), dim3(256), 0, sm_s(st), x, (half_t*)y, N, C, H, W, y_ld, ht, hl, hb, hr);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+int sm_nchw_f32_to_rowpair_f16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t Hs, int32_t Ws, int32_t pt, int32_t pl,
+                               sm_stream_t st) {
+    SM_REQUIRE(x && y && N > 0 && C > 0 && C <= 4 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && pt >= 0 && pl >= 0, "sm_nchw_f32_to_rowpair_f16: bad argument");
+    SM_REQUIRE((((uintptr_t)y) & 15) == 0, "sm_nchw_f32_to_rowpair_f16: destination not 16-byte aligned");
+    long pix = (long)N * Hs * Ws;
+    hipLaunchKernelGGL(nchw_to_rowpair_kernel, dim3(sm_stream_grid(pix, 256)), dim3(256), 0, sm_s(st), x, (half_t*)y, N, C, H, W, Hs, Ws, pt, pl);
     SM_LAUNCH_CHECK(); return SM_OK;
 }
 

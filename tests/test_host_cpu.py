@@ -142,9 +142,13 @@ def test_bn_fold_fp16_cast_and_ohwi_match_numpy_restatement():
     s = gamma / np.sqrt(var + np.float32(1e-5))
     w_f = (w * s[:, None, None, None]).astype(np.float32)
     b_f = ((0 - mean) * s + beta).astype(np.float32)
-    ohwi = np.zeros((8, 3, 3, 8), np.float32)          # first layer: Cin padded 3 -> 8 with zero columns
-    ohwi[..., :3] = w_f.transpose(0, 2, 3, 1)
-    expect_w = ohwi.astype(np.float16).view(np.uint16).ravel()
+    # first layer ("image stem"): OHWI regrouped as [Cout][kernel-row pair][8 pixels][row 2j | row 2j+1][4 channels],
+    # zero where kh >= kH, kw >= kW or c >= Cin
+    stem = np.zeros((8, 2, 8, 2, 4), np.float32)
+    for kh in range(3):
+        for kw in range(3):
+            stem[:, kh // 2, kw, kh & 1, :3] = w_f[:, :, kh, kw]
+    expect_w = stem.astype(np.float16).view(np.uint16).ravel()
     arena = ONNXGraph(zoo.toy()).packWeights(1)
     got_w = arena[:expect_w.size * 2].view(np.uint16)
     assert np.array_equal(got_w, expect_w)

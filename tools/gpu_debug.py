@@ -18,7 +18,7 @@ def nerr(a, b):
 
 
 def layerwise(name, model, x):
-    ex = ONNXGraph(model, Configuration(useHipGraph=False)).hipGraph(0, x.shape[0])
+    ex = ONNXGraph(model, Configuration(useHipGraph=False, keepIntermediates=True)).hipGraph(0, x.shape[0])
     ex.encode(torch.from_numpy(x).cuda())
     got_final = ex.toFloatArray()
     og = O.Graph(model)
@@ -49,7 +49,9 @@ def layerwise(name, model, x):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "mbv2"
-    if which == "mbv2":
+    if which == "toy":
+        layerwise("toy", zoo.toy(), zoo.synthetic_images(2, 3, (64, 64)))
+    elif which == "mbv2":
         layerwise("mbv2", onnx2mps.optimize_model(zoo.mobilenet_v2(hw=(64, 64)), half=True), zoo.synthetic_images(3, 3, (64, 64)))
     elif which == "unet":
         layerwise("unet", onnx2mps.optimize_model(zoo.unet(hw=(64, 48)), half=True), zoo.synthetic_images(2, 3, (64, 48)))
