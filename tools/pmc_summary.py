@@ -28,7 +28,7 @@ def main():
             d = int(r["Dispatch_Id"])
             if d not in seen:
                 seen.add(d); ids.append((d, r["Kernel_Name"]))
-        starts = [i for i, (_, n) in enumerate(ids) if "nchw_to_nhwc" in n]
+        starts = [i for i, (_, n) in enumerate(ids) if "nchw_to_" in n]
         lo, hi = starts[-2], starts[-1]
         ordinal = {d: i - lo for i, (d, _) in enumerate(ids) if lo <= i < hi}
         for r in rows:

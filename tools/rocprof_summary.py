@@ -47,7 +47,7 @@ def main():
     ap.add_argument("--flops-per-step", type=float, default=64 * 2 * 4089184256.0)
     a = ap.parse_args()
     rows = load(a.path)
-    starts = [i for i, r in enumerate(rows) if "nchw_to_nhwc" in r[2]]
+    starts = [i for i, r in enumerate(rows) if "nchw_to_" in r[2]]
     assert len(starts) >= a.steps + 1, "found %d encode() calls" % len(starts)
     lo = starts[-a.steps - 1]
     hi = starts[-1]                      # the last encode may be followed by read-back kernels: use complete segments only
@@ -78,7 +78,7 @@ if __name__ == "__main__":
 def last_step_listing(path, steps):
     """per-dispatch durations of the last complete encode() step, in launch order"""
     rows = load(path)
-    starts = [i for i, r in enumerate(rows) if "nchw_to_nhwc" in r[2]]
+    starts = [i for i, r in enumerate(rows) if "nchw_to_" in r[2]]
     lo, hi = starts[-2], starts[-1]
     out = []
     for s, e, n in rows[lo:hi]:
