@@ -67,6 +67,10 @@ typedef struct sm_conv_desc {
     int32_t Ho, Wo;
     int32_t act; float slope;     /* fused neuron */
     int32_t x_ld, y_ld, res_ld;   /* pixel strides in elements; 0 = dense (Cin / Cout / Cout) */
+    /* Output placement (all 0 = dense): output pixel (n, oy, ox) of the Ho x Wo grid is written to pixel
+     * (n, oy*y_sH + y_oH, ox*y_sW + y_oW) of an image of y_H x y_W pixels.  This is how a stride-s ConvTranspose runs as
+     * s*s ordinary convolutions, one per output phase (smelter_graph_compile); no residual operand in this mode. */
+    int32_t y_sH, y_sW, y_oH, y_oW, y_H, y_W;
 } sm_conv_desc;
 
 /* MPSCNNConvolutionNode / MPSCNNFullyConnectedNode (Converters.swift:253, :297).  `residual` (nullable) is an
@@ -81,6 +85,14 @@ int sm_conv2d_fwd_ws(const sm_conv_desc* d, const void* x, const void* w_ohwi, c
 int sm_conv2d_num_configs(void);
 int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias,
                       const void* residual, void* y, void* workspace, size_t workspace_bytes, sm_stream_t stream);
+
+/* MPSCNNConvolutionTransposeNode (Converters.swift:277) + ONNX_ConvolutionPadding(isTranspose) (:66-71, :97-103).
+ * `w_ohwi_flipped` is what ConvDataSource hands MPS: out[oc][kH-1-kh][kW-1-kw][ic] = W[ic][oc][kh][kw]
+ * (Array+Extensions.swift:71-76).  y[n,oy,ox,oc] = act(bias[oc] + sum x[n,iy,ix,ic] * W[ic,oc,kh,kw]) over
+ * iy*sH - pt + kh*dH == oy; d->Ho/Wo = (in-1)*s - pads + k + output_padding; groups must be 1.  Direct gather kernel,
+ * any shape; the compiled graph runs stride/dilation-1-decomposable cases as per-phase MFMA convolutions instead. */
+int sm_conv_transpose2d_fwd(const sm_conv_desc* d, const void* x, const void* w_ohwi_flipped, const float* bias, void* y,
+                            sm_stream_t stream);
 
 /* tuning aid: average duration of `iters` back-to-back launches (HIP events on `stream`) */
 int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias, const void* residual,

@@ -85,6 +85,7 @@ def lib():
         L.orc_float_array_count.restype = C.c_size_t
         L.orc_pack_float_array.argtypes = [vp] + [C.c_int] * 4 + [vp]
         L.orc_conv2d.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp]
+        L.orc_conv_transpose2d.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp]
         L.orc_gemm_fc.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
         L.orc_batchnorm.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float]
         L.orc_relu.argtypes = [vp, vp, C.c_size_t, C.c_float]
@@ -181,6 +182,20 @@ def conv2d(x, w_ohwi, bias=None, stride=(1, 1), pads=(0, 0, 0, 0), dil=(1, 1), g
     y = np.empty((n, k, ho, wo), np.float32)
     b = _f32(bias) if bias is not None else None
     lib().orc_conv2d(C.byref(d), _p(x), _p(w), _p(b), _p(y))
+    return y
+
+
+def conv_transpose2d(x, w_ohwi_flipped, bias=None, stride=(1, 1), pads=(0, 0, 0, 0), dil=(1, 1), out_pad=(0, 0)):
+    """MPSCNNConvolutionTransposeNode over the data source's flipped OHWI weights (reformat_conv_weight(..., is_transpose=True))"""
+    x, w = _f32(x), _f32(w_ohwi_flipped)
+    n, c, h, wd = x.shape
+    k, kh, kw, cg = w.shape
+    assert cg == c
+    wo, ho = conv_padded_size(wd, h, (kh, kw), stride, pads, out_pad, is_transpose=True)
+    d = ConvDesc(n, c, h, wd, k, kh, kw, stride[0], stride[1], dil[0], dil[1], pads[0], pads[1], pads[2], pads[3], 1, ho, wo)
+    y = np.empty((n, k, ho, wo), np.float32)
+    b = _f32(bias) if bias is not None else None
+    lib().orc_conv_transpose2d(C.byref(d), _p(x), _p(w), _p(b), _p(y))
     return y
 
 

@@ -129,6 +129,10 @@ typedef struct {
 
 void orc_set_acc64(int on); /* conv accumulates in fp64 (spot checks) */
 void orc_conv2d(const orc_conv_desc* d, const float* x, const float* w_ohwi, const float* bias, float* y);
+/* MPSCNNConvolutionTransposeNode (Converters.swift:265-287) with the data source's flipped OHWI weights
+ * (Array+Extensions.swift:71-76): y[n,oc,oy,ox] = b[oc] + sum x[n,ic,iy,ix] * W[ic,oc,kh,kw] over iy*s - pt + kh*d == oy
+ * (ONNX ConvTranspose; group 1).  d->Ho/Wo = (in-1)*s - pads + k + output_padding (ONNXConvolutionPadding.swift:97-103). */
+void orc_conv_transpose2d(const orc_conv_desc* d, const float* x, const float* w_ohwi_flipped, const float* bias, float* y);
 void orc_gemm_fc(const float* x, const float* w_oi, const float* bias, float* y, int n, int in_f, int out_f);
 void orc_batchnorm(const float* x, float* y, int n, int c, int hw, const float* gamma, const float* beta,
                    const float* mean, const float* var, float eps);

@@ -159,20 +159,21 @@ static int conv_like(orc_graph* g, const orc_node* nd) { /* ConvolutionConverter
     }
     if (is_gemm) { kh = kw = dh = dw = sh = sw = 1; have_k = have_d = have_s = 1; }            /* :228-232 */
     if (!have_k || !have_d || !have_s) return fail(ORC_ERR_NOT_ENOUGH_ATTRIBUTES, "Conv: kernel_shape/dilations/strides required"); /* :234-237 */
-    if (is_tr) return fail(ORC_ERR_INCONSISTENT_STATE, "ConvTranspose: not restated yet (SURVEY.md §8f rank 1)");
+    if (is_tr && groups != 1) return fail(ORC_ERR_INCONSISTENT_STATE, "ConvTranspose: group=%d is outside the restated subset (group=1)", groups);
 
     /* ConvDataSource.init :20-138 */
     int OC, IC, wkh, wkw;
     if (is_gemm) { if (wt->ndims < 2) return fail(ORC_ERR_INSUFFICIENT_INPUTS, "Gemm weight rank"); OC = (int)wt->dims[0]; IC = (int)wt->dims[1]; wkh = wkw = 1; }
     else { if (wt->ndims < 4) return fail(ORC_ERR_INSUFFICIENT_INPUTS, "Conv weight rank");
         if (g->mps_flavor) { OC = (int)wt->dims[0]; wkh = (int)wt->dims[1]; wkw = (int)wt->dims[2]; IC = (int)wt->dims[3]; }   /* :40-44 */
+        else if (is_tr) { OC = (int)wt->dims[1]; IC = (int)wt->dims[0]; wkh = (int)wt->dims[2]; wkw = (int)wt->dims[3]; }         /* :48-50 [I,O,kH,kW] */
         else { OC = (int)wt->dims[0]; IC = (int)wt->dims[1]; wkh = (int)wt->dims[2]; wkw = (int)wt->dims[3]; } }               /* :46-54 */
     if (wt->data_type != 1 && wt->data_type != 10) return fail(ORC_ERR_UNSUPPORTED_DTYPE, "Conv weight dtype %d", wt->data_type); /* :82-89 .invalid */
     long nw = 0; float* wsrc = tensor_floats_alloc(wt, &nw);
     if (!wsrc) return fail((int)nw, "Conv weight accessor");
     if (nw != (long)OC * IC * wkh * wkw) { free(wsrc); return fail(ORC_ERR_INCONSISTENT_STATE, "Conv weight has %ld elements, dims say %ld", nw, (long)OC * IC * wkh * wkw); }
     float* w = wsrc;
-    if (!g->mps_flavor && !is_gemm) { w = malloc(sizeof(float) * nw); orc_reformat_conv_weight(wsrc, w, 4, OC, IC, wkh, wkw, 0); free(wsrc); } /* :91-124 */
+    if (!g->mps_flavor && !is_gemm) { w = malloc(sizeof(float) * nw); orc_reformat_conv_weight(wsrc, w, 4, OC, IC, wkh, wkw, is_tr); free(wsrc); } /* :91-124 */
     float* bias = NULL; long nb = 0;
     if (bt) { bias = tensor_floats_alloc(bt, &nb); if (!bias) { free(w); return fail((int)nb, "Conv bias accessor"); }
         if (nb != OC) { free(w); free(bias); return fail(ORC_ERR_INCONSISTENT_STATE, "Conv bias has %ld elements for %d channels", nb, OC); } }
@@ -188,11 +189,12 @@ static int conv_like(orc_graph* g, const orc_node* nd) { /* ConvolutionConverter
         int depthwise = (groups != 1) && (groups == OC);                                        /* :57 */
         int cin_total = depthwise ? OC : IC * groups;                                           /* :59-74 */
         if (cin_total != in->c) { rc = fail(ORC_ERR_INCONSISTENT_STATE, "Conv: input C=%d, weight expects %d", in->c, cin_total); goto done; }
-        orc_conv_padded_size(in->w, in->h, kh, kw, sh, sw, pt, pl, pb, pr, oph, opw, 0, &Wo, &Ho);
+        orc_conv_padded_size(in->w, in->h, kh, kw, sh, sw, pt, pl, pb, pr, oph, opw, is_tr, &Wo, &Ho);
         if (Ho <= 0 || Wo <= 0) { rc = fail(ORC_ERR_INCONSISTENT_STATE, "Conv: empty output"); goto done; }
         orc_conv_desc d = {N, in->c, in->h, in->w, OC, kh, kw, sh, sw, dh, dw, pt, pl, pb, pr, groups, Ho, Wo};
         y = malloc(sizeof(float) * (size_t)N * OC * Ho * Wo);
-        orc_conv2d(&d, in->data, w, bias, y);
+        if (is_tr) orc_conv_transpose2d(&d, in->data, w, bias, y);                              /* :265-287 */
+        else orc_conv2d(&d, in->data, w, bias, y);
     }
     if (wants_round(g, nd->output[0])) orc_round_to_half(y, (size_t)N * OC * Ho * Wo);
     for (int i = 0; i < nd->n_output; i++) {  /* addFilter publishes under every output name, ONNXGraph.swift:263-273 */

@@ -67,6 +67,35 @@ void orc_conv2d(const orc_conv_desc* d, const float* x, const float* w, const fl
     if (g_acc64) { ORC_CONV_BODY(double) } else { ORC_CONV_BODY(float) }
 }
 
+/* Converters.swift:265-287 (MPSCNNConvolutionTransposeNode).  The data source hands MPS W_t[oc][kh'][kw'][ic] =
+ * W[ic][oc][kH-1-kh'][kW-1-kw'] (Array+Extensions.swift:71-76); in those terms the ONNX ConvTranspose sum is a gather:
+ * input row iy feeds output row oy through tap kh' iff iy*sH == oy + pt - (kH-1-kh')*dH. */
+#define ORC_CONVT_BODY(ACC)                                                                                         \
+    const int N = d->N, C = d->C, H = d->H, W = d->W, OC = d->K, KH = d->kh, KW = d->kw, Ho = d->Ho, Wo = d->Wo;   \
+    _Pragma("omp parallel for collapse(2) schedule(static)")                                                        \
+    for (int n = 0; n < N; n++)                                                                                     \
+        for (int oc = 0; oc < OC; oc++)                                                                             \
+            for (int oy = 0; oy < Ho; oy++)                                                                         \
+                for (int ox = 0; ox < Wo; ox++) {                                                                   \
+                    ACC acc = 0;                                                                                    \
+                    for (int kh = 0; kh < KH; kh++) {                                                               \
+                        int ty = oy + d->pt - (KH - 1 - kh) * d->dh;                                                \
+                        if (ty < 0 || ty % d->sh) continue;                                                         \
+                        int iy = ty / d->sh; if (iy >= H) continue;                                                 \
+                        for (int kw = 0; kw < KW; kw++) {                                                           \
+                            int tx = ox + d->pl - (KW - 1 - kw) * d->dw;                                            \
+                            if (tx < 0 || tx % d->sw) continue;                                                     \
+                            int ix = tx / d->sw; if (ix >= W) continue;                                             \
+                            const float* wp = w + (((size_t)oc * KH + kh) * KW + kw) * C;                           \
+                            for (int ic = 0; ic < C; ic++) acc += (ACC)x[(((size_t)n * C + ic) * H + iy) * W + ix] * (ACC)wp[ic]; \
+                        }                                                                                           \
+                    }                                                                                               \
+                    y[(((size_t)n * OC + oc) * Ho + oy) * Wo + ox] = (float)acc + (bias ? bias[oc] : 0.f);          \
+                }
+void orc_conv_transpose2d(const orc_conv_desc* d, const float* x, const float* w, const float* bias, float* y) {
+    if (g_acc64) { ORC_CONVT_BODY(double) } else { ORC_CONVT_BODY(float) }
+}
+
 /* Converters.swift:288-302 (MPSCNNFullyConnectedNode), weight read as [out,in] :35-39 ; alpha/beta/trans ignored */
 void orc_gemm_fc(const float* x, const float* w, const float* bias, float* y, int n, int in_f, int out_f) {
 #pragma omp parallel for collapse(2) schedule(static)

@@ -29,7 +29,7 @@ class SmelterError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "Cout", "kH", "kW", "sH", "sW", "dH", "dW",
                                          "pt", "pl", "pb", "pr", "groups", "Ho", "Wo", "act")] + \
-               [("slope", C.c_float)] + [(n, C.c_int32) for n in ("x_ld", "y_ld", "res_ld")]
+               [("slope", C.c_float)] + [(n, C.c_int32) for n in ("x_ld", "y_ld", "res_ld", "y_sH", "y_sW", "y_oH", "y_oW", "y_H", "y_W")]
 
 
 class PoolDesc(C.Structure):
@@ -57,6 +57,7 @@ SYMBOLS = {
     "sm_conv2d_fwd_ws": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sm_conv2d_num_configs": (_i32, []),
     "sm_conv2d_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sm_conv_transpose2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "sm_conv2d_time": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, C.POINTER(_f)]),
     "sm_batchnorm": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp]),
     "sm_add": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _f, _vp]),

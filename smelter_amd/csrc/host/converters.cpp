@@ -48,9 +48,8 @@ struct ConvolutionConverter : NodeConverter {
         const bool isGemm = node.op_type == "Gemm", isTranspose = node.op_type == "ConvTranspose";
         if (isGemm) { kh = kw = dh = dw = sh = sw = 1; hasK = hasD = hasS = true; }                                                     // :228-232
         if (!hasK || !hasD || !hasS) SM_FAIL(SM_ERR_NOT_ENOUGH_ATTRIBUTES, "%.*s: kernel_shape, dilations and strides are all required", SV(node.op_type));  // :234-237
-        if (isTranspose) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "ConvTranspose is not implemented yet (SURVEY.md §8f rank 1)");
+        if (isTranspose && groups != 1) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "ConvTranspose: group=%d is not supported (group=1 only)", groups);
         if (sh <= 0 || sw <= 0 || dh <= 0 || dw <= 0 || groups <= 0 || kh <= 0 || kw <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: non-positive attribute");
-        (void)oph; (void)opw;
 
         // ConvDataSource.init: channel/kernel extents from the weight dims (:35-54)
         const bool mps = graph.modelFormat == Format::mpsFlavor;
@@ -59,13 +58,14 @@ struct ConvolutionConverter : NodeConverter {
         else {
             if (weight->dims.size() < 4) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "Conv: weight rank < 4");
             if (mps) { OC = (int)weight->dims[0]; wkh = (int)weight->dims[1]; wkw = (int)weight->dims[2]; IC = (int)weight->dims[3]; }     // :40-44
+            else if (isTranspose) { OC = (int)weight->dims[1]; IC = (int)weight->dims[0]; wkh = (int)weight->dims[2]; wkw = (int)weight->dims[3]; }  // :48-50 [I,O,kH,kW]
             else { OC = (int)weight->dims[0]; IC = (int)weight->dims[1]; wkh = (int)weight->dims[2]; wkw = (int)weight->dims[3]; }        // :46-54
         }
         if (weight->data_type != pb::FLOAT && weight->data_type != pb::FLOAT16)                                                          // :82-89 (.invalid)
             SM_FAIL(SM_ERR_UNSUPPORTED_DTYPE, "%.*s: weight data_type %d (FLOAT or FLOAT16 expected)", SV(node.op_type), weight->data_type);
         if (!isGemm && (wkh != kh || wkw != kw)) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: kernel_shape %dx%d disagrees with weight dims %dx%d", kh, kw, wkh, wkw);
 
-        Op op; op.kind = isGemm ? OpKind::FullyConnected : OpKind::Conv;
+        Op op; op.kind = isGemm ? OpKind::FullyConnected : isTranspose ? OpKind::ConvTranspose : OpKind::Conv;
         op.inputs = {in}; op.cout = OC; op.kh = kh; op.kw = kw; op.sh = sh; op.sw = sw; op.dh = dh; op.dw = dw;
         op.pt = pt; op.pl = pl; op.pb = pb_; op.pr = pr; op.groups = groups;
         op.weight_was_fp16 = weight->data_type == pb::FLOAT16;
@@ -75,7 +75,7 @@ struct ConvolutionConverter : NodeConverter {
         if (w.size() != expect) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "%.*s: weight holds %zu elements, dims say %zu", SV(node.op_type), w.size(), expect);
         if (!mps && !isGemm) {                                            // re-layout unless ONNX2MPS already did it (:91-124)
             op.weight.resize(expect);
-            sm_reformat_conv_weight(w.data(), op.weight.data(), 4, OC, IC, wkh, wkw, 0);
+            sm_reformat_conv_weight(w.data(), op.weight.data(), 4, OC, IC, wkh, wkw, isTranspose ? 1 : 0);   // transpose: + flip (:71-76)
         } else op.weight = std::move(w);
         if (bias) {                                                       // :126-135 (+ typed float_data accepted)
             rc = pb::tensor_floats(*bias, &op.bias); if (rc) SM_FAIL(rc, "Conv: bias accessor");
@@ -93,7 +93,7 @@ struct ConvolutionConverter : NodeConverter {
             if (cinTotal != iv.c) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: input has %d channels, weight expects %d", iv.c, cinTotal);
             if (OC % groups) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: %d output channels not divisible by group %d", OC, groups);
             op.cin = cinTotal;
-            sm_conv_padded_size(iv.w, iv.h, kh, kw, sh, sw, pt, pl, pb_, pr, 0, 0, 0, &Wo, &Ho);                                        // :311-322
+            sm_conv_padded_size(iv.w, iv.h, kh, kw, sh, sw, pt, pl, pb_, pr, oph, opw, isTranspose ? 1 : 0, &Wo, &Ho);                  // :311-322
             if (Ho <= 0 || Wo <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: empty output %dx%d", Ho, Wo);
         }
         return graph.addFilter(std::move(op), OC, Ho, Wo, mkShape(1, Wo, Ho, OC), node.output);                                         // :311-336

@@ -29,13 +29,13 @@ namespace {
 
 constexpr size_t kAlign = 256;
 size_t alignUp(size_t v, size_t a = kAlign) { return (v + a - 1) / a * a; }
-bool isConvLike(OpKind k) { return k == OpKind::Conv || k == OpKind::FullyConnected; }
+bool isConvLike(OpKind k) { return k == OpKind::Conv || k == OpKind::FullyConnected || k == OpKind::ConvTranspose; }
 const char* kindName(OpKind k) {
     switch (k) {
     case OpKind::Conv: return "Conv"; case OpKind::FullyConnected: return "FC"; case OpKind::BatchNorm: return "BatchNorm";
     case OpKind::Neuron: return "Neuron"; case OpKind::Add: return "Add"; case OpKind::MaxPool: return "MaxPool";
     case OpKind::AvgPool: return "AvgPool"; case OpKind::GlobalAvgPool: return "GlobalAvgPool"; case OpKind::Upsample: return "Upsample";
-    case OpKind::Concat: return "Concat"; case OpKind::Alias: return "Alias";
+    case OpKind::Concat: return "Concat"; case OpKind::Alias: return "Alias"; case OpKind::ConvTranspose: return "ConvTranspose";
     }
     return "?";
 }
@@ -91,7 +91,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 }
             } else if (op.kind == OpKind::Add) {
                 int pa = producerOf(op.inputs[0]), pb = producerOf(op.inputs[1]);
-                auto ok = [&](int p, int v) { return p >= 0 && isConvLike(ops[p].kind) && ops[p].act == SM_ACT_NONE && ops[p].residual < 0 && consumers(v) == 1; };
+                auto ok = [&](int p, int v) { return p >= 0 && isConvLike(ops[p].kind) && ops[p].kind != OpKind::ConvTranspose && ops[p].act == SM_ACT_NONE && ops[p].residual < 0 && consumers(v) == 1; };
                 int cand = -1, other = -1;
                 bool oka = ok(pa, op.inputs[0]), okb = ok(pb, op.inputs[1]) && op.inputs[0] != op.inputs[1];
                 if (oka && okb) { if (pa > pb) { cand = pa; other = op.inputs[1]; } else { cand = pb; other = op.inputs[0]; } }
@@ -196,10 +196,52 @@ int Executor::plan(ONNXGraph& g, int batch) {
             }
             continue;
         }
+        if (op.kind == OpKind::ConvTranspose && op.groups == 1 && op.dh == 1 && op.dw == 1 && (op.cin % 8) == 0) {
+            // A stride-s transposed convolution = s*s ordinary stride-1 convolutions, one per output phase
+            // (py, px) = ((oy + pt) mod sH, (ox + pl) mod sW): output row oy = q*sH + py - pt only sees kernel rows
+            // kh = py + sH*a, through input row iy = q - a.  Each phase gets its sub-kernel (taken from the flipped OHWI
+            // master copy), its own padding (A - 1 - q_min, may be negative) and writes its pixels strided into the
+            // shared output image (sm_conv_desc.y_sH ...).  No zero-inserted input, no wasted MACs.
+            const Value& iv = values_[op.inputs[0]]; const Value& ov = values_[op.output];
+            struct Ph { int A, qmin, Q, o0, pad; };
+            auto phase = [](int k, int s, int p, int out, int ph) {
+                Ph r; r.A = ph < k ? (k - ph + s - 1) / s : 0;
+                r.qmin = (p - ph + s - 1) / s;                              // ceil((p - ph) / s), numerator + s - 1 >= 0
+                const int num = out - 1 + p - ph;
+                r.Q = num < 0 ? 0 : num / s - r.qmin + 1; if (r.Q < 0) r.Q = 0;
+                r.o0 = r.qmin * s + ph - p; r.pad = (r.A > 0 ? r.A - 1 : 0) - r.qmin;
+                return r;
+            };
+            (void)iv;
+            for (int py = 0; py < op.sh; py++)
+                for (int px = 0; px < op.sw; px++) {
+                    const Ph y = phase(op.kh, op.sh, op.pt, ov.h, py), x = phase(op.kw, op.sw, op.pl, ov.w, px);
+                    if (y.Q == 0 || x.Q == 0) continue;
+                    Step st; Op po = op;                                    // copy: inputs, output, bias, act, name
+                    po.kind = OpKind::Conv; po.sh = po.sw = 1; po.dh = po.dw = 1; po.pb = po.pr = 0;
+                    const int Ay = y.A > 0 && x.A > 0 ? y.A : 1, Ax = y.A > 0 && x.A > 0 ? x.A : 1;   // tap-less phase: 1x1 zero kernel
+                    po.kh = Ay; po.kw = Ax; po.pt = y.pad; po.pl = x.pad;
+                    po.weight.assign((size_t)op.cout * Ay * Ax * op.cin, 0.f);
+                    if (y.A > 0 && x.A > 0)
+                        for (int oc = 0; oc < op.cout; oc++)
+                            for (int a = 0; a < Ay; a++)
+                                for (int b = 0; b < Ax; b++) {
+                                    const int kh = py + op.sh * (Ay - 1 - a), kw = px + op.sw * (Ax - 1 - b);
+                                    const float* src = op.weight.data() + (((size_t)oc * op.kh + (op.kh - 1 - kh)) * op.kw + (op.kw - 1 - kw)) * op.cin;
+                                    std::copy(src, src + op.cin, po.weight.begin() + (((size_t)oc * Ay + a) * Ax + b) * op.cin);
+                                }
+                    po.y_sh = op.sh; po.y_sw = op.sw; po.y_oh = y.o0; po.y_ow = x.o0; po.y_h = ov.h; po.y_w = ov.w; po.grid_h = y.Q; po.grid_w = x.Q;
+                    st.M = batch * y.Q * x.Q; st.real_cin = op.cin; st.real_k = (y.A > 0 && x.A > 0) ? Ay * Ax * op.cin : 0; st.real_kh = Ay; st.real_kw = Ax;
+                    st.op = std::move(po);
+                    steps_.push_back(std::move(st));
+                }
+            continue;
+        }
         Step st; st.M = batch * values_[op.output].h * values_[op.output].w;
         st.real_cin = op.cin;
         if (op.kind == OpKind::FullyConnected && fc_permute[i]) { const Value& src = values_[fc_permute[i] - 1]; st.fc_h = src.h; st.fc_w = src.w; }
         st.real_k = isConvLike(op.kind) ? op.kh * op.kw * (op.cin / op.groups) : 0; st.real_kh = op.kh; st.real_kw = op.kw;
+        if (op.kind == OpKind::ConvTranspose) st.real_k = std::max(1, st.real_k / (op.sh * op.sw));   // an output pixel sees ~1/(sH*sW) of the taps
         if (i == stem_op) {
             // weights [Cout][kH][kW][C] -> [Cout][P][8 pixels][row 2j | row 2j+1][4 channels], zero where kh >= kH, kw >= kW, c >= C
             const Value& ov = values_[op.output];
@@ -286,14 +328,14 @@ int Executor::plan(ONNXGraph& g, int batch) {
         char buf[256];
         if (isConvLike(op.kind))
             snprintf(buf, sizeof buf, "%s %s M=%d N=%d K=%d k=%dx%d s=%d g=%d%s%s%s", kindName(op.kind), op.name.c_str(), st.M, op.cout, op.kh * op.kw * (op.cin / op.groups),
-                     st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem ? " stem" : "");
+                     st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem ? " stem" : op.grid_h ? " convT-phase" : "");
         else snprintf(buf, sizeof buf, "%s %s pixels=%d C=%d%s", kindName(op.kind), op.name.c_str(), st.M, values_[op.output].c, op.act ? " +act" : "");
         st.desc = buf;
     }
     arena_bytes_ = std::max(off, (size_t)kAlign);
     value_names_.resize(nv); for (int v = 0; v < nv; v++) value_names_[v] = values_[v].name;
     materialized_.clear(); materialized_.push_back(values_[input_value_].name);
-    for (auto& st : steps_) if (st.op.kind != OpKind::Concat) materialized_.push_back(values_[st.op.output].name);
+    for (auto& st : steps_) if (st.op.kind != OpKind::Concat && materialized_.back() != values_[st.op.output].name) materialized_.push_back(values_[st.op.output].name);
     return SM_OK;
 }
 
@@ -381,9 +423,18 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
         if (op.kind == OpKind::Conv) { d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.x_ld = valueLd(op.inputs[0]); }
         else { d.H = d.W = d.Ho = d.Wo = 1; d.x_ld = st.fc_h * st.fc_w > 1 ? op.cin : valueLd(op.inputs[0]); }   // flattened map: one dense row per image
         if (st.stem) { d.H = stem_h_; d.W = stem_w_; d.x_ld = 8; }                                             // row-pair image
+        if (op.grid_h) { d.Ho = op.grid_h; d.Wo = op.grid_w; d.y_sH = op.y_sh; d.y_sW = op.y_sw; d.y_oH = op.y_oh; d.y_oW = op.y_ow; d.y_H = op.y_h; d.y_W = op.y_w; }   // ConvTranspose phase
         d.y_ld = y_ld; d.res_ld = op.residual >= 0 ? valueLd(op.residual) : 0;
         return sm_conv2d_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
                                  op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, ws_, ws_bytes_, ss);
+    }
+    case OpKind::ConvTranspose: {   // shapes the phase decomposition does not take: direct gather kernel
+        const Value& iv = values_[op.inputs[0]];
+        sm_conv_desc d{};
+        d.N = batch_; d.H = iv.h; d.W = iv.w; d.Cin = op.cin; d.Cout = op.cout; d.kH = op.kh; d.kW = op.kw; d.sH = op.sh; d.sW = op.sw; d.dH = op.dh; d.dW = op.dw;
+        d.pt = op.pt; d.pl = op.pl; d.pb = op.pb; d.pr = op.pr; d.groups = 1; d.Ho = ov.h; d.Wo = ov.w; d.act = op.act; d.slope = op.slope;
+        d.x_ld = valueLd(op.inputs[0]); d.y_ld = y_ld;
+        return sm_conv_transpose2d_fwd(&d, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, y, ss);
     }
     case OpKind::BatchNorm:
         return sm_batchnorm(valuePtr(op.inputs[0]), y, st.M, ov.c, valueLd(op.inputs[0]), y_ld, (const float*)(arena_ + st.s_off), (const float*)(arena_ + st.t_off), op.act, op.slope, ss);

@@ -30,7 +30,7 @@ struct Configuration {
 
 enum class Format { onnx, mpsFlavor };   // ONNXGraph.swift:49-52
 
-enum class OpKind { Conv, FullyConnected, BatchNorm, Neuron, Add, MaxPool, AvgPool, GlobalAvgPool, Upsample, Concat, Alias };
+enum class OpKind { Conv, FullyConnected, BatchNorm, Neuron, Add, MaxPool, AvgPool, GlobalAvgPool, Upsample, Concat, Alias, ConvTranspose };
 
 // One record per converted node (the analogue of an MPSNNFilterNode + its data source / padding policy).
 struct Op {
@@ -43,6 +43,8 @@ struct Op {
     std::vector<float> weight;           // OHWI fp32 master copy (cast to fp16 when the arena is packed)
     std::vector<float> bias;             // empty = none
     bool weight_was_fp16 = false;        // ConvDataSource.dataType() (:140-149)
+    // output placement of a ConvTranspose phase (executor.cpp): sm_conv_desc.y_sH ... ; conv grid of the phase
+    int y_sh = 0, y_sw = 0, y_oh = 0, y_ow = 0, y_h = 0, y_w = 0, grid_h = 0, grid_w = 0;
     // fused epilogue (set by the executor's fusion passes, or by Neuron ops)
     int act = 0; float slope = 0.f;      // SM_ACT_*
     int residual = -1;                   // value id added before the activation

@@ -38,6 +38,7 @@ struct ConvParams {
     unsigned dhw_mul, dhw_sh, dw_mul, dw_sh;   // sm_fastdiv constants for / (Ho*Wo) and / Wo
     unsigned pm_mul, pm_sh, mt_mul, mt_sh, nt_mul, nt_sh;   // ... for / (nt*splitk), / mt, / nt (map_block)
     unsigned rowpat;                 // sum over kh < kH of 1 << (kh*kW): tap-mask pattern (conv_igemm64.hpp)
+    int yplace, ysH, ysW, yoH, yoW, yH, yW;   // output placement (sm_conv_desc.y_sH ...): strided/offset output pixels
 };
 
 // Division of n < 2^31 by a launch-time constant d: q = (n * mul) >> sh with s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1
@@ -48,6 +49,13 @@ inline void sm_fastdiv_make(unsigned d, unsigned* mul, unsigned* sh) {
     *mul = (unsigned)(((1ull << (31 + s)) / d) + 1); *sh = 31 + s;
 }
 __device__ __forceinline__ unsigned sm_fastdiv(unsigned n, unsigned mul, unsigned sh) { return (unsigned)(((unsigned long long)n * mul) >> sh); }
+// pixel index of output row m (= (n, oy, ox) of the Ho x Wo grid) inside the destination image
+__device__ __forceinline__ long sm_out_pixel(const ConvParams& p, int m) {
+    if (!p.yplace) return m;
+    const int n = (int)sm_fastdiv((unsigned)m, p.dhw_mul, p.dhw_sh), r = m - n * (p.Ho * p.Wo);
+    const int oy = (int)sm_fastdiv((unsigned)r, p.dw_mul, p.dw_sh), ox = r - oy * p.Wo;
+    return ((long)n * p.yH + oy * p.ysH + p.yoH) * p.yW + ox * p.ysW + p.yoW;
+}
 
 constexpr int BK = 32;
 
@@ -191,6 +199,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     for (int b = 0; b < TM; b++) {
         const int m = mtile * BM + (wm * TM + b) * 32 + (lane & 31);
         if (m >= p.M) continue;
+        const long opix = sm_out_pixel(p, m);
 #pragma unroll
         for (int a = 0; a < TN; a++) {
 #pragma unroll
@@ -210,13 +219,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
                     half4_t o;
 #pragma unroll
                     for (int j = 0; j < 4; j++) o[j] = (half_t)sm_act(v[j], p.act, p.slope);
-                    *(half4_t*)(p.y + (long)m * p.y_ld + co) = o;
+                    *(half4_t*)(p.y + opix * p.y_ld + co) = o;
                 } else {
                     for (int j = 0; j < 4 && co + j < p.Cout; j++) {
                         float t = v[j];
                         if (p.bias) t += p.bias[co + j];
                         if (p.res) t += (float)p.res[(long)m * p.res_ld + co + j];
-                        p.y[(long)m * p.y_ld + co + j] = (half_t)sm_act(t, p.act, p.slope);
+                        p.y[opix * p.y_ld + co + j] = (half_t)sm_act(t, p.act, p.slope);
                     }
                 }
             }
@@ -258,6 +267,31 @@ __global__ void conv_direct_kernel(ConvParams p, int groups) {
         }
         if (p.bias) acc += p.bias[co];
         if (p.res) acc += (float)p.res[m * p.res_ld + co];
+        p.y[sm_out_pixel(p, (int)m) * p.y_ld + co] = (half_t)sm_act(acc, p.act, p.slope);
+    }
+}
+
+// Transposed convolution (MPSCNNConvolutionTransposeNode, Converters.swift:277): direct gather over the data source's
+// flipped OHWI weights, one thread per output element, fp32 accumulate.  Input row iy feeds output row oy through tap kh
+// iff iy*sH == oy + pt - (kH-1-kh)*dH.  Any shape; the compiled graph uses per-phase MFMA convolutions where it can.
+__global__ void convt_direct_kernel(ConvParams p) {
+    const long total = (long)p.M * p.Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long m = i / p.Cout; int co = (int)(i - m * p.Cout);
+        int n = (int)(m / (p.Ho * p.Wo)), r = (int)(m - (long)n * p.Ho * p.Wo), oy = r / p.Wo, ox = r - oy * p.Wo;
+        float acc = 0.f;
+        for (int kh = 0; kh < p.kH; kh++) {
+            int ty = oy + p.pt - (p.kH - 1 - kh) * p.dH; if (ty < 0 || ty % p.sH) continue;
+            int iy = ty / p.sH; if (iy >= p.H) continue;
+            for (int kw = 0; kw < p.kW; kw++) {
+                int tx = ox + p.pl - (p.kW - 1 - kw) * p.dW; if (tx < 0 || tx % p.sW) continue;
+                int ix = tx / p.sW; if (ix >= p.W) continue;
+                const half_t* xp = p.x + (((long)n * p.H + iy) * p.W + ix) * p.x_ld;
+                const half_t* wp = p.w + (((long)co * p.kH + kh) * p.kW + kw) * p.Cin;
+                for (int c = 0; c < p.Cin; c++) acc += (float)xp[c] * (float)wp[c];
+            }
+        }
+        if (p.bias) acc += p.bias[co];
         p.y[m * p.y_ld + co] = (half_t)sm_act(acc, p.act, p.slope);
     }
 }
@@ -455,6 +489,13 @@ int fill_params(const sm_conv_desc* d, const void* x, const void* w, const float
     SM_REQUIRE((long)d->N * d->H * d->W < (1L << 31) - (1L << 24), "sm_conv2d_fwd: more than 2^31 input pixels");
     sm_fastdiv_make((unsigned)(d->Ho * d->Wo), &p->dhw_mul, &p->dhw_sh); sm_fastdiv_make((unsigned)d->Wo, &p->dw_mul, &p->dw_sh);
     p->rowpat = 0; if (d->kH * d->kW <= 32) for (int kh = 0; kh < d->kH; kh++) p->rowpat |= 1u << (kh * d->kW);
+    p->yplace = (d->y_sH | d->y_sW | d->y_oH | d->y_oW | d->y_H | d->y_W) != 0;
+    p->ysH = d->y_sH ? d->y_sH : 1; p->ysW = d->y_sW ? d->y_sW : 1; p->yoH = d->y_oH; p->yoW = d->y_oW;
+    p->yH = d->y_H ? d->y_H : d->Ho; p->yW = d->y_W ? d->y_W : d->Wo;
+    if (p->yplace) {
+        SM_REQUIRE(d->y_sH >= 0 && d->y_sW >= 0 && d->y_oH >= 0 && d->y_oW >= 0 && !res && d->groups == 1, "sm_conv2d_fwd: bad output placement (no residual, groups 1)");
+        SM_REQUIRE((long)(d->Ho - 1) * p->ysH + p->yoH < p->yH && (long)(d->Wo - 1) * p->ysW + p->yoW < p->yW, "sm_conv2d_fwd: output placement leaves the destination image");
+    }
     return SM_OK;
 }
 
@@ -491,7 +532,7 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     // split-K only for launches that cannot fill the chip and have a long K loop (e.g. the FC layer)
     p.splitk = 1;
     long blocks = (long)p.mt * p.nt;
-    if (ws && blocks < SM_NUM_CU / 2 && ktiles >= 16) {
+    if (ws && blocks < SM_NUM_CU / 2 && ktiles >= 16 && !p.yplace) {
         int want = (int)((SM_NUM_CU + blocks - 1) / blocks);
         int maxs = ktiles / 4; if (want > maxs) want = maxs; if (want > 32) want = 32;
         while (want > 1 && (size_t)want * p.M * p.Cout * sizeof(float) > ws_bytes) want--;
@@ -545,6 +586,14 @@ int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void*
                       void* ws, size_t ws_bytes, sm_stream_t stream) {
     ConvParams p; int rc = fill_params(d, x, w, bias, res, y, &p); if (rc) return rc;
     return launch(d, p, cfg, ws, ws_bytes, sm_s(stream));
+}
+
+int sm_conv_transpose2d_fwd(const sm_conv_desc* d, const void* x, const void* w, const float* bias, void* y, sm_stream_t stream) {
+    ConvParams p; int rc = fill_params(d, x, w, bias, nullptr, y, &p); if (rc) return rc;
+    SM_REQUIRE(d->groups == 1, "sm_conv_transpose2d_fwd: groups != 1");
+    SM_REQUIRE(!p.yplace, "sm_conv_transpose2d_fwd: output placement not supported");
+    hipLaunchKernelGGL(convt_direct_kernel, dim3(sm_stream_grid((long)p.M * p.Cout, 256)), dim3(256), 0, sm_s(stream), p);
+    SM_LAUNCH_CHECK(); return SM_OK;
 }
 
 // Times `iters` back-to-back launches with HIP events on `stream` (host launch cost is hidden once the queue is full).

@@ -318,6 +318,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
             const int row = it / CHUNKS, ch = it - row * CHUNKS;
             const int m = mtile * BM + pw * EP_ROWS + row, co = ntile * BN + ch * 8;
             if (m >= p.M || co >= p.Cout) continue;
+            const long opix = sm_out_pixel(p, m);
             floatx4 v0 = *(const floatx4*)(stg + row * EP_LD + ch * 8), v1 = *(const floatx4*)(stg + row * EP_LD + ch * 8 + 4);
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             if (p.splitk > 1) {
@@ -333,12 +334,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
                 half8_t o;
 #pragma unroll
                 for (int j = 0; j < 8; j++) o[j] = (half_t)sm_act(v[j], p.act, p.slope);
-                *(half8_t*)(p.y + (long)m * p.y_ld + co) = o;
+                *(half8_t*)(p.y + opix * p.y_ld + co) = o;
             } else {
                 for (int j = 0; j < 8 && co + j < p.Cout; j++) {
                     float t = v[j];
                     if (p.res) t += (float)p.res[(long)m * p.res_ld + co + j];
-                    p.y[(long)m * p.y_ld + co + j] = (half_t)sm_act(t, p.act, p.slope);
+                    p.y[opix * p.y_ld + co + j] = (half_t)sm_act(t, p.act, p.slope);
                 }
             }
         }

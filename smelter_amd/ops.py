@@ -81,6 +81,20 @@ def conv2d(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0)
     return out
 
 
+def conv_transpose2d(x, w_ohwi_flipped, bias=None, stride=(1, 1), pads=(0, 0, 0, 0), dilation=(1, 1), out_pad=(0, 0), act=ACT_NONE, slope=0.0):
+    """sm_conv_transpose2d_fwd: direct kernel over the flipped OHWI weights the reference's ConvDataSource produces"""
+    n, h, w, cin, x_ld = _check_nhwc(x)
+    cout, kh, kw, cg = w_ohwi_flipped.shape
+    assert w_ohwi_flipped.dtype == torch.float16 and w_ohwi_flipped.is_contiguous() and cg == cin
+    ho = (h - 1) * stride[0] - pads[0] - pads[2] + kh + out_pad[0]
+    wo = (w - 1) * stride[1] - pads[1] - pads[3] + kw + out_pad[1]
+    out = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x.device)
+    d = ConvDesc(n, h, w, cin, cout, kh, kw, stride[0], stride[1], dilation[0], dilation[1], pads[0], pads[1], pads[2], pads[3], 1, ho, wo,
+                 act, slope, x_ld, cout, 0)
+    check(lib().sm_conv_transpose2d_fwd(C.byref(d), _ptr(x), _ptr(w_ohwi_flipped), _ptr(bias), _ptr(out), _stream()))
+    return out
+
+
 def conv2d_time(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0), groups=1, act=ACT_NONE, cfg=-1, iters=20, out=None):
     """average ms per launch of one conv shape / tile config, timed inside the library (no Python launch overhead)"""
     n, h, w, cin, x_ld = _check_nhwc(x)

@@ -196,6 +196,42 @@ def unet(seed: int = 1, batch: int = 1, hw=(512, 512), base: int = 32, levels: i
     return (m, net.macs) if return_macs else m
 
 
+def deconv_net(seed: int = 1, batch: int = 1, hw=(32, 32), base: int = 16, dtype=np.float32, return_macs: bool = False):
+    """a small segmentation-style decoder built on ConvTranspose instead of Upsample:
+    Conv3x3(3->base)-ReLU, MaxPool2, Conv3x3(base->2base)-BN-ReLU, MaxPool2, ConvTranspose 2x2 s2 (2base->base)-BN-ReLU,
+    Concat(skip), ConvTranspose 3x3 s2 p1 output_padding 1 (2base->base)-ReLU, Conv1x1 head."""
+    net = _Net("deconv_net", seed, dtype)
+    g = net.g
+
+    def convT(x, cur, cin, cout, k, s, p, op, bias=True):
+        std = np.sqrt(2.0 / (cin * k * k / (s * s)))
+        w = g.add_init(g.fresh("wt"), (net.rng.standard_normal((cin, cout, k, k)) * std).astype(net.dtype))
+        ins = [x, w]
+        if bias:
+            ins.append(g.add_init(g.fresh("b"), (net.rng.standard_normal(cout) * 0.1).astype(net.dtype)))
+        y = g.add_node("ConvTranspose", ins, dilations=[1, 1], group=1, kernel_shape=[k, k], pads=[p, p, p, p], strides=[s, s],
+                       output_padding=[op, op])
+        net.macs += cur[0] * cur[1] * cin * cout * k * k
+        return y, ((cur[0] - 1) * s - 2 * p + k + op, (cur[1] - 1) * s - 2 * p + k + op)
+
+    x, cur = net.conv("input", hw, 3, base, 3, bias=True)
+    x = net.relu(x)
+    skip, skip_hw = x, cur
+    x, cur = net.maxpool(x, cur, 2, 2, 0)
+    x, cur = net.conv_bn(x, cur, base, 2 * base, 3)
+    x, cur = net.maxpool(x, cur, 2, 2, 0)
+    x, cur = convT(x, cur, 2 * base, base, 2, 2, 0, 0, bias=False)
+    x = net.relu(net.bn(x, base))
+    x2, cur2 = net.maxpool(skip, skip_hw, 2, 2, 0)
+    assert cur2 == cur
+    x = g.add_node("Concat", [x, x2], axis=1)
+    x, cur = convT(x, cur, 2 * base, base, 3, 2, 1, 1)
+    x = net.relu(x)
+    x, cur = net.conv(x, cur, base, 8, 1, p=0, bias=True)
+    m = _finish(net, x, [batch, 3, hw[0], hw[1]], [batch, 8, cur[0], cur[1]])
+    return (m, net.macs) if return_macs else m
+
+
 def synthetic_images(batch: int, c: int = 3, hw=(224, 224), seed: int = 0) -> np.ndarray:
     """NCHW fp32 i.i.d. uniform [0,1) — what an RGBA8-unorm texture yields in the reference flow
     (/root/reference/README.md:33-39)."""

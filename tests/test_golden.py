@@ -25,7 +25,7 @@ def close(a, b, tol=TOL):
 
 def test_fixture_inventory():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "*.npz")))
-    assert len(names) >= 17 and "toy_end_to_end" in names
+    assert len(names) >= 22 and "toy_end_to_end" in names and "ct3x3_s2_p1_op1" in names
 
 
 @pytest.mark.parametrize("name", ["c1x1_s1", "c1x1_s2", "c3x3_s1", "c3x3_s2", "c7x7_s2_p3", "dw3x3_s1", "dw3x3_s2"])
@@ -36,6 +36,16 @@ def test_conv(name):
     oc, icg = w.shape[:2]
     w_ohwi = O.reformat_conv_weight(w, oc, icg, k, k).reshape(oc, k, k, icg)
     close(O.conv2d(d["x"], w_ohwi, d["b"], stride=(s, s), pads=(p, p, p, p), groups=g), d["y"])
+
+
+@pytest.mark.parametrize("name", ["ct2x2_s2", "ct3x3_s2_p1_op1", "ct4x4_s2_p1", "ct3x3_s1_p1", "ct3x3_s3_op2"])
+def test_conv_transpose(name):
+    d = load(name)
+    k, s, p, op = (int(v) for v in d["meta"])
+    w = d["w_iohw"]
+    ic, oc = w.shape[:2]
+    w_flipped = O.reformat_conv_weight(w, oc, ic, k, k, is_transpose=True).reshape(oc, k, k, ic)   # what ConvDataSource hands MPS
+    close(O.conv_transpose2d(d["x"], w_flipped, d["b"], stride=(s, s), pads=(p, p, p, p), out_pad=(op, op)), d["y"])
 
 
 def test_pools_and_gap():

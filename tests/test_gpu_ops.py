@@ -197,3 +197,61 @@ def test_bad_arguments_are_errors_not_crashes():
     with pytest.raises(SmelterError) as e:
         ops.conv2d(x, w, dilation=(0, 1), pads=(1, 1, 1, 1))
     assert e.value.kind == "invalidArgument"
+
+
+# ---- ConvTranspose: MPSCNNConvolutionTransposeNode, Converters.swift:265-287 ---------------------
+CONVT_CASES = [
+    # n, h, w, cin, cout, k, s, p, out_pad, dil, act
+    (2, 5, 6, 16, 8, 2, 2, 0, 0, 1, 1),       # the U-Net up-convolution: every phase is a 1x1 conv
+    (2, 6, 5, 8, 12, 3, 2, 1, 1, 1, 0),       # PyTorch's "same x2" ConvTranspose (k3 s2 p1 op1)
+    (1, 7, 7, 24, 8, 4, 2, 1, 0, 1, 1),       # k4 s2 p1
+    (1, 5, 5, 3, 5, 3, 1, 1, 0, 1, 0),        # stride 1 = correlation with the flipped kernel; Cin % 8 != 0
+    (1, 4, 5, 8, 4, 3, 3, 0, 2, 1, 2),        # stride 3 > taps per phase, output_padding 2, PRelu
+    (2, 6, 6, 8, 6, 3, 2, 2, 1, 2, 1),        # dilation 2 (size rule ignores it, like the reference)
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose2d_direct(case):
+    n, hh, ww, cin, cout, k, s, p, op, dil, act = case
+    rng = np.random.default_rng(31)
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w_iohw = h(rng.standard_normal((cin, cout, k, k)) * 0.3)
+    b = rng.standard_normal(cout).astype(np.float32)
+    w_flip = O.reformat_conv_weight(w_iohw, cout, cin, k, k, is_transpose=True).reshape(cout, k, k, cin)
+    ref = O.conv_transpose2d(x, w_flip, b, stride=(s, s), pads=(p, p, p, p), dil=(dil, dil), out_pad=(op, op))
+    if act:
+        ref = O.relu(ref, 0.0 if act == 1 else 0.25)
+    got = ops.conv_transpose2d(to_dev(x), torch.from_numpy(w_flip).cuda().half().contiguous(), torch.from_numpy(b).cuda(), stride=(s, s),
+                               pads=(p, p, p, p), dilation=(dil, dil), out_pad=(op, op), act=act, slope=0.25 if act == 2 else 0.0)
+    assert_close(to_host(got), ref, k=cin * k * k)
+
+
+@pytest.mark.parametrize("cfg", [None, 3, 9, 15, 32])
+def test_conv2d_output_placement(cfg):
+    """sm_conv_desc.y_sH...: the conv's Ho x Wo grid lands on a strided, offset pixel lattice of a larger image"""
+    import ctypes as C
+    from smelter_amd import _native as N
+    rng = np.random.default_rng(32)
+    n, hh, ww, cin, cout = 2, 9, 7, 64, 24
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * 0.1)
+    b = rng.standard_normal(cout).astype(np.float32)
+    dense = h(O.conv2d(x, w, b, pads=(1, 1, 1, 1)))
+    xd, wd, bd = to_dev(x), torch.from_numpy(w).cuda().half().contiguous(), torch.from_numpy(b).cuda()
+    YH, YW, sH, sW, oH, oW = 2 * hh + 1, 3 * ww, 2, 3, 1, 2
+    y = torch.full((n, YH, YW, cout), -7.0, dtype=torch.float16, device="cuda")
+    d = N.ConvDesc(n, hh, ww, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, hh, ww, 0, 0.0, cin, cout, 0, sH, sW, oH, oW, YH, YW)
+    N.check(N.lib().sm_conv2d_fwd_cfg(C.byref(d), -1 if cfg is None else cfg, C.c_void_p(xd.data_ptr()), C.c_void_p(wd.data_ptr()), C.c_void_p(bd.data_ptr()),
+                                      None, C.c_void_p(y.data_ptr()), None, 0, None))
+    got = to_host(y)
+    expect = np.full((n, cout, YH, YW), -7.0, np.float32)
+    expect[:, :, oH::sH, oW::sW][:, :, :hh, :ww] = dense
+    placed = got[:, :, oH:oH + sH * hh:sH, oW:oW + sW * ww:sW]
+    assert_close(placed, dense, k=cin * 9)
+    mask = np.ones_like(got, bool); mask[:, :, oH:oH + sH * hh:sH, oW:oW + sW * ww:sW] = False
+    assert (got[mask] == -7.0).all()                                   # nothing else was touched
+    # a residual operand or a lattice that leaves the image is rejected
+    bad = N.ConvDesc(n, hh, ww, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, hh, ww, 0, 0.0, cin, cout, 0, sH, sW, oH, oW, YH - 2, YW)
+    with pytest.raises(N.SmelterError):
+        N.check(N.lib().sm_conv2d_fwd_cfg(C.byref(bad), -1, C.c_void_p(xd.data_ptr()), C.c_void_p(wd.data_ptr()), None, None, C.c_void_p(y.data_ptr()), None, 0, None))

@@ -89,6 +89,8 @@ ERRORS = [
     ("notEnoughAttributes", _conv_model(FULL, extra_nodes=[ow.node("Upsample", ["y"], ["z"], mode="nearest")])),  # scales missing
     ("unknownNodeOpType", _conv_model(FULL, extra_nodes=[ow.node("Upsample", ["y"], ["z"], mode="cubic", scales=[1.0, 1.0, 2.0, 2.0])])),
     ("insufficientInputs", _conv_model(FULL, extra_nodes=[ow.node("BatchNormalization", ["y", "w"], ["z"])])),    # :803-809
+    ("inconsistentState", _conv_model(dict(FULL, group=2), op="ConvTranspose")),                  # outside the restated subset (group 1)
+    ("notEnoughAttributes", _conv_model({k: v for k, v in FULL.items() if k != "strides"}, op="ConvTranspose")),
 ]
 
 
@@ -100,6 +102,33 @@ def test_error_cases_match_the_reference_and_the_oracle(kind, model):
     with pytest.raises(O.OracleError) as e2:
         O.Graph(model).run(np.zeros((1, 8, 6, 6), np.float32))
     assert e2.value.kind == kind, e2.value
+
+
+def test_conv_transpose_shape_rule_and_weight_layout():
+    # out = (in-1)*s - pt - pb + k + output_padding (ONNXConvolutionPadding.swift:97-103); weights [I,O,kH,kW] -> O, flipH, flipW, I
+    b = ow.GraphBuilder("g")
+    b.add_input("input", [1, 8, 5, 7])
+    w = np.arange(8 * 4 * 3 * 3, dtype=np.float32).reshape(8, 4, 3, 3) / 64
+    b.add_init("w", w)
+    b.add_node_named("ConvTranspose", ["input", "w"], ["y"], dilations=[1, 1], group=1, kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2], output_padding=[1, 0])
+    b.add_output("y", [1, 4, 10, 13])
+    m = b.to_model()
+    x = np.random.default_rng(3).standard_normal((2, 8, 5, 7)).astype(np.float32)
+    y = O.Graph(m).run(x)
+    assert y.shape == (2, 4, (5 - 1) * 2 - 2 + 3 + 1, (7 - 1) * 2 - 2 + 3 + 0)
+    g = ONNXGraph(m)
+    # one stride-2 3x3 ConvTranspose = 4 per-phase convolutions with 2x2, 2x1, 1x2 and 1x1 taps (9 in total) of 4x8 fp16 weights,
+    # each block padded to the arena's 256-byte alignment: 256 + 128 + 128 + 64 -> 4 x 256
+    assert g.weightBytes(1) == 1024
+    arena = g.packWeights(1).view(np.uint16)
+    flipped = O.reformat_conv_weight(w, 4, 8, 3, 3, is_transpose=True).reshape(4, 3, 3, 8)
+    # phase (py, px) = (0, 0): taps kh in {0, 2}, kw in {0, 2}, stored correlation-order (a' = A-1-a) from the flipped master copy
+    sub = np.zeros((4, 2, 2, 8), np.float32)
+    for a in range(2):
+        for bb in range(2):
+            kh, kw = 2 * (1 - a), 2 * (1 - bb)
+            sub[:, a, bb, :] = flipped[:, 2 - kh, 2 - kw, :]
+    assert np.array_equal(arena[:sub.size], sub.astype(np.float16).view(np.uint16).ravel())
 
 
 def test_unknown_op_error_carries_the_op_type():

@@ -41,6 +41,21 @@ def conv_cases():
     return cases
 
 
+def convt_cases():
+    """ConvTranspose: torch.conv_transpose2d, weights [Cin, Cout, kH, kW] as ONNX stores them"""
+    rng = np.random.default_rng(13)
+    cases = {}
+    specs = {"ct2x2_s2": (2, 8, 5, 6, 6, 2, 2, 0, 0), "ct3x3_s2_p1_op1": (2, 8, 6, 5, 4, 3, 2, 1, 1), "ct4x4_s2_p1": (1, 4, 5, 5, 8, 4, 2, 1, 0),
+             "ct3x3_s1_p1": (1, 6, 7, 7, 5, 3, 1, 1, 0), "ct3x3_s3_op2": (1, 3, 4, 5, 4, 3, 3, 0, 2)}
+    for name, (n, cin, h, w, cout, k, s, p, op) in specs.items():
+        x = rng.standard_normal((n, cin, h, w)).astype(np.float32)
+        wt = (rng.standard_normal((cin, cout, k, k)) * 0.3).astype(np.float32)
+        b = rng.standard_normal(cout).astype(np.float32)
+        y = F.conv_transpose2d(t64(x), t64(wt), t64(b), stride=s, padding=p, output_padding=op).numpy().astype(np.float32)
+        cases[name] = dict(x=x, w_iohw=wt, b=b, y=y, meta=np.array([k, s, p, op]))
+    return cases
+
+
 def misc_cases():
     rng = np.random.default_rng(12)
     c = {}
@@ -90,6 +105,8 @@ def toy_end_to_end():
 def main():
     os.makedirs(OUT, exist_ok=True)
     for name, d in {**conv_cases(), **misc_cases()}.items():
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    for name, d in convt_cases().items():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
     np.savez_compressed(os.path.join(OUT, "toy_end_to_end.npz"), **toy_end_to_end())
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
