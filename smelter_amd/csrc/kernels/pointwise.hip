@@ -52,35 +52,58 @@ __global__ void affine_scalar_kernel(const half_t* x, half_t* y, long pixels, in
 }
 
 // ---- MPSCNNPoolingMaxNode / MPSCNNPoolingAverageNode (:662, :617) -------------------------------------
+// One block row per output image row (wave-uniform n, oy: no per-thread 64-bit division), threads over (ox, 8-channel
+// vector).  Block b runs on XCD b % 8 and the XCD L2s are private, so XCD x takes the CONTIGUOUS band of output rows
+// [x*R/8, (x+1)*R/8): the input rows that overlapping windows share are then fetched into one L2 instead of two or three
+// (a 3x3/2 max-pool re-reads every input pixel 2.25 times).  Max pooling of fp16 data is exact in fp16 (v_pk_max_f16);
+// averages accumulate in fp32.
 template <bool MAX, int V>
-__global__ void pool_kernel(sm_pool_desc d, const half_t* x, half_t* y) {
+__global__ __launch_bounds__(256) void pool_kernel(sm_pool_desc d, const half_t* x, half_t* y) {
     const int cv = (d.C + V - 1) / V;
-    const long total = (long)d.N * d.Ho * d.Wo * cv;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long m = i / cv; int c = (int)(i - m * cv) * V;
-        int n = (int)(m / (d.Ho * d.Wo)), r = (int)(m - (long)n * d.Ho * d.Wo), oy = r / d.Wo, ox = r - oy * d.Wo;
-        float acc[V];
+    const int rows = d.N * d.Ho, rpx = (rows + SM_NUM_XCD - 1) / SM_NUM_XCD;
+    const int row = (blockIdx.x & (SM_NUM_XCD - 1)) * rpx + (blockIdx.x >> 3);
+    if (row >= rows || (int)(blockIdx.x >> 3) >= rpx) return;
+    const int n = row / d.Ho, oy = row - n * d.Ho;
+    const int idx = blockIdx.y * 256 + threadIdx.x;
+    if (idx >= d.Wo * cv) return;
+    const int ox = idx / cv, c = (idx - ox * cv) * V;
+    const int ix0 = ox * d.sW + d.x0;
+    half_t* py = y + ((long)row * d.Wo + ox) * d.y_ld + c;
+    if (MAX && V == 8) {
+        half8_t m;
 #pragma unroll
-        for (int j = 0; j < V; j++) acc[j] = MAX ? -3.0e38f : 0.f;
+        for (int j = 0; j < 8; j++) m[j] = (half_t)(-__builtin_inff());
         for (int a = 0; a < d.kH; a++) {
-            int iy = oy * d.sH + d.y0 + a; if ((unsigned)iy >= (unsigned)d.H) continue;
+            const int iy = oy * d.sH + d.y0 + a; if ((unsigned)iy >= (unsigned)d.H) continue;
+            const half_t* prow = x + ((long)n * d.H + iy) * d.W * d.x_ld + c;
             for (int b = 0; b < d.kW; b++) {
-                int ix = ox * d.sW + d.x0 + b; if ((unsigned)ix >= (unsigned)d.W) continue;
-                const half_t* px = x + (((long)n * d.H + iy) * d.W + ix) * d.x_ld + c;
-                if (V == 8) { half8_t v = *(const half8_t*)px;
-#pragma unroll
-                    for (int j = 0; j < V; j++) acc[j] = MAX ? fmaxf(acc[j], (float)v[j]) : acc[j] + (float)v[j];
-                } else acc[0] = MAX ? fmaxf(acc[0], (float)px[0]) : acc[0] + (float)px[0];
+                const int ix = ix0 + b; if ((unsigned)ix >= (unsigned)d.W) continue;
+                m = __builtin_elementwise_max(m, *(const half8_t*)(prow + (long)ix * d.x_ld));
             }
         }
-        const float inv = 1.f / (float)(d.kH * d.kW);
-        half_t* py = y + m * d.y_ld + c;
-        if (V == 8) { half8_t o;
-#pragma unroll
-            for (int j = 0; j < V; j++) o[j] = (half_t)(MAX ? acc[j] : acc[j] * inv);
-            *(half8_t*)py = o;
-        } else py[0] = (half_t)(MAX ? acc[0] : acc[0] * inv);
+        *(half8_t*)py = m;
+        return;
     }
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; j++) acc[j] = MAX ? -3.0e38f : 0.f;
+    for (int a = 0; a < d.kH; a++) {
+        const int iy = oy * d.sH + d.y0 + a; if ((unsigned)iy >= (unsigned)d.H) continue;
+        for (int b = 0; b < d.kW; b++) {
+            const int ix = ix0 + b; if ((unsigned)ix >= (unsigned)d.W) continue;
+            const half_t* px = x + (((long)n * d.H + iy) * d.W + ix) * d.x_ld + c;
+            if (V == 8) { half8_t v = *(const half8_t*)px;
+#pragma unroll
+                for (int j = 0; j < V; j++) acc[j] = MAX ? fmaxf(acc[j], (float)v[j]) : acc[j] + (float)v[j];
+            } else acc[0] = MAX ? fmaxf(acc[0], (float)px[0]) : acc[0] + (float)px[0];
+        }
+    }
+    const float inv = 1.f / (float)(d.kH * d.kW);
+    if (V == 8) { half8_t o;
+#pragma unroll
+        for (int j = 0; j < V; j++) o[j] = (half_t)(MAX ? acc[j] : acc[j] * inv);
+        *(half8_t*)py = o;
+    } else py[0] = (half_t)(MAX ? acc[0] : acc[0] * inv);
 }
 
 // ---- GlobalAveragePoolConverter (:578-605): mean over H*W.  One block per (image, 64-channel group):
@@ -176,13 +199,13 @@ int sm_relu(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int
 static int pool_common(const sm_pool_desc* d0, const void* x, void* y, bool is_max, sm_stream_t st) {
     SM_REQUIRE(d0 && x && y && d0->N > 0 && d0->C > 0 && d0->Ho > 0 && d0->Wo > 0 && d0->kH > 0 && d0->kW > 0 && d0->sH > 0 && d0->sW > 0, "sm_pool: bad argument");
     sm_pool_desc d = *d0; d.x_ld = d.x_ld ? d.x_ld : d.C; d.y_ld = d.y_ld ? d.y_ld : d.C;
-    long pix = (long)d.N * d.Ho * d.Wo;
+    SM_REQUIRE((long)d.N * d.Ho < (1L << 31), "sm_pool2d: too many output rows");
     if (vec8(d.C, {d.x_ld, d.y_ld}, {x, y})) {
-        dim3 g(sm_stream_grid(pix * (d.C / 8), 256));
+        dim3 g(sm_ceil_div((long)d.N * d.Ho, SM_NUM_XCD) * SM_NUM_XCD, sm_ceil_div((long)d.Wo * (d.C / 8), 256));
         if (is_max) hipLaunchKernelGGL((pool_kernel<true, 8>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
         else hipLaunchKernelGGL((pool_kernel<false, 8>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
     } else {
-        dim3 g(sm_stream_grid(pix * d.C, 256));
+        dim3 g(sm_ceil_div((long)d.N * d.Ho, SM_NUM_XCD) * SM_NUM_XCD, sm_ceil_div((long)d.Wo * d.C, 256));
         if (is_max) hipLaunchKernelGGL((pool_kernel<true, 1>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
         else hipLaunchKernelGGL((pool_kernel<false, 1>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
     }
