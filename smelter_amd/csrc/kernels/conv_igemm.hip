@@ -233,7 +233,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     }
 }
 
-// split-K second pass: sum fp32 partials, bias/residual/activation, fp16 store
+// split-K second pass: sum fp32 partials, bias/residual/activation, fp16 store.  Vector form: 8 consecutive couts per
+// thread (two 16-byte loads per split, one 16-byte store); scalar form for odd shapes.
+__global__ __launch_bounds__(256) void splitk_reduce_vec8_kernel(ConvParams p) {
+    const int cv = p.Cout >> 3;
+    const long items = (long)p.M * cv, total = (long)p.M * p.Cout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < items; i += (long)gridDim.x * blockDim.x) {
+        const long m = i / cv; const int co = (int)(i - m * cv) * 8;
+        const float* src = p.ws + m * p.Cout + co;
+        floatx4 a0 = *(const floatx4*)src, a1 = *(const floatx4*)(src + 4);
+        for (int s = 1; s < p.splitk; s++) { a0 += *(const floatx4*)(src + (long)s * total); a1 += *(const floatx4*)(src + (long)s * total + 4); }
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (p.bias) { const floatx4 b0 = *(const floatx4*)(p.bias + co), b1 = *(const floatx4*)(p.bias + co + 4);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { v[j] += b0[j]; v[4 + j] += b1[j]; } }
+        if (p.res) { const half8_t r = *(const half8_t*)(p.res + m * p.res_ld + co);
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] += (float)r[j]; }
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (half_t)sm_act(v[j], p.act, p.slope);
+        *(half8_t*)(p.y + m * p.y_ld + co) = o;
+    }
+}
 __global__ void splitk_reduce_kernel(ConvParams p) {
     long total = (long)p.M * p.Cout;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -533,7 +555,7 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     p.splitk = 1;
     long blocks = (long)p.mt * p.nt;
     if (ws && blocks < SM_NUM_CU / 2 && ktiles >= 16 && !p.yplace) {
-        int want = (int)((SM_NUM_CU + blocks - 1) / blocks);
+        int want = (int)(SM_NUM_CU / blocks);                        // one wave of blocks: a second, partial wave costs a whole K pass
         int maxs = ktiles / 4; if (want > maxs) want = maxs; if (want > 32) want = 32;
         while (want > 1 && (size_t)want * p.M * p.Cout * sizeof(float) > ws_bytes) want--;
         if (want > 1) p.splitk = want;
@@ -554,7 +576,10 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     hipLaunchKernelGGL(c.fn, dim3(grid), dim3(c.threads), 0, s, p);
     SM_LAUNCH_CHECK();
     if (p.splitk > 1) {
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(sm_stream_grid((long)p.M * p.Cout, 256)), dim3(256), 0, s, p);
+        const bool vec = (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) | ((uintptr_t)p.ws) | ((uintptr_t)p.bias)) & 15) == 0 &&
+                         (!p.res || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0));
+        if (vec) hipLaunchKernelGGL(splitk_reduce_vec8_kernel, dim3(sm_stream_grid((long)p.M * (p.Cout / 8), 256)), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(splitk_reduce_kernel, dim3(sm_stream_grid((long)p.M * p.Cout, 256)), dim3(256), 0, s, p);
         SM_LAUNCH_CHECK();
     }
     return SM_OK;
@@ -567,11 +592,16 @@ extern "C" {
 int sm_conv2d_num_configs(void) { return kNumCfgs; }
 
 size_t sm_conv2d_workspace_bytes(const sm_conv_desc* d) {
+    // split-K is considered by launch() when a tile config leaves more than half of the CUs without a block and the K loop is
+    // long; the largest tile (256x128) decides whether that can happen, the smallest split count it would use bounds the size
     if (!d || d->groups != 1 || (d->Cin % 8)) return 0;
     long M = (long)d->N * d->Ho * d->Wo, K = (long)d->kH * d->kW * d->Cin;
-    long blocks = (long)sm_ceil_div(M, 64) * sm_ceil_div(d->Cout, 64);
-    if (blocks >= SM_NUM_CU / 2 || sm_ceil_div(K, BK) < 16) return 0;
-    return (size_t)32 * M * d->Cout * sizeof(float);
+    long blocks = (long)sm_ceil_div(M, 256) * sm_ceil_div(d->Cout, 128);
+    if (blocks >= SM_NUM_CU / 2 || sm_ceil_div(K, 64) < 16) return 0;
+    long want = SM_NUM_CU / blocks, maxs = sm_ceil_div(K, 64) / 4;
+    if (want > maxs) want = maxs;
+    if (want > 32) want = 32;
+    return want > 1 ? (size_t)want * M * d->Cout * sizeof(float) : 0;
 }
 
 int sm_conv2d_fwd_ws(const sm_conv_desc* d, const void* x, const void* w, const float* bias, const void* res, void* y,

@@ -95,7 +95,7 @@ def conv_transpose2d(x, w_ohwi_flipped, bias=None, stride=(1, 1), pads=(0, 0, 0,
     return out
 
 
-def conv2d_time(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0), groups=1, act=ACT_NONE, cfg=-1, iters=20, out=None):
+def conv2d_time(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0), groups=1, act=ACT_NONE, cfg=-1, iters=20, out=None, workspace=None):
     """average ms per launch of one conv shape / tile config, timed inside the library (no Python launch overhead)"""
     n, h, w, cin, x_ld = _check_nhwc(x)
     cout, kh, kw, cg = w_ohwi.shape
@@ -105,7 +105,8 @@ def conv2d_time(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 
     d = ConvDesc(n, h, w, cin, cout, kh, kw, stride[0], stride[1], 1, 1, pads[0], pads[1], pads[2], pads[3], groups, ho, wo, act, 0.0,
                  x_ld, _ld(out), _ld(residual) if residual is not None else 0)
     ms = C.c_float()
-    check(lib().sm_conv2d_time(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(out), None, 0, iters, _stream(), C.byref(ms)))
+    wsb = workspace.numel() * workspace.element_size() if workspace is not None else 0
+    check(lib().sm_conv2d_time(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(out), _ptr(workspace), wsb, iters, _stream(), C.byref(ms)))
     return ms.value
 
 

@@ -11,6 +11,7 @@ ap.add_argument("--shape", default="64,56,56,64,64,3,1,1")
 ap.add_argument("--cfg", default="all")
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--res", action="store_true")
+ap.add_argument("--ws", action="store_true", help="give the launcher a split-K workspace")
 a = ap.parse_args()
 n, h, w, cin, cout, k, s, p = map(int, a.shape.split(","))
 x = torch.randn((n, h, w, cin), device="cuda").half()
@@ -21,10 +22,11 @@ y = torch.empty((n, ho, wo, cout), device="cuda", dtype=torch.float16)
 r = torch.randn((n, ho, wo, cout), device="cuda").half() if a.res else None
 flops = 2.0 * n * ho * wo * cout * cin * k * k
 byts = 2.0 * (x.numel() + y.numel() * (2 if a.res else 1) + wt.numel())
+ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda") if a.ws else None
 cfgs = range(ops.num_conv_configs()) if a.cfg == "all" else [int(c) for c in a.cfg.split(",")]
 for cfg in cfgs:
     try:
-        ms = ops.conv2d_time(x, wt, b, residual=r, stride=(s, s), pads=(p, p, p, p), act=1, cfg=cfg, iters=a.iters, out=y)
+        ms = ops.conv2d_time(x, wt, b, residual=r, stride=(s, s), pads=(p, p, p, p), act=1, cfg=cfg, iters=a.iters, out=y, workspace=ws)
     except Exception as e:
         continue
     us = ms * 1e3
