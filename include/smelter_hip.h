@@ -53,7 +53,15 @@ const char* smelter_version(void);
 
 /* ======================================= (1) kernel level ======================================= */
 
-enum { SM_ACT_NONE = 0, SM_ACT_RELU = 1, SM_ACT_PRELU = 2 }; /* MPSCNNNeuronReLUNode(a:) Converters.swift:342-384 */
+/* Fused / stand-alone neurons.  RELU, PRELU: MPSCNNNeuronReLUNode(a:) Converters.swift:342-384.  The rest are the MPSCNNNeuron*Node
+ * classes the reference instantiates with their DEFAULT parameters (Converters.swift:386-428, 466-476, 1056-1175):
+ * SIGMOID 1/(1+e^-x); HARD_SIGMOID clamp(0.2x+0.5, 0, 1) (node attributes are not read); TANH; ELU x>=0 ? x : a(e^x-1) with
+ * a = `slope`; ABS; SOFTPLUS log(1+e^x); SOFTSIGN x/(1+|x|); EXP e^x; LOG ln x.  (Pow is MPSCNNNeuronPowerNode(source:) with
+ * its default exponent 1, i.e. the identity: the compiler aliases it.) */
+enum { SM_ACT_NONE = 0, SM_ACT_RELU = 1, SM_ACT_PRELU = 2, SM_ACT_SIGMOID = 3, SM_ACT_HARD_SIGMOID = 4, SM_ACT_TANH = 5, SM_ACT_ELU = 6,
+       SM_ACT_ABS = 7, SM_ACT_SOFTPLUS = 8, SM_ACT_SOFTSIGN = 9, SM_ACT_EXP = 10, SM_ACT_LOG = 11 };
+enum { SM_BIN_ADD = 0, SM_BIN_SUB = 1, SM_BIN_MUL = 2, SM_BIN_DIV = 3 };   /* MPSNNAddition/Subtraction/Multiplication/DivisionNode */
+enum { SM_PAD_CONSTANT = 0, SM_PAD_REFLECT = 1, SM_PAD_EDGE = 2 };          /* MPSImageEdgeMode .constant(0) / .mirror / .clamp */
 
 /* Replaces MPSCNNConvolutionDescriptor (Converters.swift:57-79) + ONNX_ConvolutionPadding
  * (Padding/ONNXConvolutionPadding.swift:57-89).  Shapes are resolved when the graph is compiled, not at
@@ -124,6 +132,23 @@ int sm_upsample_nearest(const void* x, void* y, int32_t N, int32_t H, int32_t W,
                         int32_t sx, int32_t x_ld, int32_t y_ld, sm_stream_t stream);
 int sm_upsample_bilinear(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t sy,
                          int32_t sx, int32_t align_corners, int32_t x_ld, int32_t y_ld, sm_stream_t stream);
+/* MPSNNSubtraction/Multiplication/DivisionNode (Converters.swift:1177-1211, :453-464) and Addition: y = act(a op b), same shape */
+int sm_binary(int32_t op, const void* a, const void* b, void* y, int64_t pixels, int32_t C, int32_t a_ld, int32_t b_ld,
+              int32_t y_ld, int32_t act, float slope, sm_stream_t stream);
+/* any SM_ACT_* neuron as a stand-alone pass (the compiler fuses it into the producing conv/add when it can) */
+int sm_neuron(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, int32_t act, float slope,
+              sm_stream_t stream);
+/* MPSCNNSoftMaxNode / MPSCNNLogSoftMaxNode (Converters.swift:697-714, :1213-1232; axis must be 1): over the C channels of a pixel */
+int sm_softmax(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, int32_t log_softmax,
+               sm_stream_t stream);
+/* MPSCNNInstanceNormalizationNode (:992-1011) / MPSCNNGroupNormalizationNode (:1273-1300): per image and group of C/groups
+ * channels, y = (x - mean) / sqrt(var + eps) * gamma[c] + beta[c] over H*W*(C/groups) elements (biased variance).
+ * groups == C is instance normalisation. */
+int sm_group_norm(const void* x, void* y, int32_t N, int32_t HW, int32_t C, int32_t groups, const float* gamma,
+                  const float* beta, float eps, int32_t x_ld, int32_t y_ld, sm_stream_t stream);
+/* MPSNNPadNode (Converters.swift:944-990): spatial padding, mode SM_PAD_* (constant value 0) */
+int sm_pad2d(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pad_t, int32_t pad_l,
+             int32_t pad_b, int32_t pad_r, int32_t mode, int32_t x_ld, int32_t y_ld, sm_stream_t stream);
 /* MPSNNConcatenationNode (:564): strided channel copy; the compiler avoids it by placement when it can */
 int sm_copy_channels(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld,
                      sm_stream_t stream);

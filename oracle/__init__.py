@@ -86,6 +86,11 @@ def lib():
         L.orc_pack_float_array.argtypes = [vp] + [C.c_int] * 4 + [vp]
         L.orc_conv2d.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp]
         L.orc_conv_transpose2d.argtypes = [C.POINTER(ConvDesc), vp, vp, vp, vp]
+        L.orc_binary.argtypes = [C.c_int, vp, vp, vp, C.c_size_t]
+        L.orc_neuron.argtypes = [C.c_int, vp, vp, C.c_size_t, C.c_float]
+        L.orc_softmax.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.orc_group_norm.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float]
+        L.orc_pad2d.argtypes = [vp, vp] + [C.c_int] * 9
         L.orc_gemm_fc.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
         L.orc_batchnorm.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float]
         L.orc_relu.argtypes = [vp, vp, C.c_size_t, C.c_float]
@@ -227,6 +232,41 @@ def add(a, b):
     a, b = _f32(a), _f32(b)
     y = np.empty_like(a)
     lib().orc_add(_p(a), _p(b), _p(y), a.size)
+    return y
+
+
+NEURON = {"sigmoid": 3, "hardsigmoid": 4, "tanh": 5, "elu": 6, "abs": 7, "softplus": 8, "softsign": 9, "exp": 10, "log": 11}
+BINARY = {"add": 0, "sub": 1, "mul": 2, "div": 3}
+
+
+def neuron(kind: str, x, a: float = 0.0):
+    x = _f32(x); y = np.empty_like(x)
+    lib().orc_neuron(NEURON[kind], _p(x), _p(y), x.size, a)
+    return y
+
+
+def binary(op: str, a, b):
+    a, b = _f32(a), _f32(b); y = np.empty_like(a)
+    lib().orc_binary(BINARY[op], _p(a), _p(b), _p(y), a.size)
+    return y
+
+
+def softmax(x, log: bool = False):
+    x = _f32(x); n, c, h, w = x.shape; y = np.empty_like(x)
+    lib().orc_softmax(_p(x), _p(y), n, c, h * w, 1 if log else 0)
+    return y
+
+
+def group_norm(x, groups, gamma, beta, eps=1e-5):
+    x = _f32(x); n, c, h, w = x.shape; y = np.empty_like(x)
+    lib().orc_group_norm(_p(x), _p(y), n, c, h * w, groups, _p(_f32(gamma)), _p(_f32(beta)), eps)
+    return y
+
+
+def pad2d(x, pads, mode: str = "constant"):
+    x = _f32(x); n, c, h, w = x.shape; pt, pl, pb, pr = pads
+    y = np.empty((n, c, h + pt + pb, w + pl + pr), np.float32)
+    lib().orc_pad2d(_p(x), _p(y), n, c, h, w, pt, pl, pb, pr, {"constant": 0, "reflect": 1, "edge": 2}[mode])
     return y
 
 

@@ -138,6 +138,17 @@ void orc_batchnorm(const float* x, float* y, int n, int c, int hw, const float* 
                    const float* mean, const float* var, float eps);
 void orc_relu(const float* x, float* y, size_t n, float slope);
 void orc_add(const float* a, const float* b, float* y, size_t n);
+/* MPSNNSubtraction/Multiplication/DivisionNode (Converters.swift:1177-1211, :453-464): op 0 add, 1 sub, 2 mul, 3 div */
+void orc_binary(int op, const float* a, const float* b, float* y, size_t n);
+/* MPSCNNNeuron*Node with default parameters (:386-428, :466-476, :1056-1175): kind 3 sigmoid, 4 hard sigmoid (0.2x+0.5 clamped;
+ * attributes not read), 5 tanh, 6 elu(a), 7 abs, 8 softplus, 9 softsign, 10 exp, 11 log — same codes as SM_ACT_* */
+void orc_neuron(int kind, const float* x, float* y, size_t n, float a);
+/* MPSCNNSoftMaxNode / MPSCNNLogSoftMaxNode (:697-714, :1213-1232): over C for every (n, h, w) */
+void orc_softmax(const float* x, float* y, int n, int c, int hw, int log_softmax);
+/* MPSCNNInstanceNormalizationNode (:992-1011) / MPSCNNGroupNormalizationNode (:1273-1300): biased variance over HW*(C/groups) */
+void orc_group_norm(const float* x, float* y, int n, int c, int hw, int groups, const float* gamma, const float* beta, float eps);
+/* MPSNNPadNode (:944-990): mode 0 constant (0), 1 reflect, 2 edge; spatial pads only */
+void orc_pad2d(const float* x, float* y, int n, int c, int h, int w, int pt, int pl, int pb, int pr, int mode);
 void orc_maxpool(const float* x, float* y, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int ph,
                  int pw, int ho, int wo);
 void orc_avgpool(const float* x, float* y, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int ph,

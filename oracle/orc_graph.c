@@ -247,6 +247,86 @@ static int add_conv(orc_graph* g, const orc_node* nd) { /* AddConverter :430-451
     return ORC_OK;
 }
 
+/* Sub :1177, Mul :453, Div :1195 — same guard and shape bookkeeping as Add */
+static int binary_conv(orc_graph* g, const orc_node* nd, int op) {
+    value* a = nd->n_input >= 2 ? find_value(g, nd->input[0]) : NULL;
+    value* b = nd->n_input >= 2 ? find_value(g, nd->input[1]) : NULL;
+    if (!a || !b) return fail(ORC_ERR_NO_SUCH_OUTPUT, "%.*s: operand is not a graph value", (int)nd->op_type.n, nd->op_type.p);
+    if (a->c != b->c || a->h != b->h || a->w != b->w) return fail(ORC_ERR_INCONSISTENT_STATE, "%.*s: shape mismatch (no broadcasting restated)", (int)nd->op_type.n, nd->op_type.p);
+    size_t cnt = (size_t)g->batch * a->c * a->h * a->w; float* y = malloc(sizeof(float) * cnt);
+    orc_binary(op, a->data, b->data, y, cnt);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
+    put_value(g, nd->output[0], y, a->c, a->h, a->w, a->ref);
+    return ORC_OK;
+}
+
+/* the MPSCNNNeuron*Node converters with default parameters: Elu :386-409 (alpha attribute required, >= 1 attribute),
+ * Exp :411-428, Sigmoid :466-476, Abs :1056, HardSigmoid :1073, Softplus :1090, Softsign :1107, Tanh :1124, Log :1142,
+ * Pow :1160 (MPSCNNNeuronPowerNode(source:) = default exponent 1: the identity, kind 0) */
+static int neuron_conv(orc_graph* g, const orc_node* nd, int kind) {
+    value* in = nd->n_input >= 1 ? find_value(g, nd->input[0]) : NULL;
+    if (!in) return fail(ORC_ERR_NO_SUCH_OUTPUT, "%.*s: input value missing", (int)nd->op_type.n, nd->op_type.p);
+    float a = 0.f;
+    if (kind == 6) { const orc_attr* al = find_attr(nd, "alpha"); if (nd->n_attr < 1 || !al) return fail(ORC_ERR_NO_SUCH_OUTPUT, "Elu: alpha attribute required"); a = al->f; }
+    size_t cnt = (size_t)g->batch * in->c * in->h * in->w; float* y = malloc(sizeof(float) * cnt);
+    orc_neuron(kind, in->data, y, cnt, a);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
+    for (int i = 0; i < nd->n_output; i++) { float* dat = y; if (i > 0) { dat = malloc(sizeof(float) * cnt); memcpy(dat, y, sizeof(float) * cnt); }
+        put_value(g, nd->output[i], dat, in->c, in->h, in->w, in->ref); }
+    return ORC_OK;
+}
+
+static int softmax_conv(orc_graph* g, const orc_node* nd, int logsm) { /* :697-714, :1213-1232: axis attribute present and == 1 */
+    value* in = nd->n_input >= 1 ? find_value(g, nd->input[0]) : NULL;
+    const orc_attr* ax = find_attr(nd, "axis");
+    if (!in || nd->n_attr < 1 || !ax || ax->i != 1) return fail(ORC_ERR_NO_SUCH_OUTPUT, "Softmax: input missing or axis != 1");
+    size_t cnt = (size_t)g->batch * in->c * in->h * in->w; float* y = malloc(sizeof(float) * cnt);
+    orc_softmax(in->data, y, g->batch, in->c, in->h * in->w, logsm);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
+    put_value(g, nd->output[0], y, in->c, in->h, in->w, in->ref);
+    return ORC_OK;
+}
+
+/* InstanceNormalization :992-1011 (inputs x, gamma, beta) ; custom_group_norm :1273-1300 (inputs x, groups, gamma, beta).
+ * epsilon: the ONNX attribute is honoured (default 1e-5), as for BatchNormalization (quirk dropped, see header). */
+static int norm_conv(orc_graph* g, const orc_node* nd, int is_group) {
+    const int need = is_group ? 4 : 3;
+    value* in = nd->n_input >= need ? find_value(g, nd->input[0]) : NULL;
+    const orc_tensor* gt = nd->n_input >= need ? find_tensor(g, nd->input[need - 2]) : NULL;
+    const orc_tensor* bt = nd->n_input >= need ? find_tensor(g, nd->input[need - 1]) : NULL;
+    const orc_tensor* nt = is_group && nd->n_input >= need ? find_tensor(g, nd->input[1]) : NULL;
+    if (!in || !gt || !bt || (is_group && !nt)) return fail(ORC_ERR_NO_SUCH_OUTPUT, "%.*s: input or parameter tensor missing", (int)nd->op_type.n, nd->op_type.p);
+    long ng = 0, nb = 0; float* gamma = tensor_floats_alloc(gt, &ng); float* beta = tensor_floats_alloc(bt, &nb);
+    int groups = in->c, rc = ORC_OK;
+    if (is_group) { int64_t gi = 0; if (orc_tensor_integers(nt, &gi, 1) < 1) { free(gamma); free(beta); return fail(ORC_ERR_NO_SUCH_OUTPUT, "custom_group_norm: groups tensor empty"); } groups = (int)gi; }
+    if (!gamma || !beta || ng != in->c || nb != in->c || groups <= 0 || in->c % groups) { free(gamma); free(beta); return fail(ORC_ERR_INCONSISTENT_STATE, "%.*s: parameter size / groups", (int)nd->op_type.n, nd->op_type.p); }
+    const orc_attr* e = find_attr(nd, "epsilon"); float eps = e ? e->f : 1e-5f;
+    size_t cnt = (size_t)g->batch * in->c * in->h * in->w; float* y = malloc(sizeof(float) * cnt);
+    orc_group_norm(in->data, y, g->batch, in->c, in->h * in->w, groups, gamma, beta, eps);
+    free(gamma); free(beta);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
+    put_value(g, nd->output[0], y, in->c, in->h, in->w, in->ref);
+    return rc;
+}
+
+static int pad_conv(orc_graph* g, const orc_node* nd) { /* PaddingConverter :944-990: pads = [n,c,h,w begin ; n,c,h,w end] */
+    value* in = nd->n_input >= 1 ? find_value(g, nd->input[0]) : NULL;
+    const orc_attr* pd = find_attr(nd, "pads");
+    if (!in || !pd) return fail(ORC_ERR_NO_SUCH_OUTPUT, "Pad: input or pads attribute missing");
+    if (pd->n_ints < 8) return fail(ORC_ERR_INCONSISTENT_STATE, "Pad: 8 pads expected");
+    int mode = 0; const orc_attr* ma = find_attr(nd, "mode");
+    if (ma && ma->s.n) { if (bis(ma->s, "constant")) mode = 0; else if (bis(ma->s, "reflect")) mode = 1; else if (bis(ma->s, "edge")) mode = 2;
+        else return fail(ORC_ERR_INCONSISTENT_STATE, "Pad: mode"); }                                  /* :966-967 */
+    if (pd->ints[1] || pd->ints[5] || pd->ints[0] || pd->ints[4]) return fail(ORC_ERR_INCONSISTENT_STATE, "Pad: channel/batch padding is outside the restated subset");
+    int pt = (int)pd->ints[2], pl = (int)pd->ints[3], pb = (int)pd->ints[6], pr = (int)pd->ints[7];
+    if (pt < 0 || pl < 0 || pb < 0 || pr < 0) return fail(ORC_ERR_INCONSISTENT_STATE, "Pad: negative pads");
+    int ho = in->h + pt + pb, wo = in->w + pl + pr;
+    size_t cnt = (size_t)g->batch * in->c * ho * wo; float* y = malloc(sizeof(float) * cnt);
+    orc_pad2d(in->data, y, g->batch, in->c, in->h, in->w, pt, pl, pb, pr, mode);
+    put_value(g, nd->output[0], y, in->c, ho, wo, REF(in->ref.channels, wo, ho, in->ref.depth));   /* :980-985 */
+    return ORC_OK;
+}
+
 static int pool_conv(orc_graph* g, const orc_node* nd, int is_max) { /* MaxPool :652-695, AveragePool :607-650 */
     value* in = nd->n_input >= 1 ? find_value(g, nd->input[0]) : NULL;
     const orc_attr *ks = find_attr(nd, "kernel_shape"), *pd = find_attr(nd, "pads"), *st = find_attr(nd, "strides");
@@ -373,6 +453,24 @@ int orc_graph_run(orc_graph* g, const float* in_nchw, int batch, float** out, in
         else if (bis(op, "PRelu")) rc = unary_like(g, nd, 1);
         else if (bis(op, "BatchNormalization")) rc = unary_like(g, nd, 2);
         else if (bis(op, "Add")) rc = add_conv(g, nd);
+        else if (bis(op, "Sub")) rc = binary_conv(g, nd, 1);
+        else if (bis(op, "Mul")) rc = binary_conv(g, nd, 2);
+        else if (bis(op, "Div")) rc = binary_conv(g, nd, 3);
+        else if (bis(op, "Sigmoid")) rc = neuron_conv(g, nd, 3);
+        else if (bis(op, "HardSigmoid")) rc = neuron_conv(g, nd, 4);
+        else if (bis(op, "Tanh")) rc = neuron_conv(g, nd, 5);
+        else if (bis(op, "Elu")) rc = neuron_conv(g, nd, 6);
+        else if (bis(op, "Abs")) rc = neuron_conv(g, nd, 7);
+        else if (bis(op, "Softplus")) rc = neuron_conv(g, nd, 8);
+        else if (bis(op, "Softsign")) rc = neuron_conv(g, nd, 9);
+        else if (bis(op, "Exp")) rc = neuron_conv(g, nd, 10);
+        else if (bis(op, "Log")) rc = neuron_conv(g, nd, 11);
+        else if (bis(op, "Pow")) rc = neuron_conv(g, nd, 0);
+        else if (bis(op, "Softmax")) rc = softmax_conv(g, nd, 0);
+        else if (bis(op, "LogSoftmax")) rc = softmax_conv(g, nd, 1);
+        else if (bis(op, "InstanceNormalization")) rc = norm_conv(g, nd, 0);
+        else if (bis(op, "custom_group_norm")) rc = norm_conv(g, nd, 1);
+        else if (bis(op, "Pad")) rc = pad_conv(g, nd);
         else if (bis(op, "MaxPool")) rc = pool_conv(g, nd, 1);
         else if (bis(op, "AveragePool")) rc = pool_conv(g, nd, 0);
         else if (bis(op, "GlobalAveragePool")) rc = gap_conv(g, nd);

@@ -132,6 +132,76 @@ void orc_add(const float* a, const float* b, float* y, size_t n) {
     for (long i = 0; i < (long)n; i++) y[i] = a[i] + b[i];
 }
 
+void orc_binary(int op, const float* a, const float* b, float* y, size_t n) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; i++) y[i] = op == 0 ? a[i] + b[i] : op == 1 ? a[i] - b[i] : op == 2 ? a[i] * b[i] : a[i] / b[i];
+}
+
+void orc_neuron(int kind, const float* x, float* y, size_t n, float a) {
+#pragma omp parallel for schedule(static)
+    for (long i = 0; i < (long)n; i++) {
+        float v = x[i], r = v;
+        switch (kind) {
+        case 3: r = 1.f / (1.f + expf(-v)); break;
+        case 4: r = fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f); break;     /* MPSCNNNeuronHardSigmoidNode(source:) defaults a=0.2 b=0.5 */
+        case 5: r = tanhf(v); break;
+        case 6: r = v >= 0.f ? v : a * (expf(v) - 1.f); break;
+        case 7: r = fabsf(v); break;
+        case 8: r = log1pf(expf(v)); break;
+        case 9: r = v / (1.f + fabsf(v)); break;
+        case 10: r = expf(v); break;
+        case 11: r = logf(v); break;
+        }
+        y[i] = r;
+    }
+}
+
+void orc_softmax(const float* x, float* y, int n, int c, int hw, int logsm) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < n; i++)
+        for (int p = 0; p < hw; p++) {
+            const float* xp = x + (size_t)i * c * hw + p; float* yp = y + (size_t)i * c * hw + p;
+            float mx = xp[0]; for (int k = 1; k < c; k++) if (xp[(size_t)k * hw] > mx) mx = xp[(size_t)k * hw];
+            float sum = 0.f; for (int k = 0; k < c; k++) sum += expf(xp[(size_t)k * hw] - mx);
+            for (int k = 0; k < c; k++) { float t = xp[(size_t)k * hw] - mx; yp[(size_t)k * hw] = logsm ? t - logf(sum) : expf(t) / sum; }
+        }
+}
+
+void orc_group_norm(const float* x, float* y, int n, int c, int hw, int groups, const float* gamma, const float* beta, float eps) {
+    const int cg = c / groups;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < n; i++)
+        for (int g = 0; g < groups; g++) {
+            const float* xp = x + ((size_t)i * c + (size_t)g * cg) * hw; float* yp = y + ((size_t)i * c + (size_t)g * cg) * hw;
+            const size_t cnt = (size_t)cg * hw;
+            double s = 0; for (size_t k = 0; k < cnt; k++) s += xp[k];
+            const float mean = (float)(s / (double)cnt);
+            double q = 0; for (size_t k = 0; k < cnt; k++) { double d = (double)xp[k] - mean; q += d * d; }
+            const float rstd = 1.f / sqrtf((float)(q / (double)cnt) + eps);
+            for (int ch = 0; ch < cg; ch++) {
+                const float ga = gamma ? gamma[g * cg + ch] : 1.f, be = beta ? beta[g * cg + ch] : 0.f;
+                for (int k = 0; k < hw; k++) yp[(size_t)ch * hw + k] = (xp[(size_t)ch * hw + k] - mean) * rstd * ga + be;
+            }
+        }
+}
+
+void orc_pad2d(const float* x, float* y, int n, int c, int h, int w, int pt, int pl, int pb, int pr, int mode) {
+    const int ho = h + pt + pb, wo = w + pl + pr;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < n; i++)
+        for (int ch = 0; ch < c; ch++)
+            for (int oy = 0; oy < ho; oy++)
+                for (int ox = 0; ox < wo; ox++) {
+                    int iy = oy - pt, ix = ox - pl, zero = 0;
+                    if (mode == 2) { iy = iy < 0 ? 0 : iy >= h ? h - 1 : iy; ix = ix < 0 ? 0 : ix >= w ? w - 1 : ix; }
+                    else if (mode == 1) {
+                        if (h > 1) { int per = 2 * (h - 1); iy = ((iy % per) + per) % per; if (iy >= h) iy = per - iy; } else iy = 0;
+                        if (w > 1) { int per = 2 * (w - 1); ix = ((ix % per) + per) % per; if (ix >= w) ix = per - ix; } else ix = 0;
+                    } else zero = iy < 0 || iy >= h || ix < 0 || ix >= w;
+                    y[(((size_t)i * c + ch) * ho + oy) * wo + ox] = zero ? 0.f : x[(((size_t)i * c + ch) * h + iy) * w + ix];
+                }
+}
+
 /* Converters.swift:652-695 (MPSCNNPoolingMaxNode) + PyTorchPoolPadding.swift:56-75 (window start) */
 void orc_maxpool(const float* x, float* y, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int ph,
                  int pw, int ho, int wo) {

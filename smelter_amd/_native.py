@@ -61,6 +61,11 @@ SYMBOLS = {
     "sm_conv2d_time": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, C.POINTER(_f)]),
     "sm_batchnorm": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp]),
     "sm_add": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
+    "sm_binary": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _f, _vp]),
+    "sm_neuron": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f, _vp]),
+    "sm_softmax": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp]),
+    "sm_group_norm": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _f, _i32, _i32, _vp]),
+    "sm_pad2d": (_i32, [_vp, _vp] + [_i32] * 11 + [_vp]),
     "sm_relu": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _f, _vp]),
     "sm_maxpool2d": (_i32, [C.POINTER(PoolDesc), _vp, _vp, _vp]),
     "sm_avgpool2d": (_i32, [C.POINTER(PoolDesc), _vp, _vp, _vp]),

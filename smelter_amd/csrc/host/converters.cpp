@@ -283,6 +283,118 @@ struct DropoutConverter : NodeConverter {   // inference identity (the reference
     }
 };
 
+// ---- SubConverter (:1177-1193), MulConverter (:453-464), DivConverter (:1195-1211): MPSNN{Subtraction,Multiplication,Division}Node
+struct BinaryConverter : NodeConverter {
+    int binop; const char* name;
+    BinaryConverter(int op, const char* n) : binop(op), name(n) {}
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int a = node.input.size() >= 2 ? graph.output(node.input[0]) : -1;
+        const int b = node.input.size() >= 2 ? graph.output(node.input[1]) : -1;
+        if (a < 0 || b < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "%s: an operand is not a graph value", name);
+        const Value va = graph.value(a), vb = graph.value(b);
+        if (va.c != vb.c || va.h != vb.h || va.w != vb.w) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "%s: operand shapes differ (no broadcasting)", name);
+        Op op; op.kind = OpKind::Add; op.binop = binop; op.inputs = {a, b};
+        return graph.addFilter(std::move(op), va.c, va.h, va.w, va.ref, node.output);
+    }
+};
+struct SubConverter : BinaryConverter { SubConverter() : BinaryConverter(SM_BIN_SUB, "Sub") {} };
+struct MulConverter : BinaryConverter { MulConverter() : BinaryConverter(SM_BIN_MUL, "Mul") {} };
+struct DivConverter : BinaryConverter { DivConverter() : BinaryConverter(SM_BIN_DIV, "Div") {} };
+
+// ---- the MPSCNNNeuron*Node converters, all with the node's DEFAULT parameters: Elu (:386-409, alpha attribute required),
+// Exp (:411-428), Sigmoid (:466-476), Abs (:1056), HardSigmoid (:1073, attributes not read), Softplus (:1090), Softsign (:1107),
+// Tanh (:1124), Log (:1142), Pow (:1160: MPSCNNNeuronPowerNode(source:) has exponent 1 -> identity, aliased like Dropout) ----
+struct NeuronConverter : NodeConverter {
+    int act; const char* name;
+    NeuronConverter(int a, const char* n) : act(a), name(n) {}
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        if (in < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "%s: input is not a graph value", name);
+        float a = 0.f;
+        if (act == SM_ACT_ELU) { const pb::Attribute* al = node.attr("alpha"); if (node.attribute.empty() || !al) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Elu: alpha attribute required"); a = al->f; }
+        const Value iv = graph.value(in);
+        Op op; op.inputs = {in};
+        if (act == SM_ACT_NONE) op.kind = OpKind::Alias;
+        else { op.kind = OpKind::Neuron; op.act = act; op.slope = a; }
+        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);
+    }
+};
+struct EluConverter : NeuronConverter { EluConverter() : NeuronConverter(SM_ACT_ELU, "Elu") {} };
+struct ExpConverter : NeuronConverter { ExpConverter() : NeuronConverter(SM_ACT_EXP, "Exp") {} };
+struct SigmoidConverter : NeuronConverter { SigmoidConverter() : NeuronConverter(SM_ACT_SIGMOID, "Sigmoid") {} };
+struct AbsConverter : NeuronConverter { AbsConverter() : NeuronConverter(SM_ACT_ABS, "Abs") {} };
+struct HardSigmoidConverter : NeuronConverter { HardSigmoidConverter() : NeuronConverter(SM_ACT_HARD_SIGMOID, "HardSigmoid") {} };
+struct SoftplusConverter : NeuronConverter { SoftplusConverter() : NeuronConverter(SM_ACT_SOFTPLUS, "Softplus") {} };
+struct SoftsignConverter : NeuronConverter { SoftsignConverter() : NeuronConverter(SM_ACT_SOFTSIGN, "Softsign") {} };
+struct TanhConverter : NeuronConverter { TanhConverter() : NeuronConverter(SM_ACT_TANH, "Tanh") {} };
+struct LogConverter : NeuronConverter { LogConverter() : NeuronConverter(SM_ACT_LOG, "Log") {} };
+struct PowConverter : NeuronConverter { PowConverter() : NeuronConverter(SM_ACT_NONE, "Pow") {} };
+
+// ---- SoftmaxConverter (:697-714), LogSoftmaxConverter (:1213-1232): an `axis` attribute must be present and equal 1 -------
+struct SoftmaxConverter : NodeConverter {
+    bool logsm;
+    explicit SoftmaxConverter(bool l = false) : logsm(l) {}
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        const pb::Attribute* ax = node.attr("axis");
+        if (in < 0 || node.attribute.empty() || !ax || ax->i != 1) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "%s: input missing or axis != 1", logsm ? "LogSoftmax" : "Softmax");
+        const Value iv = graph.value(in);
+        Op op; op.kind = OpKind::Softmax; op.inputs = {in}; op.logSoftmax = logsm;
+        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);
+    }
+};
+struct LogSoftmaxConverter : SoftmaxConverter { LogSoftmaxConverter() : SoftmaxConverter(true) {} };
+
+// ---- InstanceNormConverter (:992-1011: x, gamma, beta), GroupNormConverter (:1273-1300: x, groups, gamma, beta) ------------
+// epsilon: the ONNX attribute is honoured (default 1e-5), as for BatchNormalization.
+struct InstanceNormConverter : NodeConverter {
+    bool isGroup;
+    explicit InstanceNormConverter(bool g = false) : isGroup(g) {}
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const size_t need = isGroup ? 4 : 3;
+        const char* nm = isGroup ? "custom_group_norm" : "InstanceNormalization";
+        const int in = node.input.size() >= need ? graph.output(node.input[0]) : -1;
+        const pb::Tensor* gt = node.input.size() >= need ? graph.tensor(node.input[need - 2]) : nullptr;
+        const pb::Tensor* bt = node.input.size() >= need ? graph.tensor(node.input[need - 1]) : nullptr;
+        const pb::Tensor* nt = isGroup && node.input.size() >= need ? graph.tensor(node.input[1]) : nullptr;
+        if (in < 0 || !gt || !bt || (isGroup && !nt)) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "%s: input value or parameter tensor missing", nm);
+        const Value iv = graph.value(in);
+        Op op; op.kind = OpKind::GroupNorm; op.inputs = {in};
+        int rc = pb::tensor_floats(*gt, &op.scale); if (rc) SM_FAIL(rc, "%s: gamma dtype", nm);
+        rc = pb::tensor_floats(*bt, &op.shift); if (rc) SM_FAIL(rc, "%s: beta dtype", nm);
+        op.normGroups = iv.c;
+        if (isGroup) { std::vector<int64_t> gi; rc = pb::tensor_integers(*nt, &gi); if (rc) SM_FAIL(rc, "custom_group_norm: groups dtype");
+            if (gi.empty()) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "custom_group_norm: groups tensor empty"); op.normGroups = (int)gi[0]; }
+        if ((int)op.scale.size() != iv.c || (int)op.shift.size() != iv.c || op.normGroups <= 0 || iv.c % op.normGroups)
+            SM_FAIL(SM_ERR_INCONSISTENT_STATE, "%s: parameter sizes / groups do not fit %d channels", nm, iv.c);
+        const pb::Attribute* e = node.attr("epsilon"); op.eps = e ? e->f : 1e-5f;
+        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);
+    }
+};
+struct GroupNormConverter : InstanceNormConverter { GroupNormConverter() : InstanceNormConverter(true) {} };
+
+// ---- PaddingConverter (:944-990): pads = [n,c,h,w begins ; n,c,h,w ends], mode constant(0) / reflect / edge ------------------
+struct PaddingConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        const pb::Attribute* pd = node.attr("pads");
+        if (in < 0 || !pd) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Pad: input value or pads attribute missing");
+        if (pd->ints.size() < 8) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Pad: 8 pads expected");
+        int mode = SM_PAD_CONSTANT; const pb::Attribute* ma = node.attr("mode");
+        if (ma && !ma->s.empty()) {
+            if (ma->s == "constant") mode = SM_PAD_CONSTANT; else if (ma->s == "reflect") mode = SM_PAD_REFLECT; else if (ma->s == "edge") mode = SM_PAD_EDGE;
+            else SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Pad: unknown mode '%.*s'", SV(ma->s));                                           // :966-967
+        }
+        if (pd->ints[0] || pd->ints[1] || pd->ints[4] || pd->ints[5]) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Pad: batch / channel padding is not supported");
+        const Value iv = graph.value(in);
+        Op op; op.kind = OpKind::Pad; op.inputs = {in}; op.padMode = mode;
+        op.pt = (int)pd->ints[2]; op.pl = (int)pd->ints[3]; op.pb = (int)pd->ints[6]; op.pr = (int)pd->ints[7];
+        if (op.pt < 0 || op.pl < 0 || op.pb < 0 || op.pr < 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Pad: negative pads");
+        const int ho = iv.h + op.pt + op.pb, wo = iv.w + op.pl + op.pr;
+        return graph.addFilter(std::move(op), iv.c, ho, wo, mkShape(iv.ref.channels, wo, ho, iv.ref.depth), node.output);              // :980-985
+    }
+};
+
 }  // namespace
 
 void registerDefaultConverters(ONNXGraph& g) {    // ONNXGraph.swift:110-155, hot-path subset (SURVEY.md §2a ★ rows)
@@ -302,7 +414,26 @@ void registerDefaultConverters(ONNXGraph& g) {    // ONNXGraph.swift:110-155, ho
         .registerConverter("BatchNormalization", std::make_shared<BatchNormalizationConverter>())
         .registerConverter("Dropout", std::make_shared<DropoutConverter>())
         .registerConverter("Reshape", std::make_shared<ReshapeConverter>())
-        .registerConverter("Flatten", std::make_shared<FlattenConverter>());
+        .registerConverter("Flatten", std::make_shared<FlattenConverter>())
+        // the rest of the registry of ONNXGraph.swift:110-155
+        .registerConverter("Sub", std::make_shared<SubConverter>())
+        .registerConverter("Mul", std::make_shared<MulConverter>())
+        .registerConverter("Div", std::make_shared<DivConverter>())
+        .registerConverter("Elu", std::make_shared<EluConverter>())
+        .registerConverter("Exp", std::make_shared<ExpConverter>())
+        .registerConverter("Sigmoid", std::make_shared<SigmoidConverter>())
+        .registerConverter("Abs", std::make_shared<AbsConverter>())
+        .registerConverter("HardSigmoid", std::make_shared<HardSigmoidConverter>())
+        .registerConverter("Softplus", std::make_shared<SoftplusConverter>())
+        .registerConverter("Softsign", std::make_shared<SoftsignConverter>())
+        .registerConverter("Tanh", std::make_shared<TanhConverter>())
+        .registerConverter("Log", std::make_shared<LogConverter>())
+        .registerConverter("Pow", std::make_shared<PowConverter>())
+        .registerConverter("Softmax", std::make_shared<SoftmaxConverter>())
+        .registerConverter("LogSoftmax", std::make_shared<LogSoftmaxConverter>())
+        .registerConverter("InstanceNormalization", std::make_shared<InstanceNormConverter>())
+        .registerConverter("custom_group_norm", std::make_shared<GroupNormConverter>())
+        .registerConverter("Pad", std::make_shared<PaddingConverter>());
 }
 
 }  // namespace smelter

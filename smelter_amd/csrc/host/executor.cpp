@@ -36,6 +36,7 @@ const char* kindName(OpKind k) {
     case OpKind::Neuron: return "Neuron"; case OpKind::Add: return "Add"; case OpKind::MaxPool: return "MaxPool";
     case OpKind::AvgPool: return "AvgPool"; case OpKind::GlobalAvgPool: return "GlobalAvgPool"; case OpKind::Upsample: return "Upsample";
     case OpKind::Concat: return "Concat"; case OpKind::Alias: return "Alias"; case OpKind::ConvTranspose: return "ConvTranspose";
+    case OpKind::Softmax: return "Softmax"; case OpKind::GroupNorm: return "GroupNorm"; case OpKind::Pad: return "Pad";
     }
     return "?";
 }
@@ -89,7 +90,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                     }
                     c.output = op.output; dead[i] = 1;
                 }
-            } else if (op.kind == OpKind::Add) {
+            } else if (op.kind == OpKind::Add && op.binop == SM_BIN_ADD) {
                 int pa = producerOf(op.inputs[0]), pb = producerOf(op.inputs[1]);
                 auto ok = [&](int p, int v) { return p >= 0 && isConvLike(ops[p].kind) && ops[p].kind != OpKind::ConvTranspose && ops[p].act == SM_ACT_NONE && ops[p].residual < 0 && consumers(v) == 1; };
                 int cand = -1, other = -1;
@@ -315,7 +316,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             sm_conv_desc d{}; d.N = batch; d.H = op.kind == OpKind::Conv ? iv.h : 1; d.W = op.kind == OpKind::Conv ? iv.w : 1; d.Cin = op.cin; d.Cout = op.cout;
             d.kH = op.kh; d.kW = op.kw; d.groups = op.groups; d.Ho = ov.h; d.Wo = ov.w;
             ws_bytes_ = std::max(ws_bytes_, sm_conv2d_workspace_bytes(&d));
-        } else if (op.kind == OpKind::BatchNorm) {
+        } else if (op.kind == OpKind::BatchNorm || op.kind == OpKind::GroupNorm) {
             st.s_off = off; off = alignUp(off + op.scale.size() * 4);
             st.t_off = off; off = alignUp(off + op.shift.size() * 4);
         }
@@ -356,7 +357,7 @@ int Executor::packWeights(std::vector<uint8_t>* host) const {
                 sm_float_to_half(op.weight.data(), dst, op.weight.size());   // fp16 cast, RNE (ONNX2MPS.py:27 numpy astype(float16))
             }
             if (st.has_bias) memcpy(host->data() + st.b_off, op.bias.data(), op.bias.size() * 4);
-        } else if (op.kind == OpKind::BatchNorm) {
+        } else if (op.kind == OpKind::BatchNorm || op.kind == OpKind::GroupNorm) {
             memcpy(host->data() + st.s_off, op.scale.data(), op.scale.size() * 4);
             memcpy(host->data() + st.t_off, op.shift.data(), op.shift.size() * 4);
         }
@@ -441,7 +442,18 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
     case OpKind::Neuron:
         return sm_batchnorm(valuePtr(op.inputs[0]), y, st.M, ov.c, valueLd(op.inputs[0]), y_ld, nullptr, nullptr, op.act, op.slope, ss);
     case OpKind::Add:
-        return sm_add(valuePtr(op.inputs[0]), valuePtr(op.inputs[1]), y, st.M, ov.c, valueLd(op.inputs[0]), valueLd(op.inputs[1]), y_ld, op.act, op.slope, ss);
+        return sm_binary(op.binop, valuePtr(op.inputs[0]), valuePtr(op.inputs[1]), y, st.M, ov.c, valueLd(op.inputs[0]), valueLd(op.inputs[1]), y_ld, op.act, op.slope, ss);
+    case OpKind::Softmax:
+        return sm_softmax(valuePtr(op.inputs[0]), y, st.M, ov.c, valueLd(op.inputs[0]), y_ld, op.logSoftmax ? 1 : 0, ss);
+    case OpKind::GroupNorm: {
+        const Value& iv = values_[op.inputs[0]];
+        return sm_group_norm(valuePtr(op.inputs[0]), y, batch_, iv.h * iv.w, iv.c, op.normGroups, (const float*)(arena_ + st.s_off), (const float*)(arena_ + st.t_off),
+                             op.eps, valueLd(op.inputs[0]), y_ld, ss);
+    }
+    case OpKind::Pad: {
+        const Value& iv = values_[op.inputs[0]];
+        return sm_pad2d(valuePtr(op.inputs[0]), y, batch_, iv.h, iv.w, iv.c, op.pt, op.pl, op.pb, op.pr, op.padMode, valueLd(op.inputs[0]), y_ld, ss);
+    }
     case OpKind::MaxPool: case OpKind::AvgPool: {
         const Value& iv = values_[op.inputs[0]];
         sm_pool_desc d{batch_, iv.h, iv.w, iv.c, op.kh, op.kw, op.sh, op.sw, op.y0, op.x0, ov.h, ov.w, valueLd(op.inputs[0]), y_ld};

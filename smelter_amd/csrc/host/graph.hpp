@@ -30,7 +30,7 @@ struct Configuration {
 
 enum class Format { onnx, mpsFlavor };   // ONNXGraph.swift:49-52
 
-enum class OpKind { Conv, FullyConnected, BatchNorm, Neuron, Add, MaxPool, AvgPool, GlobalAvgPool, Upsample, Concat, Alias, ConvTranspose };
+enum class OpKind { Conv, FullyConnected, BatchNorm, Neuron, Add, MaxPool, AvgPool, GlobalAvgPool, Upsample, Concat, Alias, ConvTranspose, Softmax, GroupNorm, Pad };
 
 // One record per converted node (the analogue of an MPSNNFilterNode + its data source / padding policy).
 struct Op {
@@ -54,6 +54,8 @@ struct Op {
     int y0 = 0, x0 = 0;
     // upsample
     int sy = 1, sx = 1; bool bilinear = false, alignCorners = true;
+    // Add family (SM_BIN_*), Softmax (log flag), GroupNorm / InstanceNorm (groups, eps; gamma/beta in scale/shift), Pad (SM_PAD_*, pads in pt..pr)
+    int binop = 0; bool logSoftmax = false; int normGroups = 0; float eps = 1e-5f; int padMode = 0;
 };
 
 // A value = one named tensor flowing through the graph (MPSNNImageNode in the reference).

@@ -41,9 +41,26 @@ void sm_set_error(const char* fmt, ...);
         if (!(cond)) { sm_set_error(__VA_ARGS__); return SM_ERR_INVALID_ARGUMENT; }                   \
     } while (0)
 
+// the MPSCNNNeuron*Node family with default parameters (smelter_hip.h SM_ACT_*); out of line: the conv epilogues only pay a
+// uniform branch for it
+__device__ __noinline__ static float sm_act_other(float v, int act, float slope) {
+    switch (act) {
+    case SM_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    case SM_ACT_HARD_SIGMOID: return fminf(fmaxf(0.2f * v + 0.5f, 0.f), 1.f);
+    case SM_ACT_TANH: return tanhf(v);
+    case SM_ACT_ELU: return v >= 0.f ? v : slope * (expf(v) - 1.f);
+    case SM_ACT_ABS: return fabsf(v);
+    case SM_ACT_SOFTPLUS: return log1pf(expf(v));
+    case SM_ACT_SOFTSIGN: return v / (1.f + fabsf(v));
+    case SM_ACT_EXP: return expf(v);
+    case SM_ACT_LOG: return logf(v);
+    }
+    return v;
+}
 __device__ __forceinline__ float sm_act(float v, int act, float slope) {
     // MPSCNNNeuronReLUNode(a): f(x) = x >= 0 ? x : a*x   (Converters.swift:351,376)
-    return (act != SM_ACT_NONE && v < 0.f) ? v * slope : v;
+    if (act <= SM_ACT_PRELU) return (act != SM_ACT_NONE && v < 0.f) ? v * slope : v;
+    return sm_act_other(v, act, slope);
 }
 
 static inline int sm_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }

@@ -13,21 +13,24 @@ namespace {
 __device__ __forceinline__ bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // ---- MPSNNAdditionNode (Converters.swift:440) [+ fused MPSCNNNeuronReLUNode] --------------------------
-__global__ void add_vec_kernel(const half_t* a, const half_t* b, half_t* y, long pixels, int cv, int a_ld, int b_ld, int y_ld, int act, float slope) {
+__device__ __forceinline__ float sm_binop(float a, float b, int op) {   // MPSNNAddition/Subtraction/Multiplication/DivisionNode
+    return op == SM_BIN_ADD ? a + b : op == SM_BIN_SUB ? a - b : op == SM_BIN_MUL ? a * b : a / b;
+}
+__global__ void add_vec_kernel(const half_t* a, const half_t* b, half_t* y, long pixels, int cv, int a_ld, int b_ld, int y_ld, int act, float slope, int op) {
     long total = pixels * cv;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long m = i / cv; int c = (int)(i - m * cv) * 8;
         half8_t va = *(const half8_t*)(a + m * a_ld + c), vb = *(const half8_t*)(b + m * b_ld + c), o;
 #pragma unroll
-        for (int j = 0; j < 8; j++) o[j] = (half_t)sm_act((float)va[j] + (float)vb[j], act, slope);
+        for (int j = 0; j < 8; j++) o[j] = (half_t)sm_act(sm_binop((float)va[j], (float)vb[j], op), act, slope);
         *(half8_t*)(y + m * y_ld + c) = o;
     }
 }
-__global__ void add_scalar_kernel(const half_t* a, const half_t* b, half_t* y, long pixels, int C, int a_ld, int b_ld, int y_ld, int act, float slope) {
+__global__ void add_scalar_kernel(const half_t* a, const half_t* b, half_t* y, long pixels, int C, int a_ld, int b_ld, int y_ld, int act, float slope, int op) {
     long total = pixels * C;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long m = i / C; int c = (int)(i - m * C);
-        y[m * y_ld + c] = (half_t)sm_act((float)a[m * a_ld + c] + (float)b[m * b_ld + c], act, slope);
+        y[m * y_ld + c] = (half_t)sm_act(sm_binop((float)a[m * a_ld + c], (float)b[m * b_ld + c], op), act, slope);
     }
 }
 
@@ -106,6 +109,71 @@ __global__ __launch_bounds__(256) void pool_kernel(sm_pool_desc d, const half_t*
     } else py[0] = (half_t)(MAX ? acc[0] : acc[0] * inv);
 }
 
+// ---- MPSCNNSoftMaxNode / MPSCNNLogSoftMaxNode (:697-714, :1213-1232): over the channels of one pixel.  One wave per pixel,
+// lanes stride over C; max and sum by cross-lane butterflies; fp32 math, one rounding to fp16. -------------------------------
+__global__ __launch_bounds__(256) void softmax_kernel(const half_t* x, half_t* y, long pixels, int C, int x_ld, int y_ld, int logsm) {
+    const int lane = threadIdx.x & 63;
+    for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < pixels; m += (long)gridDim.x * 4) {
+        const half_t* px = x + m * x_ld; half_t* py = y + m * y_ld;
+        float mx = -3.0e38f;
+        for (int c = lane; c < C; c += 64) mx = fmaxf(mx, (float)px[c]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int c = lane; c < C; c += 64) sum += expf((float)px[c] - mx);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum, lse = logf(sum);
+        for (int c = lane; c < C; c += 64) { const float t = (float)px[c] - mx; py[c] = (half_t)(logsm ? t - lse : expf(t) * inv); }
+    }
+}
+
+// ---- MPSCNNInstanceNormalizationNode (:992-1011) / MPSCNNGroupNormalizationNode (:1273-1300): one block per (image, group);
+// two-pass mean / biased variance in fp32 over HW x (C/groups) elements, then normalise + per-channel gamma/beta. ------------
+__global__ __launch_bounds__(256) void group_norm_kernel(const half_t* x, half_t* y, int HW, int C, int groups, const float* gamma, const float* beta,
+                                                         float eps, int x_ld, int y_ld) {
+    const int n = blockIdx.x / groups, g = blockIdx.x - n * groups, cg = C / groups, c0 = g * cg;
+    const long base = (long)n * HW; const int total = HW * cg;
+    __shared__ float red[4]; __shared__ float s_mean, s_rstd;
+    auto block_sum = [&](float v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    float s = 0.f;
+    for (int i = threadIdx.x; i < total; i += 256) { const int p = i / cg, c = i - p * cg; s += (float)x[(base + p) * x_ld + c0 + c]; }
+    const float mean = block_sum(s) / (float)total;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < total; i += 256) { const int p = i / cg, c = i - p * cg; const float d = (float)x[(base + p) * x_ld + c0 + c] - mean; q += d * d; }
+    const float rstd = 1.f / sqrtf(block_sum(q) / (float)total + eps);
+    if (threadIdx.x == 0) { s_mean = mean; s_rstd = rstd; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int p = i / cg, c = i - p * cg;
+        const float v = ((float)x[(base + p) * x_ld + c0 + c] - s_mean) * s_rstd;
+        y[(base + p) * y_ld + c0 + c] = (half_t)(v * (gamma ? gamma[c0 + c] : 1.f) + (beta ? beta[c0 + c] : 0.f));
+    }
+}
+
+// ---- MPSNNPadNode (:944-990): constant 0 / reflect (mirror without repeating the edge) / edge (clamp) ----------------------
+__global__ void pad_kernel(const half_t* x, half_t* y, int N, int H, int W, int C, int pt, int pl, int Ho, int Wo, int mode, int x_ld, int y_ld) {
+    const long total = (long)N * Ho * Wo * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); long m = i / C;
+        const int ox = (int)(m % Wo); m /= Wo; const int oy = (int)(m % Ho), n = (int)(m / Ho);
+        int iy = oy - pt, ix = ox - pl; bool zero = false;
+        if (mode == SM_PAD_EDGE) { iy = min(max(iy, 0), H - 1); ix = min(max(ix, 0), W - 1); }
+        else if (mode == SM_PAD_REFLECT) {
+            if (H > 1) { const int per = 2 * (H - 1); iy = ((iy % per) + per) % per; if (iy >= H) iy = per - iy; } else iy = 0;
+            if (W > 1) { const int per = 2 * (W - 1); ix = ((ix % per) + per) % per; if (ix >= W) ix = per - ix; } else ix = 0;
+        } else zero = (unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)W;
+        y[(((long)n * Ho + oy) * Wo + ox) * y_ld + c] = zero ? (half_t)0.f : x[(((long)n * H + iy) * W + ix) * x_ld + c];
+    }
+}
+
 // ---- GlobalAveragePoolConverter (:578-605): mean over H*W.  One block per (image, 64-channel group):
 // 4 waves stride over the pixels (lane = 8-channel vector ... C small) then combine through LDS. -----------
 __global__ __launch_bounds__(256) void gap_kernel(const half_t* x, half_t* y, int HW, int C, int x_ld, int y_ld) {
@@ -172,14 +240,17 @@ bool vec8(int C, std::initializer_list<int> lds, std::initializer_list<const voi
 
 extern "C" {
 
-int sm_add(const void* a, const void* b, void* y, int64_t pixels, int32_t C, int32_t a_ld, int32_t b_ld, int32_t y_ld, int32_t act, float slope, sm_stream_t st) {
-    SM_REQUIRE(a && b && y && pixels > 0 && C > 0, "sm_add: bad argument");
+int sm_binary(int32_t op, const void* a, const void* b, void* y, int64_t pixels, int32_t C, int32_t a_ld, int32_t b_ld, int32_t y_ld, int32_t act, float slope, sm_stream_t st) {
+    SM_REQUIRE(a && b && y && pixels > 0 && C > 0 && op >= SM_BIN_ADD && op <= SM_BIN_DIV, "sm_binary: bad argument");
     a_ld = a_ld ? a_ld : C; b_ld = b_ld ? b_ld : C; y_ld = y_ld ? y_ld : C; if (act == SM_ACT_RELU) slope = 0.f;
     if (vec8(C, {a_ld, b_ld, y_ld}, {a, b, y}))
-        hipLaunchKernelGGL(add_vec_kernel, dim3(sm_stream_grid(pixels * (C / 8), 256)), dim3(256), 0, sm_s(st), (const half_t*)a, (const half_t*)b, (half_t*)y, (long)pixels, C / 8, a_ld, b_ld, y_ld, act, slope);
+        hipLaunchKernelGGL(add_vec_kernel, dim3(sm_stream_grid(pixels * (C / 8), 256)), dim3(256), 0, sm_s(st), (const half_t*)a, (const half_t*)b, (half_t*)y, (long)pixels, C / 8, a_ld, b_ld, y_ld, act, slope, op);
     else
-        hipLaunchKernelGGL(add_scalar_kernel, dim3(sm_stream_grid(pixels * C, 256)), dim3(256), 0, sm_s(st), (const half_t*)a, (const half_t*)b, (half_t*)y, (long)pixels, C, a_ld, b_ld, y_ld, act, slope);
+        hipLaunchKernelGGL(add_scalar_kernel, dim3(sm_stream_grid(pixels * C, 256)), dim3(256), 0, sm_s(st), (const half_t*)a, (const half_t*)b, (half_t*)y, (long)pixels, C, a_ld, b_ld, y_ld, act, slope, op);
     SM_LAUNCH_CHECK(); return SM_OK;
+}
+int sm_add(const void* a, const void* b, void* y, int64_t pixels, int32_t C, int32_t a_ld, int32_t b_ld, int32_t y_ld, int32_t act, float slope, sm_stream_t st) {
+    return sm_binary(SM_BIN_ADD, a, b, y, pixels, C, a_ld, b_ld, y_ld, act, slope, st);
 }
 
 int sm_batchnorm(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, const float* scale, const float* shift, int32_t act, float slope, sm_stream_t st) {
@@ -194,6 +265,35 @@ int sm_batchnorm(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld
 
 int sm_relu(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, float slope, sm_stream_t st) {
     return sm_batchnorm(x, y, pixels, C, x_ld, y_ld, nullptr, nullptr, SM_ACT_PRELU, slope, st);
+}
+int sm_neuron(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, int32_t act, float slope, sm_stream_t st) {
+    SM_REQUIRE(act >= SM_ACT_NONE && act <= SM_ACT_LOG, "sm_neuron: unknown activation");
+    return sm_batchnorm(x, y, pixels, C, x_ld, y_ld, nullptr, nullptr, act, slope, st);
+}
+
+int sm_softmax(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, int32_t logsm, sm_stream_t st) {
+    SM_REQUIRE(x && y && pixels > 0 && C > 0, "sm_softmax: bad argument");
+    x_ld = x_ld ? x_ld : C; y_ld = y_ld ? y_ld : C;
+    hipLaunchKernelGGL(softmax_kernel, dim3(sm_stream_grid(pixels * 64, 256)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, (long)pixels, C, x_ld, y_ld, logsm);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+int sm_group_norm(const void* x, void* y, int32_t N, int32_t HW, int32_t C, int32_t groups, const float* gamma, const float* beta, float eps,
+                  int32_t x_ld, int32_t y_ld, sm_stream_t st) {
+    SM_REQUIRE(x && y && N > 0 && HW > 0 && C > 0 && groups > 0 && C % groups == 0, "sm_group_norm: bad argument");
+    x_ld = x_ld ? x_ld : C; y_ld = y_ld ? y_ld : C;
+    hipLaunchKernelGGL(group_norm_kernel, dim3(N * groups), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, HW, C, groups, gamma, beta, eps, x_ld, y_ld);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+int sm_pad2d(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t pt, int32_t pl, int32_t pb, int32_t pr, int32_t mode,
+             int32_t x_ld, int32_t y_ld, sm_stream_t st) {
+    SM_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0 && pt >= 0 && pl >= 0 && pb >= 0 && pr >= 0 && mode >= SM_PAD_CONSTANT && mode <= SM_PAD_EDGE,
+               "sm_pad2d: bad argument");
+    x_ld = x_ld ? x_ld : C; y_ld = y_ld ? y_ld : C;
+    const int Ho = H + pt + pb, Wo = W + pl + pr;
+    hipLaunchKernelGGL(pad_kernel, dim3(sm_stream_grid((long)N * Ho * Wo * C, 256)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, N, H, W, C, pt, pl, Ho, Wo, mode, x_ld, y_ld);
+    SM_LAUNCH_CHECK(); return SM_OK;
 }
 
 static int pool_common(const sm_pool_desc* d0, const void* x, void* y, bool is_max, sm_stream_t st) {

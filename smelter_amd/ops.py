@@ -137,6 +137,47 @@ def add(a, b, act=ACT_NONE, slope=0.0, out=None):
     return out
 
 
+ACT_CODES = {"none": 0, "relu": 1, "prelu": 2, "sigmoid": 3, "hardsigmoid": 4, "tanh": 5, "elu": 6, "abs": 7, "softplus": 8, "softsign": 9, "exp": 10, "log": 11}
+BIN_CODES = {"add": 0, "sub": 1, "mul": 2, "div": 3}
+PAD_CODES = {"constant": 0, "reflect": 1, "edge": 2}
+
+
+def binary(op, a, b, act=ACT_NONE, slope=0.0):
+    n, h, w, c, a_ld = _check_nhwc(a)
+    out = torch.empty((n, h, w, c), dtype=torch.float16, device=a.device)
+    check(lib().sm_binary(BIN_CODES[op], _ptr(a), _ptr(b), _ptr(out), n * h * w, c, a_ld, _ld(b), _ld(out), act, slope, _stream()))
+    return out
+
+
+def neuron(kind, x, a=0.0):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    out = torch.empty((n, h, w, c), dtype=torch.float16, device=x.device)
+    check(lib().sm_neuron(_ptr(x), _ptr(out), n * h * w, c, x_ld, _ld(out), ACT_CODES[kind], a, _stream()))
+    return out
+
+
+def softmax(x, log=False):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    out = torch.empty((n, h, w, c), dtype=torch.float16, device=x.device)
+    check(lib().sm_softmax(_ptr(x), _ptr(out), n * h * w, c, x_ld, _ld(out), 1 if log else 0, _stream()))
+    return out
+
+
+def group_norm(x, groups, gamma, beta, eps=1e-5):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    out = torch.empty((n, h, w, c), dtype=torch.float16, device=x.device)
+    check(lib().sm_group_norm(_ptr(x), _ptr(out), n, h * w, c, groups, _ptr(gamma), _ptr(beta), eps, x_ld, _ld(out), _stream()))
+    return out
+
+
+def pad2d(x, pads, mode="constant"):
+    n, h, w, c, x_ld = _check_nhwc(x)
+    pt, pl, pb, pr = pads
+    out = torch.empty((n, h + pt + pb, w + pl + pr, c), dtype=torch.float16, device=x.device)
+    check(lib().sm_pad2d(_ptr(x), _ptr(out), n, h, w, c, pt, pl, pb, pr, PAD_CODES[mode], x_ld, _ld(out), _stream()))
+    return out
+
+
 def relu(x, slope=0.0, out=None):
     n, h, w, c, x_ld = _check_nhwc(x)
     out = torch.empty((n, h, w, c), dtype=torch.float16, device=x.device) if out is None else out

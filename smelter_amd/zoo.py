@@ -232,6 +232,46 @@ def deconv_net(seed: int = 1, batch: int = 1, hw=(32, 32), base: int = 16, dtype
     return (m, net.macs) if return_macs else m
 
 
+def misc_ops_net(seed: int = 1, batch: int = 1, hw=(24, 20), final: str = "LogSoftmax", dtype=np.float32):
+    """one graph through every remaining converter of ONNXGraph.swift:110-155 — Sub/Mul/Div, Sigmoid/HardSigmoid/
+    Tanh/Elu/Abs/Softplus/Softsign/Exp/Log/Pow, Pad (reflect, edge, constant), InstanceNormalization, custom_group_norm, Softmax/LogSoftmax."""
+    net = _Net("misc_ops", seed, dtype)
+    g = net.g
+    # the two normalisation layers sit right behind convolutions of well-spread data (1/sigma amplifies fp16 rounding noise)
+    x, cur = net.conv("input", hw, 3, 16, 3, bias=True)
+    gam = g.add_init(g.fresh("in_g"), net.rng.uniform(0.5, 1.5, 16).astype(net.dtype))
+    bet = g.add_init(g.fresh("in_b"), (net.rng.standard_normal(16) * 0.1).astype(net.dtype))
+    n1 = g.add_node("InstanceNormalization", [x, gam, bet], epsilon=1e-5)
+    a = g.add_node("Sigmoid", [n1])
+    b, _ = net.conv(a, cur, 16, 16, 1, p=0, bias=True)
+    b = g.add_node("Tanh", [b])                                      # fused into the conv epilogue
+    m = g.add_node("Mul", [a, b])
+    sp = g.add_node("Softplus", [b])                                 # > 0: a safe divisor
+    d = g.add_node("Div", [m, sp])
+    s = g.add_node("Sub", [d, a])
+    e = g.add_node("Elu", [s], alpha=0.8)
+    e = g.add_node("Pad", [e], pads=[0, 0, 1, 2, 0, 0, 2, 1], mode=b"reflect")
+    cur = (cur[0] + 3, cur[1] + 3)
+    c2, cur = net.conv(e, cur, 16, 16, 3, p=0, bias=True)
+    grp = g.add_init(g.fresh("gn_groups"), np.array([4], np.int64))
+    gam2 = g.add_init(g.fresh("gn_g"), net.rng.uniform(0.5, 1.5, 16).astype(net.dtype))
+    bet2 = g.add_init(g.fresh("gn_b"), (net.rng.standard_normal(16) * 0.1).astype(net.dtype))
+    gn = g.add_node("custom_group_norm", [c2, grp, gam2, bet2])
+    h1 = g.add_node("HardSigmoid", [gn])
+    ab = g.add_node("Abs", [gn])
+    ss = g.add_node("Softsign", [ab])
+    ex = g.add_node("Exp", [ss])                                     # in [1, e)
+    lg = g.add_node("Log", [ex])
+    pw = g.add_node("Pow", [lg, g.add_init(g.fresh("pow_e"), np.array([2.0], net.dtype))])   # the reference ignores the exponent (identity)
+    ad = g.add_node("Add", [pw, h1])
+    ad = g.add_node("Pad", [ad], pads=[0, 0, 1, 1, 0, 0, 0, 0], mode=b"edge")
+    gn = g.add_node("Pad", [ad], pads=[0, 0, 0, 0, 0, 0, 1, 1])      # default mode: constant 0
+    cur = (cur[0] + 2, cur[1] + 2)
+    y, cur = net.conv(gn, cur, 16, 8, 1, p=0, bias=True)
+    y = g.add_node(final, [y], axis=1)
+    return _finish(net, y, [batch, 3, hw[0], hw[1]], [batch, 8, cur[0], cur[1]])
+
+
 def synthetic_images(batch: int, c: int = 3, hw=(224, 224), seed: int = 0) -> np.ndarray:
     """NCHW fp32 i.i.d. uniform [0,1) — what an RGBA8-unorm texture yields in the reference flow
     (/root/reference/README.md:33-39)."""

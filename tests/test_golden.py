@@ -25,7 +25,7 @@ def close(a, b, tol=TOL):
 
 def test_fixture_inventory():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "*.npz")))
-    assert len(names) >= 22 and "toy_end_to_end" in names and "ct3x3_s2_p1_op1" in names
+    assert len(names) >= 27 and "toy_end_to_end" in names and "ct3x3_s2_p1_op1" in names
 
 
 @pytest.mark.parametrize("name", ["c1x1_s1", "c1x1_s2", "c3x3_s1", "c3x3_s2", "c7x7_s2_p3", "dw3x3_s1", "dw3x3_s2"])
@@ -46,6 +46,25 @@ def test_conv_transpose(name):
     ic, oc = w.shape[:2]
     w_flipped = O.reformat_conv_weight(w, oc, ic, k, k, is_transpose=True).reshape(oc, k, k, ic)   # what ConvDataSource hands MPS
     close(O.conv_transpose2d(d["x"], w_flipped, d["b"], stride=(s, s), pads=(p, p, p, p), out_pad=(op, op)), d["y"])
+
+
+def test_rank3_elementwise_and_normalisation_ops():
+    d = load("r3_unary")
+    for kind in ("sigmoid", "hardsigmoid", "tanh", "abs", "softplus", "softsign", "exp"):
+        close(O.neuron(kind, d["x"]), d[kind])
+    close(O.neuron("elu", d["x"], 0.7), d["elu"])
+    close(O.neuron("log", d["log_in"]), d["log"])
+    d = load("r3_binary")
+    for op in ("sub", "mul", "div"):
+        close(O.binary(op, d["a"], d["b"]), d[op])
+    d = load("r3_softmax")
+    close(O.softmax(d["x"]), d["softmax"]); close(O.softmax(d["x"], log=True), d["logsoftmax"])
+    d = load("r3_norms")
+    close(O.group_norm(d["x"], 6, d["gamma"], d["beta"]), d["instance"]); close(O.group_norm(d["x"], 3, d["gamma"], d["beta"]), d["group3"])
+    d = load("r3_pad")
+    pads = tuple(int(v) for v in d["pads"])
+    for mode in ("constant", "reflect", "edge"):
+        close(O.pad2d(d["x"], pads, mode), d[mode], 0)
 
 
 def test_pools_and_gap():

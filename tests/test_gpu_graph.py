@@ -29,6 +29,8 @@ MODELS = {
     "unet_nearest": (lambda: zoo.unet(hw=(64, 48)), (2, 3, 64, 48)),
     "unet_bilinear_bn": (lambda: zoo.unet(hw=(32, 32), mode="bilinear", with_bn=True, levels=3), (1, 3, 32, 32)),
     "deconv_net": (lambda: zoo.deconv_net(hw=(32, 40)), (2, 3, 32, 40)),          # ConvTranspose decoder
+    "misc_ops_logsoftmax": (lambda: zoo.misc_ops_net(), (2, 3, 24, 20)),           # every remaining converter
+    "misc_ops_softmax": (lambda: zoo.misc_ops_net(final="Softmax"), (2, 3, 24, 20)),
 }
 
 
@@ -233,3 +235,35 @@ def test_conv_transpose_layer_through_the_graph(case, autotune):
     assert got.shape == ref.shape == (3, cout, ho, wo)
     tol = np.abs(ref) * 2.0 ** -10 + np.abs(ref).max() * 2.0 ** -11 * max(1.0, np.sqrt(cin * k * k)) * 1e-2 + 1e-7
     assert (np.abs(got - ref) <= tol).all(), float(np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("final", ["LogSoftmax", "Softmax"])
+@pytest.mark.parametrize("flavour", ["onnx_fp32", "mps_fp16"])
+@pytest.mark.parametrize("fuse", [True, False])
+def test_misc_ops_network_every_remaining_converter(final, flavour, fuse):
+    """every intermediate of the graph against the oracle (which rounds where the executor materialises).
+    The two normalisation layers amplify an fp16 rounding flip of their input by 1/sigma, hence 5e-3 here; the kernels themselves
+    are held to 1 fp16 ulp in test_gpu_ops.py, the end-to-end result to the tight bound of the parity tests above."""
+    import ctypes as C
+    model = zoo.misc_ops_net(final=final)
+    if flavour == "mps_fp16":
+        model = onnx2mps.optimize_model(model, half=True)
+    x = zoo.synthetic_images(2, 3, (24, 20))
+    ex, got = run_hip(model, x, fuse=fuse, useHipGraph=False, keepIntermediates=True)
+    og = O.Graph(model)
+    og.set_round_list(ex.valueNames)
+    ref = og.run(x)
+    assert got.shape == ref.shape == (2, 8, 27, 23) and np.isfinite(got).all()
+    assert nerr(got, ref) <= 5e-3, nerr(got, ref)
+    for name in ex.valueNames[1:]:
+        v = og.value(name)
+        assert v is not None, name
+        p, c, h, w = v
+        r = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), (2 * c * h * w,)).reshape(2, c, h, w)
+        assert nerr(ex.readValue(name).reshape(r.shape), r) <= 5e-3, name
+    n_nodes = ONNXGraph(model).numNodes
+    assert n_nodes == 24
+    if fuse:
+        descs = [ex.opDesc(i) for i in range(ex.numOps)]
+        assert ex.numOps <= n_nodes - 3                      # Tanh (into its conv), Elu (into Sub), Pow (alias) disappear
+        assert any(d.startswith("Conv") and "+act" in d for d in descs)    # Tanh fused into the 1x1 conv's epilogue

@@ -255,3 +255,57 @@ def test_conv2d_output_placement(cfg):
     bad = N.ConvDesc(n, hh, ww, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, hh, ww, 0, 0.0, cin, cout, 0, sH, sW, oH, oW, YH - 2, YW)
     with pytest.raises(N.SmelterError):
         N.check(N.lib().sm_conv2d_fwd_cfg(C.byref(bad), -1, C.c_void_p(xd.data_ptr()), C.c_void_p(wd.data_ptr()), None, None, C.c_void_p(y.data_ptr()), None, 0, None))
+
+
+# ---- the remaining MPSCNNNeuron* / MPSNN arithmetic / normalisation / padding nodes -------------------
+def assert_close_f(got, ref, rel=2.0 ** -10, floor=1e-3):
+    """fp16 output of an fp32 transcendental: 1 fp16 ulp + the libm difference between device and host expf/logf/tanhf"""
+    ref16 = h(ref)
+    tol = np.abs(ref16) * rel * 2 + floor * 2.0 ** -10 * max(1.0, np.abs(ref).max())
+    assert (np.abs(got - ref16) <= tol).all(), float(np.abs(got - ref16).max())
+
+
+@pytest.mark.parametrize("kind", ["sigmoid", "hardsigmoid", "tanh", "elu", "abs", "softplus", "softsign", "exp", "log"])
+@pytest.mark.parametrize("c", [16, 6])
+def test_neuron_family(kind, c):
+    rng = np.random.default_rng(51)
+    x = h(rng.standard_normal((2, c, 7, 9)) * 2)
+    if kind == "log":
+        x = h(np.abs(x) + 0.1)
+    a = 0.7 if kind == "elu" else 0.0
+    assert_close_f(to_host(ops.neuron(kind, to_dev(x), a)), O.neuron(kind, x, a))
+
+
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div"])
+@pytest.mark.parametrize("c", [24, 5])
+def test_binary_family(op, c):
+    rng = np.random.default_rng(52)
+    a = h(rng.standard_normal((2, c, 6, 5)))
+    b = h(rng.standard_normal((2, c, 6, 5)) + 3.0)
+    assert_close(to_host(ops.binary(op, to_dev(a), to_dev(b))), O.binary(op, a, b))
+
+
+@pytest.mark.parametrize("c", [8, 10, 1000, 3])
+@pytest.mark.parametrize("log", [False, True])
+def test_softmax_over_channels(c, log):
+    rng = np.random.default_rng(53)
+    x = h(rng.standard_normal((2, c, 3, 4)) * 3)
+    assert_close_f(to_host(ops.softmax(to_dev(x), log)), O.softmax(x, log), floor=2e-3)
+
+
+@pytest.mark.parametrize("c,groups,hw", [(16, 16, (9, 7)), (16, 4, (8, 8)), (6, 3, (5, 5)), (8, 1, (13, 3))])
+def test_instance_and_group_norm(c, groups, hw):
+    rng = np.random.default_rng(54)
+    x = h(rng.standard_normal((3, c, hw[0], hw[1])) * 2 + 0.5)
+    g, b = rng.uniform(0.5, 1.5, c).astype(np.float32), rng.standard_normal(c).astype(np.float32)
+    got = to_host(ops.group_norm(to_dev(x), groups, torch.from_numpy(g).cuda(), torch.from_numpy(b).cuda()))
+    assert_close_f(got, O.group_norm(x, groups, g, b), floor=4e-3)
+
+
+@pytest.mark.parametrize("mode", ["constant", "reflect", "edge"])
+@pytest.mark.parametrize("c", [8, 3])
+def test_pad2d_is_byte_exact(mode, c):
+    rng = np.random.default_rng(55)
+    x = h(rng.standard_normal((2, c, 6, 7)))
+    got = to_host(ops.pad2d(to_dev(x), (1, 2, 3, 1), mode))
+    assert np.array_equal(got, O.pad2d(x, (1, 2, 3, 1), mode))

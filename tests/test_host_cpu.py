@@ -89,6 +89,13 @@ ERRORS = [
     ("notEnoughAttributes", _conv_model(FULL, extra_nodes=[ow.node("Upsample", ["y"], ["z"], mode="nearest")])),  # scales missing
     ("unknownNodeOpType", _conv_model(FULL, extra_nodes=[ow.node("Upsample", ["y"], ["z"], mode="cubic", scales=[1.0, 1.0, 2.0, 2.0])])),
     ("insufficientInputs", _conv_model(FULL, extra_nodes=[ow.node("BatchNormalization", ["y", "w"], ["z"])])),    # :803-809
+    ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("Softmax", ["y"], ["z"], axis=2)])),               # axis must be 1 (:703-704)
+    ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("LogSoftmax", ["y"], ["z"])])),                   # axis attribute missing
+    ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("Elu", ["y"], ["z"])])),                          # alpha attribute missing (:392-396)
+    ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("Mul", ["y", "w"], ["z"])])),                     # initializer operand (:455-459)
+    ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("Pad", ["y"], ["z"], mode=b"reflect")])),         # pads missing (:948-949)
+    ("inconsistentState", _conv_model(FULL, extra_nodes=[ow.node("Pad", ["y"], ["z"], pads=[0, 0, 1, 1, 0, 0, 1, 1], mode=b"wrap")])),   # :966-967
+    ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("InstanceNormalization", ["y", "w"], ["z"])])),   # 3 inputs required (:994-999)
     ("inconsistentState", _conv_model(dict(FULL, group=2), op="ConvTranspose")),                  # outside the restated subset (group 1)
     ("notEnoughAttributes", _conv_model({k: v for k, v in FULL.items() if k != "strides"}, op="ConvTranspose")),
 ]

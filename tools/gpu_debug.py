@@ -49,7 +49,9 @@ def layerwise(name, model, x):
 
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "mbv2"
-    if which == "toy":
+    if which == "misc":
+        layerwise("misc", onnx2mps.optimize_model(zoo.misc_ops_net(final="Softmax"), half=True), zoo.synthetic_images(2, 3, (24, 20)))
+    elif which == "toy":
         layerwise("toy", zoo.toy(), zoo.synthetic_images(2, 3, (64, 64)))
     elif which == "mbv2":
         layerwise("mbv2", onnx2mps.optimize_model(zoo.mobilenet_v2(hw=(64, 64)), half=True), zoo.synthetic_images(3, 3, (64, 64)))

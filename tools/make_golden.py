@@ -56,6 +56,26 @@ def convt_cases():
     return cases
 
 
+def rank3_cases():
+    """elementwise / normalisation ops, torch fp64 (HardSigmoid by its ONNX formula: torch's differs)"""
+    rng = np.random.default_rng(14)
+    c = {}
+    x = rng.standard_normal((2, 6, 5, 7)).astype(np.float32) * 2
+    b = (rng.standard_normal((2, 6, 5, 7)).astype(np.float32) + 3.0)
+    X = t64(x)
+    c["unary"] = dict(x=x, sigmoid=torch.sigmoid(X).numpy(), hardsigmoid=torch.clamp(0.2 * X + 0.5, 0, 1).numpy(), tanh=torch.tanh(X).numpy(),
+                      elu=F.elu(X, alpha=0.7).numpy(), abs=X.abs().numpy(), softplus=F.softplus(X).numpy(), softsign=F.softsign(X).numpy(),
+                      exp=X.exp().numpy(), log=torch.log(X.abs() + 0.1).numpy(), log_in=(np.abs(x.astype(np.float64)) + 0.1).astype(np.float32))
+    c["binary"] = dict(a=x, b=b, sub=(X - t64(b)).numpy(), mul=(X * t64(b)).numpy(), div=(X / t64(b)).numpy())
+    c["softmax"] = dict(x=x, softmax=F.softmax(X, dim=1).numpy(), logsoftmax=F.log_softmax(X, dim=1).numpy())
+    g, be = rng.uniform(0.5, 1.5, 6).astype(np.float32), rng.standard_normal(6).astype(np.float32)
+    c["norms"] = dict(x=x, gamma=g, beta=be, instance=F.instance_norm(X, weight=t64(g), bias=t64(be), eps=1e-5).numpy(),
+                      group3=F.group_norm(X, 3, t64(g), t64(be), eps=1e-5).numpy())
+    c["pad"] = dict(x=x, constant=F.pad(X, (2, 1, 1, 3)).numpy(), reflect=F.pad(X, (2, 1, 1, 3), mode="reflect").numpy(),
+                    edge=F.pad(X, (2, 1, 1, 3), mode="replicate").numpy(), pads=np.array([1, 2, 3, 1]))   # pads = top, left, bottom, right
+    return {k: {kk: np.asarray(vv, np.float32) if kk != "pads" else vv for kk, vv in v.items()} for k, v in c.items()}
+
+
 def misc_cases():
     rng = np.random.default_rng(12)
     c = {}
@@ -108,6 +128,8 @@ def main():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
     for name, d in convt_cases().items():
         np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    for name, d in rank3_cases().items():
+        np.savez_compressed(os.path.join(OUT, "r3_" + name + ".npz"), **d)
     np.savez_compressed(os.path.join(OUT, "toy_end_to_end.npz"), **toy_end_to_end())
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote %d fixtures, %d KB" % (len(os.listdir(OUT)), tot // 1024))
