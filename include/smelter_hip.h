@@ -159,6 +159,12 @@ int sm_nchw_f32_to_nhwc_f16(const float* x, void* y, int32_t N, int32_t C, int32
                             int32_t halo_t, int32_t halo_l, int32_t halo_b, int32_t halo_r, sm_stream_t stream);
 int sm_nhwc_f16_to_nchw_f32(const void* x, float* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t x_ld,
                             sm_stream_t stream);
+/* MPSNNBilinearScaleNode / MPSNNLanczosScaleNode (ONNXGraph.swift:222-239) on NCHW fp32 planes.  mode SM_INPUT_FORCE_SCALE_BILINEAR:
+ * pixel-centre sampling, src = (dst + 0.5) * in/out - 0.5, clamped to the edge.  SM_INPUT_FORCE_SCALE_LANCZOS: separable
+ * Lanczos-3 resampling, support widened by max(1, in/out) when shrinking, weights normalised, edge clamp.  (Apple's scalers are
+ * closed source: these are the textbook definitions, pinned in tests to torch bilinear / a numpy Lanczos.) */
+int sm_resize_nchw_f32(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t mode,
+                       sm_stream_t stream);
 /* First-layer image (C <= 4), NCHW fp32 -> "row-pair image" fp16 [N][Hs][Ws][8]: pixel (y, x) = image pixel
  * (y - pad_t, x - pad_l) in halfs 0..3 and the pixel below it in halfs 4..7, zeros outside the image.  The compiled
  * graph runs the first convolution (ConvolutionConverter, kernel width <= 8) on this layout as a Cin = 64, kW = 1 GEMM. */
@@ -209,7 +215,8 @@ int sm_timer_destroy(sm_timer* t);
 /* ONNXGraph.Configuration (ONNXGraph.swift:6-36) */
 enum { SM_INPUT_NONE = 0, SM_INPUT_FORCE_SCALE_LANCZOS = 1, SM_INPUT_FORCE_SCALE_BILINEAR = 2 };
 typedef struct smelter_config {
-    int32_t input_constraint;     /* Configuration.InputConstraint; only SM_INPUT_NONE is implemented */
+    int32_t input_constraint;     /* Configuration.InputConstraint: with FORCE_SCALE_* the source image may have any size and is
+                                   * resampled to the model's input size first (smelter_exec_encode_sized) */
     int32_t align_corners;        /* billinearUpsamplingConfiguration.alignCorners, default 1 (:20) */
     int32_t dims[4];              /* Configuration.dims: per-axis input-dim override, -1 = keep (:25,200-202) */
     /* --- executor options (no reference counterpart) --- */
@@ -253,6 +260,10 @@ void smelter_exec_destroy(smelter_exec* e);
  * sync.  in_nchw_f32: device pointer, [batch][C][H][W] fp32.  The result stays in an executor-owned device
  * image (NHWC fp16) until read. */
 int smelter_exec_encode(smelter_exec* e, sm_stream_t stream, const float* in_nchw_f32);
+/* Configuration.inputConstraint = .forceInputScale (ONNXGraph.swift:219-241: MPSNNLanczosScaleNode / MPSNNBilinearScaleNode in front
+ * of the graph): the source images are [batch][C][in_h][in_w] and are resampled to the model's input size on `stream` before the
+ * pass.  Fails with SM_ERR_UNSUPPORTED_INPUT when the graph was created with SM_INPUT_NONE and the size differs. */
+int smelter_exec_encode_sized(smelter_exec* e, sm_stream_t stream, const float* in_nchw_f32, int32_t in_h, int32_t in_w);
 /* toFloatArray (MPSImage+Extensions.swift:9-24): converts the result image to fp32 on `stream`, copies it to
  * host memory and synchronises.  layout 0 = NCHW, 1 = the reference's slice-packed order. */
 int smelter_exec_output_dims(const smelter_exec* e, int32_t* n, int32_t* c, int32_t* h, int32_t* w);

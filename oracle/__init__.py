@@ -91,6 +91,7 @@ def lib():
         L.orc_softmax.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
         L.orc_group_norm.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_float]
         L.orc_pad2d.argtypes = [vp, vp] + [C.c_int] * 9
+        L.orc_resize_nchw.argtypes = [vp, vp] + [C.c_int] * 6
         L.orc_gemm_fc.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int]
         L.orc_batchnorm.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_float]
         L.orc_relu.argtypes = [vp, vp, C.c_size_t, C.c_float]
@@ -270,6 +271,14 @@ def pad2d(x, pads, mode: str = "constant"):
     return y
 
 
+def resize(x, size, mode: str = "bilinear"):
+    """Configuration.inputConstraint .forceInputScale: resample NCHW planes to size = (H, W); mode 'bilinear' | 'lanczos'"""
+    x = _f32(x); n, c, h, w = x.shape
+    y = np.empty((n, c, size[0], size[1]), np.float32)
+    lib().orc_resize_nchw(_p(x), _p(y), n * c, h, w, size[0], size[1], {"lanczos": 1, "bilinear": 2}[mode])
+    return y
+
+
 def _pool(fn, x, k, s, p):
     x = _f32(x)
     n, c, h, w = x.shape
@@ -313,8 +322,10 @@ def round_to_half(x):
 class Graph:
     """Oracle counterpart of ONNXGraph(data:configuration:) + encode + toFloatArray."""
 
-    def __init__(self, onnx_bytes: bytes, align_corners: bool = True, dims: dict | None = None, act_fp16: bool = False):
+    def __init__(self, onnx_bytes: bytes, align_corners: bool = True, dims: dict | None = None, act_fp16: bool = False,
+                 input_constraint: str = "none"):
         L = lib()
+        self.input_constraint = input_constraint      # Configuration.inputConstraint: "none" | "lanczos" | "bilinear"
         cfg = Config()
         L.orc_config_default(C.byref(cfg))
         cfg.align_corners = int(align_corners)
@@ -357,6 +368,11 @@ class Graph:
 
     def run(self, x_nchw: np.ndarray) -> np.ndarray:
         x = _f32(x_nchw)
+        _, ih, iw = self.input_chw
+        if x.shape[2:] != (ih, iw):                   # .forceInputScale puts a scale node in front (ONNXGraph.swift:219-241)
+            if self.input_constraint == "none":
+                raise OracleError(-1, "source image %dx%d, model takes %dx%d, inputConstraint .none" % (x.shape[2], x.shape[3], ih, iw))
+            x = resize(x, (ih, iw), self.input_constraint)
         L = lib()
         out = C.c_void_p()
         oc, oh, ow = C.c_int(), C.c_int(), C.c_int()

@@ -149,6 +149,10 @@ void orc_softmax(const float* x, float* y, int n, int c, int hw, int log_softmax
 void orc_group_norm(const float* x, float* y, int n, int c, int hw, int groups, const float* gamma, const float* beta, float eps);
 /* MPSNNPadNode (:944-990): mode 0 constant (0), 1 reflect, 2 edge; spatial pads only */
 void orc_pad2d(const float* x, float* y, int n, int c, int h, int w, int pt, int pl, int pb, int pr, int mode);
+/* Configuration.inputConstraint .forceInputScale (ONNXGraph.swift:219-241): MPSNNLanczosScaleNode (mode 1) / MPSNNBilinearScaleNode
+ * (mode 2) in front of the graph.  Apple's scalers are closed source; restated as the textbook resamplers: bilinear with pixel-centre
+ * sampling src = (dst + 0.5) in/out - 0.5 clamped to the edge; separable Lanczos-3 widened by max(1, in/out), normalised, edge clamp. */
+void orc_resize_nchw(const float* x, float* y, int planes, int h, int w, int ho, int wo, int mode);
 void orc_maxpool(const float* x, float* y, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int ph,
                  int pw, int ho, int wo);
 void orc_avgpool(const float* x, float* y, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int ph,

@@ -202,6 +202,52 @@ void orc_pad2d(const float* x, float* y, int n, int c, int h, int w, int pt, int
                 }
 }
 
+static float orc_lanczos3(float t) {
+    t = fabsf(t);
+    if (t < 1e-6f) return 1.f;
+    if (t >= 3.f) return 0.f;
+    const float pt = 3.14159265358979f * t;
+    return 3.f * sinf(pt) * sinf(pt / 3.f) / (pt * pt);
+}
+void orc_resize_nchw(const float* x, float* y, int planes, int H, int W, int Ho, int Wo, int mode) {
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+#pragma omp parallel for schedule(static)
+    for (int pl = 0; pl < planes; pl++) {
+        const float* src = x + (size_t)pl * H * W; float* dst = y + (size_t)pl * Ho * Wo;
+        for (int oy = 0; oy < Ho; oy++)
+            for (int ox = 0; ox < Wo; ox++) {
+                const float cy = ((float)oy + 0.5f) * sy - 0.5f, cx = ((float)ox + 0.5f) * sx - 0.5f;
+                float r;
+                if (mode == 2) {
+                    const float fy = fminf(fmaxf(cy, 0.f), (float)(H - 1)), fx = fminf(fmaxf(cx, 0.f), (float)(W - 1));
+                    const int y0 = (int)fy, x0 = (int)fx, y1 = y0 + 1 < H ? y0 + 1 : H - 1, x1 = x0 + 1 < W ? x0 + 1 : W - 1;
+                    const float wy = fy - (float)y0, wx = fx - (float)x0;
+                    r = (src[(size_t)y0 * W + x0] * (1.f - wx) + src[(size_t)y0 * W + x1] * wx) * (1.f - wy) +
+                        (src[(size_t)y1 * W + x0] * (1.f - wx) + src[(size_t)y1 * W + x1] * wx) * wy;
+                } else {
+                    const float fsy = fmaxf(sy, 1.f), fsx = fmaxf(sx, 1.f);
+                    const int ry = (int)ceilf(3.f * fsy), rx = (int)ceilf(3.f * fsx), by = (int)floorf(cy), bx = (int)floorf(cx);
+                    float acc = 0.f, wsum = 0.f;
+                    for (int dy = -ry + 1; dy <= ry; dy++) {
+                        const float wy = orc_lanczos3(((float)(by + dy) - cy) / fsy);
+                        if (wy == 0.f) continue;
+                        int iy = by + dy; iy = iy < 0 ? 0 : iy >= H ? H - 1 : iy;
+                        float racc = 0.f, rw = 0.f;
+                        for (int dx = -rx + 1; dx <= rx; dx++) {
+                            const float wx = orc_lanczos3(((float)(bx + dx) - cx) / fsx);
+                            if (wx == 0.f) continue;
+                            int ix = bx + dx; ix = ix < 0 ? 0 : ix >= W ? W - 1 : ix;
+                            racc += wx * src[(size_t)iy * W + ix]; rw += wx;
+                        }
+                        acc += wy * racc; wsum += wy * rw;
+                    }
+                    r = acc / wsum;
+                }
+                dst[(size_t)oy * Wo + ox] = r;
+            }
+    }
+}
+
 /* Converters.swift:652-695 (MPSCNNPoolingMaxNode) + PyTorchPoolPadding.swift:56-75 (window start) */
 void orc_maxpool(const float* x, float* y, int n, int c, int h, int w, int kh, int kw, int sh, int sw, int ph,
                  int pw, int ho, int wo) {

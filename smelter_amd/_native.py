@@ -74,6 +74,7 @@ SYMBOLS = {
     "sm_upsample_bilinear": (_i32, [_vp, _vp] + [_i32] * 9 + [_vp]),
     "sm_copy_channels": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
     "sm_nchw_f32_to_nhwc_f16": (_i32, [_vp, _vp] + [_i32] * 9 + [_vp]),
+    "sm_resize_nchw_f32": (_i32, [_vp, _vp] + [_i32] * 6 + [_vp]),
     "sm_nchw_f32_to_rowpair_f16": (_i32, [_vp, _vp] + [_i32] * 8 + [_vp]),
     "sm_nhwc_f16_to_nchw_f32": (_i32, [_vp, _vp] + [_i32] * 5 + [_vp]),
     "sm_nhwc_f16_to_float_array": (_i32, [_vp, _vp] + [_i32] * 5 + [_vp]),
@@ -110,6 +111,7 @@ SYMBOLS = {
     "smelter_graph_pack_weights": (_i32, [_vp, _i32, _vp, _sz]),
     "smelter_graph_compile": (_i32, [_vp, _i32, _i32, _vp, _i32, C.POINTER(_vp)]),
     "smelter_exec_destroy": (None, [_vp]),
+    "smelter_exec_encode_sized": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     "smelter_exec_encode": (_i32, [_vp, _vp, _vp]),
     "smelter_exec_output_dims": (_i32, [_vp, _pi32, _pi32, _pi32, _pi32]),
     "smelter_exec_read_float": (_i32, [_vp, _vp, _vp, _sz, _i32]),

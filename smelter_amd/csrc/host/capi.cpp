@@ -72,6 +72,10 @@ int smelter_exec_encode(smelter_exec* e, sm_stream_t s, const float* in) {
     SM_REQUIRE(e, "smelter_exec_encode: null executor");
     return e->e->encode((hipStream_t)s, in);
 }
+int smelter_exec_encode_sized(smelter_exec* e, sm_stream_t s, const float* in, int32_t in_h, int32_t in_w) {
+    SM_REQUIRE(e, "smelter_exec_encode_sized: null executor");
+    return e->e->encodeSized((hipStream_t)s, in, in_h, in_w);
+}
 int smelter_exec_output_dims(const smelter_exec* e, int32_t* n, int32_t* c, int32_t* h, int32_t* w) {
     SM_REQUIRE(e && n && c && h && w, "smelter_exec_output_dims: null argument");
     e->e->outputDims(n, c, h, w); return SM_OK;

@@ -48,6 +48,7 @@ Executor::~Executor() {
     if (graph_) (void)hipGraphDestroy(graph_);
     if (own_arena_ && arena_) (void)hipFree(arena_);
     if (act_) (void)hipFree(act_);
+    if (resized_) (void)hipFree(resized_);
     if (ws_) (void)hipFree(ws_);
     if (out_f32_) (void)hipFree(out_f32_);
 }
@@ -509,6 +510,21 @@ int Executor::encode(hipStream_t s, const float* in) {
     }
     SM_HIP_CHECK(hipGraphLaunch(graph_exec_, s));
     return SM_OK;
+}
+
+int Executor::encodeSized(hipStream_t s, const float* in, int in_h, int in_w) {
+    const Value& iv = values_[input_value_];
+    if (in_h == iv.h && in_w == iv.w) return encode(s, in);
+    if (cfg_.inputConstraint == Configuration::InputConstraint::none) {
+        sm_set_error("source image is %dx%d, the model takes %dx%d and Configuration.inputConstraint is .none", in_h, in_w, iv.h, iv.w);
+        return SM_ERR_UNSUPPORTED_INPUT;
+    }
+    if (!in || in_h <= 0 || in_w <= 0) { sm_set_error("smelter_exec_encode_sized: bad argument"); return SM_ERR_INVALID_ARGUMENT; }
+    if (!resized_) SM_HIP_CHECK(hipMalloc((void**)&resized_, (size_t)batch_ * iv.c * iv.h * iv.w * sizeof(float)));
+    const int mode = cfg_.inputConstraint == Configuration::InputConstraint::forceInputScaleLanczos ? SM_INPUT_FORCE_SCALE_LANCZOS : SM_INPUT_FORCE_SCALE_BILINEAR;
+    int rc = sm_resize_nchw_f32(in, resized_, batch_ * iv.c, in_h, in_w, iv.h, iv.w, mode, (sm_stream_t)s);   // MPSNN{Lanczos,Bilinear}ScaleNode (:222-239)
+    if (rc) return rc;
+    return encode(s, resized_);                                       // the captured hipGraph is keyed on this fixed buffer
 }
 
 int Executor::readFloat(hipStream_t s, float* dst, size_t cap, int layout) {

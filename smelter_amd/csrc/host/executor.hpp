@@ -42,6 +42,8 @@ class Executor {
     ~Executor();
 
     int encode(hipStream_t s, const float* in_nchw);
+    // Configuration.inputConstraint .forceInputScale: source images of any size, resampled to the model's input size first
+    int encodeSized(hipStream_t s, const float* in_nchw, int in_h, int in_w);
     int readFloat(hipStream_t s, float* dst, size_t cap, int layout);
     int readValue(hipStream_t s, const char* name, float* dst, size_t cap, int* c, int* h, int* w);
     int timeOp(hipStream_t s, int idx, int iters, float* ms);
@@ -82,6 +84,7 @@ class Executor {
     std::vector<size_t> root_offset_;    // per value id (roots only), byte offset in the activation arena
     std::vector<Step> steps_;
     int input_value_ = -1, output_value_ = -1, input_ld_ = 0;
+    float* resized_ = nullptr;       // forceInputScale: the resampled batch (NCHW fp32), allocated on first use
     bool stem_ = false; int stem_h_ = 0, stem_w_ = 0, stem_pt_ = 0, stem_pl_ = 0;   // row-pair image geometry
     std::vector<std::string> value_names_, materialized_;
 

@@ -62,10 +62,8 @@ int ONNXGraph::initOutputs() {                                           // :197
         if (shape.size() == 3) { channels = shape[0]; height = shape[1]; width = shape[2]; }
         else if (shape.size() == 4) { channels = shape[1]; height = shape[2]; width = shape[3]; }   // N dropped (:209-212)
         else { sm_set_error("graph input '%.*s' has rank %zu", (int)vi.name.size(), vi.name.data(), shape.size()); return SM_ERR_UNSUPPORTED_INPUT; }
-        if (configuration.inputConstraint != Configuration::InputConstraint::none) {
-            sm_set_error("Configuration.inputConstraint .forceInputScale is not implemented (SURVEY.md §8f rank 4)");
-            return SM_ERR_UNSUPPORTED_INPUT;
-        }
+        // Configuration.inputConstraint .forceInputScale(:219-241) puts a scale node in front of the graph; the model-side shape
+        // recorded here is the same either way, the executor resamples the caller's image first (smelter_exec_encode_sized)
         if (input_value_ >= 0) { sm_set_error("more than one image input"); return SM_ERR_UNSUPPORTED_INPUT; }
         if (channels <= 0 || height <= 0 || width <= 0) { sm_set_error("graph input has a non-positive dimension"); return SM_ERR_UNSUPPORTED_INPUT; }
         Value v; v.name = std::string(vi.name); v.c = channels; v.h = height; v.w = width;

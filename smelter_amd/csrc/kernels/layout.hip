@@ -56,6 +56,51 @@ __global__ void nchw_to_rowpair_kernel(const float* x, half_t* y, int N, int C, 
     }
 }
 
+// Configuration.inputConstraint .forceInputScale (ONNXGraph.swift:219-241): resample every fp32 plane to the model's input size.
+__device__ __forceinline__ float lanczos3(float t) {
+    t = fabsf(t);
+    if (t < 1e-6f) return 1.f;
+    if (t >= 3.f) return 0.f;
+    const float pt = 3.14159265358979f * t;
+    return 3.f * sinf(pt) * sinf(pt / 3.f) / (pt * pt);
+}
+__global__ void resize_plane_kernel(const float* x, float* y, int planes, int H, int W, int Ho, int Wo, int mode) {
+    const long total = (long)planes * Ho * Wo;
+    const float sy = (float)H / (float)Ho, sx = (float)W / (float)Wo;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % Wo); long t = i / Wo; const int oy = (int)(t % Ho); const long pl = t / Ho;
+        const float* src = x + pl * H * W;
+        const float cy = ((float)oy + 0.5f) * sy - 0.5f, cx = ((float)ox + 0.5f) * sx - 0.5f;
+        float r;
+        if (mode == SM_INPUT_FORCE_SCALE_BILINEAR) {
+            const float fy = fminf(fmaxf(cy, 0.f), (float)(H - 1)), fx = fminf(fmaxf(cx, 0.f), (float)(W - 1));
+            const int y0 = (int)fy, x0 = (int)fx, y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+            const float wy = fy - (float)y0, wx = fx - (float)x0;
+            r = (src[(long)y0 * W + x0] * (1.f - wx) + src[(long)y0 * W + x1] * wx) * (1.f - wy) +
+                (src[(long)y1 * W + x0] * (1.f - wx) + src[(long)y1 * W + x1] * wx) * wy;
+        } else {
+            const float fsy = fmaxf(sy, 1.f), fsx = fmaxf(sx, 1.f);                 // filter scale: wider when shrinking
+            const int ry = (int)ceilf(3.f * fsy), rx = (int)ceilf(3.f * fsx);
+            const int by = (int)floorf(cy), bx = (int)floorf(cx);
+            float acc = 0.f, wsum = 0.f;
+            for (int dy = -ry + 1; dy <= ry; dy++) {
+                const float wy = lanczos3(((float)(by + dy) - cy) / fsy);
+                if (wy == 0.f) continue;
+                const int iy = min(max(by + dy, 0), H - 1);
+                float racc = 0.f, rw = 0.f;
+                for (int dx = -rx + 1; dx <= rx; dx++) {
+                    const float wx = lanczos3(((float)(bx + dx) - cx) / fsx);
+                    if (wx == 0.f) continue;
+                    racc += wx * src[(long)iy * W + min(max(bx + dx, 0), W - 1)]; rw += wx;
+                }
+                acc += wy * racc; wsum += wy * rw;
+            }
+            r = acc / wsum;
+        }
+        y[i] = r;
+    }
+}
+
 // NHWC fp16 -> NCHW fp32.  32x32 (pixel x channel) tile transposed through LDS so both sides are coalesced.
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const half_t* x, float* y, int HW, int C, int ld) {
     __shared__ float tile[32][33];
@@ -106,6 +151,13 @@ int sm_nchw_f32_to_rowpair_f16(const float* x, void* y, int32_t N, int32_t C, in
     SM_REQUIRE((((uintptr_t)y) & 15) == 0, "sm_nchw_f32_to_rowpair_f16: destination not 16-byte aligned");
     long pix = (long)N * Hs * Ws;
     hipLaunchKernelGGL(nchw_to_rowpair_kernel, dim3(sm_stream_grid(pix, 256)), dim3(256), 0, sm_s(st), x, (half_t*)y, N, C, H, W, Hs, Ws, pt, pl);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+int sm_resize_nchw_f32(const float* x, float* y, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t mode, sm_stream_t st) {
+    SM_REQUIRE(x && y && planes > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && (mode == SM_INPUT_FORCE_SCALE_BILINEAR || mode == SM_INPUT_FORCE_SCALE_LANCZOS),
+               "sm_resize_nchw_f32: bad argument");
+    hipLaunchKernelGGL(resize_plane_kernel, dim3(sm_stream_grid((long)planes * Ho * Wo, 256)), dim3(256), 0, sm_s(st), x, y, planes, H, W, Ho, Wo, mode);
     SM_LAUNCH_CHECK(); return SM_OK;
 }
 

@@ -34,7 +34,7 @@ class Shape:  # TypeDefinitions.swift:1-33
 
 @dataclass
 class Configuration:  # ONNXGraph.swift:6-36 (+ executor options)
-    inputConstraint: str = "none"            # "none" | "lanczos" | "bilinear" (only "none" is implemented)
+    inputConstraint: str = "none"            # "none" | "lanczos" | "bilinear" (.forceInputScale: source images of any size)
     alignCorners: bool = True                # billinearUpsamplingConfiguration.alignCorners
     dims: Dict[int, int] = field(default_factory=dict)
     fuse: bool = True
@@ -146,7 +146,7 @@ class Executor:
         """images: torch float32 CUDA tensor [batch, C, H, W] (contiguous).  Asynchronous."""
         assert images.is_cuda and images.is_contiguous() and images.dtype.is_floating_point and images.element_size() == 4
         assert images.shape[0] == self.batch
-        N.check(N.lib().smelter_exec_encode(self._h, _stream_ptr(stream), C.c_void_p(images.data_ptr())))
+        N.check(N.lib().smelter_exec_encode_sized(self._h, _stream_ptr(stream), C.c_void_p(images.data_ptr()), images.shape[2], images.shape[3]))
 
     def toFloatArray(self, stream=None, layout: str = "nchw") -> np.ndarray:
         n, c, h, w = self.outputDims

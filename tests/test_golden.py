@@ -25,7 +25,7 @@ def close(a, b, tol=TOL):
 
 def test_fixture_inventory():
     names = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(G, "*.npz")))
-    assert len(names) >= 27 and "toy_end_to_end" in names and "ct3x3_s2_p1_op1" in names
+    assert len(names) >= 28 and "toy_end_to_end" in names and "ct3x3_s2_p1_op1" in names
 
 
 @pytest.mark.parametrize("name", ["c1x1_s1", "c1x1_s2", "c3x3_s1", "c3x3_s2", "c7x7_s2_p3", "dw3x3_s1", "dw3x3_s2"])
@@ -61,6 +61,8 @@ def test_rank3_elementwise_and_normalisation_ops():
     close(O.softmax(d["x"]), d["softmax"]); close(O.softmax(d["x"], log=True), d["logsoftmax"])
     d = load("r3_norms")
     close(O.group_norm(d["x"], 6, d["gamma"], d["beta"]), d["instance"]); close(O.group_norm(d["x"], 3, d["gamma"], d["beta"]), d["group3"])
+    d = load("r3_resize")     # Configuration.inputConstraint .forceInputScale(.bilinear): pixel-centre sampling, edge clamp
+    close(O.resize(d["x"], (8, 9), "bilinear"), d["down"]); close(O.resize(d["x"], (40, 31), "bilinear"), d["up"])
     d = load("r3_pad")
     pads = tuple(int(v) for v in d["pads"])
     for mode in ("constant", "reflect", "edge"):

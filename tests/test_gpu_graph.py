@@ -267,3 +267,18 @@ def test_misc_ops_network_every_remaining_converter(final, flavour, fuse):
         descs = [ex.opDesc(i) for i in range(ex.numOps)]
         assert ex.numOps <= n_nodes - 3                      # Tanh (into its conv), Elu (into Sub), Pow (alias) disappear
         assert any(d.startswith("Conv") and "+act" in d for d in descs)    # Tanh fused into the 1x1 conv's epilogue
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "lanczos"])
+def test_force_input_scale_accepts_any_source_size(mode):
+    # Configuration.inputConstraint = .forceInputScale(scale:) (ONNXGraph.swift:219-241)
+    model = zoo.toy()
+    big = zoo.synthetic_images(2, 3, (100, 90), seed=3)
+    ex, got = run_hip(model, big, inputConstraint=mode)
+    ref = O.Graph(model, input_constraint=mode).run(big)
+    assert got.shape == ref.shape and nerr(got, ref) <= 2e-3
+    ex.encode(torch.from_numpy(zoo.synthetic_images(2, 3, (64, 64), seed=3)).cuda())            # the model's own size: no scale pass
+    assert nerr(ex.toFloatArray(), O.Graph(model).run(zoo.synthetic_images(2, 3, (64, 64), seed=3))) <= 2e-3
+    with pytest.raises(Exception) as e:                                                      # .none rejects a foreign size
+        run_hip(model, big)
+    assert "unsupportedInput" in str(e.value) or getattr(e.value, "kind", "") == "unsupportedInput"

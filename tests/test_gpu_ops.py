@@ -309,3 +309,17 @@ def test_pad2d_is_byte_exact(mode, c):
     x = h(rng.standard_normal((2, c, 6, 7)))
     got = to_host(ops.pad2d(to_dev(x), (1, 2, 3, 1), mode))
     assert np.array_equal(got, O.pad2d(x, (1, 2, 3, 1), mode))
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "lanczos"])
+@pytest.mark.parametrize("size", [(8, 20), (38, 26), (19, 13), (64, 64)])
+def test_resize_planes_for_force_input_scale(mode, size):
+    import ctypes as C
+    from smelter_amd import _native as N
+    x = np.random.default_rng(61).standard_normal((2, 3, 19, 13)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    y = torch.empty((2, 3, size[0], size[1]), dtype=torch.float32, device="cuda")
+    N.check(N.lib().sm_resize_nchw_f32(C.c_void_p(xd.data_ptr()), C.c_void_p(y.data_ptr()), 6, 19, 13, size[0], size[1], {"lanczos": 1, "bilinear": 2}[mode], None))
+    torch.cuda.synchronize()
+    ref = O.resize(x, size, mode)
+    assert np.abs(y.cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())

@@ -157,10 +157,39 @@ def test_unsupported_input_rank_and_dims_override():
     assert O.Graph(zoo.toy(), dims={2: 32, 3: 48}).run(np.zeros((1, 3, 32, 48), np.float32)).shape == (1, 16, 32, 48)
 
 
-def test_force_input_scale_is_declared_unsupported():
-    with pytest.raises(SmelterError) as e:
-        ONNXGraph(zoo.toy(), Configuration(inputConstraint="bilinear")).packWeights(1)
-    assert e.value.kind == "unsupportedInput" and "inputConstraint" in e.value.detail
+def _lanczos_matrix(n_in, n_out):
+    """independent numpy restatement of the separable Lanczos-3 resampler (support widened when shrinking, normalised, edge clamp)"""
+    scale = n_in / n_out
+    fs = max(scale, 1.0)
+    m = np.zeros((n_out, n_in))
+    for o in range(n_out):
+        c = (o + 0.5) * scale - 0.5
+        b = int(np.floor(c)); r = int(np.ceil(3 * fs))
+        for i in range(b - r + 1, b + r + 1):
+            t = abs((i - c) / fs)
+            wgt = 1.0 if t < 1e-6 else (0.0 if t >= 3 else 3 * np.sin(np.pi * t) * np.sin(np.pi * t / 3) / (np.pi * t) ** 2)
+            m[o, min(max(i, 0), n_in - 1)] += wgt
+        m[o] /= m[o].sum()
+    return m
+
+
+def test_force_input_scale_resamplers():
+    # Configuration.inputConstraint .forceInputScale (ONNXGraph.swift:219-241): the graph builds, and the oracle's two resamplers
+    # match independent restatements (bilinear is also pinned to a torch fixture in test_golden.py)
+    ONNXGraph(zoo.toy(), Configuration(inputConstraint="bilinear")).packWeights(1)
+    ONNXGraph(zoo.toy(), Configuration(inputConstraint="lanczos")).packWeights(1)
+    x = np.random.default_rng(5).standard_normal((2, 3, 19, 13)).astype(np.float32)
+    for size in ((8, 20), (38, 26), (19, 13), (7, 5)):
+        my, mx = _lanczos_matrix(19, size[0]), _lanczos_matrix(13, size[1])
+        ref = np.einsum("oy,ncyx,px->ncop", my, x.astype(np.float64), mx)
+        assert np.abs(O.resize(x, size, "lanczos") - ref).max() <= 2e-5
+    assert np.array_equal(O.resize(x, (19, 13), "bilinear"), x)
+    # the oracle graph applies the scale node only when configured, like the reference
+    big = np.random.default_rng(6).random((1, 3, 100, 90), dtype=np.float32)
+    y = O.Graph(zoo.toy(), input_constraint="bilinear").run(big)
+    assert np.array_equal(y, O.Graph(zoo.toy()).run(O.resize(big, (64, 64), "bilinear")))
+    with pytest.raises(O.OracleError):
+        O.Graph(zoo.toy()).run(big)
 
 
 def _arena_weights(model_bytes, n_convs):

@@ -71,6 +71,9 @@ def rank3_cases():
     g, be = rng.uniform(0.5, 1.5, 6).astype(np.float32), rng.standard_normal(6).astype(np.float32)
     c["norms"] = dict(x=x, gamma=g, beta=be, instance=F.instance_norm(X, weight=t64(g), bias=t64(be), eps=1e-5).numpy(),
                       group3=F.group_norm(X, 3, t64(g), t64(be), eps=1e-5).numpy())
+    xr = rng.standard_normal((2, 3, 17, 23)).astype(np.float32)
+    c["resize"] = dict(x=xr, down=F.interpolate(t64(xr), size=(8, 9), mode="bilinear", align_corners=False).numpy(),
+                       up=F.interpolate(t64(xr), size=(40, 31), mode="bilinear", align_corners=False).numpy())
     c["pad"] = dict(x=x, constant=F.pad(X, (2, 1, 1, 3)).numpy(), reflect=F.pad(X, (2, 1, 1, 3), mode="reflect").numpy(),
                     edge=F.pad(X, (2, 1, 1, 3), mode="replicate").numpy(), pads=np.array([1, 2, 3, 1]))   # pads = top, left, bottom, right
     return {k: {kk: np.asarray(vv, np.float32) if kk != "pads" else vv for kk, vv in v.items()} for k, v in c.items()}
