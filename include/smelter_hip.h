@@ -224,6 +224,9 @@ typedef struct smelter_config {
     int32_t use_hip_graph;        /* 1 (default): replay the launch sequence as one hipGraph */
     int32_t autotune;             /* 1: time the conv tile configs per layer at compile; 0 (default): heuristic */
     int32_t keep_intermediates;   /* 1: no activation-buffer reuse, every tensor stays readable (debug / layer parity) */
+    int32_t branch_concurrency;   /* 1: a conv only read as a later step's residual (projection shortcut) is hoisted and runs on a
+                                   * second stream beside the main branch; 0 (default): strictly one kernel at a time.  Measured on
+                                   * ResNet-50 bs=64: the kernels do overlap, but each fork/join pair costs ~16 us of graph-edge latency */
 } smelter_config;
 void smelter_config_default(smelter_config* c);
 

@@ -39,7 +39,8 @@ class PoolDesc(C.Structure):
 
 class Config(C.Structure):
     _fields_ = [("input_constraint", C.c_int32), ("align_corners", C.c_int32), ("dims", C.c_int32 * 4),
-                ("fuse", C.c_int32), ("use_hip_graph", C.c_int32), ("autotune", C.c_int32), ("keep_intermediates", C.c_int32)]
+                ("fuse", C.c_int32), ("use_hip_graph", C.c_int32), ("autotune", C.c_int32), ("keep_intermediates", C.c_int32),
+                ("branch_concurrency", C.c_int32)]
 
 
 class Shape(C.Structure):

@@ -18,7 +18,7 @@ void smelter_config_default(smelter_config* c) {
     if (!c) return;
     c->input_constraint = SM_INPUT_NONE; c->align_corners = 1;
     for (int i = 0; i < 4; i++) c->dims[i] = -1;
-    c->fuse = 1; c->use_hip_graph = 1; c->autotune = 0; c->keep_intermediates = 0;
+    c->fuse = 1; c->use_hip_graph = 1; c->autotune = 0; c->keep_intermediates = 0; c->branch_concurrency = 0;
 }
 
 int smelter_graph_create(const void* onnx, size_t n, const smelter_config* cfg, smelter_graph** out) {
@@ -31,6 +31,7 @@ int smelter_graph_create(const void* onnx, size_t n, const smelter_config* cfg, 
     c.alignCorners = cfg->align_corners != 0;
     for (int i = 0; i < 4; i++) if (cfg->dims[i] >= 0) c.dims[i] = cfg->dims[i];
     c.fuse = cfg->fuse != 0; c.useHipGraph = cfg->use_hip_graph != 0; c.autotune = cfg->autotune != 0; c.keepIntermediates = cfg->keep_intermediates != 0;
+    c.branchConcurrency = cfg->branch_concurrency != 0;
     int err = SM_OK;
     std::unique_ptr<ONNXGraph> g(new ONNXGraph(onnx, n, c, &err));
     if (err) return err;

@@ -14,6 +14,8 @@
 //                        batch-shard replica can receive it with a single RCCL broadcast.
 //   6. launch sequence   sm_* C-ABI calls only; replayed as a hipGraph when configured.
 #include "executor.hpp"
+#include <cstring>
+#include <cstdlib>
 
 #include <algorithm>
 #include <functional>
@@ -51,6 +53,9 @@ Executor::~Executor() {
     if (resized_) (void)hipFree(resized_);
     if (ws_) (void)hipFree(ws_);
     if (out_f32_) (void)hipFree(out_f32_);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+    if (side_) (void)hipStreamDestroy(side_);
 }
 
 void* Executor::valuePtr(int v) const {
@@ -96,6 +101,19 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 auto ok = [&](int p, int v) { return p >= 0 && isConvLike(ops[p].kind) && ops[p].kind != OpKind::ConvTranspose && ops[p].act == SM_ACT_NONE && ops[p].residual < 0 && consumers(v) == 1; };
                 int cand = -1, other = -1;
                 bool oka = ok(pa, op.inputs[0]), okb = ok(pb, op.inputs[1]) && op.inputs[0] != op.inputs[1];
+                if (oka && okb && cfg_.branchConcurrency) {
+                    // Projection shortcut: of the two convolutions feeding the Add, the LATER one in file order may depend only on
+                    // values that existed before the other branch started (ResNet: the 1x1 on the block input, exported after
+                    // the three main-branch convs).  Hoisted to right behind the producer of its input it becomes the plain
+                    // conv, the end of the main branch fuses the Add, and the executor can run it on the side stream.
+                    const int hi = std::max(pa, pb), lo = std::min(pa, pb);
+                    int ready = -1; for (int u : ops[hi].inputs) ready = std::max(ready, producerOf(u));
+                    if (ready + 1 < lo) {
+                        std::rotate(ops.begin() + ready + 1, ops.begin() + hi, ops.begin() + hi + 1);
+                        std::rotate(dead.begin() + ready + 1, dead.begin() + hi, dead.begin() + hi + 1);
+                        pa = producerOf(ops[i].inputs[0]); pb = producerOf(ops[i].inputs[1]);
+                    }
+                }
                 if (oka && okb) { if (pa > pb) { cand = pa; other = op.inputs[1]; } else { cand = pb; other = op.inputs[0]; } }
                 else if (oka) { cand = pa; other = op.inputs[1]; }
                 else if (okb) { cand = pb; other = op.inputs[0]; }
@@ -273,11 +291,35 @@ int Executor::plan(ONNXGraph& g, int batch) {
     const int ns = (int)steps_.size();
     std::vector<int> first(nv, INT32_MAX), last(nv, -1);   // per ROOT value: live step interval
     auto touch = [&](int v, int t) { int r = place_[v].root; first[r] = std::min(first[r], t); last[r] = std::max(last[r], t); };
+    // ---- side branch: a convolution whose result is read ONLY as the fused residual operand of one later step (ResNet's
+    // projection shortcut: conv1x1 on the block input, consumed three launches later) has no dependency on the steps in
+    // between -> it runs on a second stream, forked before it and joined before its consumer; its tiles fill the CUs the
+    // main branch's small-M layers leave idle.  At most one side step is in flight at a time.
+    if (cfg_.branchConcurrency) {
+        int busy_until = -1;
+        for (int t = 0; t + 2 < ns; t++) {
+            Step& st = steps_[t];
+            if (t <= busy_until || !isConvLike(st.op.kind) || st.op.kind == OpKind::ConvTranspose || st.op.grid_h || st.op.output == output_value_) continue;
+            const int r = place_[st.op.output].root; if (r != st.op.output || place_[st.op.output].c_off) continue;
+            int users = 0, join = -1; bool other_use = false;
+            for (int j = 0; j < ns; j++) {
+                if (j == t) continue;
+                const Op& o = steps_[j].op;
+                for (int u : o.inputs) if (place_[u].root == r) other_use = true;
+                if (place_[o.output].root == r) other_use = true;
+                if (o.residual >= 0 && place_[o.residual].root == r) { users++; join = j; }
+            }
+            if (getenv("SMELTER_DEBUG_PLAN") && users) fprintf(stderr, "[plan] step %d %s: residual users %d, join %d, other_use %d\n", t, st.op.name.c_str(), users, join, (int)other_use);
+            if (other_use || users != 1 || join < t + 2) continue;
+            st.join = join; steps_[join].waits_side = true; busy_until = join;
+        }
+    }
     touch(input_value_, -1);
     for (int t = 0; t < ns; t++) {
         const Op& op = steps_[t].op;
-        for (int u : op.inputs) touch(u, t);
-        if (op.residual >= 0) touch(op.residual, t);
+        const int until = steps_[t].join >= 0 ? steps_[t].join : t;   // a side step may still be reading its operands at the join
+        for (int u : op.inputs) { touch(u, t); touch(u, until); }
+        if (op.residual >= 0) { touch(op.residual, t); touch(op.residual, until); }
         touch(op.output, t);
     }
     touch(output_value_, ns);                               // result image must survive until read back
@@ -333,6 +375,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                      st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem ? " stem" : op.grid_h ? " convT-phase" : "");
         else snprintf(buf, sizeof buf, "%s %s pixels=%d C=%d%s", kindName(op.kind), op.name.c_str(), st.M, values_[op.output].c, op.act ? " +act" : "");
         st.desc = buf;
+        if (st.join >= 0) st.desc += " side-stream";
     }
     arena_bytes_ = std::max(off, (size_t)kAlign);
     value_names_.resize(nv); for (int v = 0; v < nv; v++) value_names_[v] = values_[v].name;
@@ -391,6 +434,12 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     SM_HIP_CHECK(hipMalloc((void**)&e->act_, e->act_bytes_ + kAlign));
     SM_HIP_CHECK(hipMemset(e->act_, 0, e->act_bytes_ + kAlign));
     if (e->ws_bytes_) SM_HIP_CHECK(hipMalloc((void**)&e->ws_, e->ws_bytes_));
+    bool any_side = false; for (auto& st : e->steps_) any_side |= st.join >= 0;
+    if (any_side) {
+        SM_HIP_CHECK(hipStreamCreateWithFlags(&e->side_, hipStreamNonBlocking));
+        SM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_fork_, hipEventDisableTiming));
+        SM_HIP_CHECK(hipEventCreateWithFlags(&e->ev_join_, hipEventDisableTiming));
+    }
     if (ext_arena) { e->arena_ = (char*)ext_arena; e->own_arena_ = false; }
     else { SM_HIP_CHECK(hipMalloc((void**)&e->arena_, e->arena_bytes_)); e->own_arena_ = true; upload = true; }
     if (upload) {
@@ -428,7 +477,7 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
         if (op.grid_h) { d.Ho = op.grid_h; d.Wo = op.grid_w; d.y_sH = op.y_sh; d.y_sW = op.y_sw; d.y_oH = op.y_oh; d.y_oW = op.y_ow; d.y_H = op.y_h; d.y_W = op.y_w; }   // ConvTranspose phase
         d.y_ld = y_ld; d.res_ld = op.residual >= 0 ? valueLd(op.residual) : 0;
         return sm_conv2d_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
-                                 op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, ws_, ws_bytes_, ss);
+                                 op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, st.join >= 0 ? nullptr : ws_, st.join >= 0 ? 0 : ws_bytes_, ss);   // the split-K scratch belongs to the main branch
     }
     case OpKind::ConvTranspose: {   // shapes the phase decomposition does not take: direct gather kernel
         const Value& iv = values_[op.inputs[0]];
@@ -488,7 +537,17 @@ int Executor::convertInput(hipStream_t s, const float* in) const {
 int Executor::launchAll(hipStream_t s, const float* in) const {
     int rc = convertInput(s, in);
     if (rc) return rc;
-    for (auto& st : steps_) { rc = launchStep(st, s); if (rc) return rc; }
+    for (auto& st : steps_) {
+        if (st.join >= 0 && side_) {                            // fork: the side stream sees everything enqueued so far
+            SM_HIP_CHECK(hipEventRecord(ev_fork_, s));
+            SM_HIP_CHECK(hipStreamWaitEvent(side_, ev_fork_, 0));
+            rc = launchStep(st, side_); if (rc) return rc;
+            SM_HIP_CHECK(hipEventRecord(ev_join_, side_));
+            continue;
+        }
+        if (st.waits_side && side_) SM_HIP_CHECK(hipStreamWaitEvent(s, ev_join_, 0));
+        rc = launchStep(st, s); if (rc) return rc;
+    }
     return SM_OK;
 }
 
@@ -591,6 +650,8 @@ int Executor::autotune(hipStream_t s) {
     // HBM / Infinity Cache, never in an L2 warmed by the previous launch of the same kernel (L2 is invalidated at kernel
     // boundaries).  Ranking on back-to-back warm launches picked configs that were up to 1.5x slower in the graph.
     const int ncfg = sm_conv2d_num_configs();
+    const char* mode = getenv("SMELTER_AUTOTUNE");
+    const bool insitu = mode && !strcmp(mode, "insitu");
     char* flush = nullptr; const size_t flush_bytes = (size_t)640 << 20;
     if (hipMalloc((void**)&flush, flush_bytes) != hipSuccess) { flush = nullptr; (void)hipGetLastError(); }
     hipEvent_t a, b; SM_HIP_CHECK(hipEventCreate(&a)); SM_HIP_CHECK(hipEventCreate(&b));
@@ -603,7 +664,10 @@ int Executor::autotune(hipStream_t s) {
             st.conv_cfg = c;
             float tot = 1e30f; bool ok = true;                           // best of 4 timed launches: robust against stragglers
             for (int it = 0; it < 5 && ok && !rc; it++) {
-                if (flush) SM_HIP_CHECK(hipMemsetAsync(flush, it, flush_bytes, s));
+                if (insitu && i >= 2) {                                    // the cache state the graph leaves: run the two predecessors
+                    for (size_t q = i - 2; q < i && !rc; q++) rc = launchStep(steps_[q], s);
+                    if (rc) break;
+                } else if (flush) SM_HIP_CHECK(hipMemsetAsync(flush, it, flush_bytes, s));
                 SM_HIP_CHECK(hipEventRecord(a, s));
                 int r = launchStep(st, s);
                 SM_HIP_CHECK(hipEventRecord(b, s));

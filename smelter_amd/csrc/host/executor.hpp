@@ -30,6 +30,10 @@ struct Step {                // one op after fusion, with everything resolved
     bool stem = false;       // first-layer conv running on the row-pair image (executor.cpp "image stem")
     int real_k = 0;          // kH*kW*Cin/groups of the model (FLOP / byte accounting, description)
     int real_kh = 0, real_kw = 0;
+    // branch concurrency (executor.cpp "side branch"): a conv whose result is only read as the residual operand of a later
+    // step `join` runs on the side stream, concurrently with the steps in between
+    int join = -1;           // >= 0: this step runs on the side stream and step `join` waits for it
+    bool waits_side = false; // this step is the join of an earlier side step
     std::string desc;
 };
 
@@ -97,6 +101,8 @@ class Executor {
 
     // hipGraph replay
     hipGraph_t graph_ = nullptr; hipGraphExec_t graph_exec_ = nullptr; const float* captured_in_ = nullptr;
+    // side branch: one extra stream, fork/join events (timing disabled)
+    hipStream_t side_ = nullptr; hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
 };
 
 }  // namespace smelter

@@ -25,7 +25,7 @@ struct Configuration {
     bool alignCorners = true;            // billinearUpsamplingConfiguration.alignCorners (default true, :20)
     std::map<int, int> dims;             // per-axis input-dim override (:25, :200-202)
     // executor options (no reference counterpart)
-    bool fuse = true, useHipGraph = true, autotune = false, keepIntermediates = false;
+    bool fuse = true, useHipGraph = true, autotune = false, keepIntermediates = false, branchConcurrency = false;
 };
 
 enum class Format { onnx, mpsFlavor };   // ONNXGraph.swift:49-52

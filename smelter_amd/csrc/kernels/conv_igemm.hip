@@ -464,9 +464,22 @@ const TileCfg kCfgs[] = {
     {256, 64, 1, 512, conv_igemm64_kernel<256, 64, 4, 2, 3, 0, 1>, "k64w8s3i:256x64"},            // 36
     {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 4, 2, 3, 0, 1>, "k64w8s3i:128x64"},            // 37
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 1>, "k64w8i:128x128(64x32)"},    // 38
+    // loader/consumer wave specialisation: WGM x WGN MFMA waves + 4 loader waves (one per SIMD) that issue all LDS-DMA
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 2, 3, 0, 0, 4>, "k64ws4+4s3:128x128"},        // 39
+    {128, 128, 1, 768, conv_igemm64_kernel<128, 128, 2, 4, 3, 0, 0, 4>, "k64ws8+4s3:128x128(64x32)"}, // 40
+    {128, 128, 1, 768, conv_igemm64_kernel<128, 128, 4, 2, 3, 0, 0, 4>, "k64ws8+4s3:128x128(32x64)"}, // 41
+    {256, 128, 1, 768, conv_igemm64_kernel<256, 128, 4, 2, 3, 0, 0, 4>, "k64ws8+4s3:256x128"},        // 42
+    {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 2, 2, 3, 0, 0, 4>, "k64ws4+4s3:128x64"},           // 43
+    {256, 64, 1, 768, conv_igemm64_kernel<256, 64, 4, 2, 3, 0, 0, 4>, "k64ws8+4s3:256x64"},           // 44
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 2, 4, 0, 0, 4>, "k64ws4+4s4:128x128"},        // 45
+    {64, 64, 1, 384, conv_igemm64_kernel<64, 64, 2, 2, 3, 0, 0, 2>, "k64ws4+2s3:64x64"},              // 46
+    {64, 128, 1, 512, conv_igemm64_kernel<64, 128, 2, 2, 3, 0, 0, 4>, "k64ws4+4s3:64x128"},           // 47
 #ifdef SM_ABLATION   // tools/conv_bench.py only: never built into the product library
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 1>, "abl:w8 noMFMA"},
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 2>, "abl:w8 noGlobal"},
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 3>, "abl:w8 no A traffic"},
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 3, 3>, "abl:w8s3 no A traffic"},
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 3, 0>, "abl-ref:w8s3"},
 #endif
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
@@ -668,6 +681,10 @@ int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w,
             if (!e[0] || !e[15]) continue;                       // unused slot or a block that map_block() retired
             nb++; for (int q = 0; q < 8; q++) ph[q] += (double)(e[2 + q] - e[1 + q]);
             wall += (double)(e[15] - e[0]); if (e[0] < w0) w0 = e[0]; if (e[15] > w1) w1 = e[15];
+        }
+        if (const char* dp = getenv("SM_TL_DUMP")) {              // raw per-block stamps for offline analysis
+            char fn[512]; snprintf(fn, sizeof fn, "%s.cfg%d.bin", dp, cfg);
+            if (FILE* f = fopen(fn, "wb")) { fwrite(h, 1, sizeof h, f); fclose(f); }
         }
         if (nb) {
             fprintf(stderr, "[timeline cfg %d] %d blocks:", cfg, nb);

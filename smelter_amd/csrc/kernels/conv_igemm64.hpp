@@ -46,14 +46,22 @@ template <int N> __device__ __forceinline__ void sm_wait_vmcnt() { asm volatile(
 constexpr int sm_pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; return r; }
 
 // ABL: ablation switch for tools/conv_bench.py (0 = product; 1 = no MFMA; 2 = no global->LDS traffic after the prologue)
-template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams p) {
-    static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
+// NLW > 0: wave specialisation.  A VMEM instruction stalls the issuing wave while the address queue is full, and one K tile
+// is 32..48 KB of LDS-DMA: with every wave issuing its share, the MFMA waves spend about as long stalled on the DMA issue
+// as they spend on MFMAs (ablations: LDS->MFMA only 833 clk per 128x128x64 tile, + DMA issue 1300..1450 clk).  With NLW
+// extra LOADER waves (one per SIMD) that issue all LDS-DMA of the block and never touch the matrix pipe, the WGM*WGN
+// CONSUMER waves only read fragments and issue MFMAs; both roles meet at the ONE barrier per K tile of the ring protocol.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0, int NLW = 0>
+__global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(ConvParams p) {
+    static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 MFMA waves");
     static_assert(NSTAGE >= 1 && NSTAGE <= 4, "1..4 stages");
-    constexpr int NT = WGM * WGN * 64;                          // threads per block
+    static_assert(NLW == 0 || (ILV == 0 && NSTAGE >= 2), "loader waves: no interleaved issue, >= 2 stages");
+    constexpr int NCW = WGM * WGN;                              // consumer (MFMA) waves
+    constexpr int NT = (NCW + NLW) * 64;                        // threads per block
+    constexpr int NLT = NLW ? NLW * 64 : NT;                    // threads that issue the LDS-DMA
     constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
-    constexpr int A_IT = BM * 8 / NT, B_IT = BN * 8 / NT;      // 16-byte pieces per thread per tile
-    constexpr int RPI = NT / 8;                                 // tile rows covered by one DMA instruction of the whole block
+    constexpr int A_IT = BM * 8 / NLT, B_IT = BN * 8 / NLT;    // 16-byte pieces per loader thread per tile
+    constexpr int RPI = NLT / 8;                                // tile rows covered by one DMA instruction of all loader waves
     static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
     constexpr int LOADS = A_IT + B_IT;                          // LDS-DMA instructions per wave per tile
     constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128, PIPE_BYTES = NSTAGE * STAGE_BYTES;
@@ -80,8 +88,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> LDS bases live in SGPRs
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int csrc = (tid & 7) ^ ((tid >> 4) & 7);             // source chunk for this thread's LDS slot (rows j*RPI + tid/8)
+    const bool is_loader = NLW == 0 || wave >= NCW, is_consumer = NLW == 0 || wave < NCW;   // wave-uniform roles
+    const int wm = (NLW && wave >= NCW) ? 0 : wave / WGN, wn = (NLW && wave >= NCW) ? 0 : wave % WGN;
+    const int ltid = NLW ? (tid - NCW * 64) & (NLT - 1) : tid;  // index among the loader threads (consumers: unused alias)
+    const int lwave = NLW ? (wave >= NCW ? wave - NCW : 0) : wave;
+    const int csrc = (ltid & 7) ^ ((ltid >> 4) & 7);           // source chunk for this thread's LDS slot (rows j*RPI + ltid/8)
     const half_t* zero = (const half_t*)g_zero_page;
 
     // ---- per-thread row state -----------------------------------------------------------------------
@@ -122,14 +133,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
     const half_t* arow[A_IT]; unsigned amask[A_IT];
 #pragma unroll
     for (int j = 0; j < A_IT; j++) {
-        const int2 ri = ((const int2*)(smem_raw + LDS_BYTES - BM * 8))[j * RPI + (tid >> 3)];
+        const int2 ri = ((const int2*)(smem_raw + LDS_BYTES - BM * 8))[j * RPI + (ltid >> 3)];
         arow[j] = p.x + (long)ri.x * p.x_ld + csrc * 8; amask[j] = (unsigned)ri.y;
     }
     SM_TL(2);
     const half_t* brow[B_IT];
 #pragma unroll
     for (int j = 0; j < B_IT; j++) {
-        int n = ntile * BN + j * RPI + (tid >> 3); if (n >= p.Cout) n = p.Cout - 1;
+        int n = ntile * BN + j * RPI + (ltid >> 3); if (n >= p.Cout) n = p.Cout - 1;
         brow[j] = p.w + (long)n * p.K + csrc * 8;
     }
     // ---- K-tile cursor of the NEXT tile to issue: all wave-uniform, advanced with a few SALU ops per tile -------------
@@ -148,12 +159,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
     const long a_wrap_c = (long)p.dW * p.x_ld - (long)(cpt - 1) * 64;      // next tap, same kernel row
     const long a_wrap_w = ((long)p.dH * p.W - (long)p.kW * p.dW) * p.x_ld;  // ... and on to the next kernel row
 
+    int issued = 0;                                             // K tiles put in flight so far
     auto piece = [&](int slot, int i) {                         // i-th LDS-DMA instruction of the tile under the cursor
-        unsigned char* sa = smem_raw + slot * STAGE_BYTES + wave * 1024;   // wave-uniform LDS base; lane*16 B added by the DMA
+        unsigned char* sa = smem_raw + slot * STAGE_BYTES + lwave * 1024;  // wave-uniform LDS base; lane*16 B added by the DMA
         if (i < A_IT) {
+            if (ABL == 3 && issued >= NSTAGE - 1) return;       // ablation: no activation traffic after the prologue
             const half_t* src = (amask[i] & tapbit) ? arow[i] + a_off : zero;
-            SM_GLDS16(src, sa + i * NT * 16);
-        } else SM_GLDS16(brow[i - A_IT] + b_off, sa + A_BYTES + (i - A_IT) * NT * 16);
+            SM_GLDS16(src, sa + i * NLT * 16);
+        } else SM_GLDS16(brow[i - A_IT] + b_off, sa + A_BYTES + (i - A_IT) * NLT * 16);
     };
     auto advance = [&]() {
         b_off += 64;
@@ -163,8 +176,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
         } else a_off += 64;
     };
     auto issue = [&](int slot) {
+        if (is_loader) {
 #pragma unroll
-        for (int i = 0; i < LOADS; i++) piece(slot, i);
+            for (int i = 0; i < LOADS; i++) piece(slot, i);
+        }
         advance();
     };
 
@@ -172,7 +187,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
     // ---- first tiles in flight as early as possible; everything else of the prologue hides behind their latency --------
     // Tile i lives in ring slot i % NSTAGE.  Short K (nk <= NSTAGE, the HBM-streaming 1x1 layers): everything the block
     // will ever read is in flight at once.
-    int issued = 0;
     const int pre = nk <= NSTAGE ? nk : NSTAGE - 1;
 #pragma unroll
     for (int s = 0; s < NSTAGE; s++) if (s < pre) { issue(s); ++issued; }
@@ -275,10 +289,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
     // ---- main loop: ONE barrier per K tile; the counted vmcnt leaves the newer tiles (and nothing older) in flight -------
     for (int i = 0; i < nk; i++) {
         const int newer = issued - i - 1;                       // tiles issued after tile i, allowed to stay in flight
-        if (NSTAGE >= 4 && newer >= 3) sm_wait_vmcnt<(NSTAGE >= 4 ? 3 : 0) * LOADS>();
-        else if (NSTAGE >= 3 && newer == 2) sm_wait_vmcnt<(NSTAGE >= 3 ? 2 : 0) * LOADS>();
-        else if (NSTAGE >= 2 && newer == 1) sm_wait_vmcnt<(NSTAGE >= 2 ? 1 : 0) * LOADS>();
-        else sm_wait_vmcnt<0>();
+        if (is_loader) {                                        // (consumer waves of a specialised block have no DMA in flight)
+            if (NSTAGE >= 4 && newer >= 3) sm_wait_vmcnt<(NSTAGE >= 4 ? 3 : 0) * LOADS>();
+            else if (NSTAGE >= 3 && newer == 2) sm_wait_vmcnt<(NSTAGE >= 3 ? 2 : 0) * LOADS>();
+            else if (NSTAGE >= 2 && newer == 1) sm_wait_vmcnt<(NSTAGE >= 2 ? 1 : 0) * LOADS>();
+            else sm_wait_vmcnt<0>();
+        }
         __builtin_amdgcn_s_barrier();                           // everybody's share of tile i landed; the slot of tile i-1 is free
         __builtin_amdgcn_sched_barrier(0);
 #ifdef SM_TIMELINE
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
 #endif
         const bool more = issued < nk && ABL != 2;
         if (!ILV && more) issue(islot);
-        compute(slot, islot, more);
+        if (is_consumer) compute(slot, islot, more);
         if (more) { ++issued; if (++islot == NSTAGE) islot = 0; }
         if (++slot == NSTAGE) slot = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's fragment reads are done before it passes the next barrier
@@ -298,7 +314,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
     float* stg = (float*)smem_raw;
 #pragma unroll
     for (int pw = 0; pw < EP_PASSES; pw++) {
-        if (wm / WPP == pw) {
+        if (is_consumer && wm / WPP == pw) {
             const int wrow = (wm % WPP) * WROWS;
 #pragma unroll
             for (int b = 0; b < TM; b++)
@@ -311,6 +327,38 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_igemm64_kernel(ConvParams
                     }
         }
         __syncthreads();
+        // Fast path (every ResNet / MobileNet / U-Net layer): dense 16-byte output, no placement, no split-K, ReLU-family
+        // activation.  Straight-line: all staging reads of the thread requested up front, one select per value, no per-element
+        // branches or calls (the generic loop below costs ~1300 clk per 8-value item, this one ~1/3 of that).
+        if (vec_ok && !p.yplace && p.splitk == 1 && p.act <= SM_ACT_PRELU) {
+            const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;        // f(v) = v < 0 ? v*sl : v
+            const int m0 = mtile * BM + pw * EP_ROWS, co0 = ntile * BN;
+            floatx4 s0[IPT], s1[IPT]; int rowi[IPT], chi[IPT];
+#pragma unroll
+            for (int k2 = 0; k2 < IPT; k2++) {
+                int it = tid + k2 * NT; if (ITEMS % NT != 0 && it >= ITEMS) it = ITEMS - 1;
+                rowi[k2] = it / CHUNKS; chi[k2] = it - rowi[k2] * CHUNKS;
+                s0[k2] = *(const floatx4*)(stg + rowi[k2] * EP_LD + chi[k2] * 8); s1[k2] = *(const floatx4*)(stg + rowi[k2] * EP_LD + chi[k2] * 8 + 4);
+            }
+            auto emit = [&](const bool has_res) {
+#pragma unroll
+                for (int k2 = 0; k2 < IPT; k2++) {
+                    const int m = m0 + rowi[k2], co = co0 + chi[k2] * 8;
+                    float v[8] = {s0[k2][0], s0[k2][1], s0[k2][2], s0[k2][3], s1[k2][0], s1[k2][1], s1[k2][2], s1[k2][3]};
+                    if (has_res) { const half8_t rr = rres[pw][k2];
+#pragma unroll
+                        for (int j = 0; j < 8; j++) v[j] += (float)rr[j]; }
+                    half8_t o;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) o[j] = (half_t)(v[j] < 0.f ? v[j] * sl : v[j]);
+                    const bool live = (ITEMS % NT == 0 || tid + k2 * NT < ITEMS) && m < p.M && co < p.Cout;
+                    if (live) *(half8_t*)(p.y + (long)m * p.y_ld + co) = o;
+                }
+            };
+            if (p.res) emit(true); else emit(false);
+            if (pw + 1 < EP_PASSES) __syncthreads();
+            continue;
+        }
 #pragma unroll
         for (int k2 = 0; k2 < IPT; k2++) {
             const int it = tid + k2 * NT;

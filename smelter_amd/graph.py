@@ -41,6 +41,7 @@ class Configuration:  # ONNXGraph.swift:6-36 (+ executor options)
     useHipGraph: bool = True
     autotune: bool = False
     keepIntermediates: bool = False
+    branchConcurrency: bool = False          # projection-shortcut convs on a second stream (measured: fork/join gaps eat the gain)
 
     def _c(self) -> N.Config:
         c = N.Config()
@@ -51,6 +52,7 @@ class Configuration:  # ONNXGraph.swift:6-36 (+ executor options)
             c.dims[k] = v
         c.fuse, c.use_hip_graph, c.autotune = int(self.fuse), int(self.useHipGraph), int(self.autotune)
         c.keep_intermediates = int(self.keepIntermediates)
+        c.branch_concurrency = int(self.branchConcurrency)
         return c
 
 

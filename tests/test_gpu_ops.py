@@ -52,7 +52,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg", [None] + list(range(39)))
+@pytest.mark.parametrize("cfg", [None] + list(range(48)))
 def test_conv2d(case, cfg):
     n, hh, ww, cin, cout, k, s, p, res, act = case
     if cfg is not None and (cin % 8 or cfg >= ops.num_conv_configs() or (cfg >= 6 and cin % 64)):
