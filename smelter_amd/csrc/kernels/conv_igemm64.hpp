@@ -194,14 +194,29 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
     __builtin_amdgcn_sched_barrier(0);
     SM_TL(4);
 
-    // Residual operand (fused MPSNNAdditionNode): its loads do not depend on the GEMM, so they are put in flight right behind
-    // the first tiles (16-byte coalesced, same (row, chunk) ownership as the epilogue stores) and consumed ~a whole K loop later.
-    // Unconditional loads from clamped (always valid) addresses: what a ragged tile reads extra is never stored.
+    // ---- the only ordinary loads of the kernel: EXTRA = 2 + EP_PASSES*IPT 16-byte loads per thread, ALWAYS issued ------
+    // (from the zero page when there is nothing to fetch) right behind the first tiles, so that the counted waits of the
+    // main loop know exactly how many younger VMEM operations sit behind a prologue tile; consumed in the epilogue.
+    //  * residual operand (fused MPSNNAdditionNode): same (row, chunk) ownership as the epilogue stores, clamped addresses
+    //    (what a ragged tile reads extra is never stored);
+    //  * bias of the thread's 8 output channels for the fast epilogue.  The accumulators then start at ZERO: nothing the
+    //    main loop needs comes from an ordinary load, so it starts as soon as tile 0 has landed (bias-initialised
+    //    accumulators made every block wait for bias AND residual, the youngest loads, before its first MFMA).
     constexpr int CHUNKS = BN / 8, ITEMS = EP_ROWS * CHUNKS, IPT = (ITEMS + NT - 1) / NT;
+    constexpr int EXTRA = 2 + EP_PASSES * IPT;
+    static_assert(NT % CHUNKS == 0, "a thread keeps its channel chunk across items");
+    static_assert((NSTAGE - 1) * LOADS + EXTRA <= 63, "vmcnt range");
     const bool vec_ok = ((p.y_ld & 7) == 0) && ((((uintptr_t)p.y) & 15) == 0) && ((p.Cout & 7) == 0) &&
                         (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0));
+    const bool fastep = vec_ok && !p.yplace && p.splitk == 1 && p.act <= SM_ACT_PRELU && (((uintptr_t)p.bias) & 15) == 0;
+    floatx4 eb0, eb1;
+    {
+        const float* bp = (fastep && p.bias) ? p.bias + min(ntile * BN + (tid % CHUNKS) * 8, p.Cout - 8) : (const float*)g_zero_page;
+        eb0 = *(const floatx4*)bp; eb1 = *(const floatx4*)(bp + 4);
+    }
     half8_t rres[EP_PASSES][IPT];
-    if (p.res && vec_ok && p.splitk == 1) {
+    {
+        const bool use_res = p.res && vec_ok && p.splitk == 1;
 #pragma unroll
         for (int pw = 0; pw < EP_PASSES; pw++)
 #pragma unroll
@@ -209,12 +224,13 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
                 int it = tid + k2 * NT; if (ITEMS % NT != 0 && it >= ITEMS) it = ITEMS - 1;
                 const int row = it / CHUNKS, ch = it - row * CHUNKS;
                 const int m = min(mtile * BM + pw * EP_ROWS + row, p.M - 1), co = min(ntile * BN + ch * 8, p.Cout - 8);
-                rres[pw][k2] = *(const half8_t*)(p.res + (long)m * p.res_ld + co);
+                rres[pw][k2] = *(const half8_t*)(use_res ? p.res + (long)m * p.res_ld + co : zero);
             }
     }
+    __builtin_amdgcn_sched_barrier(0);
 
-    // ---- accumulators start at the bias: register 4q+r of acc[a][*] <-> cout (wn*TN+a)*32 + 8q + 4*(lane>>5) + r ------
-    // (requested behind the first tiles, consumed just before the main loop)
+    // ---- accumulators: zero (fast epilogue adds the bias), or the bias for the generic epilogue / split-K partials:
+    // register 4q+r of acc[a][*] <-> cout (wn*TN+a)*32 + 8q + 4*(lane>>5) + r
     floatx4 bv[TN][4];
     floatx16 acc[TN][TM];
     {
@@ -225,7 +241,7 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
             for (int q = 0; q < 4; q++) {
                 const int co = ntile * BN + (wn * TN + a) * 32 + 8 * q + 4 * (lane >> 5);
                 floatx4 v = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && p.splitk == 1) {
+                if (p.bias && p.splitk == 1 && !fastep) {
                     if (bias_vec) v = *(const floatx4*)(p.bias + min(co, p.Cout - 4));   // couts >= Cout are never stored
                     else for (int r = 0; r < 4; r++) if (co + r < p.Cout) v[r] = p.bias[co + r];
                 }
@@ -290,10 +306,17 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
     for (int i = 0; i < nk; i++) {
         const int newer = issued - i - 1;                       // tiles issued after tile i, allowed to stay in flight
         if (is_loader) {                                        // (consumer waves of a specialised block have no DMA in flight)
-            if (NSTAGE >= 4 && newer >= 3) sm_wait_vmcnt<(NSTAGE >= 4 ? 3 : 0) * LOADS>();
-            else if (NSTAGE >= 3 && newer == 2) sm_wait_vmcnt<(NSTAGE >= 3 ? 2 : 0) * LOADS>();
-            else if (NSTAGE >= 2 && newer == 1) sm_wait_vmcnt<(NSTAGE >= 2 ? 1 : 0) * LOADS>();
-            else sm_wait_vmcnt<0>();
+            if (i < pre) {                                      // a prologue tile: the EXTRA ordinary loads are younger than it
+                if (NSTAGE >= 4 && newer >= 3) sm_wait_vmcnt<(NSTAGE >= 4 ? 3 : 0) * LOADS + EXTRA>();
+                else if (NSTAGE >= 3 && newer == 2) sm_wait_vmcnt<(NSTAGE >= 3 ? 2 : 0) * LOADS + EXTRA>();
+                else if (NSTAGE >= 2 && newer == 1) sm_wait_vmcnt<(NSTAGE >= 2 ? 1 : 0) * LOADS + EXTRA>();
+                else sm_wait_vmcnt<EXTRA>();
+            } else {                                            // issued in the loop: everything older, EXTRA included, has to be back
+                if (NSTAGE >= 4 && newer >= 3) sm_wait_vmcnt<(NSTAGE >= 4 ? 3 : 0) * LOADS>();
+                else if (NSTAGE >= 3 && newer == 2) sm_wait_vmcnt<(NSTAGE >= 3 ? 2 : 0) * LOADS>();
+                else if (NSTAGE >= 2 && newer == 1) sm_wait_vmcnt<(NSTAGE >= 2 ? 1 : 0) * LOADS>();
+                else sm_wait_vmcnt<0>();
+            }
         }
         __builtin_amdgcn_s_barrier();                           // everybody's share of tile i landed; the slot of tile i-1 is free
         __builtin_amdgcn_sched_barrier(0);
@@ -330,7 +353,7 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
         // Fast path (every ResNet / MobileNet / U-Net layer): dense 16-byte output, no placement, no split-K, ReLU-family
         // activation.  Straight-line: all staging reads of the thread requested up front, one select per value, no per-element
         // branches or calls (the generic loop below costs ~1300 clk per 8-value item, this one ~1/3 of that).
-        if (vec_ok && !p.yplace && p.splitk == 1 && p.act <= SM_ACT_PRELU) {
+        if (fastep) {
             const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;        // f(v) = v < 0 ? v*sl : v
             const int m0 = mtile * BM + pw * EP_ROWS, co0 = ntile * BN;
             floatx4 s0[IPT], s1[IPT]; int rowi[IPT], chi[IPT];
@@ -344,7 +367,8 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
 #pragma unroll
                 for (int k2 = 0; k2 < IPT; k2++) {
                     const int m = m0 + rowi[k2], co = co0 + chi[k2] * 8;
-                    float v[8] = {s0[k2][0], s0[k2][1], s0[k2][2], s0[k2][3], s1[k2][0], s1[k2][1], s1[k2][2], s1[k2][3]};
+                    float v[8] = {s0[k2][0] + eb0[0], s0[k2][1] + eb0[1], s0[k2][2] + eb0[2], s0[k2][3] + eb0[3],
+                                  s1[k2][0] + eb1[0], s1[k2][1] + eb1[1], s1[k2][2] + eb1[2], s1[k2][3] + eb1[3]};
                     if (has_res) { const half8_t rr = rres[pw][k2];
 #pragma unroll
                         for (int j = 0; j < 8; j++) v[j] += (float)rr[j]; }

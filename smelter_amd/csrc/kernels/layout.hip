@@ -35,24 +35,36 @@ __global__ void nchw_to_nhwc_kernel(const float* x, half_t* y, int N, int C, int
 // and the pixel BELOW it, (y + 1 - pt, x - pl), in halfs 4..7 (zeros outside the image / beyond C).  64 consecutive halfs
 // starting at (y, x) are then 8 pixels of kernel row kh and 8 pixels of kernel row kh + 1: one BK = 64 tile of the
 // first-layer convolution (executor.cpp "image stem").  One thread per pixel, one 16-byte store.
-__global__ void nchw_to_rowpair_kernel(const float* x, half_t* y, int N, int C, int H, int W, int Hs, int Ws, int pt, int pl) {
-    const long total = (long)N * Hs * Ws;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int n = (int)(i / ((long)Hs * Ws)), r = (int)(i - (long)n * Hs * Ws), py = r / Ws, px = r - py * Ws;
-        const int ix = px - pl;
-        half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if ((unsigned)ix < (unsigned)W) {
+// Grid: x = column blocks, y = groups of RP output rows, z = image.  A thread owns one column of RP consecutive rows: the
+// bottom half of row r is the top half of row r + 1, so RP + 1 input rows are read for RP output pixels (no 64-bit
+// index arithmetic, no division: the old flat grid-stride version spent 35 us on 92 MB).
+constexpr int RP_ROWS = 4;
+__global__ __launch_bounds__(256) void nchw_to_rowpair_kernel(const float* x, half_t* y, int N, int C, int H, int W, int Hs, int Ws, int pt, int pl) {
+    const int px = blockIdx.x * 256 + threadIdx.x, py0 = blockIdx.y * RP_ROWS, n = blockIdx.z;
+    if (px >= Ws) return;
+    const int ix = px - pl;
+    const bool colok = (unsigned)ix < (unsigned)W;
+    const float* plane = x + (long)n * C * H * W + (colok ? ix : 0);
+    const long cs = (long)H * W;
+    half_t top[4] = {0, 0, 0, 0};
+    {
+        const int iy = py0 - pt;
+        if (colok && (unsigned)iy < (unsigned)H)
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                const int iy = py - pt + half;
-                if ((unsigned)iy < (unsigned)H) {
-                    const float* src = x + ((long)n * C * H + iy) * W + ix;
+            for (int c = 0; c < 4; c++) if (c < C) top[c] = (half_t)plane[(long)iy * W + c * cs];
+    }
 #pragma unroll
-                    for (int c = 0; c < 4; c++) if (c < C) v[half * 4 + c] = (half_t)src[(long)c * H * W];
-                }
-            }
-        }
-        *(half8_t*)(y + i * 8) = v;
+    for (int r = 0; r < RP_ROWS; r++) {
+        const int py = py0 + r; if (py >= Hs) break;
+        half_t bot[4] = {0, 0, 0, 0};
+        const int iy = py - pt + 1;
+        if (colok && (unsigned)iy < (unsigned)H)
+#pragma unroll
+            for (int c = 0; c < 4; c++) if (c < C) bot[c] = (half_t)plane[(long)iy * W + c * cs];
+        half8_t v = {top[0], top[1], top[2], top[3], bot[0], bot[1], bot[2], bot[3]};
+        *(half8_t*)(y + (((long)n * Hs + py) * Ws + px) * 8) = v;
+#pragma unroll
+        for (int c = 0; c < 4; c++) top[c] = bot[c];
     }
 }
 
@@ -149,8 +161,8 @@ int sm_nchw_f32_to_rowpair_f16(const float* x, void* y, int32_t N, int32_t C, in
                                sm_stream_t st) {
     SM_REQUIRE(x && y && N > 0 && C > 0 && C <= 4 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && pt >= 0 && pl >= 0, "sm_nchw_f32_to_rowpair_f16: bad argument");
     SM_REQUIRE((((uintptr_t)y) & 15) == 0, "sm_nchw_f32_to_rowpair_f16: destination not 16-byte aligned");
-    long pix = (long)N * Hs * Ws;
-    hipLaunchKernelGGL(nchw_to_rowpair_kernel, dim3(sm_stream_grid(pix, 256)), dim3(256), 0, sm_s(st), x, (half_t*)y, N, C, H, W, Hs, Ws, pt, pl);
+    SM_REQUIRE(N <= 65535 && (Hs + RP_ROWS - 1) / RP_ROWS <= 65535, "sm_nchw_f32_to_rowpair_f16: grid too large");
+    hipLaunchKernelGGL(nchw_to_rowpair_kernel, dim3((Ws + 255) / 256, (Hs + RP_ROWS - 1) / RP_ROWS, N), dim3(256), 0, sm_s(st), x, (half_t*)y, N, C, H, W, Hs, Ws, pt, pl);
     SM_LAUNCH_CHECK(); return SM_OK;
 }
 
