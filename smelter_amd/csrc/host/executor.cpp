@@ -649,7 +649,8 @@ int Executor::autotune(hipStream_t s) {
     // Tile configs are ranked under COLD caches: inside the network a layer finds its weights in HBM and its input in
     // HBM / Infinity Cache, never in an L2 warmed by the previous launch of the same kernel (L2 is invalidated at kernel
     // boundaries).  Ranking on back-to-back warm launches picked configs that were up to 1.5x slower in the graph.
-    const int ncfg = sm_conv2d_num_configs();
+    int ncfg = sm_conv2d_num_configs();
+    if (const char* mx = getenv("SMELTER_AUTOTUNE_MAXCFG")) ncfg = std::min(ncfg, std::max(1, atoi(mx)));   // A/B runs on one box
     const char* mode = getenv("SMELTER_AUTOTUNE");
     const bool insitu = mode && !strcmp(mode, "insitu");
     char* flush = nullptr; const size_t flush_bytes = (size_t)640 << 20;

@@ -416,6 +416,104 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 
 #include "conv_igemm64.hpp"
 
+// 3x3 depthwise through LDS (the MobileNet-v2 path): the register-strip kernel above re-reads every input pixel 4.5x through
+// L1/L2 and needs 227 VGPRs (1.2..2 TB/s of algorithmic bytes).  Here a block owns a tile of TH x TW output pixels x `cbv`
+// channel vectors (8 channels = 16 B each; all channels of the layer whenever the patch fits, otherwise a multiple of 8
+// vectors so that a block reads whole 128-byte lines): the (TH*S+2) x (TW*S+2) input patch goes to LDS by the LDS-DMA (slot
+// L = tid + 256 k holds patch pixel L / cbv, vector L % cbv: lane-linear; zero page outside the image; all loads of a
+// thread in flight at once), then every thread owns ONE channel vector (its 72 weights live in registers, regrouped per tap)
+// and walks the output pixels of the tile with stride 256/cbv: nine ds_read_b128 + 72 v_fma_mix_f32 per 16-byte store.
+// Lanes are adjacent in channel, so LDS and global accesses are contiguous 16-byte runs.  Blocks of one spatial tile are
+// adjacent in the grid (channel block fastest).  dynamic LDS = IH*IW*cbv*16 bytes rounded up to whole 1 KB wave images.
+template <int S, int TH, int TW, int CBMAX>
+__global__ __launch_bounds__(256) void dwconv3x3_lds_kernel(ConvParams p, int cbv, int tiles_x, int tiles_y, int cblocks) {
+    constexpr int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+    extern __shared__ __attribute__((aligned(16))) unsigned char dw_smem[];
+    int b = blockIdx.x;
+    const int cb = b % cblocks; b /= cblocks;
+    const int tx = b % tiles_x; b /= tiles_x;
+    const int ty = b % tiles_y, n = b / tiles_y;
+    const int tid = threadIdx.x, npt = 256 / cbv;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool active = tid < npt * cbv;                          // 256 % cbv threads have no output column (they still load and reach the barrier)
+    const int pt = active ? tid / cbv : 0, v = active ? tid - pt * cbv : 0;
+    const int c0 = (cb * cbv + v) * 8;
+    {
+        const int iy0 = ty * TH * S - p.pt, ix0 = tx * TW * S - p.pl;
+        const half_t* img = p.x + (long)n * p.H * p.W * p.x_ld + cb * cbv * 8;
+        const int slots = IH * IW * cbv;
+        constexpr int NL = (IH * IW * CBMAX + 255) / 256;
+        int idx = tid / cbv, vv = tid - idx * cbv;
+        const int didx = 256 / cbv, dv = 256 - didx * cbv;
+#pragma unroll
+        for (int k = 0; k < NL; k++) {
+            if (k * 256 + wave * 64 < slots) {                    // wave-uniform: waves beyond the patch skip
+                const int r = idx / IW, c = idx - r * IW, iy = iy0 + r, ix = ix0 + c;
+                const bool in = idx < IH * IW && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const half_t* src = in ? img + ((long)iy * p.W + ix) * p.x_ld + vv * 8 : (const half_t*)g_zero_page;
+                SM_GLDS16(src, dw_smem + (k * 256 + wave * 64) * 16);
+            }
+            idx += didx; vv += dv; if (vv >= cbv) { vv -= cbv; idx++; }
+        }
+    }
+    // weights [c][3][3] of the thread's 8 channels: 72 contiguous halfs -> one vector of 8 channels per tap
+    half8_t wt[9];
+    {
+        half8_t wq[9];
+        const half8_t* wp = (const half8_t*)(p.w + (long)c0 * 9);
+#pragma unroll
+        for (int q = 0; q < 9; q++) wq[q] = wp[q];
+#pragma unroll
+        for (int tp = 0; tp < 9; tp++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) wt[tp][j] = wq[(j * 9 + tp) >> 3][(j * 9 + tp) & 7];
+    }
+    float bias[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) bias[j] = p.bias ? p.bias[c0 + j] : 0.f;
+    const bool relu_family = p.act <= SM_ACT_PRELU;
+    const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const half8_t* tile = (const half8_t*)dw_smem;
+    for (int o = active ? pt : TH * TW; o < TH * TW; o += npt) {
+        const int oy = o / TW, ox = o - oy * TW, gy = ty * TH + oy, gx = tx * TW + ox;
+        if (gy >= p.Ho || gx >= p.Wo) continue;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) acc[j] = bias[j];
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+            for (int kw = 0; kw < 3; kw++) {
+                // acc[j] += x[j] * w[j]: v_fma_mix_f32 (fp16 operands, fp32 accumulate; the product of two halfs is exact in
+                // fp32, so this equals mul + add bit for bit).  Written out because hipcc otherwise converts the 72 loop-invariant
+                // weights to fp32 registers: 249 VGPRs, two waves per SIMD.
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 xu = *(const u32x4*)&tile[((oy * S + kh) * IW + ox * S + kw) * cbv + v];
+                const u32x4 wu = *(const u32x4*)&wt[kh * 3 + kw];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * d]) : "v"(xu[d]), "v"(wu[d]));
+                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(acc[2 * d + 1]) : "v"(xu[d]), "v"(wu[d]));
+                }
+            }
+        const long m = ((long)n * p.Ho + gy) * p.Wo + gx;
+        if (p.res) { const half8_t rr = *(const half8_t*)(p.res + m * p.res_ld + c0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) acc[j] += (float)rr[j]; }
+        half8_t ov;
+        if (relu_family) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) ov[j] = (half_t)(acc[j] < 0.f ? acc[j] * sl : acc[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++) ov[j] = (half_t)sm_act(acc[j], p.act, p.slope);
+        }
+        *(half8_t*)(p.y + m * p.y_ld + c0) = ov;
+    }
+}
+
 // kind 0: generic (Cin % 8 == 0, BK = 32, register staging); kind 1: Cin % 64 == 0 fast path (BK = 64, LDS-DMA)
 struct TileCfg { int BM, BN, kind, threads; void (*fn)(ConvParams); const char* name; };
 const TileCfg kCfgs[] = {
@@ -474,6 +572,11 @@ const TileCfg kCfgs[] = {
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 2, 4, 0, 0, 4>, "k64ws4+4s4:128x128"},        // 45
     {64, 64, 1, 384, conv_igemm64_kernel<64, 64, 2, 2, 3, 0, 0, 2>, "k64ws4+2s3:64x64"},              // 46
     {64, 128, 1, 512, conv_igemm64_kernel<64, 128, 2, 2, 3, 0, 0, 4>, "k64ws4+4s3:64x128"},           // 47
+    // K split inside the block: 2 groups of 2x2 waves, group g multiplies K tile 2i+g of stage i (64x64 / 64x32 / 32x64 wave tiles)
+    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 2, 2, 0, 0, 0, 2>, "k64ks2:128x128"},         // 48
+    {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 2, 2, 3, 0, 0, 0, 2>, "k64ks2s3:128x64"},          // 49
+    {64, 128, 1, 512, conv_igemm64_kernel<64, 128, 2, 2, 3, 0, 0, 0, 2>, "k64ks2s3:64x128"},          // 50
+    {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 2, 2, 2, 0, 0, 0, 2>, "k64ks2:128x64"},            // 51
 #ifdef SM_ABLATION   // tools/conv_bench.py only: never built into the product library
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 1>, "abl:w8 noMFMA"},
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 2>, "abl:w8 noGlobal"},
@@ -543,7 +646,31 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         (p.y_ld % 8) == 0 && (!p.res || (p.res_ld % 8) == 0)) {
         long work = (long)p.M * (p.Cout / 8);
         const bool k3 = p.kH == 3 && p.kW == 3 && p.dH == 1 && p.dW == 1 && p.sH == p.sW && (((uintptr_t)p.w) & 15) == 0;
-        if (k3 && p.sH == 1) {
+        const bool lds_ok = k3 && (p.sH == 1 || p.sH == 2) && !getenv("SMELTER_DW_STRIP");
+        if (lds_ok) {
+            // Channel vectors per block: ALL of them when the patch of some tile fits ~52 KB of LDS; otherwise the largest divisor of
+            // C/8 that is a multiple of 8 (whole 128-byte lines per pixel), otherwise the largest divisor at all.
+            const int cvt = p.Cout / 8, S = p.sH;
+            const bool narrow = p.Wo <= 8;
+            // tile variants: wide (TW = 16) up to CB_W vectors, narrow (TW = 8) up to CB_N vectors
+            const int CB_W = S == 1 ? 12 : 6, CB_N = S == 1 ? 24 : 18;
+            int cbv;
+            if (cvt <= CB_N) cbv = cvt;
+            else { cbv = 0; for (int q = 8; q <= CB_N; q += 8) if (cvt % q == 0) cbv = q; if (!cbv) for (int q = 1; q <= CB_N; q++) if (cvt % q == 0) cbv = q; }
+            const bool wide = cbv <= CB_W && !narrow;
+            const int TH = S == 1 ? 8 : 4, TW = wide ? 16 : 8;
+            const int cblocks = cvt / cbv;
+            const int tiles_y = sm_ceil_div(p.Ho, TH), tiles_x = sm_ceil_div(p.Wo, TW);
+            const long blocks = (long)p.N * tiles_y * tiles_x * cblocks;
+            SM_REQUIRE(blocks < (1L << 31), "sm_conv2d_fwd: depthwise grid too large");
+            const int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
+            const size_t lds = ((size_t)IH * IW * cbv * 16 + 1023) / 1024 * 1024;
+            const dim3 grid((unsigned)blocks);
+            if (S == 1 && wide) hipLaunchKernelGGL((dwconv3x3_lds_kernel<1, 8, 16, 12>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
+            else if (S == 1) hipLaunchKernelGGL((dwconv3x3_lds_kernel<1, 8, 8, 24>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
+            else if (wide) hipLaunchKernelGGL((dwconv3x3_lds_kernel<2, 4, 16, 6>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
+            else hipLaunchKernelGGL((dwconv3x3_lds_kernel<2, 4, 8, 18>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
+        } else if (k3 && p.sH == 1) {
             long w4 = (long)p.N * p.Ho * sm_ceil_div(p.Wo, 4) * (p.Cout / 8);
             hipLaunchKernelGGL((dwconv3x3_kernel<1, 4>), dim3(sm_stream_grid(w4, 256)), dim3(256), 0, s, p);
         } else if (k3 && p.sH == 2) {

@@ -51,29 +51,39 @@ constexpr int sm_pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; retur
 // as they spend on MFMAs (ablations: LDS->MFMA only 833 clk per 128x128x64 tile, + DMA issue 1300..1450 clk).  With NLW
 // extra LOADER waves (one per SIMD) that issue all LDS-DMA of the block and never touch the matrix pipe, the WGM*WGN
 // CONSUMER waves only read fragments and issue MFMAs; both roles meet at the ONE barrier per K tile of the ring protocol.
-template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0, int NLW = 0>
-__global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(ConvParams p) {
-    static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 MFMA waves");
+// KS = 2: K split INSIDE the block.  The waves form KS groups of WGM x WGN; a ring stage holds KS consecutive K tiles and group g
+// multiplies tile KS*i + g of stage i, so each wave keeps the big 64x64 wave tile of a 4-wave block (fragment reads per
+// MFMA as in the 4-wave configs: LDS time 768 instead of 896 clk per 128x128x64 tile by the DESIGN 4.1b model) while 8 waves
+// hide each other's LDS latency, and there is ONE barrier per KS tiles.  The KS partial accumulators meet in the fp32 staging
+// buffers of the epilogue (one region per group, summed by the store pass in a fixed order).
+template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0, int NLW = 0, int KS = 1>
+__global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kernel(ConvParams p) {
+    static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 MFMA waves per group");
     static_assert(NSTAGE >= 1 && NSTAGE <= 4, "1..4 stages");
     static_assert(NLW == 0 || (ILV == 0 && NSTAGE >= 2), "loader waves: no interleaved issue, >= 2 stages");
-    constexpr int NCW = WGM * WGN;                              // consumer (MFMA) waves
+    static_assert(KS == 1 || (KS == 2 && NLW == 0 && ILV == 0 && ABL == 0 && NSTAGE >= 2), "K groups: plain issue only");
+    constexpr int NGW = WGM * WGN;                              // waves per K group
+    constexpr int NCW = NGW * KS;                               // consumer (MFMA) waves
     constexpr int NT = (NCW + NLW) * 64;                        // threads per block
     constexpr int NLT = NLW ? NLW * 64 : NT;                    // threads that issue the LDS-DMA
     constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
-    constexpr int A_IT = BM * 8 / NLT, B_IT = BN * 8 / NLT;    // 16-byte pieces per loader thread per tile
+    constexpr int A_IT = BM * 8 / NLT, B_IT = BN * 8 / NLT;    // 16-byte pieces per loader thread per K tile
     constexpr int RPI = NLT / 8;                                // tile rows covered by one DMA instruction of all loader waves
     static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
-    constexpr int LOADS = A_IT + B_IT;                          // LDS-DMA instructions per wave per tile
-    constexpr int A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128, PIPE_BYTES = NSTAGE * STAGE_BYTES;
-    // epilogue staging (fp32): WPP wave-rows of 32*TM pixels per pass
+    constexpr int LOADS = KS * (A_IT + B_IT);                   // LDS-DMA instructions per wave per stage
+    constexpr int A_BYTES = BM * 128, SUB_BYTES = (BM + BN) * 128, STAGE_BYTES = KS * SUB_BYTES, PIPE_BYTES = NSTAGE * STAGE_BYTES;
+    // epilogue staging (fp32): WPP wave-rows of 32*TM pixels per pass, one region per K group
     constexpr int EP_LD = BN + 4, WROWS = 32 * TM;
-    constexpr int EP_BUDGET = PIPE_BYTES > 69632 ? PIPE_BYTES : 69632;
-    constexpr int WPP_MAX = EP_BUDGET / (WROWS * EP_LD * 4);
+    constexpr int EP_MIN = KS == 2 ? 139264 : 69632;
+    constexpr int EP_BUDGET = PIPE_BYTES > EP_MIN ? PIPE_BYTES : EP_MIN;
+    constexpr int WPP_MAX = EP_BUDGET / (KS * WROWS * EP_LD * 4);
     constexpr int WPP = WPP_MAX >= WGM ? WGM : sm_pow2_floor(WPP_MAX < 1 ? 1 : WPP_MAX);
     constexpr int EP_ROWS = WROWS * WPP, EP_PASSES = WGM / WPP;
     static_assert(WGM % WPP == 0, "epilogue passes");
     // + 8 bytes per tile row at the very end: the row table of the prologue (never touched by the ring or the staging)
-    constexpr int LDS_BYTES = (PIPE_BYTES > EP_ROWS * EP_LD * 4 ? PIPE_BYTES : EP_ROWS * EP_LD * 4) + BM * 8;
+    constexpr int EP_REGION = EP_ROWS * EP_LD;                  // floats per K group
+    constexpr int LDS_BYTES = (PIPE_BYTES > KS * EP_REGION * 4 ? PIPE_BYTES : KS * EP_REGION * 4) + BM * 8;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert((NSTAGE - 1) * LOADS <= 63, "vmcnt range");
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[LDS_BYTES];
 
@@ -84,12 +94,14 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
     const int kt_begin = ksplit * p.ktiles_per_split;
     const int ktiles = p.K >> 6;
     int kt_end = kt_begin + p.ktiles_per_split; if (kt_end > ktiles) kt_end = ktiles;
-    const int nk = kt_end - kt_begin;
+    const int nk = kt_end - kt_begin;                           // K tiles of this block
+    const int nit = (nk + KS - 1) / KS;                         // ring stages (= loop iterations)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> LDS bases live in SGPRs
     const bool is_loader = NLW == 0 || wave >= NCW, is_consumer = NLW == 0 || wave < NCW;   // wave-uniform roles
-    const int wm = (NLW && wave >= NCW) ? 0 : wave / WGN, wn = (NLW && wave >= NCW) ? 0 : wave % WGN;
+    const int kgrp = KS == 1 ? 0 : (wave >= NGW ? 1 : 0), gwave = KS == 1 ? wave : wave - kgrp * NGW;   // K group, wave inside it
+    const int wm = (NLW && wave >= NCW) ? 0 : gwave / WGN, wn = (NLW && wave >= NCW) ? 0 : gwave % WGN;
     const int ltid = NLW ? (tid - NCW * 64) & (NLT - 1) : tid;  // index among the loader threads (consumers: unused alias)
     const int lwave = NLW ? (wave >= NCW ? wave - NCW : 0) : wave;
     const int csrc = (ltid & 7) ^ ((ltid >> 4) & 7);           // source chunk for this thread's LDS slot (rows j*RPI + ltid/8)
@@ -159,9 +171,10 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
     const long a_wrap_c = (long)p.dW * p.x_ld - (long)(cpt - 1) * 64;      // next tap, same kernel row
     const long a_wrap_w = ((long)p.dH * p.W - (long)p.kW * p.dW) * p.x_ld;  // ... and on to the next kernel row
 
-    int issued = 0;                                             // K tiles put in flight so far
-    auto piece = [&](int slot, int i) {                         // i-th LDS-DMA instruction of the tile under the cursor
-        unsigned char* sa = smem_raw + slot * STAGE_BYTES + lwave * 1024;  // wave-uniform LDS base; lane*16 B added by the DMA
+    int issued = 0;                                             // ring stages put in flight so far
+    int ktq = 0;                                                // KS > 1: K tiles the cursor has moved past
+    auto piece = [&](int slot, int i, int sub = 0) {            // i-th LDS-DMA instruction of the K tile under the cursor
+        unsigned char* sa = smem_raw + slot * STAGE_BYTES + sub * SUB_BYTES + lwave * 1024;  // wave-uniform LDS base; lane*16 B added by the DMA
         if (i < A_IT) {
             if (ABL == 3 && issued >= NSTAGE - 1) return;       // ablation: no activation traffic after the prologue
             const half_t* src = (amask[i] & tapbit) ? arow[i] + a_off : zero;
@@ -176,18 +189,22 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
         } else a_off += 64;
     };
     auto issue = [&](int slot) {
-        if (is_loader) {
 #pragma unroll
-            for (int i = 0; i < LOADS; i++) piece(slot, i);
+        for (int sub = 0; sub < KS; sub++) {
+            if (is_loader) {
+#pragma unroll
+                for (int i = 0; i < A_IT + B_IT; i++) piece(slot, i, sub);
+            }
+            if (KS == 1) advance();
+            else if (ktq + 1 < nk) { advance(); ++ktq; }        // an odd tail re-fetches the last K tile (never multiplied)
         }
-        advance();
     };
 
     SM_TL(3);
     // ---- first tiles in flight as early as possible; everything else of the prologue hides behind their latency --------
     // Tile i lives in ring slot i % NSTAGE.  Short K (nk <= NSTAGE, the HBM-streaming 1x1 layers): everything the block
     // will ever read is in flight at once.
-    const int pre = nk <= NSTAGE ? nk : NSTAGE - 1;
+    const int pre = nit <= NSTAGE ? nit : NSTAGE - 1;
 #pragma unroll
     for (int s = 0; s < NSTAGE; s++) if (s < pre) { issue(s); ++issued; }
     int slot = 0, islot = pre == NSTAGE ? 0 : pre;
@@ -260,7 +277,7 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
     // next tile are spread between the MFMAs of this one instead of being issued as one burst (mainloop.hip: +5 % for the
     // 8-wave 128x128 tile, +26 % for 256x128; no gain for 4-wave tiles)
     auto compute = [&](int slot, int dslot, bool dma) {
-        const unsigned sA = slot * STAGE_BYTES + wm * (TM * 4096), sB = slot * STAGE_BYTES + A_BYTES + wn * (TN * 4096);
+        const unsigned sA = slot * STAGE_BYTES + kgrp * SUB_BYTES + wm * (TM * 4096), sB = slot * STAGE_BYTES + kgrp * SUB_BYTES + A_BYTES + wn * (TN * 4096);
         half8_t fx[2][TM], fw[2][TN];
 #pragma unroll
         for (int b = 0; b < TM; b++) fx[0][b] = *(const half8_t*)(smem_raw + sA + voff[0] + b * 4096);
@@ -281,7 +298,7 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
                     if (ABL != 1) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[ks & 1][a], fx[ks & 1][b], acc[a][b], 0, 0, 0);
                     else { asm volatile("" ::"v"(fw[ks & 1][a]), "v"(fx[ks & 1][b])); }
                     if (ILV) {
-                        constexpr int NM = 4 * TM * TN, MPL = NM / LOADS > 0 ? NM / LOADS : 1;   // MFMAs per DMA instruction
+                        constexpr int NM = 4 * TM * TN, MPL = NM / LOADS > 0 ? NM / LOADS : 1;   // MFMAs per DMA instruction (ILV: KS == 1)
                         const int cnt = (ks * TN + a) * TM + b + 1;
                         if (cnt % MPL == 0 && cnt / MPL - 1 < LOADS && dma) piece(dslot, cnt / MPL - 1);
                     }
@@ -303,8 +320,8 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
     SM_TL(5);
 
     // ---- main loop: ONE barrier per K tile; the counted vmcnt leaves the newer tiles (and nothing older) in flight -------
-    for (int i = 0; i < nk; i++) {
-        const int newer = issued - i - 1;                       // tiles issued after tile i, allowed to stay in flight
+    for (int i = 0; i < nit; i++) {
+        const int newer = issued - i - 1;                       // stages issued after stage i, allowed to stay in flight
         if (is_loader) {                                        // (consumer waves of a specialised block have no DMA in flight)
             if (i < pre) {                                      // a prologue tile: the EXTRA ordinary loads are younger than it
                 if (NSTAGE >= 4 && newer >= 3) sm_wait_vmcnt<(NSTAGE >= 4 ? 3 : 0) * LOADS + EXTRA>();
@@ -323,9 +340,9 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
 #ifdef SM_TIMELINE
         if (i == 0) SM_TL(6);
 #endif
-        const bool more = issued < nk && ABL != 2;
+        const bool more = issued < nit && ABL != 2;
         if (!ILV && more) issue(islot);
-        if (is_consumer) compute(slot, islot, more);
+        if (is_consumer && (KS == 1 || KS * i + kgrp < nk)) compute(slot, islot, more);
         if (more) { ++issued; if (++islot == NSTAGE) islot = 0; }
         if (++slot == NSTAGE) slot = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's fragment reads are done before it passes the next barrier
@@ -338,7 +355,7 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
 #pragma unroll
     for (int pw = 0; pw < EP_PASSES; pw++) {
         if (is_consumer && wm / WPP == pw) {
-            const int wrow = (wm % WPP) * WROWS;
+            const int wrow = (wm % WPP) * WROWS + kgrp * EP_ROWS;   // K group g stages into region g (EP_ROWS*EP_LD floats each)
 #pragma unroll
             for (int b = 0; b < TM; b++)
 #pragma unroll
@@ -362,6 +379,10 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
                 int it = tid + k2 * NT; if (ITEMS % NT != 0 && it >= ITEMS) it = ITEMS - 1;
                 rowi[k2] = it / CHUNKS; chi[k2] = it - rowi[k2] * CHUNKS;
                 s0[k2] = *(const floatx4*)(stg + rowi[k2] * EP_LD + chi[k2] * 8); s1[k2] = *(const floatx4*)(stg + rowi[k2] * EP_LD + chi[k2] * 8 + 4);
+                if (KS == 2) {                                  // + the other K group's partial sums
+                    const floatx4 t0 = *(const floatx4*)(stg + EP_REGION + rowi[k2] * EP_LD + chi[k2] * 8), t1 = *(const floatx4*)(stg + EP_REGION + rowi[k2] * EP_LD + chi[k2] * 8 + 4);
+                    s0[k2] += t0; s1[k2] += t1;
+                }
             }
             auto emit = [&](const bool has_res) {
 #pragma unroll
@@ -392,6 +413,7 @@ __global__ __launch_bounds__((WGM * WGN + NLW) * 64) void conv_igemm64_kernel(Co
             if (m >= p.M || co >= p.Cout) continue;
             const long opix = sm_out_pixel(p, m);
             floatx4 v0 = *(const floatx4*)(stg + row * EP_LD + ch * 8), v1 = *(const floatx4*)(stg + row * EP_LD + ch * 8 + 4);
+            if (KS == 2) { v0 += *(const floatx4*)(stg + EP_REGION + row * EP_LD + ch * 8); v1 += *(const floatx4*)(stg + EP_REGION + row * EP_LD + ch * 8 + 4); }
             float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
             if (p.splitk > 1) {
                 float* dst = p.ws + ((long)ksplit * p.M + m) * p.Cout + co;

@@ -52,7 +52,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg", [None] + list(range(48)))
+@pytest.mark.parametrize("cfg", [None] + list(range(52)))
 def test_conv2d(case, cfg):
     n, hh, ww, cin, cout, k, s, p, res, act = case
     if cfg is not None and (cin % 8 or cfg >= ops.num_conv_configs() or (cfg >= 6 and cin % 64)):
@@ -104,6 +104,31 @@ def test_conv2d_writes_into_concat_slice_and_reads_from_one():
     ref = O.conv2d(x, w, None, pads=(1, 1, 1, 1))
     assert_close(to_host(big_out[..., 8:32]), ref, 144)
     assert (big_out[..., :8] == 7).all() and (big_out[..., 32:] == 7).all()      # neighbours of the slice untouched
+
+
+@pytest.mark.parametrize("c,hw,s,res,act", [
+    (144, (28, 28), 1, False, 1),      # MobileNet-v2 widths: 18 channel vectors -> 9 per block
+    (192, (14, 14), 2, False, 1),      # stride 2: 8 vectors per block, ragged 7x7 output
+    (960, (7, 7), 1, True, 2),         # small map (8x8 tile), 15 vectors per block, residual + PRelu
+    (32, (33, 17), 2, False, 0),       # odd sizes, tiles ragged in both directions, no activation
+    (8, (5, 40), 1, True, 1),          # one channel vector, wide image
+])
+def test_depthwise3x3_lds_tiles(c, hw, s, res, act):
+    """the LDS-tiled 3x3 depthwise kernel (MobileNet-v2 path) over its tile / channel-block variants; bit-level tolerance as test_depthwise"""
+    rng = np.random.default_rng(c + hw[0])
+    x = h(rng.standard_normal((3, c, hw[0], hw[1])))
+    w = h(rng.standard_normal((c, 3, 3, 1)) * 0.3)
+    b = rng.standard_normal(c).astype(np.float32)
+    ref = O.conv2d(x, w, b, stride=(s, s), pads=(1, 1, 1, 1), groups=c)
+    r = h(rng.standard_normal(ref.shape)) if res else None
+    if res:
+        ref = ref + r
+    slope = 0.25 if act == 2 else 0.0
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), residual=to_dev(r) if res else None,
+                   stride=(s, s), pads=(1, 1, 1, 1), groups=c, act=act, slope=slope)
+    assert_close(to_host(y), ref, 9)
 
 
 @pytest.mark.parametrize("c,k,s", [(16, 3, 1), (32, 3, 2), (8, 5, 1)])
