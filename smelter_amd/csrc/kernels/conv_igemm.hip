@@ -91,7 +91,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     constexpr int TM = BM / (WGM * 32), TN = BN / (WGN * 32);
     constexpr int A_IT = BM * 4 / 256, B_IT = BN * 4 / 256;
     static_assert(TM >= 1 && TN >= 1 && A_IT >= 1 && B_IT >= 1, "tile too small");
-    __shared__ __attribute__((aligned(16))) half_t smem[2][(BM + BN) * BK];
+    // the ring (2 stages of (BM+BN) x 32 halfs) and the fp32 staging tile of the coalesced epilogue share the LDS
+    constexpr int RING_HALFS = 2 * (BM + BN) * BK, EPI_LD = BN + 4, EPI_HALFS = BM * EPI_LD * 2;
+    __shared__ __attribute__((aligned(16))) half_t smem_all[RING_HALFS > EPI_HALFS ? RING_HALFS : EPI_HALFS];
+    half_t (*smem)[(BM + BN) * BK] = (half_t (*)[(BM + BN) * BK])smem_all;
 
     // ---- block -> (pixel tile, cout tile, k split) -------------------------------------------------
     int mtile, ntile, ksplit;
@@ -193,6 +196,54 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     }
 
     // ---- epilogue -----------------------------------------------------------------------------------
+    // Fast path (dense 16-byte output, no placement / split-K, ReLU family): accumulators -> LDS as fp32 [BM][BN+4], then every
+    // thread takes 8 consecutive couts of one pixel: + bias + residual, one rounding, ONE 16-byte store, 8 lanes per 128-byte
+    // line.  (The row-per-lane 8-byte stores below put 32 partial lines into every store instruction: the pointwise layers of
+    // MobileNet-v2, all epilogue, ran at 2.1 TB/s.)
+    if (!p.yplace && p.splitk == 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
+        ((((uintptr_t)p.bias) & 15) == 0) && (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0))) {
+        float* stg = (float*)smem_all;                            // (the last main-loop barrier already separates it from the ring reads)
+#pragma unroll
+        for (int b = 0; b < TM; b++)
+#pragma unroll
+            for (int a = 0; a < TN; a++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int row = (wm * TM + b) * 32 + (lane & 31), col = (wn * TN + a) * 32 + 8 * q + 4 * (lane >> 5);
+                    *(floatx4*)(stg + row * EPI_LD + col) = floatx4{acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                }
+        __syncthreads();
+        const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;
+        constexpr int CH = BN / 8, ITEMS = BM * CH, IPT = ITEMS / 256;
+        static_assert(ITEMS % 256 == 0 && 256 % CH == 0, "epilogue items");
+        const int ch = tid % CH, co = ntile * BN + ch * 8;
+        if (co < p.Cout) {
+            floatx4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+            if (p.bias) { b0 = *(const floatx4*)(p.bias + co); b1 = *(const floatx4*)(p.bias + co + 4); }
+            floatx4 s0[IPT], s1[IPT]; half8_t rr[IPT];
+#pragma unroll
+            for (int k2 = 0; k2 < IPT; k2++) {
+                const int row = (tid + k2 * 256) / CH;
+                s0[k2] = *(const floatx4*)(stg + row * EPI_LD + ch * 8); s1[k2] = *(const floatx4*)(stg + row * EPI_LD + ch * 8 + 4);
+                const int m = min(mtile * BM + row, p.M - 1);
+                if (p.res) rr[k2] = *(const half8_t*)(p.res + (long)m * p.res_ld + co);
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < IPT; k2++) {
+                const int m = mtile * BM + (tid + k2 * 256) / CH;
+                float v[8] = {s0[k2][0] + b0[0], s0[k2][1] + b0[1], s0[k2][2] + b0[2], s0[k2][3] + b0[3],
+                              s1[k2][0] + b1[0], s1[k2][1] + b1[1], s1[k2][2] + b1[2], s1[k2][3] + b1[3]};
+                if (p.res) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] += (float)rr[k2][j]; }
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; j++) o[j] = (half_t)(v[j] < 0.f ? v[j] * sl : v[j]);
+                if (m < p.M) *(half8_t*)(p.y + (long)m * p.y_ld + co) = o;
+            }
+        }
+        return;
+    }
     const bool vec_ok = ((p.y_ld & 3) == 0) && ((((uintptr_t)p.y) & 7) == 0) && ((((uintptr_t)p.bias) & 15) == 0) &&
                         (p.res == nullptr || ((p.res_ld & 3) == 0 && (((uintptr_t)p.res) & 7) == 0));
 #pragma unroll
