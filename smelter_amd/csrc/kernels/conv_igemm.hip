@@ -466,6 +466,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 }
 
 #include "conv_igemm64.hpp"
+#include "conv3x3_strip.hpp"
 
 // 3x3 depthwise through LDS (the MobileNet-v2 path): the register-strip kernel above re-reads every input pixel 4.5x through
 // L1/L2 and needs 227 VGPRs (1.2..2 TB/s of algorithmic bytes).  Here a block owns a tile of TH x TW output pixels x `cbv`
@@ -628,6 +629,15 @@ const TileCfg kCfgs[] = {
     {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 2, 2, 3, 0, 0, 0, 2>, "k64ks2s3:128x64"},          // 49
     {64, 128, 1, 512, conv_igemm64_kernel<64, 128, 2, 2, 3, 0, 0, 0, 2>, "k64ks2s3:64x128"},          // 50
     {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 2, 2, 2, 0, 0, 0, 2>, "k64ks2:128x64"},            // 51
+    // kind 3 (conv3x3_strip.hpp): 3x3 / stride 1 / pad 1, one activation strip per kernel row serves its three taps
+    {128, 128, 3, 512, conv3x3_strip_kernel<128, 128, 2, 4, 2>, "strip:128x128(64x32)"},              // 52
+    {128, 128, 3, 512, conv3x3_strip_kernel<128, 128, 4, 2, 2>, "strip:128x128(32x64)"},              // 53
+    {128, 64, 3, 256, conv3x3_strip_kernel<128, 64, 2, 2, 3>, "strip s3:128x64"},                     // 54
+    {256, 64, 3, 512, conv3x3_strip_kernel<256, 64, 4, 2, 2>, "strip:256x64"},                        // 55
+    {64, 128, 3, 256, conv3x3_strip_kernel<64, 128, 2, 2, 2>, "strip w4:64x128"},                     // 56
+    {128, 64, 3, 512, conv3x3_strip_kernel<128, 64, 4, 2, 3>, "strip w8s3:128x64"},                   // 57
+    {256, 32, 3, 256, conv3x3_strip_kernel<256, 32, 4, 1, 3>, "strip s3:256x32"},                     // 58
+    {128, 128, 3, 256, conv3x3_strip_kernel<128, 128, 2, 2, 2>, "strip w4:128x128"},                  // 59
 #ifdef SM_ABLATION   // tools/conv_bench.py only: never built into the product library
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 1>, "abl:w8 noMFMA"},
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 2>, "abl:w8 noGlobal"},
@@ -640,7 +650,16 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 // kind 2 = single LDS stage: only for K == 64 (one K tile)
 // kinds 1/2 (conv_igemm64.hpp): Cin % 64 == 0 and a tap mask of <= 32 bits
-bool cfg_eligible(const TileCfg& c, const ConvParams& p) { return c.kind == 0 || ((p.Cin % 64) == 0 && p.kH * p.kW <= 32 && (c.kind == 1 || p.K == 64)); }
+bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
+    if (c.kind == 0) return true;
+    if ((p.Cin % 64) != 0 || p.kH * p.kW > 32) return false;
+    if (c.kind == 1) return true;
+    if (c.kind == 2) return p.K == 64;
+    // kind 3: 3x3 / stride 1 / pad 1 / "same" size, and everything the fast epilogue needs (dense 16-byte output, ReLU family)
+    return p.kH == 3 && p.kW == 3 && p.sH == 1 && p.sW == 1 && p.dH == 1 && p.dW == 1 && p.pt == 1 && p.pl == 1 && p.Ho == p.H && p.Wo == p.W &&
+           !p.yplace && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) &&
+           (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0));
+}
 
 int pick_cfg(const ConvParams& p) {
     // largest tile that still gives >= ~2 blocks per CU; otherwise the one with the most blocks
@@ -745,7 +764,7 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     // split-K only for launches that cannot fill the chip and have a long K loop (e.g. the FC layer)
     p.splitk = 1;
     long blocks = (long)p.mt * p.nt;
-    if (ws && blocks < SM_NUM_CU / 2 && ktiles >= 16 && !p.yplace) {
+    if (ws && blocks < SM_NUM_CU / 2 && ktiles >= 16 && !p.yplace && c.kind != 3) {   // (the strip kernel has no split-K form)
         int want = (int)(SM_NUM_CU / blocks);                        // one wave of blocks: a second, partial wave costs a whole K pass
         int maxs = ktiles / 4; if (want > maxs) want = maxs; if (want > 32) want = 32;
         while (want > 1 && (size_t)want * p.M * p.Cout * sizeof(float) > ws_bytes) want--;

@@ -43,6 +43,10 @@ CONV_CASES = [
     (3, 9, 9, 8, 8, 7, 2, 3, False, 1),                # 7x7 s2 p3 (stem class), K = 392
     (2, 28, 28, 128, 256, 1, 2, 0, True, 1),           # 1x1 s2 downsample + residual
     (1, 7, 7, 512, 64, 3, 1, 1, False, 1),             # long K (4608)
+    (3, 9, 7, 64, 72, 3, 1, 1, True, 1),               # 3x3 s1 p1, Cin % 64 == 0: a tile spans three images (strip kernel: vertical padding across images)
+    (2, 14, 14, 128, 128, 3, 1, 1, False, 2),          # strip kernel: two cin blocks, PRelu
+    (1, 33, 5, 64, 40, 3, 1, 1, True, 0),              # strip kernel: narrow image (every third pixel touches a horizontal border), ragged M and N
+    (5, 3, 3, 192, 256, 3, 1, 1, False, 1),            # strip kernel: 3x3 images (all taps but the centre cross a border somewhere)
     (2, 5, 5, 64, 1000, 1, 1, 0, False, 0),            # Cout = 1000 (tail in N)
     (1, 1, 1, 2048, 1000, 1, 1, 0, False, 0),          # fully connected shape, M = 1
     (2, 6, 6, 24, 20, 3, 1, 1, True, 2),               # Cin % 8 == 0 but not 32; PRelu epilogue
@@ -52,7 +56,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg", [None] + list(range(52)))
+@pytest.mark.parametrize("cfg", [None] + list(range(60)))
 def test_conv2d(case, cfg):
     n, hh, ww, cin, cout, k, s, p, res, act = case
     if cfg is not None and (cin % 8 or cfg >= ops.num_conv_configs() or (cfg >= 6 and cin % 64)):
