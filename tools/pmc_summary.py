@@ -42,14 +42,15 @@ def main():
     print("%3s %-44s %10s %10s %8s %9s" % ("#", "kernel", "rd_MB", "wr_MB", "L2hit%", "mfma_busy"))
     for i, e in disp.items():
         name = e["name"]
-        short = name[name.find("conv_igemm"):][:40] if "conv_igemm" in name else name[:40]
+        key = "conv_igemm" if "conv_igemm" in name else ("conv3x3_strip" if "conv3x3_strip" in name else None)
+        short = name[name.find(key):][:40] if key else name[:40]
         rd = e.get("FETCH_SIZE", 0) * 1024 * 2 / 1e6
         wr = e.get("WRITE_SIZE", 0) * 1024 / 1e6
         hit, miss = e.get("TCC_HIT_sum", 0), e.get("TCC_MISS_sum", 0)
         hr = 100 * hit / (hit + miss) if hit + miss else float("nan")
         print("%3d %-44s %10.1f %10.1f %8.1f %9.3g" % (i, short, rd, wr, hr, e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)))
         tot["rd"] += rd; tot["wr"] += wr
-        if "conv_igemm" in name or "splitk" in name:
+        if "conv_igemm" in name or "conv3x3_strip" in name or "splitk" in name:
             conv["rd"] += rd; conv["wr"] += wr; nconv += 1
     print("step total: read %.1f MB, write %.1f MB ; conv family: read %.1f MB, write %.1f MB over %d launches" % (
         tot["rd"], tot["wr"], conv["rd"], conv["wr"], nconv))
