@@ -111,6 +111,24 @@ def test_autotuned_configs_give_the_same_numbers():
     assert nerr(a, b) <= 1e-3      # different tiles only change the accumulation split
 
 
+def test_branch_concurrency_schedule_is_the_same_function():
+    """Configuration.branchConcurrency: the projection-shortcut conv is hoisted behind the block input and runs on a second
+    stream (fork / join as hipGraph edges); which of the two convs feeding the Add fuses it changes, the function does not"""
+    model = zoo.resnet50(hw=(64, 64))
+    x = zoo.synthetic_images(3, 3, (64, 64))
+    ex0, a = run_hip(model, x)
+    for graph in (True, False):
+        ex1, b = run_hip(model, x, branchConcurrency=True, useHipGraph=graph)
+        side = [i for i in range(ex1.numOps) if "side-stream" in ex1.opDesc(i)]
+        assert len(side) == 4 and ex1.numOps == ex0.numOps          # one projection shortcut per stage
+        assert nerr(a, b) <= 1e-3
+        xd = torch.from_numpy(x).cuda()
+        for _ in range(3):                                            # replay: joins hold, results stay put
+            ex1.encode(xd)
+        assert np.array_equal(ex1.toFloatArray(), b)
+    assert not any("side-stream" in ex0.opDesc(i) for i in range(ex0.numOps))
+
+
 def test_batch_shard_outputs_equal_the_unsharded_run():
     # SURVEY.md §4 "multi-GPU" row on one GPU: images [lo,hi) run as their own executor == rows [lo,hi) of the full batch
     from smelter_amd.dist import shard_range
