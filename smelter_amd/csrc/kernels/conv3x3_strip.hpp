@@ -17,7 +17,9 @@
 //    with exact vmcnt accounting); the launcher only selects this kernel when those conditions hold.
 #pragma once
 
-template <int BM, int BN, int WGM, int WGN, int NSTAGE>
+// LEAN = 1: the strip is allocated BM+2 rows (the tail DMA runs with 16 active lanes) and the prologue's row table aliases the
+// last ring stage (free until the first loop iteration): 128x64 / 2 stages = 81,280 B, i.e. TWO blocks per CU for the N = 64 layers.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE, int LEAN = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_strip_kernel(ConvParams p) {
     static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 waves");
     static_assert(NSTAGE >= 2 && NSTAGE <= 3, "2..3 stages");
@@ -29,7 +31,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_strip_kernel(ConvParam
     constexpr int B_IT = BN * 8 / NT;
     static_assert(TM >= 1 && TN >= 1 && B_IT >= 1, "tile too small for the wave layout");
     constexpr int LOADS = A_FULL + 3 * B_IT;                    // per wave per stage (wave 0: + 1)
-    constexpr int A_ROWS = BM + 8;                              // strip rows allocated (tail instruction writes 8 rows)
+    constexpr int A_ROWS = LEAN ? BM + 2 : BM + 8;              // strip rows allocated (the tail instruction writes 8 rows, or 2 with 16 active lanes)
     constexpr int A_BYTES = A_ROWS * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + 3 * B_BYTES, PIPE_BYTES = NSTAGE * STAGE_BYTES;
     constexpr int EP_LD = BN + 4, WROWS = 32 * TM;
     constexpr int EP_BUDGET = PIPE_BYTES > 69632 ? PIPE_BYTES : 69632;
@@ -38,7 +40,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_strip_kernel(ConvParam
     constexpr int EP_ROWS = WROWS * WPP, EP_PASSES = WGM / WPP;
     static_assert(WGM % WPP == 0, "epilogue passes");
     constexpr int TABLE_BYTES = (BM + 8) * 8;                   // strip-row table of the prologue
-    constexpr int LDS_BYTES = (PIPE_BYTES > EP_ROWS * EP_LD * 4 ? PIPE_BYTES : EP_ROWS * EP_LD * 4) + TABLE_BYTES;
+    constexpr int LDS_BYTES = (PIPE_BYTES > EP_ROWS * EP_LD * 4 ? PIPE_BYTES : EP_ROWS * EP_LD * 4) + (LEAN ? 0 : TABLE_BYTES);
+    static_assert(!LEAN || (TABLE_BYTES <= STAGE_BYTES && NSTAGE == 2), "lean: the table lives in ring stage 1");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     constexpr int CHUNKS = BN / 8, ITEMS = EP_ROWS * CHUNKS, IPT = (ITEMS + NT - 1) / NT;
     constexpr int EXTRA = 2 + EP_PASSES * IPT;                  // ordinary loads behind the prologue stages (bias + residual)
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_strip_kernel(ConvParam
         }
         if (wave == 0) {                                        // tail: strip rows BM .. BM+7 (BM, BM+1 are real)
             const half_t* src = ((abits[A_FULL] >> kh_i) & 1u) ? arow[A_FULL] + a_off : zero;
-            SM_GLDS16(src, st + A_FULL * NT * 16);
+            if (!LEAN || lane < 16) SM_GLDS16(src, st + A_FULL * NT * 16);   // lean: only the 2 real rows are written
         }
 #pragma unroll
         for (int kw = 0; kw < 3; kw++)
