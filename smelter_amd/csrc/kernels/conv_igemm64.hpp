@@ -258,7 +258,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
             for (int q = 0; q < 4; q++) {
                 const int co = ntile * BN + (wn * TN + a) * 32 + 8 * q + 4 * (lane >> 5);
                 floatx4 v = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias && p.splitk == 1 && !fastep) {
+                if (p.bias && p.splitk == 1 && !fastep && kgrp == 0) {      // (K groups: the partial sums are added, the bias enters once)
                     if (bias_vec) v = *(const floatx4*)(p.bias + min(co, p.Cout - 4));   // couts >= Cout are never stored
                     else for (int r = 0; r < 4; r++) if (co + r < p.Cout) v[r] = p.bias[co + r];
                 }

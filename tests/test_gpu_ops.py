@@ -84,6 +84,31 @@ def test_conv2d(case, cfg):
     assert_close(to_host(y), ref, cin * k * k)
 
 
+@pytest.mark.parametrize("cfg", list(range(60)))
+def test_conv2d_generic_epilogue_every_config(cfg):
+    """Tanh is not a ReLU-family activation, so every kernel takes its GENERIC epilogue (bias-initialised accumulators, per-element
+    activation) instead of the straight-line fast path the ResNet cases exercise; Cin % 64 == 0 so that all BK=64 configs apply.
+    (Caught: K-group configs added the bias once per group on this path.)"""
+    if cfg >= ops.num_conv_configs():
+        pytest.skip("no such config")
+    rng = np.random.default_rng(77)
+    n, hh, ww, cin, cout, k = 2, 10, 9, 128, 72, 3
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, k, k, cin)) * np.sqrt(1.0 / (cin * k * k)))
+    b = rng.standard_normal(cout).astype(np.float32)
+    r = h(rng.standard_normal((n, cout, hh, ww)))
+    ref = np.tanh(O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1)) + r)
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), residual=to_dev(r), stride=(1, 1), pads=(1, 1, 1, 1),
+                       act=ops.ACT_CODES["tanh"], cfg=cfg)
+    except SmelterError as e:
+        if "does not apply" in e.detail:
+            pytest.skip(e.detail)
+        raise
+    assert_close(to_host(y), ref, cin * k * k)
+
+
 def test_conv2d_split_k_workspace():
     n, cin, cout = 64, 2048, 1000                       # the ResNet-50 FC: M = 64 cannot fill 256 CUs without split-K
     rng = np.random.default_rng(5)
