@@ -122,6 +122,31 @@ def test_conv2d_split_k_workspace():
     assert_close(to_host(y), O.conv2d(x, w, b), cin)
 
 
+@pytest.mark.parametrize("cfg", list(range(60)))
+def test_conv2d_split_k_every_config(cfg):
+    """few tiles + long K + a workspace: the launcher splits K across blocks (fp32 partials + reduce kernel) for every tile config
+    that has a split-K form; residual + ReLU are then applied by the reduce kernel"""
+    if cfg >= ops.num_conv_configs():
+        pytest.skip("no such config")
+    rng = np.random.default_rng(91)
+    n, hh, ww, cin, cout, k = 1, 6, 5, 512, 64, 3            # M = 30: one pixel tile; K = 4608
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, k, k, cin)) * np.sqrt(2.0 / (cin * k * k)))
+    b = rng.standard_normal(cout).astype(np.float32)
+    r = h(rng.standard_normal((n, cout, hh, ww)))
+    ref = np.maximum(O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1)) + r, 0)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device="cuda")
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), residual=to_dev(r), stride=(1, 1), pads=(1, 1, 1, 1),
+                       act=1, cfg=cfg, workspace=ws)
+    except SmelterError as e:
+        if "does not apply" in e.detail:
+            pytest.skip(e.detail)
+        raise
+    assert_close(to_host(y), ref, cin * k * k)
+
+
 def test_conv2d_writes_into_concat_slice_and_reads_from_one():
     rng = np.random.default_rng(7)
     x = h(rng.standard_normal((2, 16, 9, 9)))
