@@ -91,6 +91,9 @@ int sm_conv2d_fwd_ws(const sm_conv_desc* d, const void* x, const void* w_ohwi, c
                      const void* residual, void* y, void* workspace, size_t workspace_bytes, sm_stream_t stream);
 /* force a tile configuration (tuning / tests); cfg < 0 restores the heuristic.  Returns the number of configs. */
 int sm_conv2d_num_configs(void);
+/* 1 if this shape runs through a tile configuration (so `cfg` of sm_conv2d_fwd_cfg matters and autotuning it makes sense), 0 if a
+ * dedicated kernel takes it (depthwise, thin pointwise, direct).  Assumes 16-byte aligned operands. */
+int sm_conv2d_uses_tile_config(const sm_conv_desc* d);
 int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias,
                       const void* residual, void* y, void* workspace, size_t workspace_bytes, sm_stream_t stream);
 

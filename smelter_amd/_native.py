@@ -55,6 +55,7 @@ SYMBOLS = {
     "smelter_version": (C.c_char_p, []),
     "sm_conv2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     "sm_conv2d_workspace_bytes": (_sz, [C.POINTER(ConvDesc)]),
+    "sm_conv2d_uses_tile_config": (_i32, [C.POINTER(ConvDesc)]),
     "sm_conv2d_fwd_ws": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sm_conv2d_num_configs": (_i32, []),
     "sm_conv2d_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

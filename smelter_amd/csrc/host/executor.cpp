@@ -467,15 +467,7 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
     sm_stream_t ss = (sm_stream_t)s;
     switch (op.kind) {
     case OpKind::Conv: case OpKind::FullyConnected: {
-        const Value& iv = values_[op.inputs[0]];
-        sm_conv_desc d{};
-        d.N = batch_; d.Cin = op.cin; d.Cout = op.cout; d.kH = op.kh; d.kW = op.kw; d.sH = op.sh; d.sW = op.sw; d.dH = op.dh; d.dW = op.dw;
-        d.pt = op.pt; d.pl = op.pl; d.pb = op.pb; d.pr = op.pr; d.groups = op.groups; d.act = op.act; d.slope = op.slope;
-        if (op.kind == OpKind::Conv) { d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.x_ld = valueLd(op.inputs[0]); }
-        else { d.H = d.W = d.Ho = d.Wo = 1; d.x_ld = st.fc_h * st.fc_w > 1 ? op.cin : valueLd(op.inputs[0]); }   // flattened map: one dense row per image
-        if (st.stem) { d.H = stem_h_; d.W = stem_w_; d.x_ld = 8; }                                             // row-pair image
-        if (op.grid_h) { d.Ho = op.grid_h; d.Wo = op.grid_w; d.y_sH = op.y_sh; d.y_sW = op.y_sw; d.y_oH = op.y_oh; d.y_oW = op.y_ow; d.y_H = op.y_h; d.y_W = op.y_w; }   // ConvTranspose phase
-        d.y_ld = y_ld; d.res_ld = op.residual >= 0 ? valueLd(op.residual) : 0;
+        const sm_conv_desc d = convDesc(st);
         return sm_conv2d_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
                                  op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, st.join >= 0 ? nullptr : ws_, st.join >= 0 ? 0 : ws_bytes_, ss);   // the split-K scratch belongs to the main branch
     }
@@ -525,6 +517,20 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
     case OpKind::Alias: return SM_OK;
     }
     return SM_OK;
+}
+
+// the kernel-level descriptor of a Conv / FullyConnected step
+sm_conv_desc Executor::convDesc(const Step& st) const {
+    const Op& op = st.op; const Value& ov = values_[op.output]; const Value& iv = values_[op.inputs[0]];
+    sm_conv_desc d{};
+    d.N = batch_; d.Cin = op.cin; d.Cout = op.cout; d.kH = op.kh; d.kW = op.kw; d.sH = op.sh; d.sW = op.sw; d.dH = op.dh; d.dW = op.dw;
+    d.pt = op.pt; d.pl = op.pl; d.pb = op.pb; d.pr = op.pr; d.groups = op.groups; d.act = op.act; d.slope = op.slope;
+    if (op.kind == OpKind::Conv) { d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.x_ld = valueLd(op.inputs[0]); }
+    else { d.H = d.W = d.Ho = d.Wo = 1; d.x_ld = st.fc_h * st.fc_w > 1 ? op.cin : valueLd(op.inputs[0]); }   // flattened map: one dense row per image
+    if (st.stem) { d.H = stem_h_; d.W = stem_w_; d.x_ld = 8; }                                             // row-pair image
+    if (op.grid_h) { d.Ho = op.grid_h; d.Wo = op.grid_w; d.y_sH = op.y_sh; d.y_sW = op.y_sw; d.y_oH = op.y_oh; d.y_oW = op.y_ow; d.y_H = op.y_h; d.y_W = op.y_w; }   // ConvTranspose phase
+    d.y_ld = valueLd(op.output); d.res_ld = op.residual >= 0 ? valueLd(op.residual) : 0;
+    return d;
 }
 
 // application image (NCHW fp32) -> the layout the first layer reads
@@ -660,6 +666,7 @@ int Executor::autotune(hipStream_t s) {
     for (size_t i = 0; i < steps_.size() && !rc; i++) {
         Step& st = steps_[i];
         if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8)) continue;
+        if (st.op.kind != OpKind::ConvTranspose) { const sm_conv_desc cd = convDesc(st); if (!sm_conv2d_uses_tile_config(&cd)) continue; }   // dedicated kernel, nothing to tune
         // one config: `reps` timed launches after an untimed first one (code fetch); returns false if the config does not apply
         auto timeCfg = [&](int c, int reps, std::vector<float>& samples) -> bool {
             st.conv_cfg = c; samples.clear();

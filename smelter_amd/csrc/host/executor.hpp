@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "graph.hpp"
+#include "../../../include/smelter_hip.h"
 
 namespace smelter {
 
@@ -75,6 +76,7 @@ class Executor {
     int plan(ONNXGraph& g, int batch);                   // fusion + placement + memory plan + arena layout
     int packWeights(std::vector<uint8_t>* host) const;   // fold/cast/pad -> arena image
     int launchStep(const Step& st, hipStream_t s) const;
+    sm_conv_desc convDesc(const Step& st) const;
     int convertInput(hipStream_t s, const float* in) const;
     int launchAll(hipStream_t s, const float* in) const;
     int autotune(hipStream_t s);

@@ -467,6 +467,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 
 #include "conv_igemm64.hpp"
 #include "conv3x3_strip.hpp"
+#include "pw_thin.hpp"
 
 // 3x3 depthwise through LDS (the MobileNet-v2 path): the register-strip kernel above re-reads every input pixel 4.5x through
 // L1/L2 and needs 227 VGPRs (1.2..2 TB/s of algorithmic bytes).  Here a block owns a tile of TH x TW output pixels x `cbv`
@@ -755,6 +756,10 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         }
         SM_LAUNCH_CHECK(); return SM_OK;
     }
+    if (pw_thin_eligible(d, p)) {                                    // thin pointwise layers: untiled streaming kernel (pw_thin.hpp), no tile config
+        pw_thin_launch(p, s);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
     if (!mfma_eligible(d, p)) {
         long work = (long)p.M * p.Cout;
         hipLaunchKernelGGL(conv_direct_kernel, dim3(sm_stream_grid(work, 256)), dim3(256), 0, s, p, d->groups);
@@ -838,6 +843,17 @@ int sm_conv_transpose2d_fwd(const sm_conv_desc* d, const void* x, const void* w,
     SM_REQUIRE(!p.yplace, "sm_conv_transpose2d_fwd: output placement not supported");
     hipLaunchKernelGGL(convt_direct_kernel, dim3(sm_stream_grid((long)p.M * p.Cout, 256)), dim3(256), 0, sm_s(stream), p);
     SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+// 1 if the launch of this shape goes through a tile configuration (sm_conv2d_fwd_cfg's `cfg` matters), 0 if a dedicated kernel
+// (depthwise, thin pointwise, direct) takes it; operands are assumed 16-byte aligned, as in the executor's arenas.
+int sm_conv2d_uses_tile_config(const sm_conv_desc* d) {
+    if (!d) return 0;
+    ConvParams p; alignas(16) static char dummy[16];
+    if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
+    if (d->groups > 1 && d->groups == d->Cin && d->groups == d->Cout) return 0;
+    if (pw_thin_eligible(d, p)) return 0;
+    return mfma_eligible(d, p) ? 1 : 0;
 }
 
 // Times `iters` back-to-back launches with HIP events on `stream` (host launch cost is hidden once the queue is full).

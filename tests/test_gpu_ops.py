@@ -84,6 +84,38 @@ def test_conv2d(case, cfg):
     assert_close(to_host(y), ref, cin * k * k)
 
 
+@pytest.mark.parametrize("cin,cout,res,act", [
+    (16, 96, False, "relu"),       # MobileNet-v2 expand: one k step, 1.5 passes of 64 couts
+    (24, 144, False, "relu"),      # Cin not a multiple of 16: the second k step is half empty
+    (32, 16, False, "none"),       # projection: Cout < 64, no activation
+    (144, 24, True, "none"),       # nine k steps, residual
+    (176, 64, True, "prelu"),      # eleven of the twelve instantiated k steps, one full pass
+    (96, 24, False, "tanh"),       # activation outside the ReLU family
+])
+def test_pointwise_thin_kernel(cin, cout, res, act, monkeypatch):
+    """pw_thin.hpp: untiled streaming kernel for 1x1 / stride 1 layers with Cin % 64 != 0, Cin <= 192 and M >= 8192 (ragged M here)"""
+    monkeypatch.setenv("SMELTER_PW_THIN_RES", "1")         # the residual form is kept correct although the graph path does not select it
+    rng = np.random.default_rng(cin * 1000 + cout)
+    n, hh, ww = 3, 61, 47                                  # M = 8601 = 268 * 32 + 25
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, 1, 1, cin)) * np.sqrt(2.0 / cin))
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv2d(x, w, b)
+    r = h(rng.standard_normal(ref.shape)) if res else None
+    if res:
+        ref = ref + r
+    code = ops.ACT_CODES[act]
+    slope = 0.25 if act == "prelu" else 0.0
+    if act in ("relu", "prelu"):
+        ref = np.where(ref >= 0, ref, ref * slope)
+    elif act == "tanh":
+        ref = np.tanh(ref)
+    d = ops.ConvDesc(n, hh, ww, cin, cout, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, hh, ww, code, slope, 0, 0, 0)
+    assert ops.lib().sm_conv2d_uses_tile_config(__import__("ctypes").byref(d)) == 0      # the dedicated kernel takes this shape
+    y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), residual=to_dev(r) if res else None, act=code, slope=slope)
+    assert_close(to_host(y), ref, cin)
+
+
 @pytest.mark.parametrize("cfg", list(range(60)))
 def test_conv2d_generic_epilogue_every_config(cfg):
     """Tanh is not a ReLU-family activation, so every kernel takes its GENERIC epilogue (bias-initialised accumulators, per-element
