@@ -29,6 +29,16 @@ __device__ __attribute__((aligned(64))) unsigned int g_zero_page[64];   // zero-
 #define SM_GLDS16(gptr, ldsptr)                                                                             \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
                                      (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
+// experiment switches (make EXTRA=-DSM_A_NT=2 / -DSM_B_NT=2): cache policy of the activation / weight LDS-DMA (aux 2 = nt)
+#ifndef SM_A_NT
+#define SM_A_NT 0
+#endif
+#ifndef SM_B_NT
+#define SM_B_NT 0
+#endif
+#define SM_GLDS16_AUX(gptr, ldsptr, AUX)                                                                    \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
+                                     (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, AUX)
 
 #ifdef SM_TIMELINE   // diagnostic build (make EXTRA="-DSM_ABLATION -DSM_TIMELINE"): per-block phase timestamps
 // slot 0: wall clock at start, slots 1..13: clock64() at SM_TL(0..12), slot 15: wall clock at the end (SM_TL_END)
@@ -178,8 +188,8 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
         if (i < A_IT) {
             if (ABL == 3 && issued >= NSTAGE - 1) return;       // ablation: no activation traffic after the prologue
             const half_t* src = (amask[i] & tapbit) ? arow[i] + a_off : zero;
-            SM_GLDS16(src, sa + i * NLT * 16);
-        } else SM_GLDS16(brow[i - A_IT] + b_off, sa + A_BYTES + (i - A_IT) * NLT * 16);
+            SM_GLDS16_AUX(src, sa + i * NLT * 16, SM_A_NT);
+        } else SM_GLDS16_AUX(brow[i - A_IT] + b_off, sa + A_BYTES + (i - A_IT) * NLT * 16, SM_B_NT);
     };
     auto advance = [&]() {
         b_off += 64;
