@@ -129,6 +129,18 @@ def test_branch_concurrency_schedule_is_the_same_function():
     assert not any("side-stream" in ex0.opDesc(i) for i in range(ex0.numOps))
 
 
+@pytest.mark.parametrize("name,hw,bs", [("resnet50", (96, 160), 5), ("mobilenet_v2", (128, 96), 16), ("unet", (96, 64), 9)])
+def test_autotuned_executor_at_odd_shapes_matches_the_oracle(name, hw, bs):
+    """the autotuner picks other tile configs (loader-wave, K-group, strip ...) at other shapes than the fixed-shape tests see;
+    tools/autotune_parity_sweep.py is the long form of this"""
+    make = {"resnet50": zoo.resnet50, "mobilenet_v2": zoo.mobilenet_v2, "unet": zoo.unet}[name]
+    model = make(hw=hw)
+    x = zoo.synthetic_images(bs, 3, hw, seed=bs)
+    _, got = run_hip(model, x, autotune=True)
+    ref = O.Graph(model).run(x[:2])
+    assert nerr(got[:2], ref) <= 5e-3
+
+
 def test_batch_shard_outputs_equal_the_unsharded_run():
     # SURVEY.md §4 "multi-GPU" row on one GPU: images [lo,hi) run as their own executor == rows [lo,hi) of the full batch
     from smelter_amd.dist import shard_range
