@@ -66,12 +66,15 @@ constexpr int sm_pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; retur
 // MFMA as in the 4-wave configs: LDS time 768 instead of 896 clk per 128x128x64 tile by the DESIGN 4.1b model) while 8 waves
 // hide each other's LDS latency, and there is ONE barrier per KS tiles.  The KS partial accumulators meet in the fp32 staging
 // buffers of the epilogue (one region per group, summed by the store pass in a fixed order).
-template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0, int NLW = 0, int KS = 1>
+// KT = K tiles per ring stage (default KS).  KS = 1, KT = 2: every wave multiplies both tiles of a stage — BK = 128 per barrier: half
+// the barriers / counted waits per K tile for the one-block-per-CU layers, at twice the stage size.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0, int NLW = 0, int KS = 1, int KT = KS>
 __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kernel(ConvParams p) {
     static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 MFMA waves per group");
     static_assert(NSTAGE >= 1 && NSTAGE <= 4, "1..4 stages");
     static_assert(NLW == 0 || (ILV == 0 && NSTAGE >= 2), "loader waves: no interleaved issue, >= 2 stages");
     static_assert(KS == 1 || (KS == 2 && NLW == 0 && ILV == 0 && ABL == 0 && NSTAGE >= 2), "K groups: plain issue only");
+    static_assert(KT == KS || (KS == 1 && KT == 2 && ILV == 0 && ABL == 0 && NSTAGE >= 2), "two tiles per stage: plain issue only");
     constexpr int NGW = WGM * WGN;                              // waves per K group
     constexpr int NCW = NGW * KS;                               // consumer (MFMA) waves
     constexpr int NT = (NCW + NLW) * 64;                        // threads per block
@@ -80,8 +83,8 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
     constexpr int A_IT = BM * 8 / NLT, B_IT = BN * 8 / NLT;    // 16-byte pieces per loader thread per K tile
     constexpr int RPI = NLT / 8;                                // tile rows covered by one DMA instruction of all loader waves
     static_assert(A_IT >= 1 && B_IT >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
-    constexpr int LOADS = KS * (A_IT + B_IT);                   // LDS-DMA instructions per wave per stage
-    constexpr int A_BYTES = BM * 128, SUB_BYTES = (BM + BN) * 128, STAGE_BYTES = KS * SUB_BYTES, PIPE_BYTES = NSTAGE * STAGE_BYTES;
+    constexpr int LOADS = KT * (A_IT + B_IT);                   // LDS-DMA instructions per wave per stage
+    constexpr int A_BYTES = BM * 128, SUB_BYTES = (BM + BN) * 128, STAGE_BYTES = KT * SUB_BYTES, PIPE_BYTES = NSTAGE * STAGE_BYTES;
     // epilogue staging (fp32): WPP wave-rows of 32*TM pixels per pass, one region per K group
     constexpr int EP_LD = BN + 4, WROWS = 32 * TM;
     constexpr int EP_MIN = KS == 2 ? 139264 : 69632;
@@ -105,7 +108,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
     const int ktiles = p.K >> 6;
     int kt_end = kt_begin + p.ktiles_per_split; if (kt_end > ktiles) kt_end = ktiles;
     const int nk = kt_end - kt_begin;                           // K tiles of this block
-    const int nit = (nk + KS - 1) / KS;                         // ring stages (= loop iterations)
+    const int nit = (nk + KT - 1) / KT;                         // ring stages (= loop iterations)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform -> LDS bases live in SGPRs
@@ -200,12 +203,12 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
     };
     auto issue = [&](int slot) {
 #pragma unroll
-        for (int sub = 0; sub < KS; sub++) {
+        for (int sub = 0; sub < KT; sub++) {
             if (is_loader) {
 #pragma unroll
                 for (int i = 0; i < A_IT + B_IT; i++) piece(slot, i, sub);
             }
-            if (KS == 1) advance();
+            if (KT == 1) advance();
             else if (ktq + 1 < nk) { advance(); ++ktq; }        // an odd tail re-fetches the last K tile (never multiplied)
         }
     };
@@ -286,8 +289,8 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
     // ILV = 1: a VMEM instruction stalls its wave while the address queue is full, so the LOADS DMA instructions of the
     // next tile are spread between the MFMAs of this one instead of being issued as one burst (mainloop.hip: +5 % for the
     // 8-wave 128x128 tile, +26 % for 256x128; no gain for 4-wave tiles)
-    auto compute = [&](int slot, int dslot, bool dma) {
-        const unsigned sA = slot * STAGE_BYTES + kgrp * SUB_BYTES + wm * (TM * 4096), sB = slot * STAGE_BYTES + kgrp * SUB_BYTES + A_BYTES + wn * (TN * 4096);
+    auto compute = [&](int slot, int dslot, bool dma, int sub = 0) {
+        const unsigned sA = slot * STAGE_BYTES + (kgrp + sub) * SUB_BYTES + wm * (TM * 4096), sB = slot * STAGE_BYTES + (kgrp + sub) * SUB_BYTES + A_BYTES + wn * (TN * 4096);
         half8_t fx[2][TM], fw[2][TN];
 #pragma unroll
         for (int b = 0; b < TM; b++) fx[0][b] = *(const half8_t*)(smem_raw + sA + voff[0] + b * 4096);
@@ -352,7 +355,8 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
 #endif
         const bool more = issued < nit && ABL != 2;
         if (!ILV && more) issue(islot);
-        if (is_consumer && (KS == 1 || KS * i + kgrp < nk)) compute(slot, islot, more);
+        if (is_consumer && (KT == 1 || KT * i + kgrp < nk)) compute(slot, islot, more);
+        if (KT > KS && is_consumer && KT * i + 1 < nk) compute(slot, islot, more, 1);       // second K tile of the stage (KS = 1, KT = 2)
         if (more) { ++issued; if (++islot == NSTAGE) islot = 0; }
         if (++slot == NSTAGE) slot = 0;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's fragment reads are done before it passes the next barrier
