@@ -17,7 +17,11 @@ IFS=$'\n'; SETS=(
 "TCP_TCP_TA_DATA_STALL_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
 "TCP_GATE_EN1_sum TCP_GATE_EN2_sum"
 "TA_FLAT_READ_LDS_WAVEFRONTS_sum TA_FLAT_WAVEFRONTS_sum"
+"TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_LFIFO_STALL_CYCLES_sum"
+"TCP_RFIFO_STALL_CYCLES_sum TCP_TCR_RDRET_STALL_sum"
+"TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum"
 ); unset IFS
+if [ -n "$PMC_ONLY_LAST" ]; then SETS=("${SETS[@]: -$PMC_ONLY_LAST}"); fi
 for ctr in "${SETS[@]}"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/p$i -o p -- python $ROOT/tools/conv_bench.py --shape $SHAPE --cfg $CFG --iters 3 > $OUT/p$i.log 2>&1
