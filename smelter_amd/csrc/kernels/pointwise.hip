@@ -188,6 +188,40 @@ __global__ __launch_bounds__(256) void gap_kernel(const half_t* x, half_t* y, in
     if (pl == 0 && c < C) y[(long)n * y_ld + c] = (half_t)((part[0][c & 63] + part[1][c & 63] + part[2][c & 63] + part[3][c & 63]) / (float)HW);
 }
 
+// same, 8 channels (16 bytes) per thread: block = (image, group of 64 channel vectors = 512 channels), 4 pixel lanes; the sums are
+// formed in the same order per channel as in gap_kernel (pixel lanes p = pl, pl+4, ..., then lane 0+1+2+3), so results are identical
+__global__ __launch_bounds__(256) void gap_vec8_kernel(const half_t* x, half_t* y, int HW, int C, int x_ld, int y_ld) {
+    const int cv = C >> 3, vblocks = (cv + 63) / 64, n = blockIdx.x / vblocks, vb = blockIdx.x % vblocks;
+    const int v = vb * 64 + (threadIdx.x & 63), pl = threadIdx.x >> 6;
+    __shared__ float part[4][64][8];
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (v < cv) {
+        const half_t* src = x + (long)n * HW * x_ld + v * 8;
+        // 8 loads in flight per thread (a rolled loop pays one memory latency per pixel: 13 x ~0.5 us for a 7x7 map); the additions
+        // stay in pixel order
+        for (int p0 = pl; p0 < HW; p0 += 32) {
+            half8_t t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int p = p0 + 4 * u; t[u] = *(const half8_t*)(src + (long)(p < HW ? p : pl) * x_ld); }
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (p0 + 4 * u < HW) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) s[j] += (float)t[u][j];
+                }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) part[pl][threadIdx.x & 63][j] = s[j];
+    __syncthreads();
+    if (pl == 0 && v < cv) {
+        half8_t o; const int l = threadIdx.x & 63;
+#pragma unroll
+        for (int j = 0; j < 8; j++) o[j] = (half_t)((part[0][l][j] + part[1][l][j] + part[2][l][j] + part[3][l][j]) / (float)HW);
+        *(half8_t*)(y + (long)n * y_ld + v * 8) = o;
+    }
+}
+
 // ---- MPSCNNUpsamplingNearestNode / MPSCNNUpsamplingBilinearNode (:524, :531) ---------------------------
 template <int V>
 __global__ void upsample_kernel(const half_t* x, half_t* y, int N, int H, int W, int C, int sy, int sx, int bilinear, int align, int x_ld, int y_ld) {
@@ -317,6 +351,10 @@ int sm_avgpool2d(const sm_pool_desc* d, const void* x, void* y, sm_stream_t st) 
 int sm_global_avgpool(const void* x, void* y, int32_t N, int32_t HW, int32_t C, int32_t x_ld, int32_t y_ld, sm_stream_t st) {
     SM_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, "sm_global_avgpool: bad argument");
     x_ld = x_ld ? x_ld : C; y_ld = y_ld ? y_ld : C;
+    if (vec8(C, {x_ld, y_ld}, {x, y})) {                            // 16-byte loads: 64 channel vectors x 4 pixel lanes per block
+        hipLaunchKernelGGL(gap_vec8_kernel, dim3(N * ((C / 8 + 63) / 64)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, HW, C, x_ld, y_ld);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
     hipLaunchKernelGGL(gap_kernel, dim3(N * ((C + 63) / 64)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, HW, C, x_ld, y_ld);
     SM_LAUNCH_CHECK(); return SM_OK;
 }
