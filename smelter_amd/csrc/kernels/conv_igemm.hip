@@ -293,7 +293,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec8_kernel(ConvParams p) {
         const long m = i / cv; const int co = (int)(i - m * cv) * 8;
         const float* src = p.ws + m * p.Cout + co;
         floatx4 a0 = *(const floatx4*)src, a1 = *(const floatx4*)(src + 4);
-        for (int s = 1; s < p.splitk; s++) { a0 += *(const floatx4*)(src + (long)s * total); a1 += *(const floatx4*)(src + (long)s * total + 4); }
+        // four splits' loads in flight at a time (a rolled loop pays one memory latency per split); additions stay in split order
+        int sp = 1;
+        for (; sp + 3 < p.splitk; sp += 4) {
+            floatx4 u0[4], u1[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) { u0[q] = *(const floatx4*)(src + (long)(sp + q) * total); u1[q] = *(const floatx4*)(src + (long)(sp + q) * total + 4); }
+#pragma unroll
+            for (int q = 0; q < 4; q++) { a0 += u0[q]; a1 += u1[q]; }
+        }
+        for (; sp < p.splitk; sp++) { a0 += *(const floatx4*)(src + (long)sp * total); a1 += *(const floatx4*)(src + (long)sp * total + 4); }
         float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         if (p.bias) { const floatx4 b0 = *(const floatx4*)(p.bias + co), b1 = *(const floatx4*)(p.bias + co + 4);
 #pragma unroll
