@@ -91,6 +91,7 @@ def test_conv2d(case, cfg):
     (144, 24, True, "none"),       # nine k steps, residual
     (176, 64, True, "prelu"),      # eleven of the twelve instantiated k steps, one full pass
     (96, 24, False, "tanh"),       # activation outside the ReLU family
+    (144, 128, False, "relu"),     # largest weight image the kernel accepts: 74 KB of dynamic LDS (> 64 KB)
 ])
 def test_pointwise_thin_kernel(cin, cout, res, act, monkeypatch):
     """pw_thin.hpp: untiled streaming kernel for 1x1 / stride 1 layers with Cin % 64 != 0, Cin <= 192 and M >= 8192 (ragged M here)"""
