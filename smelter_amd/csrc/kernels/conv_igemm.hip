@@ -648,6 +648,7 @@ const TileCfg kCfgs[] = {
     {128, 64, 3, 512, conv3x3_strip_kernel<128, 64, 4, 2, 3>, "strip w8s3:128x64"},                   // 57
     {256, 32, 3, 256, conv3x3_strip_kernel<256, 32, 4, 1, 3>, "strip s3:256x32"},                     // 58
     {128, 128, 3, 256, conv3x3_strip_kernel<128, 128, 2, 2, 2>, "strip w4:128x128"},                  // 59
+    {128, 32, 3, 256, conv3x3_strip_kernel<128, 32, 4, 1, 2>, "strip w4:128x32"},                     // 60  (59 KB: two blocks per CU)
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},

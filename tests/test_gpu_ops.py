@@ -56,7 +56,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg", [None] + list(range(60)))
+@pytest.mark.parametrize("cfg", [None] + list(range(61)))
 def test_conv2d(case, cfg):
     n, hh, ww, cin, cout, k, s, p, res, act = case
     if cfg is not None and (cin % 8 or cfg >= ops.num_conv_configs() or (cfg >= 6 and cin % 64)):
@@ -117,7 +117,7 @@ def test_pointwise_thin_kernel(cin, cout, res, act, monkeypatch):
     assert_close(to_host(y), ref, cin)
 
 
-@pytest.mark.parametrize("cfg", list(range(60)))
+@pytest.mark.parametrize("cfg", list(range(61)))
 def test_conv2d_generic_epilogue_every_config(cfg):
     """Tanh is not a ReLU-family activation, so every kernel takes its GENERIC epilogue (bias-initialised accumulators, per-element
     activation) instead of the straight-line fast path the ResNet cases exercise; Cin % 64 == 0 so that all BK=64 configs apply.
@@ -155,7 +155,7 @@ def test_conv2d_split_k_workspace():
     assert_close(to_host(y), O.conv2d(x, w, b), cin)
 
 
-@pytest.mark.parametrize("cfg", list(range(60)))
+@pytest.mark.parametrize("cfg", list(range(61)))
 def test_conv2d_split_k_every_config(cfg):
     """few tiles + long K + a workspace: the launcher splits K across blocks (fp32 partials + reduce kernel) for every tile config
     that has a split-K form; residual + ReLU are then applied by the reduce kernel"""
