@@ -748,7 +748,8 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
             if (cvt <= CB_N) cbv = cvt;
             else { cbv = 0; for (int q = 8; q <= CB_N; q += 8) if (cvt % q == 0) cbv = q; if (!cbv) for (int q = 1; q <= CB_N; q++) if (cvt % q == 0) cbv = q; }
             const bool wide = cbv <= CB_W && !narrow;
-            const int TH = S == 1 ? 8 : 4, TW = wide ? 16 : 8;
+            const bool big = cbv <= 4 && p.Wo >= 32 && p.Ho >= 16;   // few channels (first MobileNet layers): 4x larger tiles, 4x fewer blocks
+            const int TH = big ? (S == 1 ? 16 : 8) : (S == 1 ? 8 : 4), TW = big ? (S == 1 ? 32 : 16) : (wide ? 16 : 8);
             const int cblocks = cvt / cbv;
             const int tiles_y = sm_ceil_div(p.Ho, TH), tiles_x = sm_ceil_div(p.Wo, TW);
             const long blocks = (long)p.N * tiles_y * tiles_x * cblocks;
@@ -756,7 +757,9 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
             const int IH = (TH - 1) * S + 3, IW = (TW - 1) * S + 3;
             const size_t lds = ((size_t)IH * IW * cbv * 16 + 1023) / 1024 * 1024;
             const dim3 grid((unsigned)blocks);
-            if (S == 1 && wide) hipLaunchKernelGGL((dwconv3x3_lds_kernel<1, 8, 16, 12>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
+            if (big && S == 1) hipLaunchKernelGGL((dwconv3x3_lds_kernel<1, 16, 32, 4>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
+            else if (big) hipLaunchKernelGGL((dwconv3x3_lds_kernel<2, 8, 16, 4>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
+            else if (S == 1 && wide) hipLaunchKernelGGL((dwconv3x3_lds_kernel<1, 8, 16, 12>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
             else if (S == 1) hipLaunchKernelGGL((dwconv3x3_lds_kernel<1, 8, 8, 24>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
             else if (wide) hipLaunchKernelGGL((dwconv3x3_lds_kernel<2, 4, 16, 6>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
             else hipLaunchKernelGGL((dwconv3x3_lds_kernel<2, 4, 8, 18>), grid, dim3(256), lds, s, p, cbv, tiles_x, tiles_y, cblocks);
