@@ -28,6 +28,9 @@ def init_from_env(backend: str = None):
     import torch.distributed as dist
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if os.environ.get("SMELTER_FORCE_LOCAL0"):        # dry run of the multi-rank path on a one-GPU box: every rank uses device 0
+        local = 0
+    backend = backend or os.environ.get("SMELTER_DIST_BACKEND")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

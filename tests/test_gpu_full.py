@@ -63,3 +63,23 @@ def test_mobilenet_v2_bs256_and_unet_bs16_run_and_are_deterministic():
         assert nerr(a[:1], sub) <= 5e-3
         del ex
         torch.cuda.empty_cache()
+
+
+def test_bench_multi_rank_path_dry_run_on_one_gpu():
+    """bench.py's N > 1 path (one process per rank, rank 0 packs, weight-arena broadcast, external arena, barrier + max-over-ranks
+    timing) run as two ranks that share device 0 over gloo — the launch line is the driver's, RCCL is the only part not exercised"""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SMELTER_FORCE_LOCAL0="1", SMELTER_DIST_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--no-autotune", "--no-roofline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["scaling"] == "weak" and d["value"] > 0
