@@ -95,7 +95,11 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
     static_assert(WGM % WPP == 0, "epilogue passes");
     // + 8 bytes per tile row at the very end: the row table of the prologue (never touched by the ring or the staging)
     constexpr int EP_REGION = EP_ROWS * EP_LD;                  // floats per K group
-    constexpr int LDS_BYTES = (PIPE_BYTES > KS * EP_REGION * 4 ? PIPE_BYTES : KS * EP_REGION * 4) + BM * 8;
+    // TABLE_ALIAS: the row table of the prologue lives in the tail of the ring (an extra barrier separates its last reader from the
+    // first DMA) instead of behind it, when those BM*8 bytes decide whether a second block fits the CU (256x64, two stages: 80 KB)
+    constexpr int RING_OR_EP = PIPE_BYTES > KS * EP_REGION * 4 ? PIPE_BYTES : KS * EP_REGION * 4;
+    constexpr bool TABLE_ALIAS = RING_OR_EP <= 80 * 1024 && RING_OR_EP + BM * 8 > 80 * 1024;
+    constexpr int LDS_BYTES = RING_OR_EP + (TABLE_ALIAS ? 0 : BM * 8);
     static_assert(LDS_BYTES <= 160 * 1024, "LDS");
     static_assert((NSTAGE - 1) * LOADS <= 63, "vmcnt range");
     __shared__ __attribute__((aligned(16))) unsigned char smem_raw[LDS_BYTES];
@@ -161,6 +165,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
         const int2 ri = ((const int2*)(smem_raw + LDS_BYTES - BM * 8))[j * RPI + (ltid >> 3)];
         arow[j] = p.x + (long)ri.x * p.x_ld + csrc * 8; amask[j] = (unsigned)ri.y;
     }
+    if (TABLE_ALIAS) __syncthreads();                           // every thread has its rows before the ring (which holds the table) fills
     SM_TL(2);
     const half_t* brow[B_IT];
 #pragma unroll
