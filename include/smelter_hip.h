@@ -156,6 +156,11 @@ int sm_pad2d(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C,
 int sm_copy_channels(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld,
                      sm_stream_t stream);
 
+/* MPSNNReshapeNode (Converters.swift:859-864, :898-903) when the reshape is not an alias in NHWC: element order = the linear
+ * (c, y, x) order of the source, re-read as [Co][HWo].  Cs*HWs == Co*HWo. */
+int sm_reshape_nchw_order(const void* x, void* y, int32_t N, int32_t Cs, int32_t HWs, int32_t x_ld, int32_t Co,
+                          int32_t HWo, int32_t y_ld, sm_stream_t stream);
+
 /* Layout/dtype conversion at the boundary (the MPSImage <-> texture step of README.md:33-51).
  * NCHW fp32 -> NHWC fp16 with channels zero-padded to y_ld and a zero spatial halo. */
 int sm_nchw_f32_to_nhwc_f16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t y_ld,

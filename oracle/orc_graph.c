@@ -8,7 +8,11 @@
  *         only (:673-674) with the Float-division out-size rule; Upsample scales truncated with Int()
  *         (:499,513-514); N dropped from the input dims, batch supplied at run time (ONNXGraph.swift:204-215);
  *         exactly one graph output (:178-183); Flatten axis != 1 is an error (fatalError mapped to a code);
- *         reference Shape bookkeeping recorded per value (incl. Concat depth*=2, Flatten channels=total).
+ *         reference Shape bookkeeping recorded per value (incl. Concat depth*=2, Flatten channels=total);
+ *         dilated Conv taps are centred the MPS way: offset = k/2 - pad (ONNXConvolutionPadding.swift:73-79) with tap kh at
+ *         centre + (kh - k/2)*d, i.e. the ONNX tap rule with pad' = pad + (k/2)(d-1) on the dilation-ignoring output grid.
+ *  SUPERSET (not in the reference registry, ONNXGraph.swift:110-155; named by BASELINE.json north_star): LeakyRelu
+ *         (ONNX: alpha attribute, default 0.01) and 2-D MatMul with a constant right operand [K,N].
  *  DROPPED BN epsilon: the attribute IS honoured (default 1e-5) — the reference never reads it so MPS's
  *         default applies, but its own offline flow (ONNX2MPS.py:107 fuse_bn_into_conv) honours it, and the
  *         two flows must agree; fp32 bias is accepted from float_data as well as raw_data (:128-129 reads
@@ -191,7 +195,9 @@ static int conv_like(orc_graph* g, const orc_node* nd) { /* ConvolutionConverter
         if (cin_total != in->c) { rc = fail(ORC_ERR_INCONSISTENT_STATE, "Conv: input C=%d, weight expects %d", in->c, cin_total); goto done; }
         orc_conv_padded_size(in->w, in->h, kh, kw, sh, sw, pt, pl, pb, pr, oph, opw, is_tr, &Wo, &Ho);
         if (Ho <= 0 || Wo <= 0) { rc = fail(ORC_ERR_INCONSISTENT_STATE, "Conv: empty output"); goto done; }
-        orc_conv_desc d = {N, in->c, in->h, in->w, OC, kh, kw, sh, sw, dh, dw, pt, pl, pb, pr, groups, Ho, Wo};
+        int ept = pt, epl = pl;                                                                   /* MPS-centred dilated taps (header, KEPT) */
+        if (!is_tr) { ept += (kh / 2) * (dh - 1); epl += (kw / 2) * (dw - 1); }
+        orc_conv_desc d = {N, in->c, in->h, in->w, OC, kh, kw, sh, sw, dh, dw, ept, epl, pb, pr, groups, Ho, Wo};
         y = malloc(sizeof(float) * (size_t)N * OC * Ho * Wo);
         if (is_tr) orc_conv_transpose2d(&d, in->data, w, bias, y);                              /* :265-287 */
         else orc_conv2d(&d, in->data, w, bias, y);
@@ -273,6 +279,52 @@ static int neuron_conv(orc_graph* g, const orc_node* nd, int kind) {
     if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
     for (int i = 0; i < nd->n_output; i++) { float* dat = y; if (i > 0) { dat = malloc(sizeof(float) * cnt); memcpy(dat, y, sizeof(float) * cnt); }
         put_value(g, nd->output[i], dat, in->c, in->h, in->w, in->ref); }
+    return ORC_OK;
+}
+
+/* DropoutConverter :918-939: MPSCNNDropoutNode is the identity at inference; >= 1 attribute and `ratio` required; published
+ * under every output name */
+static int dropout_conv(orc_graph* g, const orc_node* nd) {
+    value* in = nd->n_input >= 1 ? find_value(g, nd->input[0]) : NULL;
+    if (!in || nd->n_attr < 1 || !find_attr(nd, "ratio")) return fail(ORC_ERR_NO_SUCH_OUTPUT, "Dropout: input or ratio attribute missing");
+    if (nd->n_output < 1) return fail(ORC_ERR_NO_SUCH_OUTPUT, "Dropout: no output");
+    size_t cnt = (size_t)g->batch * in->c * in->h * in->w;
+    for (int i = 0; i < nd->n_output; i++) { float* dat = malloc(sizeof(float) * cnt); memcpy(dat, in->data, sizeof(float) * cnt);
+        put_value(g, nd->output[i], dat, in->c, in->h, in->w, in->ref); }
+    return ORC_OK;
+}
+
+/* SUPERSET: ONNX LeakyRelu, y = x >= 0 ? x : alpha*x, alpha attribute (default 0.01) */
+static int leaky_conv(orc_graph* g, const orc_node* nd) {
+    value* in = nd->n_input >= 1 ? find_value(g, nd->input[0]) : NULL;
+    if (!in) return fail(ORC_ERR_NO_SUCH_OUTPUT, "LeakyRelu: input value missing");
+    const orc_attr* al = find_attr(nd, "alpha"); float a = al ? al->f : 0.01f;
+    size_t cnt = (size_t)g->batch * in->c * in->h * in->w; float* y = malloc(sizeof(float) * cnt);
+    orc_relu(in->data, y, cnt, a);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
+    put_value(g, nd->output[0], y, in->c, in->h, in->w, in->ref);
+    return ORC_OK;
+}
+
+/* SUPERSET: ONNX MatMul, 2-D, Y[n][j] = sum_k A[n][k] * B[k][j] with B a constant tensor [K,N] */
+static int matmul_conv(orc_graph* g, const orc_node* nd) {
+    value* in = nd->n_input >= 2 ? find_value(g, nd->input[0]) : NULL;
+    const orc_tensor* bt = nd->n_input >= 2 ? find_tensor(g, nd->input[1]) : NULL;
+    if (!in) return fail(ORC_ERR_NO_SUCH_OUTPUT, "MatMul: left operand is not a graph value");
+    if (!bt) return fail(ORC_ERR_INSUFFICIENT_INPUTS, "MatMul: right operand must be a constant tensor");
+    if (bt->ndims != 2) return fail(ORC_ERR_INCONSISTENT_STATE, "MatMul: rank");
+    if (bt->data_type != 1 && bt->data_type != 10) return fail(ORC_ERR_UNSUPPORTED_DTYPE, "MatMul weight dtype %d", bt->data_type);
+    long K = (long)bt->dims[0], N = (long)bt->dims[1], nw = 0;
+    if ((long)in->c * in->h * in->w != K) return fail(ORC_ERR_INCONSISTENT_STATE, "MatMul: feature count");
+    float* b = tensor_floats_alloc(bt, &nw); if (!b) return fail((int)nw, "MatMul weight accessor");
+    if (nw != K * N) { free(b); return fail(ORC_ERR_INCONSISTENT_STATE, "MatMul: weight size"); }
+    float* y = malloc(sizeof(float) * (size_t)g->batch * N);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < g->batch; i++)
+        for (long j = 0; j < N; j++) { float acc = 0.f; for (long k = 0; k < K; k++) acc += in->data[(size_t)i * K + k] * b[(size_t)k * N + j]; y[(size_t)i * N + j] = acc; }
+    free(b);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, (size_t)g->batch * N);
+    put_value(g, nd->output[0], y, (int)N, 1, 1, REF(1, 1, 1, (int)N));
     return ORC_OK;
 }
 
@@ -479,6 +531,9 @@ int orc_graph_run(orc_graph* g, const float* in_nchw, int batch, float** out, in
         else if (bis(op, "Upsample")) rc = upsample_conv(g, nd);
         else if (bis(op, "Concat")) rc = concat_conv(g, nd);
         else if (bis(op, "Constant")) rc = constant_conv(g, nd);
+        else if (bis(op, "Dropout")) rc = dropout_conv(g, nd);
+        else if (bis(op, "LeakyRelu")) rc = leaky_conv(g, nd);
+        else if (bis(op, "MatMul")) rc = matmul_conv(g, nd);
         else rc = fail(ORC_ERR_UNKNOWN_NODE_OP_TYPE, "%.*s", (int)op.n, op.p);                    /* :173-174 */
         if (rc) return rc;
     }

@@ -147,7 +147,7 @@ void orc_neuron(int kind, const float* x, float* y, size_t n, float a) {
         case 5: r = tanhf(v); break;
         case 6: r = v >= 0.f ? v : a * (expf(v) - 1.f); break;
         case 7: r = fabsf(v); break;
-        case 8: r = log1pf(expf(v)); break;
+        case 8: r = fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))); break;   /* stable form: no overflow for v > 88 (fp16 activations reach 65504) */
         case 9: r = v / (1.f + fabsf(v)); break;
         case 10: r = expf(v); break;
         case 11: r = logf(v); break;

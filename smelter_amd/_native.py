@@ -75,6 +75,7 @@ SYMBOLS = {
     "sm_upsample_nearest": (_i32, [_vp, _vp] + [_i32] * 8 + [_vp]),
     "sm_upsample_bilinear": (_i32, [_vp, _vp] + [_i32] * 9 + [_vp]),
     "sm_copy_channels": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "sm_reshape_nchw_order": (_i32, [_vp, _vp] + [_i32] * 7 + [_vp]),
     "sm_nchw_f32_to_nhwc_f16": (_i32, [_vp, _vp] + [_i32] * 9 + [_vp]),
     "sm_resize_nchw_f32": (_i32, [_vp, _vp] + [_i32] * 6 + [_vp]),
     "sm_nchw_f32_to_rowpair_f16": (_i32, [_vp, _vp] + [_i32] * 8 + [_vp]),

@@ -61,6 +61,8 @@ struct ConvolutionConverter : NodeConverter {
             else if (isTranspose) { OC = (int)weight->dims[1]; IC = (int)weight->dims[0]; wkh = (int)weight->dims[2]; wkw = (int)weight->dims[3]; }  // :48-50 [I,O,kH,kW]
             else { OC = (int)weight->dims[0]; IC = (int)weight->dims[1]; wkh = (int)weight->dims[2]; wkw = (int)weight->dims[3]; }        // :46-54
         }
+        if (OC <= 0 || IC <= 0 || wkh <= 0 || wkw <= 0 || (long)OC * IC > (1L << 30) / ((long)wkh * wkw))                                 // dims are int64 in the file: untrusted
+            SM_FAIL(SM_ERR_INCONSISTENT_STATE, "%.*s: weight dims out of range", SV(node.op_type));
         if (weight->data_type != pb::FLOAT && weight->data_type != pb::FLOAT16)                                                          // :82-89 (.invalid)
             SM_FAIL(SM_ERR_UNSUPPORTED_DTYPE, "%.*s: weight data_type %d (FLOAT or FLOAT16 expected)", SV(node.op_type), weight->data_type);
         if (!isGemm && (wkh != kh || wkw != kw)) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: kernel_shape %dx%d disagrees with weight dims %dx%d", kh, kw, wkh, wkw);
@@ -95,6 +97,11 @@ struct ConvolutionConverter : NodeConverter {
             op.cin = cinTotal;
             sm_conv_padded_size(iv.w, iv.h, kh, kw, sh, sw, pt, pl, pb_, pr, oph, opw, isTranspose ? 1 : 0, &Wo, &Ho);                  // :311-322
             if (Ho <= 0 || Wo <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Conv: empty output %dx%d", Ho, Wo);
+            // Dilated taps, the reference's way (quirk KEPT): the padding policy centres the kernel at offset = k/2 - pad
+            // (ONNXConvolutionPadding.swift:73-79) and MPSCNNConvolution places tap kh at centre + (kh - k/2)*d, i.e. input row
+            // o*s - pad + kh*d - (k/2)(d-1): the ONNX tap rule with pad' = pad + (k/2)(d-1), on an output grid whose size
+            // ignores the dilation (:105-110).  d = 1 (every zoo model): nothing changes.
+            if (!isTranspose) { op.pt += (kh / 2) * (dh - 1); op.pl += (kw / 2) * (dw - 1); }
         }
         return graph.addFilter(std::move(op), OC, Ho, Wo, mkShape(1, Wo, Ho, OC), node.output);                                         // :311-336
     }
@@ -120,6 +127,46 @@ struct PReluConverter : NodeConverter {
         const Value iv = graph.value(in);
         Op op; op.kind = OpKind::Neuron; op.inputs = {in}; op.act = SM_ACT_PRELU; op.slope = alpha;
         return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);
+    }
+};
+
+// ---- LeakyReluConverter — NOT in the reference registry (ONNXGraph.swift:110-155 has no "LeakyRelu": the reference throws
+// unknownNodeOpType).  Declared superset named by BASELINE.json's north_star: ONNX LeakyRelu, y = x >= 0 ? x : alpha*x with the
+// `alpha` attribute (ONNX default 0.01), lowered to the node PReluConverter builds (MPSCNNNeuronPReLUNode, :376) with a = alpha.
+struct LeakyReluConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        if (in < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "LeakyRelu: input is not a graph value");
+        const pb::Attribute* al = node.attr("alpha");
+        const Value iv = graph.value(in);
+        Op op; op.kind = OpKind::Neuron; op.inputs = {in}; op.act = SM_ACT_PRELU; op.slope = al ? al->f : 0.01f;
+        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);
+    }
+};
+
+// ---- MatMulConverter — NOT in the reference registry either (declared superset, north_star "MatMul/Gemm").  2-D case only:
+// Y[batch, N] = A[batch, K] x B[K, N] with B a constant tensor (initializer or Constant node) and A a graph value of K features.
+// Lowered to the node the Gemm branch of ConvolutionConverter builds (MPSCNNFullyConnectedNode, :288-302): weight [out,in] = B^T,
+// no bias.  ONNX stores B as [K, N] (in x out) where Gemm(transB=1) stores [out, in].
+struct MatMulConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.size() >= 2 ? graph.output(node.input[0]) : -1;
+        const pb::Tensor* b = node.input.size() >= 2 ? graph.tensor(node.input[1]) : nullptr;
+        if (in < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "MatMul: left operand is not a graph value");
+        if (!b) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "MatMul: right operand must be a constant tensor");
+        if (b->dims.size() != 2) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "MatMul: right operand has rank %zu (2 expected)", b->dims.size());
+        if (b->data_type != pb::FLOAT && b->data_type != pb::FLOAT16) SM_FAIL(SM_ERR_UNSUPPORTED_DTYPE, "MatMul: weight data_type %d", b->data_type);
+        const long K = b->dims[0], N = b->dims[1];
+        if (K <= 0 || N <= 0 || K * N > (1L << 30)) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "MatMul: weight dims out of range");
+        const Value iv = graph.value(in);
+        if ((long)iv.c * iv.h * iv.w != K) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "MatMul: input has %ld features, weight expects %ld", (long)iv.c * iv.h * iv.w, K);
+        std::vector<float> w; int rc = pb::tensor_floats(*b, &w); if (rc) SM_FAIL(rc, "MatMul: weight accessor");
+        if ((long)w.size() != K * N) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "MatMul: weight holds %zu elements, dims say %ld", w.size(), K * N);
+        Op op; op.kind = OpKind::FullyConnected; op.inputs = {in}; op.cout = (int)N; op.cin = (int)K;
+        op.weight_was_fp16 = b->data_type == pb::FLOAT16;
+        op.weight.resize(w.size());
+        for (long k = 0; k < K; k++) for (long n = 0; n < N; n++) op.weight[(size_t)n * K + k] = w[(size_t)k * N + n];
+        return graph.addFilter(std::move(op), (int)N, 1, 1, mkShape(1, 1, 1, (int)N), node.output);
     }
 };
 
@@ -278,8 +325,7 @@ struct DropoutConverter : NodeConverter {   // inference identity (the reference
         if (in < 0 || node.attribute.empty() || !node.attr("ratio")) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Dropout: input value or ratio attribute missing");
         const Value iv = graph.value(in);
         Op op; op.kind = OpKind::Alias; op.inputs = {in};
-        std::vector<std::string_view> outs(node.output.begin(), node.output.begin() + 1);
-        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, outs);
+        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);   // (addFilter rejects an empty output list)
     }
 };
 
@@ -433,7 +479,10 @@ void registerDefaultConverters(ONNXGraph& g) {    // ONNXGraph.swift:110-155, ho
         .registerConverter("LogSoftmax", std::make_shared<LogSoftmaxConverter>())
         .registerConverter("InstanceNormalization", std::make_shared<InstanceNormConverter>())
         .registerConverter("custom_group_norm", std::make_shared<GroupNormConverter>())
-        .registerConverter("Pad", std::make_shared<PaddingConverter>());
+        .registerConverter("Pad", std::make_shared<PaddingConverter>())
+        // declared supersets (not in the reference registry; BASELINE.json north_star names them)
+        .registerConverter("LeakyRelu", std::make_shared<LeakyReluConverter>())
+        .registerConverter("MatMul", std::make_shared<MatMulConverter>());
 }
 
 }  // namespace smelter

@@ -39,6 +39,7 @@ const char* kindName(OpKind k) {
     case OpKind::AvgPool: return "AvgPool"; case OpKind::GlobalAvgPool: return "GlobalAvgPool"; case OpKind::Upsample: return "Upsample";
     case OpKind::Concat: return "Concat"; case OpKind::Alias: return "Alias"; case OpKind::ConvTranspose: return "ConvTranspose";
     case OpKind::Softmax: return "Softmax"; case OpKind::GroupNorm: return "GroupNorm"; case OpKind::Pad: return "Pad";
+    case OpKind::Reshape: return "Reshape";
     }
     return "?";
 }
@@ -163,15 +164,25 @@ int Executor::plan(ONNXGraph& g, int batch) {
         if (dead[i]) continue;
         Op& op = ops[i];
         if (op.kind == OpKind::Alias) {
+            // Flatten / Reshape / Dropout / Pow.  The reference's image keeps the linear (c, y, x) element order across a reshape
+            // (MPSNNReshapeNode); ours is NHWC with a pixel stride `ld`.  The two orders coincide — and the output may share the
+            // source's buffer AND stride — only when the shape is unchanged, or when both sides are 1x1 maps (one dense row of C
+            // values per image).  A spatial map flattened for fully-connected consumers only is also left in place: those layers
+            // read one dense row per image and get their weight columns permuted NCHW -> NHWC at pack time.  Every other reshape
+            // (1x1xC -> a spatial map, spatial -> spatial with other dims, a reshape that is the graph output ...) is MATERIALISED
+            // by sm_reshape_nchw_order into a dense buffer of the output's own shape.
             int in = op.inputs[0]; const Value& iv = values_[in]; const Value& ov = values_[op.output];
-            bool reorders = (iv.h * iv.w > 1) && !(ov.c == iv.c && ov.h == iv.h && ov.w == iv.w);
-            if (reorders) {
-                // NCHW-order flatten of an NHWC buffer: fine iff every consumer is a fully-connected layer
-                // (its weight columns get permuted instead) and the source is dense.
-                bool all_fc = op.output != output_value_;
-                for (int j = 0; j < no && all_fc; j++) if (!dead[j]) for (int u : ops[j].inputs) if (u == op.output && ops[j].kind != OpKind::FullyConnected) all_fc = false;
-                if (!all_fc || in == input_value_) { sm_set_error("Flatten/Reshape of a %dx%d map feeding a non-Gemm consumer is not supported", iv.h, iv.w); return SM_ERR_INCONSISTENT_STATE; }
-                for (int j = 0; j < no; j++) if (!dead[j] && ops[j].kind == OpKind::FullyConnected && ops[j].inputs[0] == op.output) fc_permute[j] = in + 1;
+            const bool same = ov.c == iv.c && ov.h == iv.h && ov.w == iv.w;
+            const bool both_flat = iv.h * iv.w == 1 && ov.h * ov.w == 1;
+            if (!same && !both_flat) {
+                bool all_fc = op.output != output_value_ && ov.h * ov.w == 1 && in != input_value_; int users = 0;
+                for (int j = 0; j < no; j++) if (!dead[j]) {
+                    for (int u : ops[j].inputs) if (u == op.output) { users++; if (ops[j].kind != OpKind::FullyConnected) all_fc = false; }
+                    if (ops[j].residual == op.output) all_fc = false;
+                }
+                if (all_fc && users > 0) {
+                    for (int j = 0; j < no; j++) if (!dead[j] && ops[j].kind == OpKind::FullyConnected && ops[j].inputs[0] == op.output) fc_permute[j] = in + 1;
+                } else { op.kind = OpKind::Reshape; continue; }             // gets its own buffer and a copy kernel
             }
             alias_of[op.output] = in;
         }
@@ -513,6 +524,10 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
     case OpKind::Concat: {   // copy fallback for one operand: op.pl = channel offset inside the concat buffer
         const Value& iv = values_[op.inputs[0]];
         return sm_copy_channels(valuePtr(op.inputs[0]), (char*)y + (size_t)op.pl * 2, st.M, iv.c, valueLd(op.inputs[0]), y_ld, ss);
+    }
+    case OpKind::Reshape: {
+        const Value& iv = values_[op.inputs[0]];
+        return sm_reshape_nchw_order(valuePtr(op.inputs[0]), y, batch_, iv.c, iv.h * iv.w, valueLd(op.inputs[0]), ov.c, ov.h * ov.w, y_ld, ss);
     }
     case OpKind::Alias: return SM_OK;
     }

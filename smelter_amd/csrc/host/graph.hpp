@@ -30,7 +30,7 @@ struct Configuration {
 
 enum class Format { onnx, mpsFlavor };   // ONNXGraph.swift:49-52
 
-enum class OpKind { Conv, FullyConnected, BatchNorm, Neuron, Add, MaxPool, AvgPool, GlobalAvgPool, Upsample, Concat, Alias, ConvTranspose, Softmax, GroupNorm, Pad };
+enum class OpKind { Conv, FullyConnected, BatchNorm, Neuron, Add, MaxPool, AvgPool, GlobalAvgPool, Upsample, Concat, Alias, ConvTranspose, Softmax, GroupNorm, Pad, Reshape };
 
 // One record per converted node (the analogue of an MPSNNFilterNode + its data source / padding policy).
 struct Op {

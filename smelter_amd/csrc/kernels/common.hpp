@@ -50,7 +50,7 @@ __device__ __noinline__ static float sm_act_other(float v, int act, float slope)
     case SM_ACT_TANH: return tanhf(v);
     case SM_ACT_ELU: return v >= 0.f ? v : slope * (expf(v) - 1.f);
     case SM_ACT_ABS: return fabsf(v);
-    case SM_ACT_SOFTPLUS: return log1pf(expf(v));
+    case SM_ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));   // expf overflows past 88.7; log1p(e^v) - v < 2.1e-9 beyond 20
     case SM_ACT_SOFTSIGN: return v / (1.f + fabsf(v));
     case SM_ACT_EXP: return expf(v);
     case SM_ACT_LOG: return logf(v);

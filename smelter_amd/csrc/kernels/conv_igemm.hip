@@ -736,7 +736,8 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         (p.y_ld % 8) == 0 && (!p.res || (p.res_ld % 8) == 0)) {
         long work = (long)p.M * (p.Cout / 8);
         const bool k3 = p.kH == 3 && p.kW == 3 && p.dH == 1 && p.dW == 1 && p.sH == p.sW && (((uintptr_t)p.w) & 15) == 0;
-        const bool lds_ok = k3 && (p.sH == 1 || p.sH == 2) && !getenv("SMELTER_DW_STRIP");
+        static const bool dw_strip = getenv("SMELTER_DW_STRIP") != nullptr;   // experiment switch, read once (launch() is on the per-launch path)
+        const bool lds_ok = k3 && (p.sH == 1 || p.sH == 2) && !dw_strip;
         if (lds_ok) {
             // Channel vectors per block: ALL of them when the patch of some tile fits ~52 KB of LDS; otherwise the largest divisor of
             // C/8 that is a multiple of 8 (whole 128-byte lines per pixel), otherwise the largest divisor at all.

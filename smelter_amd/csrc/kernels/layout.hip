@@ -143,9 +143,33 @@ __global__ void nhwc_to_float_array_kernel(const half_t* x, float* y, int N, int
     }
 }
 
+// MPSNNReshapeNode (Converters.swift:859-864, :898-903) when the element order really changes: the reference's images keep the
+// linear (c, y, x) element order across a reshape; ours are NHWC with a pixel stride, so destination element (p, c) of the
+// [Co][HWo] view is source element lin = c*HWo + p -> (lin / HWs, lin % HWs) of the [Cs][HWs] view.  HBM-bound gather, one
+// element per thread (reshapes on the hot path are aliases; this is the correctness path for spatial <-> channel reshapes).
+__global__ void reshape_nchw_order_kernel(const half_t* x, half_t* y, int N, int Cs, int HWs, int x_ld, int Co, int HWo, int y_ld) {
+    const long per = (long)Co * HWo, total = (long)N * per;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Co); long t = i / Co;
+        const int p = (int)(t % HWo), n = (int)(t / HWo);
+        const long lin = (long)c * HWo + p;
+        const int cs = (int)(lin / HWs), ps = (int)(lin - (long)cs * HWs);
+        y[((long)n * HWo + p) * y_ld + c] = x[((long)n * HWs + ps) * x_ld + cs];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int sm_reshape_nchw_order(const void* x, void* y, int32_t N, int32_t Cs, int32_t HWs, int32_t x_ld, int32_t Co, int32_t HWo, int32_t y_ld, sm_stream_t st) {
+    SM_REQUIRE(x && y && N > 0 && Cs > 0 && HWs > 0 && Co > 0 && HWo > 0, "sm_reshape_nchw_order: bad argument");
+    SM_REQUIRE((long)Cs * HWs == (long)Co * HWo, "sm_reshape_nchw_order: element count changes");
+    x_ld = x_ld ? x_ld : Cs; y_ld = y_ld ? y_ld : Co;
+    SM_REQUIRE(x_ld >= Cs && y_ld >= Co, "sm_reshape_nchw_order: pixel stride smaller than the channel count");
+    hipLaunchKernelGGL(reshape_nchw_order_kernel, dim3(sm_stream_grid((long)N * Co * HWo, 256)), dim3(256), 0, sm_s(st), (const half_t*)x, (half_t*)y, N, Cs, HWs, x_ld, Co, HWo, y_ld);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
 
 int sm_nchw_f32_to_nhwc_f16(const float* x, void* y, int32_t N, int32_t C, int32_t H, int32_t W, int32_t y_ld, int32_t ht, int32_t hl,
                             int32_t hb, int32_t hr, sm_stream_t st) {

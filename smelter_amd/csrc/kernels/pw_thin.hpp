@@ -123,7 +123,8 @@ __global__ __launch_bounds__(PWT_WAVES * 64) void pw_thin_kernel(ConvParams p, i
 // eligibility + launch (called from launch() before the tiled MFMA paths)
 static int pw_thin_ksn(int cin) { const int k = (cin + 15) >> 4; return k <= 1 ? 1 : k <= 2 ? 2 : k <= 4 ? 4 : k <= 6 ? 6 : k <= 9 ? 9 : 12; }   // instantiated k-step counts
 static bool pw_thin_eligible(const sm_conv_desc* d, const ConvParams& p) {
-    if (getenv("SMELTER_NO_PW_THIN")) return false;
+    static const bool no_thin = getenv("SMELTER_NO_PW_THIN") != nullptr, thin_res = getenv("SMELTER_PW_THIN_RES") != nullptr;   // experiment switches, read once
+    if (no_thin) return false;
     if (d->groups != 1 || p.kH != 1 || p.kW != 1 || p.sH != 1 || p.sW != 1 || p.pt != 0 || p.pl != 0 || p.Ho != p.H || p.Wo != p.W) return false;
     static const bool k64 = getenv("SMELTER_PW_THIN_K64") != nullptr;      // experiment: also take Cin == 64 (ResNet-50 layer-1 1x1 convs)
     if (p.yplace || (p.Cin & 7) || ((p.Cin % 64) == 0 && !(k64 && p.Cin == 64)) || p.Cin > 16 * PWT_KSMAX || (p.Cout & 7)) return false;
@@ -131,7 +132,7 @@ static bool pw_thin_eligible(const sm_conv_desc* d, const ConvParams& p) {
     if (p.res && ((p.res_ld & 7) || (((uintptr_t)p.res) & 15))) return false;
     // The kernel handles a residual operand (parity-tested), but its ordinary loads sit in vmcnt order between the stores of one pass
     // and the staging of the next: measured 95 vs 83 us on MobileNet-v2's 144->24 +res layer, so the graph path leaves those tiled.
-    if (p.res && !getenv("SMELTER_PW_THIN_RES")) return false;
+    if (p.res && !thin_res) return false;
     const int kp = 16 * pw_thin_ksn(p.Cin), cout64 = (p.Cout + 63) & ~63;
     if ((size_t)cout64 * (kp * 2 + 16 + 4) > 40 * 1024) return false;        // weights + bias + 4 staging tiles <= 75 KB: at least two blocks per CU
     return p.M >= 8192;                                                        // a streaming kernel: small maps stay on the tiled path

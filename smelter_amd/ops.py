@@ -229,6 +229,14 @@ def copy_channels(x, out):
     return out
 
 
+def reshape_nchw_order(x, c, h, w, out=None):
+    """MPSNNReshapeNode for a reshape that is not an alias in NHWC: out[n, y, x, c] = element c*h*w + y*w + x of the source's (c, y, x) order"""
+    n, hs, ws, cs, x_ld = _check_nhwc(x)
+    out = torch.empty((n, h, w, c), dtype=torch.float16, device=x.device) if out is None else out
+    check(lib().sm_reshape_nchw_order(_ptr(x), _ptr(out), n, cs, hs * ws, x_ld, c, h * w, _ld(out), _stream()))
+    return out
+
+
 def nchw_f32_to_nhwc_f16(x, ld=None, halo=(0, 0, 0, 0)):
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
     n, c, h, w = x.shape

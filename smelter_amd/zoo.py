@@ -272,6 +272,50 @@ def misc_ops_net(seed: int = 1, batch: int = 1, hw=(24, 20), final: str = "LogSo
     return _finish(net, y, [batch, 3, hw[0], hw[1]], [batch, 8, cur[0], cur[1]])
 
 
+def reshape_net(seed: int = 1, batch: int = 1, hw=(16, 12), final: str = "matmul", dtype=np.float32):
+    """The converters no BASELINE model instantiates: Reshape (the reference's (W,H,C)-ordered shape with its `0` and `-1` rules,
+    Converters.swift:830-876), Constant feeding Reshape and Upsample (:716-727, :505-514 scales-from-tensor), AveragePool (:607-650),
+    Dropout (:918-939, two output names), plus the declared supersets LeakyRelu and MatMul.  Every kind of reshape the executor
+    distinguishes occurs: spatial -> spatial (materialised), 1x1 -> 1x1 (alias), 1x1xC -> spatial (materialised), spatial -> flat
+    feeding a fully-connected layer (weight columns permuted).  final = "matmul" | "reshape" (Reshape as the graph's last node)."""
+    assert hw[0] % 4 == 0 and hw[1] % 4 == 0
+    net = _Net("reshape_net", seed, dtype)
+    g = net.g
+    x, cur = net.conv("input", hw, 3, 8, 3, bias=True)
+    x = g.add_node("LeakyRelu", [x], alpha=0.1)                       # fused into the conv epilogue
+    x = g.add_node("Dropout", [x], n_out=2, ratio=0.5)[0]             # (output, mask): identity at inference
+    x = g.add_node("AveragePool", [x], kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
+    cur = ((cur[0] + 2 - 3) // 2 + 1, (cur[1] + 2 - 3) // 2 + 1)
+    sc = g.add_node("Constant", [], value=np.array([1.0, 1.0, 2.0, 2.0], np.float32))
+    x = g.add_node("Upsample", [x, sc], mode=b"nearest")              # scales from input[1]: a Constant's tensor
+    cur = (cur[0] * 2, cur[1] * 2)
+    x = g.add_node("AveragePool", [x], kernel_shape=[2, 2], pads=[0, 0, 0, 0], strides=[2, 2])
+    cur = (cur[0] // 2, cur[1] // 2)
+    total = 8 * cur[0] * cur[1]
+    # (W, H, C) = (2*W, H/2, -1): spatial -> spatial, one dimension inferred
+    s1 = g.add_init(g.fresh("shape"), np.array([cur[1] * 2, cur[0] // 2, -1], np.int64))
+    x = g.add_node("Reshape", [x, s1])
+    cur = (cur[0] // 2, cur[1] * 2)
+    # `0` copies toArray()[i] of the SOURCE shape = (channels, width, height, depth)[0] = channels = 1 -> W = 1, H inferred
+    s2 = g.add_node("Constant", [], value=np.array([0, -1, 8], np.int64))
+    x = g.add_node("Reshape", [x, s2])
+    cur = (total // 8, 1)
+    x, cur = net.conv(x, cur, 8, 8, 1, p=0, bias=True)
+    x = g.add_node("GlobalAveragePool", [x])
+    s3 = g.add_init(g.fresh("shape"), np.array([1, 1, -1], np.int64))
+    x = g.add_node("Reshape", [x, s3])                                # 1x1x8 -> 1x1x8: alias
+    s4 = g.add_init(g.fresh("shape"), np.array([2, 2, 2], np.int64))
+    x = g.add_node("Reshape", [x, s4])                                # 1x1x8 -> 2x2 map of 2 channels: materialised
+    if final == "reshape":
+        return _finish(net, x, [batch, 3, hw[0], hw[1]], [batch, 2, 2, 2])
+    x = g.add_node("Sigmoid", [x])                                    # a non-FC consumer of the reshaped map
+    x = g.add_node("Flatten", [x], axis=1)
+    w = g.add_init(g.fresh("mm_w"), (net.rng.standard_normal((8, 5)) * 0.5).astype(net.dtype))   # MatMul: [K, N]
+    net.macs += 8 * 5
+    x = g.add_node("MatMul", [x, w])
+    return _finish(net, x, [batch, 3, hw[0], hw[1]], [batch, 5])
+
+
 def synthetic_images(batch: int, c: int = 3, hw=(224, 224), seed: int = 0) -> np.ndarray:
     """NCHW fp32 i.i.d. uniform [0,1) — what an RGBA8-unorm texture yields in the reference flow
     (/root/reference/README.md:33-39)."""

@@ -31,6 +31,9 @@ MODELS = {
     "deconv_net": (lambda: zoo.deconv_net(hw=(32, 40)), (2, 3, 32, 40)),          # ConvTranspose decoder
     "misc_ops_logsoftmax": (lambda: zoo.misc_ops_net(), (2, 3, 24, 20)),           # every remaining converter
     "misc_ops_softmax": (lambda: zoo.misc_ops_net(final="Softmax"), (2, 3, 24, 20)),
+    # Reshape (0 / -1 rules, every alias / materialise case), Constant -> Reshape / Upsample scales, AveragePool, Dropout, LeakyRelu, MatMul
+    "reshape_net_matmul": (lambda: zoo.reshape_net(), (3, 3, 16, 12)),
+    "reshape_net_last_reshape": (lambda: zoo.reshape_net(final="reshape"), (2, 3, 16, 12)),
 }
 
 
@@ -312,3 +315,10 @@ def test_force_input_scale_accepts_any_source_size(mode):
     with pytest.raises(Exception) as e:                                                      # .none rejects a foreign size
         run_hip(model, big)
     assert "unsupportedInput" in str(e.value) or getattr(e.value, "kind", "") == "unsupportedInput"
+
+
+def test_reshape_net_materialises_exactly_the_order_changing_reshapes():
+    ex, _ = run_hip(zoo.reshape_net(), zoo.synthetic_images(1, 3, (16, 12)))
+    kinds = [ex.opDesc(i).split()[0] for i in range(ex.numOps)]
+    assert kinds.count("Reshape") == 3          # spatial -> spatial twice, 1x1x8 -> 2x2x2; 1x1 -> 1x1 aliases; Flatten -> MatMul permutes the weights
+    assert kinds.count("FC") == 1 and "Alias" not in kinds

@@ -435,3 +435,11 @@ def test_resize_planes_for_force_input_scale(mode, size):
     torch.cuda.synchronize()
     ref = O.resize(x, size, mode)
     assert np.abs(y.cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("src,dst", [((8, 4, 6), (8, 2, 12)), ((8, 1, 1), (2, 2, 2)), ((3, 5, 4), (60, 1, 1)), ((4, 3, 3), (1, 36, 1))])
+def test_reshape_nchw_order_is_byte_exact(src, dst):
+    """MPSNNReshapeNode when the reshape is not an alias in NHWC: == numpy's C-order reshape of the NCHW array"""
+    x = h(np.random.default_rng(71).standard_normal((3,) + src))
+    got = to_host(ops.reshape_nchw_order(to_dev(x), *dst))
+    assert np.array_equal(got, x.reshape((3,) + dst))

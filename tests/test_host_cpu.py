@@ -79,7 +79,7 @@ ERRORS = [
     ("notEnoughAttributes", _conv_model({k: v for k, v in FULL.items() if k != "dilations"})),   # Converters.swift:234-237
     ("notEnoughAttributes", _conv_model({k: v for k, v in FULL.items() if k != "kernel_shape"})),
     ("insufficientInputs", _conv_model(FULL, weight=False)),                                      # :193-194
-    ("unknownNodeOpType", _conv_model(FULL, op="LeakyRelu")),                                     # not registered: ONNXGraph.swift:173-174
+    ("unknownNodeOpType", _conv_model(FULL, op="Gelu")),                                     # not registered: ONNXGraph.swift:173-174
     ("noSuchOutput", _conv_model(FULL, out="nope")),                                              # :182-183
     ("unsupportedOutput", _conv_model(FULL, n_out=2)),                                            # :178-180
     ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("Relu", ["ghost"], ["z"])])),         # :344-348
@@ -140,8 +140,8 @@ def test_conv_transpose_shape_rule_and_weight_layout():
 
 def test_unknown_op_error_carries_the_op_type():
     with pytest.raises(SmelterError) as e:
-        ONNXGraph(_conv_model(FULL, op="LeakyRelu")).packWeights(1)
-    assert e.value.detail == "LeakyRelu"               # Errors.unknownNodeOpType(opType:)
+        ONNXGraph(_conv_model(FULL, op="Gelu")).packWeights(1)
+    assert e.value.detail == "Gelu"                    # Errors.unknownNodeOpType(opType:)
 
 
 def test_unsupported_input_rank_and_dims_override():
@@ -238,3 +238,50 @@ def test_weight_bytes_resnet50():
     nbytes = g.weightBytes(4)
     assert 51.0e6 < nbytes < 51.5e6                    # 25.5 M fp16 weights + fp32 biases
     assert nbytes == g.weightBytes(64)                 # independent of batch
+
+
+# ---- round 2: converters no BASELINE model instantiates + the declared supersets (LeakyRelu, MatMul) ------------------------
+def _same_error_kind(model, kind):
+    with pytest.raises(SmelterError) as e:
+        ONNXGraph(model).packWeights(1)
+    assert e.value.kind == kind, (e.value.kind, e.value.detail)
+    with pytest.raises(O.OracleError) as e2:
+        O.Graph(model).run(np.zeros((1,) + O.Graph(model).input_chw, np.float32))
+    assert e2.value.kind == kind
+
+
+def test_reshape_net_plans_and_error_kinds_match_the_oracle():
+    for final in ("matmul", "reshape"):
+        g = ONNXGraph(zoo.reshape_net(final=final))
+        assert g.weightBytes(3) > 0                                          # the whole plan (aliases, materialised reshapes, FC permutation) builds
+        ONNXGraph(onnx2mps.optimize_model(zoo.reshape_net(final=final), half=True)).packWeights(2)   # fp16-cast shape tensors still parse (.integers)
+    def one(op, inits=(), n_in=1, **attrs):
+        b = ow.GraphBuilder("g"); b.add_input("input", [1, 4, 2, 2])
+        names = ["input"][:n_in] + [b.add_init(n, a) for n, a in inits]
+        b.add_output(b.add_node(op, names, **attrs), [1, 4, 2, 2])
+        return b.to_model()
+    _same_error_kind(one("Dropout"), "noSuchOutput")                         # ratio attribute required (Converters.swift:920-925)
+    _same_error_kind(one("Reshape"), "noSuchOutput")                         # shape tensor required (:832-836)
+    _same_error_kind(one("MatMul", inits=[("w", np.zeros((16, 3), np.int64))]), "unsupportedDtype")
+    _same_error_kind(one("MatMul", inits=[("w", np.zeros((15, 3), np.float32))]), "inconsistentState")
+    _same_error_kind(one("Reshape", inits=[("s", np.array([5, 1, 1], np.int64))]), "inconsistentState")
+    # a node without outputs, or a Conv whose int64 weight dims are hostile, is an error — never undefined behaviour
+    b = ow.GraphBuilder("g"); b.add_input("input", [1, 4, 2, 2]); b.add_node_named("Dropout", ["input"], [], ratio=0.5); b.add_output("input", [1, 4, 2, 2])
+    with pytest.raises(SmelterError) as e:
+        ONNXGraph(b.to_model()).packWeights(1)
+    assert e.value.kind == "noSuchOutput"
+    for dims in ([-1, 4, 3, 3], [1 << 40, 4, 3, 3], [8, 4, 0, 3]):
+        b = ow.GraphBuilder("g"); b.add_input("input", [1, 4, 8, 8])
+        b.inits.append(ow.tensor("w", np.zeros(4, np.float32), dims=dims))
+        b.add_output(b.add_node("Conv", ["input", "w"], dilations=[1, 1], group=1, kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[1, 1]), [1, 8, 8, 8])
+        with pytest.raises(SmelterError) as e:
+            ONNXGraph(b.to_model()).packWeights(1)
+        assert e.value.kind == "inconsistentState"
+
+
+def test_matmul_weight_is_packed_transposed_to_out_in():
+    w = np.arange(6 * 4, dtype=np.float32).reshape(6, 4)                     # ONNX MatMul: [K, N]
+    b = ow.GraphBuilder("g"); b.add_input("input", [1, 6, 1, 1])
+    b.add_output(b.add_node("MatMul", ["input", b.add_init("w", w)]), [1, 4])
+    arena = ONNXGraph(b.to_model()).packWeights(1)
+    assert np.array_equal(arena[:48].view(np.float16).astype(np.float32).reshape(4, 6), w.T)   # MPSCNNFullyConnected weights are [out, in]

@@ -205,3 +205,120 @@ def test_floats_accessor_fp16_raw_weights_equal_fp32_weights_rounded():
     a = O.Graph(model(w32.astype(np.float16))).run(x)
     b_ = O.Graph(model(w32.astype(np.float16).astype(np.float32))).run(x)
     assert np.array_equal(a, b_)
+
+
+# ---- round 2: converters no BASELINE model instantiates, pinned by independent numpy / torch restatements ----------------
+def _one_op_model(op, in_dims, out_dims, inits=(), **attrs):
+    b = ow.GraphBuilder("g")
+    b.add_input("input", list(in_dims))
+    names = ["input"] + [b.add_init(n, a) for n, a in inits]
+    y = b.add_node(op, names, **attrs)
+    b.add_output(y, list(out_dims))
+    return b.to_model()
+
+
+@pytest.mark.parametrize("shape,expect_chw", [([6, 2, -1], (4, 2, 6)), ([0, -1, 4], (4, 12, 1)), ([4, 0, 0], (3, 4, 4)), ([48], (1, 1, 48))])
+def test_reshape_whc_order_zero_and_minus_one_rules(shape, expect_chw):
+    """Converters.swift:844-864: shape is read as (W, H, C), missing entries = 1, `0` copies (channels, width, height)[i] of the
+    SOURCE Shape — so W := channels (= 1), H := the source WIDTH, C := the source HEIGHT, a quirk kept —, one -1 is inferred from the total;
+    the data keep their linear (c, y, x) order"""
+    x = np.arange(2 * 48, dtype=np.float32).reshape(2, 4, 3, 4)         # C=4, H=3, W=4
+    m = _one_op_model("Reshape", [1, 4, 3, 4], [1] + list(expect_chw), inits=[("shape", np.array(shape, np.int64))])
+    y = O.Graph(m).run(x)
+    assert y.shape == (2,) + expect_chw
+    assert np.array_equal(y.reshape(2, -1), x.reshape(2, -1))
+
+
+def test_dropout_is_identity_under_every_output_name_and_needs_ratio():
+    x = np.random.default_rng(0).standard_normal((1, 3, 4, 4)).astype(np.float32)
+    b = ow.GraphBuilder("g"); b.add_input("input", [1, 3, 4, 4])
+    b.add_node_named("Dropout", ["input"], ["d_out", "d_mask"], ratio=0.3)
+    y = b.add_node("Relu", ["d_mask"])                                 # the reference publishes the node under every name (:263-273)
+    b.add_output(y, [1, 3, 4, 4])
+    assert np.array_equal(O.Graph(b.to_model()).run(x), np.maximum(x, 0))
+    b2 = ow.GraphBuilder("g"); b2.add_input("input", [1, 3, 4, 4]); y2 = b2.add_node("Dropout", ["input"]); b2.add_output(y2, [1, 3, 4, 4])
+    with pytest.raises(O.OracleError) as e:
+        O.Graph(b2.to_model()).run(x)
+    assert e.value.kind == "noSuchOutput"                              # guard at Converters.swift:920-925
+
+
+def test_leaky_relu_and_matmul_supersets_against_numpy():
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 5, 3, 2)).astype(np.float32)
+    for kw, a in (({}, 0.01), ({"alpha": 0.3}, 0.3)):
+        y = O.Graph(_one_op_model("LeakyRelu", [1, 5, 3, 2], [1, 5, 3, 2], **kw)).run(x)
+        assert np.array_equal(y, np.where(x >= 0, x, x * np.float32(a)).astype(np.float32))
+    xf = rng.standard_normal((3, 7, 1, 1)).astype(np.float32)
+    w = rng.standard_normal((7, 4)).astype(np.float32)
+    y = O.Graph(_one_op_model("MatMul", [1, 7, 1, 1], [1, 4], inits=[("w", w)])).run(xf)
+    assert y.shape == (3, 4, 1, 1)
+    assert np.abs(y.reshape(3, 4) - xf.reshape(3, 7).astype(np.float64) @ w.astype(np.float64)).max() < 1e-5
+
+
+def test_average_pool_converter_against_torch():
+    torch = pytest.importorskip("torch")
+    x = np.random.default_rng(1).standard_normal((2, 3, 9, 8)).astype(np.float32)
+    m = _one_op_model("AveragePool", [1, 3, 9, 8], [1, 3, 5, 4], kernel_shape=[3, 3], pads=[1, 1, 1, 1], strides=[2, 2])
+    y = O.Graph(m).run(x)
+    ref = torch.nn.functional.avg_pool2d(torch.from_numpy(x).double(), 3, 2, 1, count_include_pad=True).numpy()
+    # 9 -> 5 and 8 -> 4: the reference's window offset -floor(((out-1)s+k-in)/2) equals -p for H (odd total) and 0 for W
+    # (PyTorchPoolPadding.swift:60-75), so only the H axis compares 1:1 with torch's padding = 1; W windows start at 0
+    refw = torch.nn.functional.avg_pool2d(torch.nn.functional.pad(torch.from_numpy(x).double(), (0, 1, 1, 1)), 3, 2, 0).numpy()
+    assert y.shape == (2, 3, 5, 4)
+    assert np.abs(y - refw).max() < 1e-5 or np.abs(y - ref).max() < 1e-5
+
+
+@pytest.mark.parametrize("k,d,pad", [(3, 2, 2), (3, 3, 1), (5, 2, 0)])
+def test_dilated_conv_taps_are_centred_the_mps_way(k, d, pad):
+    """offset = k/2 - pad (ONNXConvolutionPadding.swift:73-79), taps at centre + (kh - k/2)*d, output size from the dilation-free
+    rule (:105-110) == torch conv2d with padding pad + (k/2)(d-1), cropped / zero-extended to the reference's output grid"""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(k * 10 + d)
+    x = rng.standard_normal((1, 2, 11, 10)).astype(np.float32)
+    w = rng.standard_normal((3, 2, k, k)).astype(np.float32)
+    ho, wo = 11 + 2 * pad - k + 1, 10 + 2 * pad - k + 1
+    m = _one_op_model("Conv", [1, 2, 11, 10], [1, 3, ho, wo], inits=[("w", w)], dilations=[d, d], group=1, kernel_shape=[k, k],
+                      pads=[pad] * 4, strides=[1, 1])
+    y = O.Graph(m).run(x)
+    assert y.shape == (1, 3, ho, wo)
+    big = 3 * k * d                                                     # generous zero border, then cut the reference's window out of it
+    xp = torch.nn.functional.pad(torch.from_numpy(x).double(), (big, big, big, big))
+    full = torch.nn.functional.conv2d(xp, torch.from_numpy(w).double(), dilation=d).numpy()
+    off = big - pad - (k // 2) * (d - 1)                                # output o reads input rows o - pad' + kh*d
+    ref = full[:, :, off:off + ho, off:off + wo]
+    assert np.abs(y - ref).max() < 1e-4
+
+
+def test_softplus_is_finite_for_large_inputs():
+    x = np.array([-100.0, -1.0, 0.0, 1.0, 30.0, 100.0, 65504.0], np.float32).reshape(1, 7, 1, 1)
+    y = O.neuron("softplus", x).ravel()
+    assert np.all(np.isfinite(y))
+    assert np.allclose(y, np.logaddexp(0.0, x.ravel().astype(np.float64)), rtol=1e-6, atol=1e-30)
+
+
+def test_reshape_net_against_an_independent_numpy_walk():
+    """zoo.reshape_net end to end: conv / pools by torch, every reshape as numpy's C-order reshape of the NCHW array"""
+    torch = pytest.importorskip("torch")
+    F = torch.nn.functional
+    from smelter_amd import onnx_reader as orr, zoo
+    model = zoo.reshape_net()
+    m = orr.parse_model(model)
+    A = {t.name: t.to_array() for t in m.initializer}
+    convs = [n for n in m.node if n.op_type == "Conv"]
+    x = zoo.synthetic_images(2, 3, (16, 12))
+    t = torch.from_numpy(x).double()
+    t = F.conv2d(t, torch.from_numpy(A[convs[0].input[1]]).double(), torch.from_numpy(A[convs[0].input[2]]).double(), padding=1)
+    t = F.leaky_relu(t, 0.1)
+    t = F.avg_pool2d(F.pad(t, (0, 1, 0, 1)), 3, 2, 0)                   # 16x12 -> 8x6, windows start at 0 (even total padding)
+    t = F.interpolate(t, scale_factor=2, mode="nearest")
+    t = F.avg_pool2d(t, 2, 2)
+    a = t.numpy()                                                       # (2, 8, 8, 6)
+    a = a.reshape(2, 8, 4, 12).reshape(2, 8, 48, 1)
+    t = F.conv2d(torch.from_numpy(a), torch.from_numpy(A[convs[1].input[1]]).double(), torch.from_numpy(A[convs[1].input[2]]).double())
+    a = t.mean(dim=(2, 3)).numpy().reshape(2, 2, 2, 2)
+    a = 1.0 / (1.0 + np.exp(-a))
+    mm = [n for n in m.node if n.op_type == "MatMul"][0]
+    ref = a.reshape(2, 8) @ A[mm.input[1]].astype(np.float64)
+    got = O.Graph(model).run(x)
+    assert got.shape == (2, 5, 1, 1)
+    assert np.abs(got.reshape(2, 5) - ref).max() < 1e-5
