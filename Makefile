@@ -29,6 +29,19 @@ $(LIB): $(OBJS)
 oracle:
 	$(MAKE) -s -C oracle liborc.so
 
+# CPU-only AddressSanitizer + UBSan build of the HOST sources (ONNX decoder, graph builder, converters, planner, weight packing):
+# ROCm's clang as a plain x86-64 compiler, kernel entry points stubbed (tools/asan/gen_stubs.py), never run on a GPU.
+# build/asan/host_fuzz (tools/asan/host_fuzz.cpp) runs model files + structured mutations through it; tests/test_sanitizer.py drives it.
+ASAN_BIN := build/asan/host_fuzz
+CLANGXX  ?= /opt/rocm/lib/llvm/bin/clang++
+asan: $(ASAN_BIN)
+$(ASAN_BIN): $(HOSTSRC) $(wildcard $(CSRC)/host/*.hpp) $(CSRC)/kernels/common.hpp include/smelter_hip.h tools/asan/gen_stubs.py tools/asan/host_fuzz.cpp
+	@mkdir -p build/asan
+	python3 tools/asan/gen_stubs.py build/asan/stubs.cpp
+	$(CLANGXX) -std=c++17 -g -O1 -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer \
+	    -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude -Wno-unused-result -Wno-deprecated-declarations \
+	    $(HOSTSRC) build/asan/stubs.cpp tools/asan/host_fuzz.cpp -o $@ -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,/opt/rocm/lib
+
 clean:
 	rm -rf build $(LIB); $(MAKE) -C oracle clean
-.PHONY: all oracle clean FORCE
+.PHONY: all oracle clean asan FORCE

@@ -73,6 +73,8 @@ long orc_tensor_floats(const orc_tensor* t, float* dst, size_t cap) { /* :36-62 
     }
 }
 
+/* Int(Float) truncates toward zero and traps on NaN / out-of-range (Swift); here: saturate, NaN -> 0 (a C cast would be undefined) */
+static int64_t trunc_i64(double v) { return v != v ? 0 : v >= 9.2233720368547748e18 ? INT64_MAX : v <= -9.2233720368547758e18 ? INT64_MIN : (int64_t)v; }
 long orc_tensor_integers(const orc_tensor* t, int64_t* dst, size_t cap) { /* :2-34; Int(Float) truncates toward 0 */
     switch (t->data_type) {
     case DT_INT32: case DT_INT16: case DT_INT8: case DT_UINT16: case DT_UINT8: case DT_BOOL:
@@ -84,11 +86,11 @@ long orc_tensor_integers(const orc_tensor* t, int64_t* dst, size_t cap) { /* :2-
     case DT_UINT32: case DT_UINT64: EMIT(t->n_uint64, (int64_t)t->uint64_data[i]);
     case DT_FLOAT:
         if (t->n_float == 0) { const uint8_t* p = t->raw_data.p; float v;                     /* :21-24 */
-            EMIT(t->raw_data.n / 4, (memcpy(&v, p + 4 * i, 4), (int64_t)v)); }
-        EMIT(t->n_float, (int64_t)t->float_data[i]);
-    case DT_DOUBLE: EMIT(t->n_double, (int64_t)t->double_data[i]);
+            EMIT(t->raw_data.n / 4, (memcpy(&v, p + 4 * i, 4), trunc_i64(v))); }
+        EMIT(t->n_float, trunc_i64(t->float_data[i]));
+    case DT_DOUBLE: EMIT(t->n_double, trunc_i64(t->double_data[i]));
     case DT_FLOAT16: { const uint8_t* p = t->raw_data.p; uint16_t h;                          /* :29-30 */
-        EMIT(t->raw_data.n / 2, (memcpy(&h, p + 2 * i, 2), (int64_t)orc_half_to_float(h))); }
+        EMIT(t->raw_data.n / 2, (memcpy(&h, p + 2 * i, 2), trunc_i64(orc_half_to_float(h)))); }
     default: return ORC_ERR_UNSUPPORTED_DTYPE;                                                /* :32 fatalError */
     }
 }

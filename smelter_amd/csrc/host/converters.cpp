@@ -22,6 +22,15 @@ namespace {
 #define SM_FAIL(code, ...) do { sm_set_error(__VA_ARGS__); return (code); } while (0)
 #define SV(s) (int)(s).size(), (s).data()
 
+// Every integer / float the converters take out of the file is untrusted: saturate to +-2^20 (no legitimate kernel size, stride,
+// pad, scale, group count or channel count is larger; NaN -> 0) so that a hostile value ends in an error code, never in
+// implementation-defined narrowing or signed overflow.  Products of two such values go through mulSat.
+constexpr int kIntCap = 1 << 20;
+int I(int64_t v) { return v > kIntCap ? kIntCap : v < -kIntCap ? -kIntCap : (int)v; }
+int I(double v) { return v != v ? 0 : v > kIntCap ? kIntCap : v < -kIntCap ? -kIntCap : (int)v; }
+int I(float v) { return I((double)v); }
+int mulSat(int a, int b) { const long r = (long)a * b; return r > INT32_MAX ? INT32_MAX : r < INT32_MIN ? INT32_MIN : (int)r; }
+
 Shape mkShape(int channels, int width, int height, int depth) { Shape s; s.channels = channels; s.width = width; s.height = height; s.depth = depth; return s; }
 
 // ---- ConvolutionConverter (Converters.swift:187-338) + ConvDataSource (:12-185) ----------------------------
@@ -38,12 +47,12 @@ struct ConvolutionConverter : NodeConverter {
         bool hasK = false, hasD = false, hasS = false;
         int kh = 0, kw = 0, dh = 1, dw = 1, sh = 1, sw = 1, groups = 1, pt = 0, pl = 0, pb_ = 0, pr = 0, oph = 0, opw = 0;
         for (auto& a : node.attribute) {                                                                                                // :208-225
-            if (a.name == "dilations" && a.ints.size() >= 2) { dh = (int)a.ints[0]; dw = (int)a.ints[1]; hasD = true; }
-            else if (a.name == "strides" && a.ints.size() >= 2) { sh = (int)a.ints[0]; sw = (int)a.ints[1]; hasS = true; }
-            else if (a.name == "group") groups = (int)a.i;
-            else if (a.name == "pads" && a.ints.size() >= 4) { pt = (int)a.ints[0]; pl = (int)a.ints[1]; pb_ = (int)a.ints[2]; pr = (int)a.ints[3]; }
-            else if (a.name == "kernel_shape" && a.ints.size() >= 2) { kh = (int)a.ints[0]; kw = (int)a.ints[1]; hasK = true; }
-            else if (a.name == "output_padding" && a.ints.size() >= 2) { oph = (int)a.ints[0]; opw = (int)a.ints[1]; }
+            if (a.name == "dilations" && a.ints.size() >= 2) { dh = I(a.ints[0]); dw = I(a.ints[1]); hasD = true; }
+            else if (a.name == "strides" && a.ints.size() >= 2) { sh = I(a.ints[0]); sw = I(a.ints[1]); hasS = true; }
+            else if (a.name == "group") groups = I(a.i);
+            else if (a.name == "pads" && a.ints.size() >= 4) { pt = I(a.ints[0]); pl = I(a.ints[1]); pb_ = I(a.ints[2]); pr = I(a.ints[3]); }
+            else if (a.name == "kernel_shape" && a.ints.size() >= 2) { kh = I(a.ints[0]); kw = I(a.ints[1]); hasK = true; }
+            else if (a.name == "output_padding" && a.ints.size() >= 2) { oph = I(a.ints[0]); opw = I(a.ints[1]); }
         }
         const bool isGemm = node.op_type == "Gemm", isTranspose = node.op_type == "ConvTranspose";
         if (isGemm) { kh = kw = dh = dw = sh = sw = 1; hasK = hasD = hasS = true; }                                                     // :228-232
@@ -54,12 +63,12 @@ struct ConvolutionConverter : NodeConverter {
         // ConvDataSource.init: channel/kernel extents from the weight dims (:35-54)
         const bool mps = graph.modelFormat == Format::mpsFlavor;
         int OC, IC, wkh, wkw;
-        if (isGemm) { if (weight->dims.size() < 2) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "Gemm: weight rank < 2"); OC = (int)weight->dims[0]; IC = (int)weight->dims[1]; wkh = wkw = 1; }
+        if (isGemm) { if (weight->dims.size() < 2) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "Gemm: weight rank < 2"); OC = I(weight->dims[0]); IC = I(weight->dims[1]); wkh = wkw = 1; }
         else {
             if (weight->dims.size() < 4) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "Conv: weight rank < 4");
-            if (mps) { OC = (int)weight->dims[0]; wkh = (int)weight->dims[1]; wkw = (int)weight->dims[2]; IC = (int)weight->dims[3]; }     // :40-44
-            else if (isTranspose) { OC = (int)weight->dims[1]; IC = (int)weight->dims[0]; wkh = (int)weight->dims[2]; wkw = (int)weight->dims[3]; }  // :48-50 [I,O,kH,kW]
-            else { OC = (int)weight->dims[0]; IC = (int)weight->dims[1]; wkh = (int)weight->dims[2]; wkw = (int)weight->dims[3]; }        // :46-54
+            if (mps) { OC = I(weight->dims[0]); wkh = I(weight->dims[1]); wkw = I(weight->dims[2]); IC = I(weight->dims[3]); }     // :40-44
+            else if (isTranspose) { OC = I(weight->dims[1]); IC = I(weight->dims[0]); wkh = I(weight->dims[2]); wkw = I(weight->dims[3]); }  // :48-50 [I,O,kH,kW]
+            else { OC = I(weight->dims[0]); IC = I(weight->dims[1]); wkh = I(weight->dims[2]); wkw = I(weight->dims[3]); }        // :46-54
         }
         if (OC <= 0 || IC <= 0 || wkh <= 0 || wkw <= 0 || (long)OC * IC > (1L << 30) / ((long)wkh * wkw))                                 // dims are int64 in the file: untrusted
             SM_FAIL(SM_ERR_INCONSISTENT_STATE, "%.*s: weight dims out of range", SV(node.op_type));
@@ -192,13 +201,13 @@ struct UpsampleConverter : NodeConverter {
         if (in < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Upsample: input is not a graph value");
         const pb::Attribute* mode = node.attr("mode"); const pb::Attribute* sc = node.attr("scales");
         bool have = false; int sy = 1, sx = 1;
-        if (sc && sc->floats.size() >= 4) { sy = (int)sc->floats[2]; sx = (int)sc->floats[3]; have = true; }                           // :499
+        if (sc && sc->floats.size() >= 4) { sy = I(sc->floats[2]); sx = I(sc->floats[3]); have = true; }                           // :499
         if (!have) {                                                                                                                    // :505-514
             const pb::Tensor* st = node.input.size() >= 2 ? graph.tensor(node.input[1]) : nullptr;
             if (!st || st->dims.empty() || st->dims[0] != 4) SM_FAIL(SM_ERR_NOT_ENOUGH_ATTRIBUTES, "Upsample: scales missing");
             std::vector<int64_t> v; int rc = pb::tensor_integers(*st, &v); if (rc) SM_FAIL(rc, "Upsample: scales dtype");
             if (v.size() < 4) SM_FAIL(SM_ERR_NOT_ENOUGH_ATTRIBUTES, "Upsample: scales tensor too short");
-            sy = (int)v[2]; sx = (int)v[3];
+            sy = I(v[2]); sx = I(v[3]);
         }
         if (!mode) SM_FAIL(SM_ERR_NOT_ENOUGH_ATTRIBUTES, "Upsample: mode missing");                                                     // :517-519
         bool bilinear;
@@ -207,7 +216,7 @@ struct UpsampleConverter : NodeConverter {
         if (sy <= 0 || sx <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Upsample: scale %dx%d", sy, sx);
         const Value iv = graph.value(in);
         Op op; op.kind = OpKind::Upsample; op.inputs = {in}; op.sy = sy; op.sx = sx; op.bilinear = bilinear; op.alignCorners = alignCorners;
-        return graph.addFilter(std::move(op), iv.c, iv.h * sy, iv.w * sx, mkShape(iv.ref.channels, sx * iv.ref.width, sy * iv.ref.height, iv.ref.depth), node.output);
+        return graph.addFilter(std::move(op), iv.c, mulSat(iv.h, sy), mulSat(iv.w, sx), mkShape(iv.ref.channels, mulSat(sx, iv.ref.width), mulSat(sy, iv.ref.height), iv.ref.depth), node.output);
     }
 };
 
@@ -246,8 +255,8 @@ struct PoolConverter : NodeConverter {
             SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "%.*s: input, kernel_shape, pads and strides are all required", SV(node.op_type));           // :654-661
         const Value iv = graph.value(in);
         Op op; op.kind = isMax ? OpKind::MaxPool : OpKind::AvgPool; op.inputs = {in};
-        op.kh = (int)ks->ints[0]; op.kw = (int)ks->ints[1]; op.sh = (int)st->ints[0]; op.sw = (int)st->ints[1];
-        op.pt = (int)pads->ints[0]; op.pl = (int)pads->ints[1];                                                                         // :673-674 (symmetric)
+        op.kh = I(ks->ints[0]); op.kw = I(ks->ints[1]); op.sh = I(st->ints[0]); op.sw = I(st->ints[1]);
+        op.pt = I(pads->ints[0]); op.pl = I(pads->ints[1]);                                                                         // :673-674 (symmetric)
         if (op.kh <= 0 || op.kw <= 0 || op.sh <= 0 || op.sw <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Pool: non-positive attribute");
         int Ho, Wo; sm_pool_padded_size(iv.w, iv.h, op.kh, op.kw, op.sh, op.sw, op.pt, op.pl, &Wo, &Ho);
         if (Ho <= 0 || Wo <= 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Pool: empty output");
@@ -299,7 +308,7 @@ struct ReshapeConverter : NodeConverter {
         std::vector<int64_t> shape; int rc = pb::tensor_integers(*st, &shape); if (rc) SM_FAIL(rc, "Reshape: shape dtype");
         const int total = iv.ref.channels * iv.ref.depth * iv.ref.height * iv.ref.width;                                               // :840-843
         const std::vector<int> src = iv.ref.toArray(); int nd[3];
-        for (int i = 0; i < 3; i++) { int d = i < (int)shape.size() ? (int)shape[i] : 1; nd[i] = d == 0 ? src[i] : d; }                 // :844-849
+        for (int i = 0; i < 3; i++) { int d = i < (int)shape.size() ? I(shape[i]) : 1; nd[i] = d == 0 ? src[i] : d; }                 // :844-849
         int inferred = -1; for (int i = 0; i < 3; i++) if (nd[i] == -1) { inferred = i; break; }
         if (inferred >= 0) { int v = total; for (int i = 0; i < 3; i++) if (i != inferred) { if (nd[i] == 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Reshape: zero dim"); v /= nd[i]; } nd[inferred] = v; }   // :851-857
         if ((long)nd[0] * nd[1] * nd[2] != (long)iv.c * iv.h * iv.w) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Reshape: element count changes");
@@ -410,7 +419,7 @@ struct InstanceNormConverter : NodeConverter {
         rc = pb::tensor_floats(*bt, &op.shift); if (rc) SM_FAIL(rc, "%s: beta dtype", nm);
         op.normGroups = iv.c;
         if (isGroup) { std::vector<int64_t> gi; rc = pb::tensor_integers(*nt, &gi); if (rc) SM_FAIL(rc, "custom_group_norm: groups dtype");
-            if (gi.empty()) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "custom_group_norm: groups tensor empty"); op.normGroups = (int)gi[0]; }
+            if (gi.empty()) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "custom_group_norm: groups tensor empty"); op.normGroups = I(gi[0]); }
         if ((int)op.scale.size() != iv.c || (int)op.shift.size() != iv.c || op.normGroups <= 0 || iv.c % op.normGroups)
             SM_FAIL(SM_ERR_INCONSISTENT_STATE, "%s: parameter sizes / groups do not fit %d channels", nm, iv.c);
         const pb::Attribute* e = node.attr("epsilon"); op.eps = e ? e->f : 1e-5f;
@@ -434,7 +443,7 @@ struct PaddingConverter : NodeConverter {
         if (pd->ints[0] || pd->ints[1] || pd->ints[4] || pd->ints[5]) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Pad: batch / channel padding is not supported");
         const Value iv = graph.value(in);
         Op op; op.kind = OpKind::Pad; op.inputs = {in}; op.padMode = mode;
-        op.pt = (int)pd->ints[2]; op.pl = (int)pd->ints[3]; op.pb = (int)pd->ints[6]; op.pr = (int)pd->ints[7];
+        op.pt = I(pd->ints[2]); op.pl = I(pd->ints[3]); op.pb = I(pd->ints[6]); op.pr = I(pd->ints[7]);
         if (op.pt < 0 || op.pl < 0 || op.pb < 0 || op.pr < 0) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Pad: negative pads");
         const int ho = iv.h + op.pt + op.pb, wo = iv.w + op.pl + op.pr;
         return graph.addFilter(std::move(op), iv.c, ho, wo, mkShape(iv.ref.channels, wo, ho, iv.ref.depth), node.output);              // :980-985

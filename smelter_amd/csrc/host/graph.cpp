@@ -38,6 +38,10 @@ void ONNXGraph::initTensor(std::string_view name, const pb::Tensor* t) { tensors
 
 int ONNXGraph::addFilter(Op&& op, int c, int h, int w, const Shape& outputShape, const std::vector<std::string_view>& outputs) {
     if (outputs.empty()) { sm_set_error("node without outputs"); return SM_ERR_NO_SUCH_OUTPUT; }
+    if (c <= 0 || h <= 0 || w <= 0 || (long)c * h > (1L << 31) - 1 || (long)c * h * w > (1L << 31) - 1) {       // per-image element count stays an int everywhere downstream
+        sm_set_error("value '%.*s' has shape C=%d H=%d W=%d (empty, or more than 2^31 elements per image)", (int)outputs[0].size(), outputs[0].data(), c, h, w);
+        return SM_ERR_INCONSISTENT_STATE;
+    }
     Value v; v.name = std::string(outputs[0]); v.c = c; v.h = h; v.w = w; v.ref = outputShape; v.producer = (int)ops_.size();
     int id = (int)values_.size();
     values_.push_back(v);
@@ -56,7 +60,8 @@ int ONNXGraph::initOutputs() {                                           // :197
         std::vector<int> shape;
         for (size_t i = 0; i < vi.dims.size(); i++) {
             auto it = configuration.dims.find((int)i);
-            shape.push_back(it != configuration.dims.end() ? it->second : (int)vi.dims[i]);   // :200-202
+            const int64_t dv = vi.dims[i];                                // int64 in the file: saturate, the range check below rejects it
+            shape.push_back(it != configuration.dims.end() ? it->second : (int)(dv > (1 << 24) ? (1 << 24) : dv < -1 ? -1 : dv));   // :200-202
         }
         int channels, height, width;
         if (shape.size() == 3) { channels = shape[0]; height = shape[1]; width = shape[2]; }
@@ -65,7 +70,7 @@ int ONNXGraph::initOutputs() {                                           // :197
         // Configuration.inputConstraint .forceInputScale(:219-241) puts a scale node in front of the graph; the model-side shape
         // recorded here is the same either way, the executor resamples the caller's image first (smelter_exec_encode_sized)
         if (input_value_ >= 0) { sm_set_error("more than one image input"); return SM_ERR_UNSUPPORTED_INPUT; }
-        if (channels <= 0 || height <= 0 || width <= 0) { sm_set_error("graph input has a non-positive dimension"); return SM_ERR_UNSUPPORTED_INPUT; }
+        if (channels <= 0 || height <= 0 || width <= 0 || (long)channels * height * width > (1L << 31) - 1) { sm_set_error("graph input has a non-positive dimension"); return SM_ERR_UNSUPPORTED_INPUT; }
         Value v; v.name = std::string(vi.name); v.c = channels; v.h = height; v.w = width;
         v.ref = Shape{1, width, height, channels};                        // :243-248
         input_value_ = (int)values_.size();

@@ -175,6 +175,15 @@ template <class T> std::vector<T> raw_as(std::string_view raw) {   // Data+Exten
     return v;
 }
 template <class D, class S> void convert(const std::vector<S>& s, std::vector<D>* d) { d->resize(s.size()); for (size_t i = 0; i < s.size(); i++) (*d)[i] = (D)s[i]; }
+// Int(Float) / Int(Double) (Onnx_TensorProto+Extensions.swift:21-30) truncate toward zero and TRAP on NaN / out-of-range values; a C++
+// cast of such a value is undefined behaviour.  The file is untrusted input: saturate instead (NaN -> 0), never trap.
+template <class S> void convert_trunc(const std::vector<S>& s, std::vector<int64_t>* d) {
+    d->resize(s.size());
+    for (size_t i = 0; i < s.size(); i++) {
+        const double v = (double)s[i];
+        (*d)[i] = v != v ? 0 : v >= 9.2233720368547748e18 ? INT64_MAX : v <= -9.2233720368547758e18 ? INT64_MIN : (int64_t)v;
+    }
+}
 void half_raw(std::string_view raw, std::vector<float>* out) {      // Data+Extensions.swift:16-24
     size_t n = raw.size() / 2; out->resize(n);
     for (size_t i = 0; i < n; i++) { uint16_t h; memcpy(&h, raw.data() + 2 * i, 2); (*out)[i] = half_bits_to_float(h); }
@@ -198,9 +207,9 @@ int tensor_integers(const Tensor& t, std::vector<int64_t>* out) {
     case INT32: case INT16: case INT8: case UINT16: case UINT8: case BOOL: convert(t.int32_data, out); return SM_OK;
     case INT64: if (t.int64_data.empty()) *out = raw_as<int64_t>(t.raw_data); else *out = t.int64_data; return SM_OK;   // :11-17
     case UINT32: case UINT64: convert(t.uint64_data, out); return SM_OK;
-    case FLOAT: { std::vector<float> f = t.float_data.empty() ? raw_as<float>(t.raw_data) : t.float_data; convert(f, out); return SM_OK; }  // :21-27, Int(Float) truncates
-    case DOUBLE: convert(t.double_data, out); return SM_OK;
-    case FLOAT16: { std::vector<float> f; half_raw(t.raw_data, &f); convert(f, out); return SM_OK; }                    // :29-30
+    case FLOAT: { std::vector<float> f = t.float_data.empty() ? raw_as<float>(t.raw_data) : t.float_data; convert_trunc(f, out); return SM_OK; }  // :21-27, Int(Float) truncates
+    case DOUBLE: convert_trunc(t.double_data, out); return SM_OK;
+    case FLOAT16: { std::vector<float> f; half_raw(t.raw_data, &f); convert_trunc(f, out); return SM_OK; }              // :29-30
     default: return SM_ERR_UNSUPPORTED_DTYPE;                                               // :32 fatalError
     }
 }
