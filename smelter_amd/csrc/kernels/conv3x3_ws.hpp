@@ -1,0 +1,280 @@
+// conv3x3_ws.hpp — WEIGHT-STATIONARY persistent 3x3 / stride 1 / pad 1 convolution for layers whose whole weight tensor fits the
+// LDS next to two activation patches: Cin in {32, 64}, Cout in {32, 64} (ResNet-50's three 56x56 64->64 layers; the seven
+// full- and half-resolution layers of the U-Net, M = 1..4.2 M pixels).  Included by conv_igemm.hip (same ConvParams / launcher).
+//
+// Why: in the tiled implicit-GEMM kernels a 128x64 tile of such a layer re-streams (128 + 64) x 128 B per K tile through the
+// per-CU L1 -> LDS path (≈27 B/clk/CU inside a network) for 256 clk of MFMA work — L1-fill bound at ≈1/4 of the
+// MFMA rate, plus a block prologue + epilogue per tile.  Here
+//  * ONE block per CU lives for the whole launch; the weights [9 taps][Cout][Cin] (18..72 KB) and the bias go to LDS once;
+//  * a block walks a contiguous range of 2-D output tiles (TH x TW pixels of one image, TH*TW <= 32*NW*TM); per tile the
+//    (TH+2) x (TW+2) input PATCH is copied to LDS by the LDS-DMA (lane-linear image, XOR swizzle on the source side, zero page
+//    outside the image — so padding costs no masks anywhere) and serves all nine taps: tap (kh,kw) of output pixel (ty,tx) is patch
+//    pixel (ty+kh, tx+kw).  L1 traffic per output pixel: (TH+2)(TW+2)/(TH*TW) ≈ 1.3 input pixels instead of 9 (+ no weights);
+//  * two patch buffers: the DMA of tile t+1 is issued before the MFMAs of tile t; ONE barrier per tile (≥ 4.6 k clk of MFMAs);
+//  * no LDS epilogue: the accumulators get bias + activation in registers, are rounded once to fp16, and v_permlane32_swap
+//    pairs the two half-waves' 4-channel groups into 8 consecutive channels per lane -> 16-byte stores.  The stores of tile t are
+//    issued at the START of iteration t+1 (after its barrier), so the `s_waitcnt vmcnt(0)` in front of every barrier only ever
+//    waits for operations that had a whole tile of MFMAs to complete (loads and stores retire out of order relative to each
+//    other on gfx9-family counters: a counted wait across both kinds is not safe, a late vmcnt(0) is);
+//  * numerics = the tiled kernels': fp32 MFMA accumulation over k = (kh, kw, cin) ascending from zero, + bias in fp32, activation,
+//    one rounding.
+#pragma once
+
+template <int CP> __device__ __forceinline__ int ws_swz(int idx) {   // XOR key of the 16-byte chunk of LDS row `idx` (row = CP chunks)
+    static_assert(CP == 2 || CP == 4 || CP == 8 || CP == 16, "2..16 chunks per row");
+    return (idx / (16 / CP)) & (CP - 1);                              // 16 consecutive rows x one chunk -> 16 distinct 16-byte bank slots
+}
+
+constexpr int ws_pstride(int fixed_bytes) { const int half = ((160 * 1024 - fixed_bytes) / 2) & ~1023; return half < 60 * 1024 ? half : 60 * 1024; }
+// LDS-DMA as an asm statement (cdna_hip_programming.md §5.7): behind a `global_load_lds` BUILTIN hipcc's waitcnt pass treats the LGKM
+// counter as out of order and waits lgkmcnt(0) — for fragment reads it has only just issued — before the next MFMA (one exposed LDS
+// latency per DMA piece, ~30 % of the k loop).  The asm form is invisible to that pass; its completion is waited for explicitly
+// (s_waitcnt vmcnt(0) + s_barrier at the top of every tile).  M0 is saved and restored inside the statement.
+__device__ __forceinline__ void ws_glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ unsigned ws_lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
+
+template <int I, int N, class F> __device__ __forceinline__ void sm_static_for(F&& f) {       // f(integral_constant<int, I>) ... f(<N-1>)
+    if constexpr (I < N) { f(std::integral_constant<int, I>()); sm_static_for<I + 1, N>(f); }
+}
+
+constexpr int WS_DUMMY = 1024;                                        // LDS sink of the DMA instructions a wave has no patch slots for
+
+// NIC = LDS-DMA instructions per thread per patch (the launcher picks a tile geometry that needs no more)
+// ABL (tools/conv_bench.py, SM_ABLATION builds only): bit 0 = no DMA after the first patch, bit 1 = no MFMAs, bit 2 = no fragment reads, bit 3 = no stores
+template <int CIN, int NOUT, int NW, int TM, int NIC = (CIN == 64 ? 12 : 6), int ABL = 0>
+__global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
+    constexpr int NT = NW * 64, CP = CIN / 8, TN = NOUT / 32, KS = CIN / 16;
+    constexpr int ROWB = CP * 16;                                     // bytes per pixel / per weight row of one tap
+    constexpr int W_BYTES = 9 * NOUT * ROWB, BIAS_BYTES = NOUT * 4;
+    static_assert(TN >= 1 && TN <= 2 && TM >= 1 && TM <= 4, "wave tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char ws_smem[];
+    unsigned char* const wl = ws_smem;                                // weights [tap][cout][CP chunks], chunk c of row n stored at c ^ swz(n)
+    float* const bl = (float*)(ws_smem + W_BYTES);
+    unsigned char* const dummy = ws_smem + W_BYTES + BIAS_BYTES;
+    unsigned char* const patch0 = dummy + WS_DUMMY;
+    // the second patch buffer sits a COMPILE-TIME distance behind the first, so that the buffer choice is an instruction offset of the
+    // fragment reads (ds_read offset field: 16 bits), not an address computation
+    constexpr int WS_PSTRIDE = ws_pstride(W_BYTES + BIAS_BYTES + WS_DUMMY);
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const half_t* zero = (const half_t*)g_zero_page;
+    const int TH = p.ws_TH, TW = p.ws_TW, PW = TW + 2, PH = TH + 2;
+    const int patch_slots = PH * PW * CP, NI = (patch_slots + NT - 1) / NT;
+
+    // ---- weights + bias -> LDS (once per block) -------------------------------------------------------------------------
+    {
+        constexpr int WSLOTS = 9 * NOUT * CP;
+        static_assert((NOUT * CP) % 64 == 0, "a wave instruction stays inside the weight image");
+#pragma unroll 1
+        for (int s0 = wave * 64; s0 < WSLOTS; s0 += NT) {
+            const int s = s0 + lane, row = s / CP, c = s & (CP - 1);  // row = tap * NOUT + n
+            const int tap = row / NOUT, n = row - tap * NOUT;
+            SM_GLDS16(p.w + (long)n * (9 * CIN) + tap * CIN + ((c ^ ws_swz<CP>(n)) << 3), wl + s0 * 16);
+        }
+        for (int i = tid; i < NOUT; i += NT) bl[i] = p.bias ? p.bias[i] : 0.f;
+    }
+    // ---- per-thread patch DMA descriptors: slot s = i*NT + tid -> (patch row, patch column, source chunk) ---------------
+    int rel[NIC]; unsigned prpc[NIC];
+#pragma unroll
+    for (int i = 0; i < NIC; i++) {
+        const int s = i * NT + tid, ps = s / CP, c = s & (CP - 1);
+        const int pr = (int)sm_fastdiv((unsigned)ps, p.ws_pw_mul, p.ws_pw_sh), pc = ps - pr * PW;
+        rel[i] = (pr * p.W + pc) * p.x_ld + ((c ^ ws_swz<CP>(ps)) << 3);
+        prpc[i] = s < patch_slots ? ((unsigned)pr << 16) | (unsigned)pc : 0x7fff0000u;        // beyond the patch: never inside the image -> zero page
+    }
+    // ---- per-lane fragment rows: tile pixel i = (wave*TM + b)*32 + (lane & 31) -> (ty, tx) ------------------------------
+    int slot0[TM]; unsigned tyx[TM];
+#pragma unroll
+    for (int b = 0; b < TM; b++) {
+        const int i = (wave * TM + b) * 32 + l31;
+        const int ty = (int)sm_fastdiv((unsigned)i, p.ws_tw_mul, p.ws_tw_sh), tx = i - ty * TW;
+        const bool in = i < TH * TW;
+        slot0[b] = in ? ty * PW + tx : 0;
+        tyx[b] = in ? ((unsigned)ty << 16) | (unsigned)tx : 0x7fff7fffu;                        // outside the tile: fails every bounds check
+    }
+    int swn[TN];
+#pragma unroll
+    for (int a = 0; a < TN; a++) swn[a] = ws_swz<CP>(a * 32 + l31);
+
+    // ---- this block's contiguous tile range; tile id -> (image, column band, row band), row band fastest ---------------
+    const int T = p.ws_ntiles, G = gridDim.x;
+    const int t_begin = (int)((long)blockIdx.x * T / G), t_end = (int)((long)(blockIdx.x + 1) * T / G);
+    auto tile_origin = [&](int t, int& n, int& y0, int& x0) {
+        n = (int)sm_fastdiv((unsigned)t, p.ws_txy_mul, p.ws_txy_sh);
+        const int r = t - n * (p.ws_tiles_x * p.ws_tiles_y);
+        const int bx = (int)sm_fastdiv((unsigned)r, p.ws_ty_mul, p.ws_ty_sh), by = r - bx * p.ws_tiles_y;
+        y0 = by * TH; x0 = bx * TW;
+    };
+    auto issue_patch = [&](int buf, int t) {
+        int n, y0, x0; tile_origin(t, n, y0, x0);
+        const half_t* xb = p.x + (((long)n * p.H + (y0 - 1)) * p.W + (x0 - 1)) * p.x_ld;      // patch pixel (0,0); dereferenced only inside the image
+        unsigned char* dst = patch0 + buf * WS_PSTRIDE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < NIC; i++) {
+            if (i < NI && i * NT + wave * 64 < patch_slots) {         // wave-uniform
+                const int pr = (int)(prpc[i] >> 16), pc = (int)(prpc[i] & 0xffff);
+                const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)p.H && (unsigned)(x0 - 1 + pc) < (unsigned)p.W;
+                SM_GLDS16(in ? xb + rel[i] : zero, dst + i * NT * 16);
+            }
+        }
+    };
+
+    const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;            // f(v) = v < 0 ? v*sl : v  (ReLU family only: launcher)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 outv[TN][TM][2];                                            // packed results of the PREVIOUS tile: [a][b][j] = couts a*32 + 16j + 8*hi .. +7 of pixel b
+    int pn = 0, py0 = 0, px0 = 0; bool pending = false;
+    auto store_prev = [&]() {
+#pragma unroll
+        for (int b = 0; b < TM; b++) {
+            const int oy = py0 + (int)(tyx[b] >> 16), ox = px0 + (int)(tyx[b] & 0xffff);
+            if (oy < p.H && ox < p.W && (int)(tyx[b] >> 16) < TH) {
+                half_t* dst = p.y + (((long)pn * p.H + oy) * p.W + ox) * p.y_ld + 8 * hi;
+#pragma unroll
+                for (int a = 0; a < TN; a++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) { if constexpr (!(ABL & 8)) *(u32x4*)(dst + a * 32 + 16 * j) = outv[a][b][j]; else asm volatile("" ::"v"(outv[a][b][j]), "v"(dst)); }
+            }
+        }
+    };
+
+    // ---- fragment addresses: tile-invariant, computed once.  A: byte offset inside a patch of (fragment b, tap, k step) for this lane;
+    // B: the weight image never moves — one register per k step, the tap is an instruction offset.
+    constexpr int NS = 9 * KS;                                        // k steps of 16 per tile
+    unsigned aoff[TM][NS];
+#pragma unroll
+    for (int b = 0; b < TM; b++)
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int q = slot0[b] + (tap / 3) * PW + (tap % 3);
+#pragma unroll
+            for (int ks = 0; ks < KS; ks++) aoff[b][tap * KS + ks] = ws_lds_addr(patch0) + (unsigned)(q * ROWB + (((ks * 2 + hi) ^ ws_swz<CP>(q)) << 4));
+        }
+    // (ds_read offsets are 16 bits: taps 0..4 are addressed from the first base, taps 5..8 from a second one)
+    constexpr int TAPB = NOUT * ROWB;
+    static_assert(4 * TAPB < 65536, "tap offset field");
+    unsigned boff[2][TN][KS];
+#pragma unroll
+    for (int a = 0; a < TN; a++)
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+            boff[0][a][ks] = ws_lds_addr(wl) + (unsigned)(((a * 32 + l31) * CP + ((ks * 2 + hi) ^ swn[a])) * 16);
+            boff[1][a][ks] = boff[0][a][ks] + 5 * TAPB;
+        }
+
+    // one tile: DMA pieces of the NEXT patch spread between the k steps (a VMEM instruction stalls its wave while the address queue
+    // is full: issued as one burst the 11 pieces cost ~2 k clk of dead issue time per tile), fragments requested PF k steps ahead of
+    // the MFMAs that consume them (the compiler's own schedule waited lgkmcnt(0) before every MFMA pair: <= 50 % MFMA duty)
+    constexpr int PF = (TM + TN) * 4 <= 15 ? 4 : 3;                    // k steps of fragment prefetch (lgkmcnt field: PF * (TM + TN) <= 15)
+    auto do_tile = [&](auto bufc, int t) {
+        constexpr int BUF = decltype(bufc)::value;
+        int n, y0, x0; tile_origin(t, n, y0, x0);
+        // the NEXT patch (the last tile of the range re-fetches itself: no branch anywhere in the k loop — behind a join hipcc waits
+        // lgkmcnt(0) for fragment reads it has just issued).  A wave without slots in piece i sends it to the dummy sink.
+        int nn, ny0, nx0; tile_origin(t + 1 < t_end ? t + 1 : t, nn, ny0, nx0);
+        const half_t* xb = p.x + (((long)nn * p.H + (ny0 - 1)) * p.W + (nx0 - 1)) * p.x_ld;
+        const unsigned dst_a = ws_lds_addr(patch0) + (BUF ^ 1) * WS_PSTRIDE + wave * 1024, dummy_a = ws_lds_addr(dummy);
+        auto piece = [&](int i) {
+            const bool mine = i * NT + wave * 64 < patch_slots;       // wave-uniform
+            const int pr = (int)(prpc[i] >> 16), pc = (int)(prpc[i] & 0xffff);
+            const bool in = (unsigned)(ny0 - 1 + pr) < (unsigned)p.H && (unsigned)(nx0 - 1 + pc) < (unsigned)p.W;
+            ws_glds16(in ? xb + rel[i] : zero, (unsigned)__builtin_amdgcn_readfirstlane((int)(mine ? dst_a + i * NT * 16 : dummy_a)));
+        };
+        floatx16 acc[TN][TM];
+#pragma unroll
+        for (int a = 0; a < TN; a++)
+#pragma unroll
+            for (int b = 0; b < TM; b++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+        // Fragment reads are asm statements with HAND-COUNTED waits: whatever sits between two compiler-visible LDS reads (a DMA builtin,
+        // an asm statement) makes hipcc wait lgkmcnt(0) before the next MFMA, i.e. for reads it has only just issued.  DS operations
+        // return in order, so before the MFMAs of k step s exactly the fetches of steps s+1 .. s+PF may still be in flight.
+        half8_t fx[PF + 1][TM], fw[PF + 1][TN];
+        auto fetch = [&](auto sc) {
+            constexpr int S2 = decltype(sc)::value, TAP = S2 / KS, KSI = S2 % KS, SLOT = S2 % (PF + 1);
+#pragma unroll
+            for (int b = 0; b < TM; b++) { half8_t& d = fx[SLOT][b]; const unsigned ad = aoff[b][S2]; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(BUF * WS_PSTRIDE)); }
+#pragma unroll
+            for (int a = 0; a < TN; a++) { half8_t& d = fw[SLOT][a]; const unsigned ad = boff[TAP >= 5][a][KSI]; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"((TAP >= 5 ? TAP - 5 : TAP) * TAPB)); }
+        };
+        constexpr int RD = TM + TN;                                   // reads per fetch
+        static_assert(PF * RD <= 15, "lgkmcnt field");
+        if constexpr (ABL & 4) {
+#pragma unroll
+            for (int i = 0; i <= PF; i++) {
+#pragma unroll
+                for (int b = 0; b < TM; b++) fx[i][b] = half8_t{1, 2, 3, 4, 5, 6, 7, 8};
+#pragma unroll
+                for (int a = 0; a < TN; a++) fw[i][a] = half8_t{1, 2, 3, 4, 5, 6, 7, 8};
+            }
+        }
+        if constexpr (!(ABL & 4)) sm_static_for<0, PF>([&](auto sc) { fetch(sc); });
+        if (pending) store_prev();
+        sm_static_for<0, NS>([&](auto sc) {
+            constexpr int S2 = decltype(sc)::value;
+#pragma unroll
+            for (int i = 0; i < NIC; i++) if (i * NS / (3 * NIC) == S2 && !(ABL & 1)) piece(i);   // one piece per k step over the FIRST THIRD of the tile: the rest of the tile is their flight time
+            if constexpr (S2 + PF < NS && !(ABL & 4)) fetch(std::integral_constant<int, S2 + PF>());
+            constexpr int AHEAD = (NS - 1 - S2 < PF ? NS - 1 - S2 : PF) * RD;
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((ABL & 4) ? 15 : AHEAD) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < TN; a++)
+#pragma unroll
+                for (int b = 0; b < TM; b++) {
+                    if constexpr (!(ABL & 2)) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S2 % (PF + 1)][a], fx[S2 % (PF + 1)][b], acc[a][b], 0, 0, 0);
+                    else asm volatile("" ::"v"(fw[S2 % (PF + 1)][a]), "v"(fx[S2 % (PF + 1)][b]));
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        // ---- epilogue in registers: register 4q+r of acc[a][b] <-> cout a*32 + 8q + 4*hi + r of pixel b*32 + (lane & 31) ----
+#pragma unroll
+        for (int a = 0; a < TN; a++) {
+            floatx4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq[q] = *(const floatx4*)(bl + a * 32 + 8 * q + 4 * hi);
+#pragma unroll
+            for (int b = 0; b < TM; b++) {
+                unsigned d[4][2];
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; h2++) {
+                        float v0 = acc[a][b][4 * q + 2 * h2] + bq[q][2 * h2], v1 = acc[a][b][4 * q + 2 * h2 + 1] + bq[q][2 * h2 + 1];
+                        v0 = v0 < 0.f ? v0 * sl : v0; v1 = v1 < 0.f ? v1 * sl : v1;
+                        const half2_t hv = {(half_t)v0, (half_t)v1};
+                        d[q][h2] = __builtin_bit_cast(unsigned, hv);
+                    }
+                // (q, q+1): low half-wave keeps couts 8q..8q+3 and receives 8q+4..8q+7 from its partner lane; the high half-wave ends
+                // up with 8q+8..8q+15 — 8 consecutive channels = 16 bytes per lane
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(d[2 * j][0], d[2 * j + 1][0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(d[2 * j][1], d[2 * j + 1][1], false, false);
+                    outv[a][b][j] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                }
+            }
+        }
+        pn = n; py0 = y0; px0 = x0; pending = true;
+    };
+
+    if (t_begin < t_end) issue_patch(0, t_begin);
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; t += 2) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of patch t (issued during tile t-1), my stores of tile t-2, [first tile: the weights]
+        __builtin_amdgcn_s_barrier();                                 // everybody's share landed; everybody is done reading the other buffer
+        __builtin_amdgcn_sched_barrier(0);
+        do_tile(std::integral_constant<int, 0>(), t);
+        if (t + 1 >= t_end) break;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        do_tile(std::integral_constant<int, 1>(), t + 1);
+    }
+    if (pending) store_prev();
+}

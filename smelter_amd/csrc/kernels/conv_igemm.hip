@@ -39,6 +39,9 @@ struct ConvParams {
     unsigned pm_mul, pm_sh, mt_mul, mt_sh, nt_mul, nt_sh;   // ... for / (nt*splitk), / mt, / nt (map_block)
     unsigned rowpat;                 // sum over kh < kH of 1 << (kh*kW): tap-mask pattern (conv_igemm64.hpp)
     int yplace, ysH, ysW, yoH, yoW, yH, yW;   // output placement (sm_conv_desc.y_sH ...): strided/offset output pixels
+    // weight-stationary 3x3 kernel (conv3x3_ws.hpp): tile geometry chosen by ws_setup()
+    int ws_TH, ws_TW, ws_tiles_x, ws_tiles_y, ws_ntiles, ws_patch_bytes;
+    unsigned ws_pw_mul, ws_pw_sh, ws_tw_mul, ws_tw_sh, ws_txy_mul, ws_txy_sh, ws_ty_mul, ws_ty_sh;
 };
 
 // Division of n < 2^31 by a launch-time constant d: q = (n * mul) >> sh with s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1
@@ -477,6 +480,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 #include "conv_igemm64.hpp"
 #include "conv3x3_strip.hpp"
 #include "pw_thin.hpp"
+#include "conv3x3_ws.hpp"
 
 // 3x3 depthwise through LDS (the MobileNet-v2 path): the register-strip kernel above re-reads every input pixel 4.5x through
 // L1/L2 and needs 227 VGPRs (1.2..2 TB/s of algorithmic bytes).  Here a block owns a tile of TH x TW output pixels x `cbv`
@@ -649,6 +653,14 @@ const TileCfg kCfgs[] = {
     {256, 32, 3, 256, conv3x3_strip_kernel<256, 32, 4, 1, 3>, "strip s3:256x32"},                     // 58
     {128, 128, 3, 256, conv3x3_strip_kernel<128, 128, 2, 2, 2>, "strip w4:128x128"},                  // 59
     {128, 32, 3, 256, conv3x3_strip_kernel<128, 32, 4, 1, 2>, "strip w4:128x32"},                     // 60  (59 KB: two blocks per CU)
+    // kind 4 (conv3x3_ws.hpp): weight-stationary persistent 3x3 for Cin, Cout in {32, 64}; BM = pixels per tile, BN = Cout
+    {256, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 2>, "ws:64->64 w4x2"},                             // 61
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2>, "ws:64->32 w4x2"},                             // 62
+    {256, 64, 4, 256, conv3x3_ws_kernel<32, 64, 4, 2>, "ws:32->64 w4x2"},                             // 63
+    {256, 32, 4, 256, conv3x3_ws_kernel<32, 32, 4, 2>, "ws:32->32 w4x2"},                             // 64
+    {224, 64, 4, 448, conv3x3_ws_kernel<64, 64, 7, 1>, "ws:64->64 w7x1"},                             // 65  (56x56: 8 x 28 = 224-pixel tiles, no idle fragment)
+    {512, 32, 4, 512, conv3x3_ws_kernel<64, 32, 8, 2>, "ws:64->32 w8x2"},                             // 66
+    {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2>, "ws:32->32 w8x2"},                             // 67
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
@@ -657,6 +669,20 @@ const TileCfg kCfgs[] = {
 #ifdef SM_ABLATION   // 81 KB variants (two blocks per CU on the N = 64 layers): 45..50 us against 41 us for config 18 on 56x56x64 — not in the product pool
     {128, 64, 3, 256, conv3x3_strip_kernel<128, 64, 2, 2, 2, 1>, "strip lean w4:128x64"},
     {128, 64, 3, 512, conv3x3_strip_kernel<128, 64, 4, 2, 2, 1>, "strip lean w8:128x64"},
+#endif
+#ifdef SM_ABLATION   // conv3x3_ws ablations (64->32, 4 waves x 2 fragments)
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 0>, "ws:64->32 abl ref"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 1>, "ws:64->32 abl noDMA"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 2>, "ws:64->32 abl noMFMA"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 4>, "ws:64->32 abl noReads"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 8>, "ws:64->32 abl noStores"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 9>, "ws:64->32 abl noDMA noStores"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 15>, "ws:64->32 abl nothing"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 6>, "ws:64->32 abl DMA+stores only"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 13>, "ws:64->32 abl MFMA only"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 11>, "ws:64->32 abl reads only"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 14>, "ws:64->32 abl DMA only"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 7>, "ws:64->32 abl stores only"},
 #endif
 #ifdef SM_ABLATION   // tools/conv_bench.py only: never built into the product library
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 1>, "abl:w8 noMFMA"},
@@ -668,16 +694,53 @@ const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
+// Geometry of the weight-stationary kernel for tile config `c` (BM = pixel capacity of a tile = 32 * waves * TM, threads = 64 * waves):
+// TW = W split into the fewest column bands of <= 32 pixels (56 -> 28, 512 -> 32), TH = the row count that minimises the number of
+// tiles while TH*TW <= BM and weights + two patches fit 160 KiB.  Returns the dynamic LDS size in bytes, 0 if the config does not fit.
+size_t ws_setup(ConvParams& p, const TileCfg& c) {
+    const int cin = p.Cin;
+    if (cin != 32 && cin != 64) return 0;
+    const char* nm = c.name;                                         // "ws:<cin>-><cout> ..."
+    if (atoi(nm + 3) != cin) return 0;
+    const int cp = cin / 8, nt = c.threads;
+    const int bands = sm_ceil_div(p.W, 32), TW = sm_ceil_div(p.W, bands);
+    const size_t fixed = (size_t)9 * p.Cout * cin * 2 + (size_t)p.Cout * 4 + WS_DUMMY;
+    const int nic = cin == 64 ? 12 : 6;                              // the kernels' NIC
+    int best_th = 0; long best_tiles = 0; size_t best_lds = 0, best_patch = 0;
+    for (int th = 1; th * TW <= c.BM && th <= p.H; th++) {
+        const size_t slots = (size_t)(th + 2) * (TW + 2) * cp, patch = (slots * 16 + 1023) / 1024 * 1024;
+        if (sm_ceil_div((long)slots, nt) > nic) break;
+        const size_t stride = (size_t)ws_pstride((int)fixed);         // distance between the two patch buffers (compile-time in the kernel)
+        if (patch > stride) break;
+        const size_t lds = fixed + stride + patch;
+        const long tiles = (long)sm_ceil_div(p.H, th) * sm_ceil_div(p.W, TW);
+        if (!best_th || tiles < best_tiles) { best_th = th; best_tiles = tiles; best_lds = lds; best_patch = patch; }
+    }
+    if (!best_th) return 0;
+    p.ws_TH = best_th; p.ws_TW = TW; p.ws_tiles_x = sm_ceil_div(p.W, TW); p.ws_tiles_y = sm_ceil_div(p.H, best_th);
+    const long nt_all = (long)p.N * p.ws_tiles_x * p.ws_tiles_y;
+    if (nt_all >= (1L << 31)) return 0;
+    p.ws_ntiles = (int)nt_all; p.ws_patch_bytes = (int)best_patch;
+    sm_fastdiv_make((unsigned)(TW + 2), &p.ws_pw_mul, &p.ws_pw_sh); sm_fastdiv_make((unsigned)TW, &p.ws_tw_mul, &p.ws_tw_sh);
+    sm_fastdiv_make((unsigned)(p.ws_tiles_x * p.ws_tiles_y), &p.ws_txy_mul, &p.ws_txy_sh); sm_fastdiv_make((unsigned)p.ws_tiles_y, &p.ws_ty_mul, &p.ws_ty_sh);
+    return best_lds;
+}
+
 // kind 2 = single LDS stage: only for K == 64 (one K tile)
 // kinds 1/2 (conv_igemm64.hpp): Cin % 64 == 0 and a tap mask of <= 32 bits
 bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
     if (c.kind == 0) return true;
+    const bool same3x3 = p.kH == 3 && p.kW == 3 && p.sH == 1 && p.sW == 1 && p.dH == 1 && p.dW == 1 && p.pt == 1 && p.pl == 1 && p.Ho == p.H && p.Wo == p.W;
+    if (c.kind == 4) {   // weight-stationary: the template's Cin / Cout exactly, no residual, dense 16-byte rows on both sides, ReLU family
+        ConvParams q = p;
+        return same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
+               ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && p.Cout == c.BN && ws_setup(q, c) > 0;
+    }
     if ((p.Cin % 64) != 0 || p.kH * p.kW > 32) return false;
     if (c.kind == 1) return true;
     if (c.kind == 2) return p.K == 64;
     // kind 3: 3x3 / stride 1 / pad 1 / "same" size, and everything the fast epilogue needs (dense 16-byte output, ReLU family)
-    return p.kH == 3 && p.kW == 3 && p.sH == 1 && p.sW == 1 && p.dH == 1 && p.dW == 1 && p.pt == 1 && p.pl == 1 && p.Ho == p.H && p.Wo == p.W &&
-           !p.yplace && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) &&
+    return same3x3 && !p.yplace && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) &&
            (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0));
 }
 
@@ -787,6 +850,14 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     if (cfg < 0 || cfg >= kNumCfgs) cfg = pick_cfg(p);
     const TileCfg& c = kCfgs[cfg];
     if (!cfg_eligible(c, p)) { sm_set_error("conv tile config %d (%s) does not apply to Cin=%d", cfg, c.name, p.Cin); return SM_ERR_INVALID_ARGUMENT; }
+    if (c.kind == 4) {                                               // persistent: one block per CU (two when the LDS allows), contiguous tile ranges
+        const size_t lds = ws_setup(p, c);
+        const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
+        const int grid = std::min(p.ws_ntiles, SM_NUM_CU * per_cu);
+        typedef void (*WsFn)(ConvParams);
+        hipLaunchKernelGGL((WsFn)c.fn, dim3(grid), dim3(c.threads), lds, s, p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
     p.mt = sm_ceil_div(p.M, c.BM); p.nt = sm_ceil_div(p.Cout, c.BN);
     const int ktiles = sm_ceil_div(p.K, c.kind ? 64 : BK);
     // split-K only for launches that cannot fill the chip and have a long K loop (e.g. the FC layer)

@@ -56,7 +56,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg", [None] + list(range(61)))
+@pytest.mark.parametrize("cfg", [None] + list(range(80)))
 def test_conv2d(case, cfg):
     n, hh, ww, cin, cout, k, s, p, res, act = case
     if cfg is not None and (cin % 8 or cfg >= ops.num_conv_configs() or (cfg >= 6 and cin % 64)):
@@ -117,7 +117,7 @@ def test_pointwise_thin_kernel(cin, cout, res, act, monkeypatch):
     assert_close(to_host(y), ref, cin)
 
 
-@pytest.mark.parametrize("cfg", list(range(61)))
+@pytest.mark.parametrize("cfg", list(range(80)))
 def test_conv2d_generic_epilogue_every_config(cfg):
     """Tanh is not a ReLU-family activation, so every kernel takes its GENERIC epilogue (bias-initialised accumulators, per-element
     activation) instead of the straight-line fast path the ResNet cases exercise; Cin % 64 == 0 so that all BK=64 configs apply.
@@ -155,7 +155,7 @@ def test_conv2d_split_k_workspace():
     assert_close(to_host(y), O.conv2d(x, w, b), cin)
 
 
-@pytest.mark.parametrize("cfg", list(range(61)))
+@pytest.mark.parametrize("cfg", list(range(80)))
 def test_conv2d_split_k_every_config(cfg):
     """few tiles + long K + a workspace: the launcher splits K across blocks (fp32 partials + reduce kernel) for every tile config
     that has a split-K form; residual + ReLU are then applied by the reduce kernel"""
@@ -443,3 +443,51 @@ def test_reshape_nchw_order_is_byte_exact(src, dst):
     x = h(np.random.default_rng(71).standard_normal((3,) + src))
     got = to_host(ops.reshape_nchw_order(to_dev(x), *dst))
     assert np.array_equal(got, x.reshape((3,) + dst))
+
+
+WS_CASES = [
+    # n, h, w, cin, cout, act   -- conv3x3_ws.hpp: weight-stationary persistent 3x3 (tile configs 61..67)
+    (2, 56, 56, 64, 64, 1),      # ResNet-50 stage 1: 28-pixel column bands, fragments straddle tile rows
+    (1, 40, 72, 64, 32, 0),      # three 24-pixel bands, no activation
+    (3, 9, 7, 64, 64, 1),        # images smaller than a tile: one ragged tile per image, every border case
+    (2, 33, 50, 32, 32, 2),      # Cin = 32 (four chunks per pixel), PRelu, ragged rows and columns
+    (1, 64, 64, 32, 64, 1),      # 32-pixel bands, exact tiles
+    (1, 16, 130, 64, 32, 1),     # five 26-pixel bands
+    (5, 20, 32, 64, 64, 1),      # more tiles than fit one image: tile ranges cross image boundaries
+]
+
+
+@pytest.mark.parametrize("case", WS_CASES)
+@pytest.mark.parametrize("cfg", list(range(61, 68)))
+def test_conv3x3_weight_stationary(case, cfg):
+    n, hh, ww, cin, cout, act = case
+    if cfg >= ops.num_conv_configs():
+        pytest.skip("no such config")
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * np.sqrt(2.0 / (cin * 9)))
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1))
+    slope = 0.25 if act == 2 else 0.0
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), act=act, slope=slope, cfg=cfg)
+    except SmelterError as e:
+        if "does not apply" in e.detail:                      # the config's Cin / Cout is another one
+            pytest.skip(e.detail)
+        raise
+    assert_close(to_host(y), ref, cin * 9)
+
+
+def test_conv3x3_weight_stationary_writes_into_a_concat_slice():
+    """pixel strides larger than the channel count on both sides (zero-copy Concat placement)"""
+    rng = np.random.default_rng(5)
+    x = h(rng.standard_normal((2, 64, 24, 40))); w = h(rng.standard_normal((32, 3, 3, 64)) * 0.06); b = rng.standard_normal(32).astype(np.float32)
+    xin = torch.zeros((2, 24, 40, 96), dtype=torch.float16, device="cuda"); xin[..., 16:80] = to_dev(x)
+    out = torch.full((2, 24, 40, 64), 7.0, dtype=torch.float16, device="cuda")
+    ops.conv2d(xin[..., 16:80], torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), act=1, cfg=62, out=out[..., 32:])
+    ref = np.maximum(O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1)), 0)
+    assert_close(to_host(out[..., 32:]), ref, 64 * 9)
+    assert float(out[..., :32].min()) == 7.0 and float(out[..., :32].max()) == 7.0
