@@ -79,6 +79,10 @@ typedef struct sm_conv_desc {
      * (n, oy*y_sH + y_oH, ox*y_sW + y_oW) of an image of y_H x y_W pixels.  This is how a stride-s ConvTranspose runs as
      * s*s ordinary convolutions, one per output phase (smelter_graph_compile); no residual operand in this mode. */
     int32_t y_sH, y_sW, y_oH, y_oW, y_H, y_W;
+    /* 1 = `x` is given at HALF resolution ((H/2) x (W/2) pixels, H and W even) and read through a fused nearest-neighbour 2x
+     * upsampling: input pixel (iy, ix) of the H x W image is x[n, iy/2, ix/2, :].  MPSCNNUpsamplingNearestNode (Converters.swift:524)
+     * in front of a convolution without the upsampled image ever being stored.  3x3 / stride 1 / pad 1, Cin % 64 == 0 only. */
+    int32_t x_ups;
 } sm_conv_desc;
 
 /* MPSCNNConvolutionNode / MPSCNNFullyConnectedNode (Converters.swift:253, :297).  `residual` (nullable) is an

@@ -29,7 +29,7 @@ class SmelterError(RuntimeError):
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "Cin", "Cout", "kH", "kW", "sH", "sW", "dH", "dW",
                                          "pt", "pl", "pb", "pr", "groups", "Ho", "Wo", "act")] + \
-               [("slope", C.c_float)] + [(n, C.c_int32) for n in ("x_ld", "y_ld", "res_ld", "y_sH", "y_sW", "y_oH", "y_oW", "y_H", "y_W")]
+               [("slope", C.c_float)] + [(n, C.c_int32) for n in ("x_ld", "y_ld", "res_ld", "y_sH", "y_sW", "y_oH", "y_oW", "y_H", "y_W", "x_ups")]
 
 
 class PoolDesc(C.Structure):

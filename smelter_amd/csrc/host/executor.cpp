@@ -131,6 +131,21 @@ int Executor::plan(ONNXGraph& g, int batch) {
         }
     }
 
+    // ---- 1b. nearest 2x Upsample -> 3x3 convolution: the convolution gathers its patches straight from the half-resolution tensor
+    // (sm_conv_desc.x_ups, conv3x3_p9.hpp); the upsampled image — 4x the bytes, written once and read once — never exists.
+    if (cfg_.fuse && !cfg_.keepIntermediates) {
+        for (int i = 0; i < no; i++) {
+            Op& up = ops[i];
+            if (dead[i] || up.kind != OpKind::Upsample || up.bilinear || up.sy != 2 || up.sx != 2 || up.output == output_value_ || consumers(up.output) != 1) continue;
+            int c = -1; for (int j = 0; j < no; j++) if (!dead[j] && !ops[j].inputs.empty() && ops[j].inputs[0] == up.output) c = j;
+            if (c < 0) continue;
+            Op& cv = ops[c];
+            if (cv.kind != OpKind::Conv || cv.groups != 1 || cv.kh != 3 || cv.kw != 3 || cv.sh != 1 || cv.sw != 1 || cv.dh != 1 || cv.dw != 1 || cv.pt != 1 || cv.pl != 1 ||
+                cv.pb != 1 || cv.pr != 1 || ((cv.cin % 64) && !(cv.cin == 32 && (cv.cout == 32 || cv.cout == 64))) || (cv.cout % 8) || cv.residual >= 0 || cv.act > SM_ACT_PRELU || up.inputs[0] == input_value_) continue;
+            cv.inputs[0] = up.inputs[0]; cv.x_ups = true; dead[i] = 1;
+        }
+    }
+
     // ---- 2. aliasing + 3. concat placement -----------------------------------------------------------------
     place_.assign(nv, Placement());
     for (int v = 0; v < nv; v++) { place_[v].root = v; place_[v].c_off = 0; place_[v].ld = values_[v].c; }
@@ -383,7 +398,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         char buf[256];
         if (isConvLike(op.kind))
             snprintf(buf, sizeof buf, "%s %s M=%d N=%d K=%d k=%dx%d s=%d g=%d%s%s%s", kindName(op.kind), op.name.c_str(), st.M, op.cout, op.kh * op.kw * (op.cin / op.groups),
-                     st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem ? " stem" : op.grid_h ? " convT-phase" : "");
+                     st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem ? " stem" : op.grid_h ? " convT-phase" : op.x_ups ? " +ups2x" : "");
         else snprintf(buf, sizeof buf, "%s %s pixels=%d C=%d%s", kindName(op.kind), op.name.c_str(), st.M, values_[op.output].c, op.act ? " +act" : "");
         st.desc = buf;
         if (st.join >= 0) st.desc += " side-stream";
@@ -542,6 +557,7 @@ sm_conv_desc Executor::convDesc(const Step& st) const {
     d.pt = op.pt; d.pl = op.pl; d.pb = op.pb; d.pr = op.pr; d.groups = op.groups; d.act = op.act; d.slope = op.slope;
     if (op.kind == OpKind::Conv) { d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.x_ld = valueLd(op.inputs[0]); }
     else { d.H = d.W = d.Ho = d.Wo = 1; d.x_ld = st.fc_h * st.fc_w > 1 ? op.cin : valueLd(op.inputs[0]); }   // flattened map: one dense row per image
+    if (op.x_ups) { d.H = ov.h; d.W = ov.w; d.x_ups = 1; }                                                   // input value = the half-resolution tensor
     if (st.stem) { d.H = stem_h_; d.W = stem_w_; d.x_ld = 8; }                                             // row-pair image
     if (op.grid_h) { d.Ho = op.grid_h; d.Wo = op.grid_w; d.y_sH = op.y_sh; d.y_sW = op.y_sw; d.y_oH = op.y_oh; d.y_oW = op.y_ow; d.y_H = op.y_h; d.y_W = op.y_w; }   // ConvTranspose phase
     d.y_ld = valueLd(op.output); d.res_ld = op.residual >= 0 ? valueLd(op.residual) : 0;

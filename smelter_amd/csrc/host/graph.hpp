@@ -45,6 +45,7 @@ struct Op {
     bool weight_was_fp16 = false;        // ConvDataSource.dataType() (:140-149)
     // output placement of a ConvTranspose phase (executor.cpp): sm_conv_desc.y_sH ... ; conv grid of the phase
     int y_sh = 0, y_sw = 0, y_oh = 0, y_ow = 0, y_h = 0, y_w = 0, grid_h = 0, grid_w = 0;
+    bool x_ups = false;                  // executor: a nearest 2x Upsample in front of this conv is fused into its patch gather (sm_conv_desc.x_ups)
     // fused epilogue (set by the executor's fusion passes, or by Neuron ops)
     int act = 0; float slope = 0.f;      // SM_ACT_*
     int residual = -1;                   // value id added before the activation

@@ -84,7 +84,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     for (int i = 0; i < NIC; i++) {
         const int s = i * NT + tid, ps = s / CP, c = s & (CP - 1);
         const int pr = (int)sm_fastdiv((unsigned)ps, p.ws_pw_mul, p.ws_pw_sh), pc = ps - pr * PW;
-        rel[i] = (pr * p.W + pc) * p.x_ld + ((c ^ ws_swz<CP>(ps)) << 3);
+        // (p.ups: the patch is gathered from the half-resolution tensor; tile origins are even, so input pixel (y0-1+pr, x0-1+pc) of
+        //  the upsampled image is low-resolution pixel (y0/2 + ((pr-1)>>1), x0/2 + ((pc-1)>>1)) — tile-invariant like the plain case)
+        rel[i] = (p.ups ? ((pr - 1) >> 1) * (p.W >> 1) + ((pc - 1) >> 1) : pr * p.W + pc) * p.x_ld + ((c ^ ws_swz<CP>(ps)) << 3);
         prpc[i] = s < patch_slots ? ((unsigned)pr << 16) | (unsigned)pc : 0x7fff0000u;        // beyond the patch: never inside the image -> zero page
     }
     // ---- per-lane fragment rows: tile pixel i = (wave*TM + b)*32 + (lane & 31) -> (ty, tx) ------------------------------
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     };
     auto issue_patch = [&](int buf, int t) {
         int n, y0, x0; tile_origin(t, n, y0, x0);
-        const half_t* xb = p.x + (((long)n * p.H + (y0 - 1)) * p.W + (x0 - 1)) * p.x_ld;      // patch pixel (0,0); dereferenced only inside the image
+        const half_t* xb = p.ups ? p.x + (((long)n * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1)) * p.x_ld
+                                 : p.x + (((long)n * p.H + (y0 - 1)) * p.W + (x0 - 1)) * p.x_ld;   // patch pixel (0,0); dereferenced only inside the image
         unsigned char* dst = patch0 + buf * WS_PSTRIDE + wave * 1024;
 #pragma unroll
         for (int i = 0; i < NIC; i++) {
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
         // the NEXT patch (the last tile of the range re-fetches itself: no branch anywhere in the k loop — behind a join hipcc waits
         // lgkmcnt(0) for fragment reads it has just issued).  A wave without slots in piece i sends it to the dummy sink.
         int nn, ny0, nx0; tile_origin(t + 1 < t_end ? t + 1 : t, nn, ny0, nx0);
-        const half_t* xb = p.x + (((long)nn * p.H + (ny0 - 1)) * p.W + (nx0 - 1)) * p.x_ld;
+        const half_t* xb = p.ups ? p.x + (((long)nn * (p.H >> 1) + (ny0 >> 1)) * (p.W >> 1) + (nx0 >> 1)) * p.x_ld
+                                 : p.x + (((long)nn * p.H + (ny0 - 1)) * p.W + (nx0 - 1)) * p.x_ld;
         const unsigned dst_a = ws_lds_addr(patch0) + (BUF ^ 1) * WS_PSTRIDE + wave * 1024, dummy_a = ws_lds_addr(dummy);
         auto piece = [&](int i) {
             const bool mine = i * NT + wave * 64 < patch_slots;       // wave-uniform

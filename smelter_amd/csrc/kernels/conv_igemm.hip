@@ -42,6 +42,9 @@ struct ConvParams {
     // weight-stationary 3x3 kernel (conv3x3_ws.hpp): tile geometry chosen by ws_setup()
     int ws_TH, ws_TW, ws_tiles_x, ws_tiles_y, ws_ntiles, ws_patch_bytes;
     unsigned ws_pw_mul, ws_pw_sh, ws_tw_mul, ws_tw_sh, ws_txy_mul, ws_txy_sh, ws_ty_mul, ws_ty_sh;
+    // nine-tap patch kernel (conv3x3_p9.hpp): geometry chosen by p9_setup(); ups = the input is read through a fused nearest 2x upsampling
+    int p9_TW, p9_tiles_per_band, p9_patch_bytes, p9_patch_px, ups;
+    unsigned p9_pw_mul, p9_pw_sh, p9_h2_mul, p9_h2_sh;
 };
 
 // Division of n < 2^31 by a launch-time constant d: q = (n * mul) >> sh with s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1
@@ -481,6 +484,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 #include "conv3x3_strip.hpp"
 #include "pw_thin.hpp"
 #include "conv3x3_ws.hpp"
+#include "conv3x3_p9.hpp"
 
 // 3x3 depthwise through LDS (the MobileNet-v2 path): the register-strip kernel above re-reads every input pixel 4.5x through
 // L1/L2 and needs 227 VGPRs (1.2..2 TB/s of algorithmic bytes).  Here a block owns a tile of TH x TW output pixels x `cbv`
@@ -670,6 +674,13 @@ const TileCfg kCfgs[] = {
     {128, 64, 3, 256, conv3x3_strip_kernel<128, 64, 2, 2, 2, 1>, "strip lean w4:128x64"},
     {128, 64, 3, 512, conv3x3_strip_kernel<128, 64, 4, 2, 2, 1>, "strip lean w8:128x64"},
 #endif
+    // kind 5 (conv3x3_p9.hpp): 3x3 / stride 1 / pad 1, Cin % 64 == 0: one patch per cin block serves all nine taps, weights ring as kind 1
+    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 3>, "p9:256x128 s3"},                        // 68
+    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 2>, "p9:256x128 s2"},                        // 69
+    {128, 128, 5, 512, conv3x3_p9_kernel<128, 128, 4, 2, 3>, "p9:128x128(32x64) s3"},                 // 70
+    {128, 128, 5, 512, conv3x3_p9_kernel<128, 128, 2, 4, 3>, "p9:128x128(64x32) s3"},                 // 71
+    {256, 64, 5, 512, conv3x3_p9_kernel<256, 64, 4, 2, 3>, "p9:256x64 s3"},                           // 72
+    {128, 64, 5, 512, conv3x3_p9_kernel<128, 64, 4, 2, 3>, "p9:128x64 s3"},                           // 73
 #ifdef SM_ABLATION   // conv3x3_ws ablations (64->32, 4 waves x 2 fragments)
     {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 0>, "ws:64->32 abl ref"},
     {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 1>, "ws:64->32 abl noDMA"},
@@ -703,11 +714,13 @@ size_t ws_setup(ConvParams& p, const TileCfg& c) {
     const char* nm = c.name;                                         // "ws:<cin>-><cout> ..."
     if (atoi(nm + 3) != cin) return 0;
     const int cp = cin / 8, nt = c.threads;
-    const int bands = sm_ceil_div(p.W, 32), TW = sm_ceil_div(p.W, bands);
+    const int bands = sm_ceil_div(p.W, 32);
+    int TW = sm_ceil_div(p.W, bands);
+    if (p.ups && (TW & 1)) TW++;                                       // fused upsampling: even tile origins
     const size_t fixed = (size_t)9 * p.Cout * cin * 2 + (size_t)p.Cout * 4 + WS_DUMMY;
     const int nic = cin == 64 ? 12 : 6;                              // the kernels' NIC
     int best_th = 0; long best_tiles = 0; size_t best_lds = 0, best_patch = 0;
-    for (int th = 1; th * TW <= c.BM && th <= p.H; th++) {
+    for (int th = p.ups ? 2 : 1; th * TW <= c.BM && th <= p.H; th += p.ups ? 2 : 1) {
         const size_t slots = (size_t)(th + 2) * (TW + 2) * cp, patch = (slots * 16 + 1023) / 1024 * 1024;
         if (sm_ceil_div((long)slots, nt) > nic) break;
         const size_t stride = (size_t)ws_pstride((int)fixed);         // distance between the two patch buffers (compile-time in the kernel)
@@ -726,6 +739,34 @@ size_t ws_setup(ConvParams& p, const TileCfg& c) {
     return best_lds;
 }
 
+// Geometry of the nine-tap patch kernel for tile config `c`: the column-band width TW (the whole row for small images, else ~32)
+// that moves the fewest patch pixels per tile while two patches + the weight ring fit 160 KiB and a patch needs at most NIC*NT
+// 16-byte DMA slots.  Returns the dynamic LDS size in bytes, 0 if the config does not fit the layer.
+size_t p9_setup(ConvParams& p, const TileCfg& c) {
+    if ((p.Cin % 64) != 0) return 0;
+    const int nsb = strstr(c.name, " s2") ? 2 : 3, nic = 11 - nsb, nt = c.threads, BM = c.BM;
+    const size_t ring = (size_t)nsb * c.BN * 128;
+    int best_tw = 0; long best_px = 0; size_t best_patch = 0;
+    const int cand[2] = {p.W, sm_ceil_div(p.W, sm_ceil_div(p.W, 32))};
+    for (int k = 0; k < 2; k++) {
+        const int TW = cand[k]; if (TW <= 0 || TW > 126 || (k == 1 && TW == cand[0])) continue;
+        const int rows = (BM % TW) == 0 ? BM / TW : (BM - 1 + TW - 1) / TW + 1;        // output rows a tile can touch
+        const int imgs = (rows + p.H - 2) / p.H + 1;                                    // images those rows can lie in
+        const long px = (long)(rows + 2 * imgs) * (TW + 2);
+        const size_t patch = ((size_t)px * 128 + 1023) / 1024 * 1024;
+        if (px * 8 > (long)nic * nt || WS_DUMMY + 2 * patch + ring > 160 * 1024) continue;
+        const long cost = px * sm_ceil_div(p.W, TW);                                    // (ragged last band counts as a whole one)
+        if (!best_tw || cost < best_px) { best_tw = TW; best_px = cost; best_patch = patch; p.p9_patch_px = (int)px; }
+    }
+    if (!best_tw) return 0;
+    p.p9_TW = best_tw; p.p9_patch_bytes = (int)best_patch;
+    const long tpb = ((long)p.N * p.H * best_tw + BM - 1) / BM, blocks = tpb * sm_ceil_div(p.W, best_tw) * sm_ceil_div(p.Cout, c.BN);
+    if (blocks >= (1L << 31) || (long)p.N * p.H >= (1L << 31) / (best_tw + 2)) return 0;
+    p.p9_tiles_per_band = (int)tpb; p.nt = sm_ceil_div(p.Cout, c.BN);
+    sm_fastdiv_make((unsigned)(best_tw + 2), &p.p9_pw_mul, &p.p9_pw_sh); sm_fastdiv_make((unsigned)(p.H + 2), &p.p9_h2_mul, &p.p9_h2_sh);
+    return WS_DUMMY + 2 * best_patch + ring;
+}
+
 // kind 2 = single LDS stage: only for K == 64 (one K tile)
 // kinds 1/2 (conv_igemm64.hpp): Cin % 64 == 0 and a tap mask of <= 32 bits
 bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
@@ -735,6 +776,11 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
         ConvParams q = p;
         return same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
                ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && p.Cout == c.BN && ws_setup(q, c) > 0;
+    }
+    if (c.kind == 5) {   // nine-tap patch kernel: no residual, dense 16-byte rows, ReLU family
+        ConvParams q = p;
+        return same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 &&
+               ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && p9_setup(q, c) > 0;
     }
     if ((p.Cin % 64) != 0 || p.kH * p.kW > 32) return false;
     if (c.kind == 1) return true;
@@ -775,7 +821,8 @@ int fill_params(const sm_conv_desc* d, const void* x, const void* w, const float
     p->x_ld = d->x_ld ? d->x_ld : d->Cin; p->y_ld = d->y_ld ? d->y_ld : d->Cout; p->res_ld = d->res_ld ? d->res_ld : d->Cout;
     p->act = d->act; p->slope = d->act == SM_ACT_RELU ? 0.f : d->slope;
     p->M = d->N * d->Ho * d->Wo; p->K = d->kH * d->kW * (d->Cin / d->groups);
-    p->splitk = 1; p->mt = p->nt = 0; p->ktiles_per_split = 0;
+    p->splitk = 1; p->mt = p->nt = 0; p->ktiles_per_split = 0; p->ups = d->x_ups ? 1 : 0;
+    SM_REQUIRE(!d->x_ups || ((d->H & 1) == 0 && (d->W & 1) == 0 && d->groups == 1), "sm_conv2d_fwd: x_ups needs even H and W");
     SM_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "sm_conv2d_fwd: more than 2^31 output pixels");
     SM_REQUIRE((long)d->N * d->H * d->W < (1L << 31) - (1L << 24), "sm_conv2d_fwd: more than 2^31 input pixels");
     sm_fastdiv_make((unsigned)(d->Ho * d->Wo), &p->dhw_mul, &p->dhw_sh); sm_fastdiv_make((unsigned)d->Wo, &p->dw_mul, &p->dw_sh);
@@ -795,6 +842,7 @@ bool mfma_eligible(const sm_conv_desc* d, const ConvParams& p) {
 }
 
 int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_bytes, hipStream_t s) {
+    if (p.ups && (d->groups != 1 || d->kH != 3 || d->kW != 3)) { sm_set_error("sm_conv2d_fwd: x_ups is only implemented for 3x3 / stride 1 / pad 1 convolutions"); return SM_ERR_INVALID_ARGUMENT; }
     if (d->groups > 1 && d->groups == d->Cin && d->groups == d->Cout && (d->Cout % 8) == 0 && (p.x_ld % 8) == 0 &&
         (p.y_ld % 8) == 0 && (!p.res || (p.res_ld % 8) == 0)) {
         long work = (long)p.M * (p.Cout / 8);
@@ -838,7 +886,7 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         }
         SM_LAUNCH_CHECK(); return SM_OK;
     }
-    if (pw_thin_eligible(d, p)) {                                    // thin pointwise layers: untiled streaming kernel (pw_thin.hpp), no tile config
+    if (!p.ups && pw_thin_eligible(d, p)) {                                    // thin pointwise layers: untiled streaming kernel (pw_thin.hpp), no tile config
         pw_thin_launch(p, s);
         SM_LAUNCH_CHECK(); return SM_OK;
     }
@@ -847,8 +895,14 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         hipLaunchKernelGGL(conv_direct_kernel, dim3(sm_stream_grid(work, 256)), dim3(256), 0, s, p, d->groups);
         SM_LAUNCH_CHECK(); return SM_OK;
     }
-    if (cfg < 0 || cfg >= kNumCfgs) cfg = pick_cfg(p);
+    if (p.ups && !mfma_eligible(d, p)) { sm_set_error("sm_conv2d_fwd: x_ups needs the MFMA path (Cin %% 8 == 0, aligned operands)"); return SM_ERR_INVALID_ARGUMENT; }
+    if (cfg < 0 || cfg >= kNumCfgs) {
+        cfg = pick_cfg(p);
+        if (p.ups) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if ((kCfgs[i].kind == 5 || kCfgs[i].kind == 4) && cfg_eligible(kCfgs[i], p)) cfg = i; }   // only the patch kernels gather through the upsampling
+        if (cfg < 0) { sm_set_error("sm_conv2d_fwd: no kernel takes this shape with x_ups"); return SM_ERR_INVALID_ARGUMENT; }
+    }
     const TileCfg& c = kCfgs[cfg];
+    if (p.ups && c.kind != 5 && c.kind != 4) { sm_set_error("conv tile config %d (%s) does not apply to an upsampled input", cfg, c.name); return SM_ERR_INVALID_ARGUMENT; }
     if (!cfg_eligible(c, p)) { sm_set_error("conv tile config %d (%s) does not apply to Cin=%d", cfg, c.name, p.Cin); return SM_ERR_INVALID_ARGUMENT; }
     if (c.kind == 4) {                                               // persistent: one block per CU (two when the LDS allows), contiguous tile ranges
         const size_t lds = ws_setup(p, c);
@@ -856,6 +910,12 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         const int grid = std::min(p.ws_ntiles, SM_NUM_CU * per_cu);
         typedef void (*WsFn)(ConvParams);
         hipLaunchKernelGGL((WsFn)c.fn, dim3(grid), dim3(c.threads), lds, s, p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
+    if (c.kind == 5) {
+        const size_t lds = p9_setup(p, c);
+        const long grid = (long)p.p9_tiles_per_band * sm_ceil_div(p.W, p.p9_TW) * p.nt;
+        hipLaunchKernelGGL(c.fn, dim3((unsigned)grid), dim3(c.threads), lds, s, p);
         SM_LAUNCH_CHECK(); return SM_OK;
     }
     p.mt = sm_ceil_div(p.M, c.BM); p.nt = sm_ceil_div(p.Cout, c.BN);

@@ -60,6 +60,45 @@ __global__ void affine_scalar_kernel(const half_t* x, half_t* y, long pixels, in
 // [x*R/8, (x+1)*R/8): the input rows that overlapping windows share are then fetched into one L2 instead of two or three
 // (a 3x3/2 max-pool re-reads every input pixel 2.25 times).  Max pooling of fp16 data is exact in fp16 (v_pk_max_f16);
 // averages accumulate in fp32.
+// Max-pool fast path for small windows (2x2/2 of the U-Net, 3x3/2 of ResNet): same block -> row map as pool_kernel, but the KH*KW
+// 16-byte loads of an output vector are ALL issued before the first max (clamped addresses, out-of-window taps replaced by -inf
+// afterwards: no branch between loads), and a thread takes OPT output vectors — the generic kernel's nested loops with `continue`
+// waited for every load before issuing the next one (2 TB/s on the 512x512 U-Net pool: latency-, not bandwidth-bound).
+template <int KH, int KW, int OPT>
+__global__ __launch_bounds__(256) void maxpool_small_kernel(sm_pool_desc d, const half_t* x, half_t* y) {
+    const int cv = d.C >> 3;
+    const int rows = d.N * d.Ho, rpx = (rows + SM_NUM_XCD - 1) / SM_NUM_XCD;
+    const int row = (blockIdx.x & (SM_NUM_XCD - 1)) * rpx + (blockIdx.x >> 3);
+    if (row >= rows || (int)(blockIdx.x >> 3) >= rpx) return;
+    const int n = row / d.Ho, oy = row - n * d.Ho, per_row = d.Wo * cv;
+    const half_t* img = x + (long)n * d.H * d.W * d.x_ld;
+    half8_t v[OPT][KH * KW]; bool ok[OPT][KH * KW]; int idx[OPT];
+#pragma unroll
+    for (int o = 0; o < OPT; o++) {
+        idx[o] = (blockIdx.y * OPT + o) * 256 + threadIdx.x;
+        const int id = min(idx[o], per_row - 1), ox = id / cv, c = (id - ox * cv) * 8;
+#pragma unroll
+        for (int a = 0; a < KH; a++)
+#pragma unroll
+            for (int b = 0; b < KW; b++) {
+                const int iy = oy * d.sH + d.y0 + a, ix = ox * d.sW + d.x0 + b;
+                ok[o][a * KW + b] = (unsigned)iy < (unsigned)d.H && (unsigned)ix < (unsigned)d.W;
+                v[o][a * KW + b] = *(const half8_t*)(img + ((long)min(max(iy, 0), d.H - 1) * d.W + min(max(ix, 0), d.W - 1)) * d.x_ld + c);
+            }
+    }
+#pragma unroll
+    for (int o = 0; o < OPT; o++) {
+        if (idx[o] >= per_row) continue;
+        const int ox = idx[o] / cv, c = (idx[o] - ox * cv) * 8;
+        half8_t m;
+#pragma unroll
+        for (int j = 0; j < 8; j++) m[j] = (half_t)(-__builtin_inff());
+#pragma unroll
+        for (int t = 0; t < KH * KW; t++) if (ok[o][t]) m = __builtin_elementwise_max(m, v[o][t]);
+        *(half8_t*)(y + ((long)row * d.Wo + ox) * d.y_ld + c) = m;
+    }
+}
+
 template <bool MAX, int V>
 __global__ __launch_bounds__(256) void pool_kernel(sm_pool_desc d, const half_t* x, half_t* y) {
     const int cv = (d.C + V - 1) / V;
@@ -334,6 +373,16 @@ static int pool_common(const sm_pool_desc* d0, const void* x, void* y, bool is_m
     SM_REQUIRE(d0 && x && y && d0->N > 0 && d0->C > 0 && d0->Ho > 0 && d0->Wo > 0 && d0->kH > 0 && d0->kW > 0 && d0->sH > 0 && d0->sW > 0, "sm_pool: bad argument");
     sm_pool_desc d = *d0; d.x_ld = d.x_ld ? d.x_ld : d.C; d.y_ld = d.y_ld ? d.y_ld : d.C;
     SM_REQUIRE((long)d.N * d.Ho < (1L << 31), "sm_pool2d: too many output rows");
+    if (is_max && vec8(d.C, {d.x_ld, d.y_ld}, {x, y}) && ((d.kH == 2 && d.kW == 2) || (d.kH == 3 && d.kW == 3))) {
+        const long per_row = (long)d.Wo * (d.C / 8);
+        const int opt = d.kH == 2 ? (per_row >= 1024 ? 4 : 1) : (per_row >= 512 ? 2 : 1);
+        dim3 g(sm_ceil_div((long)d.N * d.Ho, SM_NUM_XCD) * SM_NUM_XCD, sm_ceil_div(per_row, 256 * opt));
+        if (d.kH == 2 && opt == 4) hipLaunchKernelGGL((maxpool_small_kernel<2, 2, 4>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
+        else if (d.kH == 2) hipLaunchKernelGGL((maxpool_small_kernel<2, 2, 1>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
+        else if (opt == 2) hipLaunchKernelGGL((maxpool_small_kernel<3, 3, 2>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
+        else hipLaunchKernelGGL((maxpool_small_kernel<3, 3, 1>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
     if (vec8(d.C, {d.x_ld, d.y_ld}, {x, y})) {
         dim3 g(sm_ceil_div((long)d.N * d.Ho, SM_NUM_XCD) * SM_NUM_XCD, sm_ceil_div((long)d.Wo * (d.C / 8), 256));
         if (is_max) hipLaunchKernelGGL((pool_kernel<true, 8>), g, dim3(256), 0, sm_s(st), d, (const half_t*)x, (half_t*)y);

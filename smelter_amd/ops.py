@@ -51,8 +51,11 @@ def conv_out_size(h, w, kh, kw, sh, sw, pads):
 
 
 def conv2d(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0), dilation=(1, 1), groups=1,
-           act=ACT_NONE, slope=0.0, out=None, cfg=None, workspace=None):
+           act=ACT_NONE, slope=0.0, out=None, cfg=None, workspace=None, ups=False):
+    """ups=True: `x` is the half-resolution tensor, read through a fused nearest 2x upsampling (sm_conv_desc.x_ups)"""
     n, h, w, cin, x_ld = _check_nhwc(x)
+    if ups:
+        h, w = 2 * h, 2 * w
     cout, kh, kw, cg = w_ohwi.shape
     assert w_ohwi.dtype == torch.float16 and w_ohwi.is_contiguous() and cg * groups == cin
     ho, wo = conv_out_size(h, w, kh, kw, stride[0], stride[1], pads)
@@ -68,6 +71,7 @@ def conv2d(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0)
         assert bias.dtype == torch.float32 and bias.numel() == cout
     d = ConvDesc(n, h, w, cin, cout, kh, kw, stride[0], stride[1], dilation[0], dilation[1], pads[0], pads[1], pads[2],
                  pads[3], groups, ho, wo, act, slope, x_ld, y_ld, res_ld)
+    d.x_ups = 1 if ups else 0
     L = lib()
     if cfg is not None:
         wsb = workspace.numel() * workspace.element_size() if workspace is not None else 0

@@ -216,10 +216,16 @@ def test_dims_override_and_errors_surface_through_compile():
     assert ex.outputDims == (1, 16, 32, 48)
     b = zoo.ow.GraphBuilder("g")
     b.add_input("input", [1, 4, 4, 4])
-    b.add_output(b.add_node("Flatten", ["input"], axis=1), [1, 64])     # Flatten of a 4x4 map feeding the graph output
+    b.add_output(b.add_node("Flatten", ["input"], axis=1), [1, 64])     # Flatten of a 4x4 map feeding the graph output: materialised in (c, y, x) order
+    x = np.random.default_rng(2).random((2, 4, 4, 4), dtype=np.float32)
+    _, got = run_hip(b.to_model(), x)
+    assert got.shape == (2, 64, 1, 1) and np.array_equal(got.reshape(2, 64), O.round_to_half(x).reshape(2, 64))
+    b = zoo.ow.GraphBuilder("g")
+    b.add_input("input", [1, 4, 4, 4])
+    b.add_output(b.add_node("Flatten", ["input"], axis=0), [1, 64])
     with pytest.raises(SmelterError) as e:
         ONNXGraph(b.to_model()).hipGraph(0, 1)
-    assert e.value.kind == "inconsistentState"
+    assert e.value.kind == "flattenAxis"
 
 
 def test_fc_after_flatten_of_spatial_map():

@@ -245,7 +245,8 @@ def test_add_relu_batchnorm(c):
     assert_close(to_host(y), O.batchnorm(a, g, be, m, v, 1e-5), 4)
 
 
-@pytest.mark.parametrize("c,hw,k,s,p", [(64, 112, 3, 2, 1), (16, 13, 3, 2, 1), (8, 12, 2, 2, 0), (5, 9, 3, 1, 1)])
+@pytest.mark.parametrize("c,hw,k,s,p", [(64, 112, 3, 2, 1), (16, 13, 3, 2, 1), (8, 12, 2, 2, 0), (5, 9, 3, 1, 1),
+                                        (64, 256, 2, 2, 0), (128, 70, 3, 2, 1), (24, 50, 2, 2, 0), (40, 101, 3, 2, 1)])   # the unrolled max-pool variants (1 / 2 / 4 outputs per thread), ragged rows
 def test_pools(c, hw, k, s, p):
     rng = np.random.default_rng(hw)
     x = h(rng.standard_normal((2, c, hw, hw)))
@@ -491,3 +492,64 @@ def test_conv3x3_weight_stationary_writes_into_a_concat_slice():
     ref = np.maximum(O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1)), 0)
     assert_close(to_host(out[..., 32:]), ref, 64 * 9)
     assert float(out[..., :32].min()) == 7.0 and float(out[..., :32].max()) == 7.0
+
+
+P9_CASES = [
+    # n, h, w, cin, cout, act   -- conv3x3_p9.hpp: one patch per cin block serves all nine taps (tile configs 68..73)
+    (2, 28, 28, 128, 128, 1),    # ResNet-50 stage 2: a tile spans ~9 rows of a 28-wide image, ragged first / last row
+    (3, 14, 14, 256, 256, 1),    # stage 3: a 256-pixel tile spans two images (two halo-row pairs in one patch)
+    (6, 7, 7, 512, 64, 2),       # stage-4 geometry: 49-pixel images, five to six images per tile, PRelu
+    (1, 64, 64, 64, 128, 0),     # wide image: 32-pixel column bands, exact row-aligned tiles, no activation
+    (2, 9, 7, 64, 72, 1),        # Cout % 32 != 0: partial cout block, tiny images
+    (1, 33, 40, 128, 200, 1),    # two 20-pixel bands, ragged everything
+    (2, 40, 72, 192, 40, 1),     # three bands of 24, three cin blocks (patch buffers alternate more than once)
+]
+
+
+@pytest.mark.parametrize("case", P9_CASES)
+@pytest.mark.parametrize("cfg", list(range(68, 74)))
+def test_conv3x3_nine_tap_patch(case, cfg):
+    n, hh, ww, cin, cout, act = case
+    if cfg >= ops.num_conv_configs():
+        pytest.skip("no such config")
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * np.sqrt(2.0 / (cin * 9)))
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1))
+    slope = 0.25 if act == 2 else 0.0
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), act=act, slope=slope, cfg=cfg)
+    except SmelterError as e:
+        if "does not apply" in e.detail:
+            pytest.skip(e.detail)
+        raise
+    assert_close(to_host(y), ref, cin * 9)
+
+
+@pytest.mark.parametrize("case", [(2, 16, 20, 64, 64, 1), (1, 32, 32, 128, 40, 0), (3, 7, 9, 64, 136, 2), (2, 21, 33, 64, 32, 1), (1, 40, 24, 32, 32, 1)])
+@pytest.mark.parametrize("cfg", [None] + list(range(61, 74)))
+def test_conv3x3_reads_through_fused_nearest_upsampling(case, cfg):
+    """sm_conv_desc.x_ups: conv(upsample2x_nearest(x)) computed from the half-resolution x (the executor fuses Upsample -> Conv this way)"""
+    n, hh, ww, cin, cout, act = case                                  # hh x ww = the LOW resolution
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * np.sqrt(2.0 / (cin * 9)))
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv2d(O.upsample(x, 2, 2), w, b, stride=(1, 1), pads=(1, 1, 1, 1))
+    slope = 0.25 if act == 2 else 0.0
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), act=act, slope=slope, cfg=cfg, ups=True)
+    except SmelterError as e:
+        if cfg is not None and "does not apply" in e.detail:
+            pytest.skip(e.detail)
+        raise
+    assert_close(to_host(y), ref, cin * 9)
+    with pytest.raises(SmelterError):                                 # every other kernel family refuses an upsampled input
+        ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), cfg=7, ups=True)
