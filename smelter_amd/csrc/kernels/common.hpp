@@ -63,6 +63,14 @@ __device__ __forceinline__ float sm_act(float v, int act, float slope) {
     return sm_act_other(v, act, slope);
 }
 
+// v_permlane32_swap_b32 a, b: lanes 32..63 of `a` trade places with lanes 0..31 of `b` (a[32+i] <-> b[i]).  As an asm statement: the
+// builtin's SECOND result was silently replaced by a copy of the first when its operands were bit-cast floats and the results were
+// consumed inside a divergent branch (ROCm 7.2, conv_igemm64.hpp's register epilogue; every second 4-channel group came out as a
+// duplicate).  The s_nop covers the VALU-write -> v_permlane* hazard the compiler would otherwise pad (cdna_hip_programming.md §5.7).
+__device__ __forceinline__ void sm_permlane32_swap(unsigned& a, unsigned& b) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
 static inline int sm_ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 static inline hipStream_t sm_s(sm_stream_t s) { return (hipStream_t)s; }
 // grid for grid-stride elementwise kernels: enough blocks to fill the chip, capped (guide G11)

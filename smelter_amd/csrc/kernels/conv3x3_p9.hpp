@@ -187,10 +187,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
                 }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const auto s0 = __builtin_amdgcn_permlane32_swap(d[2 * j][0], d[2 * j + 1][0], false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(d[2 * j][1], d[2 * j + 1][1], false, false);
+                sm_permlane32_swap(d[2 * j][0], d[2 * j + 1][0]);
+                sm_permlane32_swap(d[2 * j][1], d[2 * j + 1][1]);
                 const int co = co0 + 16 * j + 8 * hi;                 // this lane's 8 consecutive couts
-                if (ovalid[b] && co < p.Cout) *(u32x4*)(p.y + opix[b] * p.y_ld + co) = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                if (ovalid[b] && co < p.Cout) *(u32x4*)(p.y + opix[b] * p.y_ld + co) = u32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
             }
         }
     }

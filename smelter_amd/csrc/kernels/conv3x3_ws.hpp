@@ -258,9 +258,9 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
                 // up with 8q+8..8q+15 — 8 consecutive channels = 16 bytes per lane
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(d[2 * j][0], d[2 * j + 1][0], false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(d[2 * j][1], d[2 * j + 1][1], false, false);
-                    outv[a][b][j] = u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    sm_permlane32_swap(d[2 * j][0], d[2 * j + 1][0]);
+                    sm_permlane32_swap(d[2 * j][1], d[2 * j + 1][1]);
+                    outv[a][b][j] = u32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
                 }
             }
         }
