@@ -91,7 +91,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
     for (int j = 0; j < NSB - 1; j++) { ws_glds16(zero, dummy_a); issue_b(j); }
 
     // ---- per-lane fragment slots (tile-invariant part of the A addresses) and output pixels ---------------------------------------
-    unsigned aoff[TM][9][4]; long opix[TM]; bool ovalid[TM];
+    // (TM = 4: 144 precomputed fragment addresses do not fit next to 128 accumulator registers — the big tile derives them per tap)
+    constexpr bool A_RT = TM > 2;
+    unsigned aoff[A_RT ? 1 : TM][A_RT ? 1 : 9][4]; int slotq[TM]; long opix[TM]; bool ovalid[TM];
 #pragma unroll
     for (int b = 0; b < TM; b++) {
         const long f = f0 + (wm * TM + b) * 32 + l31;
@@ -102,11 +104,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
         const int ox = x0 + xx;
         ovalid[b] = in && ox < W;
         opix[b] = (long)R * W + ox;
+        slotq[b] = prow0 * PW + xx;
+        if constexpr (!A_RT) {
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int q = (prow0 + tap / 3) * PW + xx + tap % 3;
+            for (int tap = 0; tap < 9; tap++) {
+                const int q = slotq[b] + (tap / 3) * PW + tap % 3;
 #pragma unroll
-            for (int ks = 0; ks < 4; ks++) aoff[b][tap][ks] = patch_a + (unsigned)(q * 128 + (((ks * 2 + hi) ^ ws_swz<8>(q)) << 4));
+                for (int ks = 0; ks < 4; ks++) aoff[b][tap][ks] = patch_a + (unsigned)(q * 128 + (((ks * 2 + hi) ^ ws_swz<8>(q)) << 4));
+            }
         }
     }
     unsigned boffv[4];
@@ -138,10 +143,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
             issue_b(kt + NSB - 1);
             const unsigned sb = (unsigned)((kt % NSB) * B_BYTES);
             half8_t fx[PF + 1][TM], fw[PF + 1][TN];
+            unsigned abase[A_RT ? TM : 1]; int asw[A_RT ? TM : 1];
+            if constexpr (A_RT) {
+#pragma unroll
+                for (int b = 0; b < TM; b++) { const int q = slotq[b] + (TAP / 3) * PW + TAP % 3; abase[b] = patch_a + pbuf + (unsigned)(q * 128); asw[b] = ws_swz<8>(q); }
+            }
             auto fetch = [&](auto kc) {
                 constexpr int KSI = decltype(kc)::value, SLOT = KSI % (PF + 1);
 #pragma unroll
-                for (int b = 0; b < TM; b++) { half8_t& d = fx[SLOT][b]; const unsigned ad = aoff[b][TAP][KSI] + pbuf; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad)); }
+                for (int b = 0; b < TM; b++) {
+                    half8_t& d = fx[SLOT][b];
+                    unsigned ad;
+                    if constexpr (A_RT) ad = abase[b] + (unsigned)(((KSI * 2 + hi) ^ asw[b]) << 4); else ad = aoff[b][TAP][KSI] + pbuf;
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad));
+                }
 #pragma unroll
                 for (int a = 0; a < TN; a++) { half8_t& d = fw[SLOT][a]; const unsigned ad = boffv[KSI] + sb; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(ad), "n"(a * 4096)); }
             };

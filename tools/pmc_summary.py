@@ -16,6 +16,7 @@ def main():
     ap.add_argument("csvs", nargs="+")
     ap.add_argument("--out", default=None)
     ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--head", default="unrecorded", help="git revision of the measured binary (recorded in the JSON)")
     a = ap.parse_args()
     # dispatch_id -> {counter: value}, kernel name
     disp = collections.OrderedDict()
@@ -42,7 +43,7 @@ def main():
     print("%3s %-44s %10s %10s %8s %9s" % ("#", "kernel", "rd_MB", "wr_MB", "L2hit%", "mfma_busy"))
     for i, e in disp.items():
         name = e["name"]
-        key = "conv_igemm" if "conv_igemm" in name else ("conv3x3_strip" if "conv3x3_strip" in name else None)
+        key = next((k for k in ("conv_igemm", "conv3x3_strip", "conv3x3_ws", "conv3x3_p9", "pw_thin") if k in name), None)
         short = name[name.find(key):][:40] if key else name[:40]
         rd = e.get("FETCH_SIZE", 0) * 1024 * 2 / 1e6
         wr = e.get("WRITE_SIZE", 0) * 1024 / 1e6
@@ -50,14 +51,14 @@ def main():
         hr = 100 * hit / (hit + miss) if hit + miss else float("nan")
         print("%3d %-44s %10.1f %10.1f %8.1f %9.3g" % (i, short, rd, wr, hr, e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)))
         tot["rd"] += rd; tot["wr"] += wr
-        if "conv_igemm" in name or "conv3x3_strip" in name or "splitk" in name:
+        if key or "splitk" in name:
             conv["rd"] += rd; conv["wr"] += wr; nconv += 1
     print("step total: read %.1f MB, write %.1f MB ; conv family: read %.1f MB, write %.1f MB over %d launches" % (
         tot["rd"], tot["wr"], conv["rd"], conv["wr"], nconv))
     if a.out:
         json.dump({"hbm_bytes_per_launch": round((conv["rd"] + conv["wr"]) * 1e6 / max(nconv, 1)),
                    "hbm_read_bytes_per_step": round(tot["rd"] * 1e6), "hbm_write_bytes_per_step": round(tot["wr"] * 1e6),
-                   "conv_launches_per_step": nconv,
+                   "conv_launches_per_step": nconv, "head": a.head,
                    "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes with --kernel-trace; FETCH_SIZE KiB x2 (gfx950), WRITE_SIZE KiB x1"},
                   open(a.out, "w"), indent=1)
 

@@ -5,7 +5,8 @@
 #      (MI355X_MICROARCH.md §HBM: FETCH_SIZE and WRITE_SIZE do not fit one pass)          -> gpurun_out/pmc/pass*/
 # Summaries: tools/rocprof_summary.py, tools/pmc_summary.py (run here or in the build container).
 set -u
-TAG=${1:-r01d}
+TAG=${1:-r02}
+HEAD=${2:-unrecorded}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
@@ -20,6 +21,6 @@ for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" SQ_VALU_MFMA_BUSY_CY
 done
 cd $ROOT
 python tools/rocprof_summary.py $(ls $OUT/prof_kt/*/r_results.db $OUT/prof_kt/r_results.db 2>/dev/null | head -1) --steps 20 > $OUT/${TAG}_kernel_stats.txt 2>&1
-python tools/pmc_summary.py $(find $OUT/pmc -name "p_counter_collection.csv" | sort) --out $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_per_op.txt 2>&1
+python tools/pmc_summary.py $(find $OUT/pmc -name "p_counter_collection.csv" | sort) --head $HEAD --out $OUT/${TAG}_pmc_traffic.json > $OUT/${TAG}_pmc_per_op.txt 2>&1
 python bench.py --steps 50 --warmup 10 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 tail -3 $OUT/${TAG}_kernel_stats.txt; tail -2 $OUT/${TAG}_pmc_per_op.txt; tail -1 $OUT/${TAG}_bench.json | cut -c1-300
