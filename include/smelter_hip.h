@@ -101,6 +101,16 @@ int sm_conv2d_uses_tile_config(const sm_conv_desc* d);
 int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias,
                       const void* residual, void* y, void* workspace, size_t workspace_bytes, sm_stream_t stream);
 
+/* Two MPSCNNConvolutionNodes in a row, both 1x1 / stride 1 (Converters.swift:253), in ONE launch:
+ *   y = act(x * w1 + bias1 + residual)   [d: Cin = 64 -> Cout = 256]      z = act2(y * w2 + bias2)   [256 -> N2 in {64, 128}]
+ * Both tensors are stored (y is the next residual); y is rounded to fp16 once, exactly as the separate launches would store it.
+ * The executor uses it for the expand -> reduce pairs of ResNet's 56x56 stage, where the second layer would otherwise spend its
+ * whole life re-reading what the first has just written. */
+int sm_conv1x1_pair_supported(const sm_conv_desc* d, int32_t N2);
+int sm_conv1x1_pair_fwd(const sm_conv_desc* d, const void* x, const void* w1, const float* bias1, const void* residual, void* y,
+                        int32_t N2, const void* w2, const float* bias2, int32_t act2, float slope2, void* z, int32_t z_ld,
+                        sm_stream_t stream);
+
 /* MPSCNNConvolutionTransposeNode (Converters.swift:277) + ONNX_ConvolutionPadding(isTranspose) (:66-71, :97-103).
  * `w_ohwi_flipped` is what ConvDataSource hands MPS: out[oc][kH-1-kh][kW-1-kw][ic] = W[ic][oc][kh][kw]
  * (Array+Extensions.swift:71-76).  y[n,oy,ox,oc] = act(bias[oc] + sum x[n,iy,ix,ic] * W[ic,oc,kh,kw]) over

@@ -313,6 +313,33 @@ int Executor::plan(ONNXGraph& g, int batch) {
         steps_.push_back(std::move(st));
     }
 
+    // ---- 3b. pointwise pairs: a 1x1 expand (64 -> 256, + residual + ReLU) whose output feeds a 1x1 reduce (256 -> 64 | 128) runs together
+    // with it in one persistent launch (conv1x1_pair.hpp): the 256-channel tensor is written once and never read back by the reduce.
+    // The reduce moves up to the expand's position — legal, its only operand is produced there.
+    // OFF by default (SMELTER_POINTWISE_PAIRS=1 enables it): measured on ResNet-50 bs=64 the three pairs take 59 / 72 / 75 us against
+    // 74 / 73 / 82 us as separate launches — the tile-serial kernel (three barriers per tile) streams at 3.1-3.9 TB/s where the plain
+    // kernels reach 4.3-5.8, and the longer life of the moved-up output pushes the activation arena from 257 to 283 MB, past the
+    // 256 MiB Infinity Cache; the step time does not move.
+    const char* pairs_env = getenv("SMELTER_POINTWISE_PAIRS");
+    if (pairs_env && pairs_env[0] == '1' && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency) {
+        for (size_t t = 0; t < steps_.size(); t++) {
+            Step& c = steps_[t];
+            if (c.op.kind != OpKind::Conv || c.stem || c.op.grid_h || c.op.x_ups || c.op.output == output_value_) continue;
+            const Value& cin_v = values_[c.op.inputs[0]];
+            sm_conv_desc d{}; d.N = batch; d.H = d.Ho = cin_v.h; d.W = d.Wo = cin_v.w; d.Cin = c.op.cin; d.Cout = c.op.cout; d.kH = c.op.kh; d.kW = c.op.kw; d.sH = c.op.sh; d.sW = c.op.sw;
+            d.pt = c.op.pt; d.pl = c.op.pl; d.groups = c.op.groups; d.act = c.op.act;
+            if (values_[c.op.output].h != cin_v.h || values_[c.op.output].w != cin_v.w) continue;
+            for (size_t u = t + 1; u < steps_.size(); u++) {
+                Step& a = steps_[u];
+                if (a.op.kind != OpKind::Conv || a.op.inputs[0] != c.op.output || a.op.kh != 1 || a.op.kw != 1 || a.op.sh != 1 || a.op.sw != 1 || a.op.pt || a.op.pl || a.op.groups != 1 ||
+                    a.op.residual >= 0 || a.op.act > SM_ACT_PRELU || a.op.cin != c.op.cout || a.op.grid_h || a.op.x_ups || a.has_pair || !sm_conv1x1_pair_supported(&d, a.op.cout)) continue;
+                c.has_pair = true; c.pair = std::move(a.op); c.real_k += 0;
+                steps_.erase(steps_.begin() + u);
+                break;
+            }
+        }
+    }
+
     // ---- 4. memory plan ------------------------------------------------------------------------------------
     const int ns = (int)steps_.size();
     std::vector<int> first(nv, INT32_MAX), last(nv, -1);   // per ROOT value: live step interval
@@ -347,6 +374,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         for (int u : op.inputs) { touch(u, t); touch(u, until); }
         if (op.residual >= 0) { touch(op.residual, t); touch(op.residual, until); }
         touch(op.output, t);
+        if (steps_[t].has_pair) touch(steps_[t].pair.output, t);
     }
     touch(output_value_, ns);                               // result image must survive until read back
     if (cfg_.keepIntermediates) for (int v = 0; v < nv; v++) if (last[v] >= 0) { first[v] = -1; last[v] = ns; }
@@ -377,6 +405,13 @@ int Executor::plan(ONNXGraph& g, int batch) {
             st.w_off = off; off = alignUp(off + op.weight.size() * 2);
             st.has_bias = !op.bias.empty();
             if (st.has_bias) { st.b_off = off; off = alignUp(off + op.bias.size() * 4); }
+            if (st.has_pair) {
+                st.w2_off = off; off = alignUp(off + st.pair.weight.size() * 2);
+                st.has_bias2 = !st.pair.bias.empty();
+                if (st.has_bias2) { st.b2_off = off; off = alignUp(off + st.pair.bias.size() * 4); }
+                flops_ += 2.0 * st.M * st.pair.cout * (double)st.pair.cin;
+                alg_bytes_ += 2.0 * ((double)st.M * st.pair.cout + (double)st.pair.cout * st.pair.cin);     // (its input is not read from memory)
+            }
             const Value& ov = values_[op.output];
             const double K = (double)st.real_k;
             flops_ += 2.0 * st.M * op.cout * K;
@@ -401,12 +436,16 @@ int Executor::plan(ONNXGraph& g, int batch) {
                      st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem ? " stem" : op.grid_h ? " convT-phase" : op.x_ups ? " +ups2x" : "");
         else snprintf(buf, sizeof buf, "%s %s pixels=%d C=%d%s", kindName(op.kind), op.name.c_str(), st.M, values_[op.output].c, op.act ? " +act" : "");
         st.desc = buf;
+        if (st.has_pair) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.pair.name.c_str(), st.pair.cout, st.pair.cin, st.pair.act ? " +act" : ""); st.desc += buf; }
         if (st.join >= 0) st.desc += " side-stream";
     }
     arena_bytes_ = std::max(off, (size_t)kAlign);
     value_names_.resize(nv); for (int v = 0; v < nv; v++) value_names_[v] = values_[v].name;
     materialized_.clear(); materialized_.push_back(values_[input_value_].name);
-    for (auto& st : steps_) if (st.op.kind != OpKind::Concat && materialized_.back() != values_[st.op.output].name) materialized_.push_back(values_[st.op.output].name);
+    for (auto& st : steps_) {
+        if (st.op.kind != OpKind::Concat && materialized_.back() != values_[st.op.output].name) materialized_.push_back(values_[st.op.output].name);
+        if (st.has_pair) materialized_.push_back(values_[st.pair.output].name);
+    }
     return SM_OK;
 }
 
@@ -427,6 +466,10 @@ int Executor::packWeights(std::vector<uint8_t>* host) const {
                 sm_float_to_half(op.weight.data(), dst, op.weight.size());   // fp16 cast, RNE (ONNX2MPS.py:27 numpy astype(float16))
             }
             if (st.has_bias) memcpy(host->data() + st.b_off, op.bias.data(), op.bias.size() * 4);
+            if (st.has_pair) {
+                sm_float_to_half(st.pair.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.pair.weight.size());
+                if (st.has_bias2) memcpy(host->data() + st.b2_off, st.pair.bias.data(), st.pair.bias.size() * 4);
+            }
         } else if (op.kind == OpKind::BatchNorm || op.kind == OpKind::GroupNorm) {
             memcpy(host->data() + st.s_off, op.scale.data(), op.scale.size() * 4);
             memcpy(host->data() + st.t_off, op.shift.data(), op.shift.size() * 4);
@@ -475,7 +518,7 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     const Value& ov = e->values_[e->output_value_];
     e->out_f32_count_ = std::max(sm_float_array_count(batch, ov.c, ov.h, ov.w), (size_t)batch * ov.c * ov.h * ov.w);
     SM_HIP_CHECK(hipMalloc((void**)&e->out_f32_, e->out_f32_count_ * 4));
-    for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit(); }   // host masters no longer needed
+    for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit(); st.pair.weight.clear(); st.pair.weight.shrink_to_fit(); }   // host masters no longer needed
     if (e->cfg_.autotune) {   // with an external arena and upload == 0 the caller filled it before compiling
         hipStream_t s; SM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         rc = e->autotune(s);
@@ -494,6 +537,10 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
     switch (op.kind) {
     case OpKind::Conv: case OpKind::FullyConnected: {
         const sm_conv_desc d = convDesc(st);
+        if (st.has_pair)
+            return sm_conv1x1_pair_fwd(&d, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
+                                       op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, st.pair.cout, arena_ + st.w2_off, st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr,
+                                       st.pair.act, st.pair.slope, valuePtr(st.pair.output), valueLd(st.pair.output), ss);
         return sm_conv2d_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
                                  op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, st.join >= 0 ? nullptr : ws_, st.join >= 0 ? 0 : ws_bytes_, ss);   // the split-K scratch belongs to the main branch
     }
@@ -696,7 +743,7 @@ int Executor::autotune(hipStream_t s) {
     int rc = SM_OK;
     for (size_t i = 0; i < steps_.size() && !rc; i++) {
         Step& st = steps_[i];
-        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8)) continue;
+        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8) || st.has_pair) continue;
         if (st.op.kind != OpKind::ConvTranspose) { const sm_conv_desc cd = convDesc(st); if (!sm_conv2d_uses_tile_config(&cd)) continue; }   // dedicated kernel, nothing to tune
         // one config: `reps` timed launches after an untimed first one (code fetch); returns false if the config does not apply
         auto timeCfg = [&](int c, int reps, std::vector<float>& samples) -> bool {

@@ -35,6 +35,9 @@ struct Step {                // one op after fusion, with everything resolved
     // step `join` runs on the side stream, concurrently with the steps in between
     int join = -1;           // >= 0: this step runs on the side stream and step `join` waits for it
     bool waits_side = false; // this step is the join of an earlier side step
+    // pointwise pair (executor.cpp pass 3b): `pair` is the 1x1 convolution that consumes this step's output, run in the same launch
+    // (sm_conv1x1_pair_fwd); both outputs are materialised
+    bool has_pair = false; Op pair; size_t w2_off = 0, b2_off = 0; bool has_bias2 = false;
     std::string desc;
 };
 

@@ -485,6 +485,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 #include "pw_thin.hpp"
 #include "conv3x3_ws.hpp"
 #include "conv3x3_p9.hpp"
+#include "conv1x1_pair.hpp"
 
 // 3x3 depthwise through LDS (the MobileNet-v2 path): the register-strip kernel above re-reads every input pixel 4.5x through
 // L1/L2 and needs 227 VGPRs (1.2..2 TB/s of algorithmic bytes).  Here a block owns a tile of TH x TW output pixels x `cbv`
@@ -992,6 +993,31 @@ int sm_conv_transpose2d_fwd(const sm_conv_desc* d, const void* x, const void* w,
     SM_REQUIRE(d->groups == 1, "sm_conv_transpose2d_fwd: groups != 1");
     SM_REQUIRE(!p.yplace, "sm_conv_transpose2d_fwd: output placement not supported");
     hipLaunchKernelGGL(convt_direct_kernel, dim3(sm_stream_grid((long)p.M * p.Cout, 256)), dim3(256), 0, sm_s(stream), p);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+// Two chained pointwise convolutions in one launch (conv1x1_pair.hpp): d = the first one (1x1 / stride 1, Cin = 64, Cout = 256, optional
+// residual, ReLU-family activation); the second maps its 256 channels to N2 in {64, 128}.
+int sm_conv1x1_pair_supported(const sm_conv_desc* d, int32_t N2) {
+    return d && d->groups == 1 && d->kH == 1 && d->kW == 1 && d->sH == 1 && d->sW == 1 && d->pt == 0 && d->pl == 0 && d->Cin == 64 && d->Cout == 256 &&
+           (N2 == 64 || N2 == 128) && d->act <= SM_ACT_PRELU && !d->x_ups && !(d->y_sH | d->y_sW | d->y_oH | d->y_oW | d->y_H | d->y_W) && d->Ho == d->H && d->Wo == d->W;
+}
+int sm_conv1x1_pair_fwd(const sm_conv_desc* d, const void* x, const void* w1, const float* bias1, const void* residual, void* y, int32_t N2, const void* w2,
+                        const float* bias2, int32_t act2, float slope2, void* z, int32_t z_ld, sm_stream_t stream) {
+    SM_REQUIRE(sm_conv1x1_pair_supported(d, N2) && act2 <= SM_ACT_PRELU && w2 && z, "sm_conv1x1_pair_fwd: unsupported geometry (1x1 s1, 64 -> 256 -> 64|128, ReLU family)");
+    ConvParams p; int rc = fill_params(d, x, w1, bias1, residual, y, &p); if (rc) return rc;
+    z_ld = z_ld ? z_ld : N2;
+    SM_REQUIRE((p.x_ld & 7) == 0 && (p.y_ld & 7) == 0 && (z_ld & 7) == 0 && (!residual || (p.res_ld & 7) == 0) &&
+               ((((uintptr_t)x) | ((uintptr_t)w1) | ((uintptr_t)w2) | ((uintptr_t)y) | ((uintptr_t)z) | ((uintptr_t)residual)) & 15) == 0, "sm_conv1x1_pair_fwd: operands must be 16-byte aligned with pixel strides % 8 == 0");
+    const float s2 = act2 == SM_ACT_RELU ? 0.f : slope2;
+    const int tiles = sm_ceil_div(p.M, 64);
+    if (N2 == 64) {        // weights in registers: 4-wave blocks, 41 KB of LDS, two blocks per CU
+        const size_t lds = (size_t)64 * 64 * 2 + (size_t)64 * 256 * 2 + (256 + N2) * 4;
+        hipLaunchKernelGGL((conv1x1_pair_kernel<64, 256, 64, 64, 4, true>), dim3(std::min(tiles, 2 * SM_NUM_CU)), dim3(256), lds, sm_s(stream), p, (const half_t*)w2, bias2, (half_t*)z, z_ld, act2, s2);
+    } else {               // weights in LDS: 8-wave blocks, one per CU
+        const size_t lds = (size_t)256 * 64 * 2 + (size_t)N2 * 256 * 2 + (size_t)64 * 64 * 2 + (size_t)64 * 256 * 2 + (256 + N2) * 4;
+        hipLaunchKernelGGL((conv1x1_pair_kernel<64, 256, 128, 64, 8, false>), dim3(std::min(tiles, SM_NUM_CU)), dim3(512), lds, sm_s(stream), p, (const half_t*)w2, bias2, (half_t*)z, z_ld, act2, s2);
+    }
     SM_LAUNCH_CHECK(); return SM_OK;
 }
 

@@ -85,6 +85,18 @@ def conv2d(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0)
     return out
 
 
+def conv1x1_pair(x, w1, b1, residual, w2, b2, act1=ACT_RELU, act2=ACT_RELU, out_y=None, out_z=None):
+    """y = act1(conv1x1(x, w1) + b1 + residual), z = act2(conv1x1(y, w2) + b2) in one launch (sm_conv1x1_pair_fwd)"""
+    n, h, w, cin, x_ld = _check_nhwc(x)
+    n1, n2 = w1.shape[0], w2.shape[0]
+    y = torch.empty((n, h, w, n1), dtype=torch.float16, device=x.device) if out_y is None else out_y
+    z = torch.empty((n, h, w, n2), dtype=torch.float16, device=x.device) if out_z is None else out_z
+    res_ld = _check_nhwc(residual)[4] if residual is not None else 0
+    d = ConvDesc(n, h, w, cin, n1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, h, w, act1, 0.0, x_ld, _ld(y), res_ld)
+    check(lib().sm_conv1x1_pair_fwd(C.byref(d), _ptr(x), _ptr(w1), _ptr(b1), _ptr(residual), _ptr(y), n2, _ptr(w2), _ptr(b2), act2, 0.0, _ptr(z), _ld(z), _stream()))
+    return y, z
+
+
 def conv_transpose2d(x, w_ohwi_flipped, bias=None, stride=(1, 1), pads=(0, 0, 0, 0), dilation=(1, 1), out_pad=(0, 0), act=ACT_NONE, slope=0.0):
     """sm_conv_transpose2d_fwd: direct kernel over the flipped OHWI weights the reference's ConvDataSource produces"""
     n, h, w, cin, x_ld = _check_nhwc(x)

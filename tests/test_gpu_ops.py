@@ -553,3 +553,23 @@ def test_conv3x3_reads_through_fused_nearest_upsampling(case, cfg):
     assert_close(to_host(y), ref, cin * 9)
     with pytest.raises(SmelterError):                                 # every other kernel family refuses an upsampled input
         ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), cfg=7, ups=True)
+
+
+@pytest.mark.parametrize("n,hw,n2,res", [(2, (56, 56), 64, True), (1, (23, 17), 64, True), (3, (9, 11), 128, True), (2, (16, 16), 128, False), (1, (56, 56), 128, True)])
+def test_conv1x1_pair_equals_two_launches(n, hw, n2, res):
+    """sm_conv1x1_pair_fwd: y = relu(x*w1 + b1 + r), z = relu(y*w2 + b2); y bit-for-bit what the single conv stores, z within an ulp of the
+    oracle run on the fp16-rounded y (the unfused pair re-reads exactly that)"""
+    rng = np.random.default_rng(n * 100 + n2)
+    x = h(rng.standard_normal((n, 64, hw[0], hw[1])))
+    w1 = h(rng.standard_normal((256, 1, 1, 64)) * np.sqrt(2.0 / 64)); b1 = rng.standard_normal(256).astype(np.float32)
+    w2 = h(rng.standard_normal((n2, 1, 1, 256)) * np.sqrt(2.0 / 256)); b2 = rng.standard_normal(n2).astype(np.float32)
+    r = h(rng.standard_normal((n, 256, hw[0], hw[1]))) if res else None
+    yref = O.conv2d(x, w1, b1) + (r if res else 0)
+    yref = np.maximum(yref, 0)
+    zref = np.maximum(O.conv2d(h(yref), w2, b2), 0)
+    y, z = ops.conv1x1_pair(to_dev(x), torch.from_numpy(w1).cuda().half(), torch.from_numpy(b1).cuda(), to_dev(r) if res else None,
+                            torch.from_numpy(w2).cuda().half(), torch.from_numpy(b2).cuda())
+    y1 = ops.conv2d(to_dev(x), torch.from_numpy(w1).cuda().half(), torch.from_numpy(b1).cuda(), residual=to_dev(r) if res else None, act=1)
+    assert_close(to_host(y), yref, 64)
+    assert np.array_equal(to_host(y), to_host(y1))                     # same k order, same single rounding as the stand-alone kernel
+    assert_close(to_host(z), zref, 256)
