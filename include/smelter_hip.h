@@ -111,6 +111,22 @@ int sm_conv1x1_pair_fwd(const sm_conv_desc* d, const void* x, const void* w1, co
                         int32_t N2, const void* w2, const float* bias2, int32_t act2, float slope2, void* z, int32_t z_ld,
                         sm_stream_t stream);
 
+/* Three MPSCNNConvolutionNodes in a row — [1x1 expand + act1] -> depthwise 3x3 (pad 1, stride 1|2) + act2 -> 1x1 project + act3
+ * (+ the block input as residual) — in ONE launch; the two hidden tensors stay in LDS (the "inverted residual" block of
+ * MobileNet-v2).  expand = 0: no 1x1 in front (Ch == Cin).  Weights: w1 [Ch][Cin], wd [Ch][3][3] (the depthwise data source's
+ * OHWI image), w2 [Cout][Ch], fp16; biases fp32 or NULL.  Cin <= 32, Ch <= 192, Cout <= 64, all % 8 == 0; ReLU-family activations.
+ * Same roundings as the separate launches: the hidden tensors are rounded to fp16 once each. */
+typedef struct sm_mbconv_desc {
+    int32_t N, H, W, Ho, Wo, stride;
+    int32_t Cin, Ch, Cout, expand, residual;
+    int32_t act1; float slope1; int32_t act2; float slope2; int32_t act3; float slope3;
+    int32_t x_ld, y_ld;           /* pixel strides in elements, 0 = dense */
+} sm_mbconv_desc;
+int sm_mbconv_supported(const sm_mbconv_desc* d);
+size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d);
+int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const float* b1, const void* wd, const float* bd,
+                  const void* w2, const float* b2, void* y, sm_stream_t stream);
+
 /* MPSCNNConvolutionTransposeNode (Converters.swift:277) + ONNX_ConvolutionPadding(isTranspose) (:66-71, :97-103).
  * `w_ohwi_flipped` is what ConvDataSource hands MPS: out[oc][kH-1-kh][kW-1-kw][ic] = W[ic][oc][kh][kw]
  * (Array+Extensions.swift:71-76).  y[n,oy,ox,oc] = act(bias[oc] + sum x[n,iy,ix,ic] * W[ic,oc,kh,kw]) over

@@ -32,6 +32,12 @@ class ConvDesc(C.Structure):
                [("slope", C.c_float)] + [(n, C.c_int32) for n in ("x_ld", "y_ld", "res_ld", "y_sH", "y_sW", "y_oH", "y_oW", "y_H", "y_W", "x_ups")]
 
 
+class MbConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "Ho", "Wo", "stride", "Cin", "Ch", "Cout", "expand", "residual")] + \
+               [("act1", C.c_int32), ("slope1", C.c_float), ("act2", C.c_int32), ("slope2", C.c_float), ("act3", C.c_int32), ("slope3", C.c_float),
+                ("x_ld", C.c_int32), ("y_ld", C.c_int32)]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "C", "kH", "kW", "sH", "sW", "y0", "x0", "Ho", "Wo",
                                          "x_ld", "y_ld")]
@@ -61,6 +67,9 @@ SYMBOLS = {
     "sm_conv2d_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sm_conv1x1_pair_supported": (_i32, [C.POINTER(ConvDesc), _i32]),
     "sm_conv1x1_pair_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _vp, _i32, _vp]),
+    "sm_mbconv_supported": (_i32, [C.POINTER(MbConvDesc)]),
+    "sm_mbconv_lds_bytes": (_sz, [C.POINTER(MbConvDesc)]),
+    "sm_mbconv_fwd": (_i32, [C.POINTER(MbConvDesc)] + [_vp] * 9),
     "sm_conv_transpose2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "sm_conv2d_time": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, C.POINTER(_f)]),
     "sm_batchnorm": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp]),

@@ -1,0 +1,272 @@
+// mbconv.hip — fused inverted-residual block for gfx950:  [1x1 expand + act] -> depthwise 3x3 (stride 1|2, pad 1) + act -> 1x1 project
+// (+ residual) in ONE launch.  Replaces three MPSCNNConvolutionNodes in a row (Converters.swift:253; the depthwise one built from the
+// descriptor of :57-66) whose two intermediate "hidden" tensors — 6x the block's input, the bulk of MobileNet-v2's HBM traffic —
+// are written once and read once by the separate launches (16->96->24 at 112x112, bs=256: 616 + 616 + 154 + 154 MB around 103 MB of
+// input and 38 MB of output).  Here they live in LDS only:
+//   phase A  hidden patch = act1(X_patch * W1^T + b1), ((TH-1)s+3) x ((TW-1)s+3) pixels x Ch channels, fp16, ZERO outside the image
+//            (the depthwise layer pads its INPUT with zeros, i.e. the hidden tensor, not X): MFMA, A fragments gathered straight from
+//            global memory (a pixel row of Cin <= 32 halfs), W1 from LDS; rounded to fp16 once, as the stored tensor would be;
+//   phase B  depthwise 3x3 on the LDS patch: one thread = 8 channels of one output pixel, nine 16-byte LDS reads + 72 fp16 x fp16 -> fp32
+//            FMAs (weights [tap][Ch] in LDS), + bias, act2, rounded to fp16 once -> hidden tile in LDS;
+//   phase C  Y tile = act3(hidden tile * W2^T + b2 (+ X)) : MFMA with both operands from LDS, epilogue in registers
+//            (v_permlane32_swap -> 8 consecutive couts per lane -> 16-byte stores).
+// Blocks are persistent (weights stay in LDS) and 16 waves wide: every phase is a short dependent chain (gather -> MFMA -> LDS, LDS -> FMA ->
+// LDS, LDS -> MFMA -> store), so the tile time is latency, not throughput — 4-wave blocks took 20 k clk per tile, 16 waves spread the
+// (row block, channel block) pairs of phase A and the pixel x channel-vector items of phase B over the whole CU.
+// Numerics = the three separate launches: same fp32 accumulation order over k, the same two intermediate roundings to fp16.
+#include <algorithm>
+
+#include "common.hpp"
+
+namespace {
+
+struct MbParams {
+    const half_t* x; half_t* y; const half_t *w1, *wd, *w2; const float *b1, *bd, *b2;
+    int N, H, W, Ho, Wo, s, Cin, Ch, Cout, x_ld, y_ld;
+    int expand, res;                 // expand = 0: no 1x1 in front (the depthwise layer reads X itself, Ch == Cin)
+    int act1, act2, act3; float sl1, sl2, sl3;
+    int ChP, hstride;                // Ch rounded up to 32; LDS bytes per hidden pixel = ChP*2 + 16 (an odd number of 16-byte slots: conflict-free b128 columns)
+    int tiles_x, tiles_y, ntiles;
+    unsigned tx_mul, tx_sh, txy_mul, txy_sh, pw_mul, pw_sh;
+};
+
+inline void fastdiv_make(unsigned d, unsigned* mul, unsigned* sh) { unsigned s = 0; while ((1ull << s) < d) s++; *mul = (unsigned)(((1ull << (31 + s)) / d) + 1); *sh = 31 + s; }
+__device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned mul, unsigned sh) { return (unsigned)(((unsigned long long)n * mul) >> sh); }
+__device__ __forceinline__ float relu_family(float v, float sl) { return v < 0.f ? v * sl : v; }
+
+// TH x TW output pixels per tile (TH*TW = 32 or 64); S = depthwise stride
+template <int TH, int TW, int S>
+__global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
+    constexpr int NT = 1024, NW = 16, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, HP = PH * PW, OP = TH * TW;
+    constexpr int MFA = (HP + 31) / 32, MFC = OP / 32;
+    static_assert(OP % 32 == 0, "whole MFMA row blocks per tile");
+    extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
+    const int ChP = p.ChP, hs = p.hstride, KP1 = (p.Cin + 15) & ~15, CoP = (p.Cout + 31) & ~31;
+    // LDS: X patch [2][MFA*32][KP1] (expand) | hidden patch [HP][hs] (x2 without expand: it IS the X patch) | hidden tile [OP][hs] |
+    //      W1 [ChP][KP1] | Wd [9][ChP] | W2 [CoP][hs] | b1[ChP] bd[ChP] b2[CoP]
+    // The X patch of tile t+1 is fetched (one 16-byte load per thread) at the START of tile t and written to LDS at its end: no global
+    // load latency sits inside a tile's dependent chain (gather -> MFMA -> ... took 14 k clk per tile with the gather in phase A).
+    const int XPB = p.expand ? MFA * 32 * KP1 * 2 : 0, HIDB = MFA * 32 * hs;
+    unsigned char* const xpl = mb_smem;
+    unsigned char* const hid0 = xpl + 2 * XPB;
+    unsigned char* const hid2 = hid0 + (p.expand ? 1 : 2) * HIDB;
+    half_t* const w1l = (half_t*)(hid2 + OP * hs);
+    half_t* const wdl = w1l + ChP * KP1;
+    unsigned char* const w2l = (unsigned char*)(wdl + 9 * ChP);
+    float* const b1l = (float*)(w2l + CoP * hs);
+    float* const bdl = b1l + ChP;
+    float* const b2l = bdl + ChP;
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // ---- weights -> LDS once per block, zero-padded (Ch -> ChP, Cin -> KP1, Cout -> CoP) so that padded lanes multiply zeros --------
+    if (p.expand) for (int i = tid; i < ChP * KP1; i += NT) { const int n = i / KP1, k = i - n * KP1; w1l[i] = (n < p.Ch && k < p.Cin) ? p.w1[(long)n * p.Cin + k] : (half_t)0.f; }
+    for (int i = tid; i < 9 * ChP; i += NT) { const int t = i / ChP, c = i - t * ChP; wdl[i] = c < p.Ch ? p.wd[(long)c * 9 + t] : (half_t)0.f; }
+    for (int i = tid; i < CoP * (hs / 2); i += NT) { const int n = i / (hs / 2), k = i - n * (hs / 2); ((half_t*)w2l)[i] = (n < p.Cout && k < p.Ch) ? p.w2[(long)n * p.Ch + k] : (half_t)0.f; }
+    for (int i = tid; i < ChP; i += NT) { b1l[i] = (p.expand && p.b1 && i < p.Ch) ? p.b1[i] : 0.f; bdl[i] = (p.bd && i < p.Ch) ? p.bd[i] : 0.f; }
+    for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
+    for (int i = tid; i < OP * (hs / 2); i += NT) ((half_t*)hid2)[i] = (half_t)0.f;      // (the pad channels / pad slot of the hidden tile stay zero for good)
+    if (!p.expand) for (int i = tid; i < 2 * HIDB / 2; i += NT) ((half_t*)hid0)[i] = (half_t)0.f;   // (pad channels of the copied patch)
+
+    const int T = p.ntiles, G = gridDim.x;
+    const int t_begin = (int)((long)blockIdx.x * T / G), t_end = (int)((long)(blockIdx.x + 1) * T / G);
+    const int nfa = ChP >> 5, ks1 = KP1 >> 4, ks2 = ChP >> 4, nfc = CoP >> 5, cvn = p.Ch >> 3;
+    // X patch slot of this thread: patch pixel xs_pp, 16-byte chunk xs_c (slots = MFA*32 pixels x KP1/8 chunks <= NT)
+    const int xchunks = KP1 >> 3, xs_pp = tid / xchunks, xs_c = tid - xs_pp * xchunks;
+    const bool xs_mine = xs_pp < MFA * 32;
+    const int xs_py = (int)fastdiv((unsigned)xs_pp, p.pw_mul, p.pw_sh), xs_px = xs_pp - xs_py * PW;
+    auto tile_origin = [&](int t, int& n, int& oy0, int& ox0) {
+        n = (int)fastdiv((unsigned)t, p.txy_mul, p.txy_sh);
+        const int r = t - n * (p.tiles_x * p.tiles_y), by = (int)fastdiv((unsigned)r, p.tx_mul, p.tx_sh);
+        oy0 = by * TH; ox0 = (r - by * p.tiles_x) * TW;
+    };
+    auto fetch_patch = [&](int t) -> half8_t {                       // this thread's slot of tile t's zero-padded X patch
+        int n, oy0, ox0; tile_origin(t, n, oy0, ox0);
+        const int iy = oy0 * S - 1 + xs_py, ix = ox0 * S - 1 + xs_px;
+        half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (xs_mine && xs_pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && xs_c * 8 < p.Cin)
+            v = *(const half8_t*)(p.x + (((long)n * p.H + iy) * p.W + ix) * p.x_ld + xs_c * 8);
+        return v;
+    };
+    auto store_patch = [&](int buf, half8_t v) {
+        if (!xs_mine) return;
+        if (p.expand) *(half8_t*)(xpl + buf * XPB + (xs_pp * KP1 + xs_c * 8) * 2) = v;
+        else *(half8_t*)(hid0 + buf * HIDB + xs_pp * hs + xs_c * 16) = v;
+    };
+    __syncthreads();                                                  // (the zero fills above are done before anyone overwrites a patch slot)
+    if (t_begin < t_end) store_patch(0, fetch_patch(t_begin));
+    __syncthreads();
+
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; t++) {
+        const int buf = (t - t_begin) & 1;
+        int n, oy0, ox0; tile_origin(t, n, oy0, ox0);
+        const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+        half8_t xnext = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (t + 1 < t_end) xnext = fetch_patch(t + 1);               // in flight for the whole tile
+        const unsigned char* const xp_l = xpl + buf * XPB;
+        unsigned char* const hid = p.expand ? hid0 : hid0 + buf * HIDB;
+
+        // ---- phase A: hidden patch.  (patch row block, hidden channel block) pairs over the waves; X fragments from the LDS patch ------
+        for (int item = wave; item < (p.expand ? MFA * nfa : 0); item += NW) {
+            const int mf = item / nfa, nf = item - mf * nfa;
+            const int pp = mf * 32 + l31;
+            const int py = (int)fastdiv((unsigned)pp, p.pw_mul, p.pw_sh), px = pp - py * PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            const bool inimg = pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            floatx16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++)
+                if (ks < ks1) {
+                    const int k = ks * 16 + hi * 8;
+                    const half8_t fx = *(const half8_t*)(xp_l + (pp * KP1 + k) * 2);     // (zero outside the image and beyond Cin)
+                    const half8_t fw = *(const half8_t*)(w1l + (nf * 32 + l31) * KP1 + k);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fx, acc, 0, 0, 0);
+                }
+            // register 4q+r <-> hidden channel nf*32 + 8q + 4*hi + r of patch pixel pp; pixels outside the image must be ZERO
+            floatx4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq[q] = *(const floatx4*)(b1l + nf * 32 + 8 * q + 4 * hi);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                float o[8];
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++) {
+                    unsigned ua = __builtin_bit_cast(unsigned, acc[4 * (2 * j) + r2] + bq[2 * j][r2]), ub = __builtin_bit_cast(unsigned, acc[4 * (2 * j + 1) + r2] + bq[2 * j + 1][r2]);
+                    sm_permlane32_swap(ua, ub);
+                    o[r2] = __builtin_bit_cast(float, ua); o[4 + r2] = __builtin_bit_cast(float, ub);
+                }
+                half8_t ov;
+#pragma unroll
+                for (int r2 = 0; r2 < 8; r2++) ov[r2] = inimg ? (half_t)relu_family(o[r2], p.sl1) : (half_t)0.f;
+                *(half8_t*)(hid + pp * hs + (nf * 4 + 2 * j + hi) * 16) = ov;
+            }
+        }
+        __syncthreads();
+
+        // ---- phase B: depthwise 3x3, one thread = one output pixel x 8 channels --------------------------------------------------
+        for (int it = tid; it < OP * cvn; it += NT) {
+            const int op = it / cvn, cv = it - op * cvn, oy = op / TW, ox = op - oy * TW;
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) a[j] = bdl[cv * 8 + j];
+#pragma unroll
+            for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                for (int kw = 0; kw < 3; kw++) {
+                    // a[j] += x[j] * w[j] as v_fma_mix_f32 (fp16 operands, fp32 accumulate; the product of two halfs is exact in fp32, so this is
+                    // mul + add bit for bit) — written out: hipcc otherwise spends two conversions per multiply-add
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 xu = *(const u32x4*)(hid + ((oy * S + kh) * PW + ox * S + kw) * hs + cv * 16);
+                    const u32x4 wu = *(const u32x4*)(wdl + (kh * 3 + kw) * ChP + cv * 8);
+#pragma unroll
+                    for (int d2 = 0; d2 < 4; d2++) {
+                        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2]) : "v"(xu[d2]), "v"(wu[d2]));
+                        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2 + 1]) : "v"(xu[d2]), "v"(wu[d2]));
+                    }
+                }
+            half8_t ov;
+#pragma unroll
+            for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+            *(half8_t*)(hid2 + op * hs + cv * 16) = ov;
+        }
+        __syncthreads();
+
+        // ---- phase C: project.  (row block, cout block) pairs over the waves ------------------------------------------------------
+        for (int item = wave; item < MFC * nfc; item += NW) {
+            const int mf = item / nfc, nf = item - mf * nfc;
+            const int op = mf * 32 + l31, oy = oy0 + op / TW, ox = ox0 + op % TW;
+            floatx16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[i] = 0.f;
+            for (int ks = 0; ks < ks2; ks++) {
+                const half8_t fy = *(const half8_t*)(hid2 + op * hs + (ks * 2 + hi) * 16);
+                const half8_t fw = *(const half8_t*)(w2l + (nf * 32 + l31) * hs + (ks * 2 + hi) * 16);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fy, acc, 0, 0, 0);
+            }
+            floatx4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq[q] = *(const floatx4*)(b2l + nf * 32 + 8 * q + 4 * hi);
+            const bool pin = oy < p.Ho && ox < p.Wo;
+            const long opix = ((long)n * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                float o[8];
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++) {
+                    unsigned ua = __builtin_bit_cast(unsigned, acc[4 * (2 * j) + r2] + bq[2 * j][r2]), ub = __builtin_bit_cast(unsigned, acc[4 * (2 * j + 1) + r2] + bq[2 * j + 1][r2]);
+                    sm_permlane32_swap(ua, ub);
+                    o[r2] = __builtin_bit_cast(float, ua); o[4 + r2] = __builtin_bit_cast(float, ub);
+                }
+                const int co = nf * 32 + 16 * j + 8 * hi;
+                if (pin && co < p.Cout) {
+                    if (p.res) { const half8_t rv = *(const half8_t*)(xp_l + (((op / TW + 1) * PW + op % TW + 1) * KP1 + co) * 2);   // residual = the block input at the same pixel (stride 1, Cin == Cout): the patch centre
+#pragma unroll
+                        for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
+                    half8_t ov;
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                    *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
+                }
+            }
+        }
+        if (t + 1 < t_end) store_patch(buf ^ 1, xnext);              // the other buffer: nobody reads it during this tile
+        __syncthreads();                                              // next tile's patch visible; this tile's reads of the hidden tile are over
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d) {
+    if (!d) return 0;
+    const int ChP = (d->Ch + 31) & ~31, hs = ChP * 2 + 16, KP1 = (d->Cin + 15) & ~15, CoP = (d->Cout + 31) & ~31;
+    const int TH = d->stride == 1 ? 8 : 4, TW = 8, PH = (TH - 1) * d->stride + 3, PW = (TW - 1) * d->stride + 3, MFA = (PH * PW + 31) / 32;
+    return (size_t)(d->expand ? 2 * MFA * 32 * KP1 * 2 + MFA * 32 * hs : 2 * MFA * 32 * hs) + (size_t)TH * TW * hs + (size_t)ChP * KP1 * 2 + (size_t)9 * ChP * 2 + (size_t)CoP * hs +
+           (size_t)(2 * ChP + CoP) * 4;
+}
+
+int sm_mbconv_supported(const sm_mbconv_desc* d) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    if (d->stride != 1 && d->stride != 2) return 0;
+    if ((d->Cin & 7) || d->Cin > 32 || (d->Ch & 7) || d->Ch > 192 || (d->Cout & 7) || d->Cout > 64) return 0;
+    if (!d->expand && d->Ch != d->Cin) return 0;
+    if (d->residual && (d->stride != 1 || d->Cin != d->Cout)) return 0;
+    if (d->act1 > SM_ACT_PRELU || d->act2 > SM_ACT_PRELU || d->act3 > SM_ACT_PRELU) return 0;
+    if (d->Ho != (d->H + 2 - 3) / d->stride + 1 || d->Wo != (d->W + 2 - 3) / d->stride + 1) return 0;
+    return sm_mbconv_lds_bytes(d) <= 160 * 1024;
+}
+
+int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const float* b1, const void* wd, const float* bd, const void* w2, const float* b2, void* y,
+                  sm_stream_t stream) {
+    SM_REQUIRE(sm_mbconv_supported(d) && x && wd && w2 && y && (!d->expand || w1), "sm_mbconv_fwd: unsupported block geometry");
+    MbParams p{};
+    p.x = (const half_t*)x; p.y = (half_t*)y; p.w1 = (const half_t*)w1; p.wd = (const half_t*)wd; p.w2 = (const half_t*)w2; p.b1 = b1; p.bd = bd; p.b2 = b2;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.s = d->stride; p.Cin = d->Cin; p.Ch = d->Ch; p.Cout = d->Cout;
+    p.x_ld = d->x_ld ? d->x_ld : d->Cin; p.y_ld = d->y_ld ? d->y_ld : d->Cout; p.expand = d->expand ? 1 : 0; p.res = d->residual ? 1 : 0;
+    SM_REQUIRE((p.x_ld & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0, "sm_mbconv_fwd: operands must be 16-byte aligned, pixel strides % 8 == 0");
+    SM_REQUIRE((long)d->N * d->H * d->W < (1L << 31), "sm_mbconv_fwd: too many pixels");
+    p.act1 = d->act1; p.act2 = d->act2; p.act3 = d->act3;
+    p.sl1 = d->act1 == SM_ACT_NONE ? 1.f : d->act1 == SM_ACT_RELU ? 0.f : d->slope1;
+    p.sl2 = d->act2 == SM_ACT_NONE ? 1.f : d->act2 == SM_ACT_RELU ? 0.f : d->slope2;
+    p.sl3 = d->act3 == SM_ACT_NONE ? 1.f : d->act3 == SM_ACT_RELU ? 0.f : d->slope3;
+    p.ChP = (d->Ch + 31) & ~31; p.hstride = p.ChP * 2 + 16;
+    const int TH = d->stride == 1 ? 8 : 4, TW = 8, PW = (TW - 1) * d->stride + 3;
+    p.tiles_x = sm_ceil_div(d->Wo, TW); p.tiles_y = sm_ceil_div(d->Ho, TH);
+    const long nt = (long)d->N * p.tiles_x * p.tiles_y;
+    SM_REQUIRE(nt < (1L << 31), "sm_mbconv_fwd: too many tiles");
+    p.ntiles = (int)nt;
+    fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh); fastdiv_make((unsigned)PW, &p.pw_mul, &p.pw_sh);
+    const size_t lds = sm_mbconv_lds_bytes(d);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (size_t)(160 * 1024) / lds));
+    const int grid = (int)std::min<long>(nt, (long)SM_NUM_CU * std::min(per_cu, 2));      // 16-wave blocks: at most two per CU
+    if (d->stride == 1) hipLaunchKernelGGL((mbconv_kernel<8, 8, 1>), dim3(grid), dim3(1024), lds, sm_s(stream), p);
+    else hipLaunchKernelGGL((mbconv_kernel<4, 8, 2>), dim3(grid), dim3(1024), lds, sm_s(stream), p);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+}  // extern "C"

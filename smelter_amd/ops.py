@@ -97,6 +97,18 @@ def conv1x1_pair(x, w1, b1, residual, w2, b2, act1=ACT_RELU, act2=ACT_RELU, out_
     return y, z
 
 
+def mbconv(x, w1, b1, wd, bd, w2, b2, stride=1, residual=False, acts=(ACT_RELU, ACT_RELU, ACT_NONE)):
+    """fused inverted-residual block (sm_mbconv_fwd): [1x1 expand w1 (None = absent)] -> depthwise 3x3 wd [Ch,3,3] -> 1x1 project w2 (+ x)"""
+    from ._native import MbConvDesc
+    n, h, w, cin, x_ld = _check_nhwc(x)
+    ch, cout = wd.shape[0], w2.shape[0]
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x.device)
+    d = MbConvDesc(n, h, w, ho, wo, stride, cin, ch, cout, 1 if w1 is not None else 0, 1 if residual else 0, acts[0], 0.0, acts[1], 0.0, acts[2], 0.0, x_ld, _ld(y))
+    check(lib().sm_mbconv_fwd(C.byref(d), _ptr(x), _ptr(w1), _ptr(b1), _ptr(wd), _ptr(bd), _ptr(w2), _ptr(b2), _ptr(y), _stream()))
+    return y
+
+
 def conv_transpose2d(x, w_ohwi_flipped, bias=None, stride=(1, 1), pads=(0, 0, 0, 0), dilation=(1, 1), out_pad=(0, 0), act=ACT_NONE, slope=0.0):
     """sm_conv_transpose2d_fwd: direct kernel over the flipped OHWI weights the reference's ConvDataSource produces"""
     n, h, w, cin, x_ld = _check_nhwc(x)

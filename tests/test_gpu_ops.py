@@ -573,3 +573,31 @@ def test_conv1x1_pair_equals_two_launches(n, hw, n2, res):
     assert_close(to_host(y), yref, 64)
     assert np.array_equal(to_host(y), to_host(y1))                     # same k order, same single rounding as the stand-alone kernel
     assert_close(to_host(z), zref, 256)
+
+
+@pytest.mark.parametrize("n,hw,cin,ch,cout,stride,res,expand", [
+    (2, (56, 56), 24, 144, 24, 1, True, True),     # MobileNet-v2 block 3: + residual
+    (2, (56, 48), 16, 96, 24, 2, False, True),     # block 2: stride 2, Cin = 16 (one k step)
+    (1, (28, 28), 32, 192, 32, 1, True, True),     # block 5: widest hidden tensor (192)
+    (3, (29, 27), 32, 192, 64, 2, False, True),    # stride 2 on odd sizes, Cout = 64 (two cout blocks)
+    (2, (19, 21), 32, 32, 16, 1, False, False),    # block 1: no expand (depthwise reads the input), ragged tiles
+    (1, (9, 9), 24, 144, 32, 2, False, True),      # image barely larger than a tile
+])
+def test_mbconv_fused_block_equals_the_three_layers(n, hw, cin, ch, cout, stride, res, expand):
+    """sm_mbconv_fwd against the oracle's three convolutions with the hidden tensors rounded to fp16 where the separate launches store them"""
+    rng = np.random.default_rng(cin * 7 + ch + stride)
+    x = h(rng.standard_normal((n, cin, hw[0], hw[1])))
+    w1 = h(rng.standard_normal((ch, 1, 1, cin)) * np.sqrt(2.0 / cin)) if expand else None
+    b1 = rng.standard_normal(ch).astype(np.float32) * 0.1 if expand else None
+    wd = h(rng.standard_normal((ch, 3, 3, 1)) * np.sqrt(2.0 / 9)); bd = rng.standard_normal(ch).astype(np.float32) * 0.1
+    w2 = h(rng.standard_normal((cout, 1, 1, ch)) * np.sqrt(1.0 / ch)); b2 = rng.standard_normal(cout).astype(np.float32) * 0.1
+    hid = h(np.maximum(O.conv2d(x, w1, b1), 0)) if expand else x
+    hid2 = h(np.maximum(O.conv2d(hid, wd, bd, stride=(stride, stride), pads=(1, 1, 1, 1), groups=ch), 0))
+    ref = O.conv2d(hid2, w2, b2) + (x if res else 0)
+    dev = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    y = ops.mbconv(to_dev(x), dev(w1).half() if expand else None, dev(b1), dev(wd.reshape(ch, 3, 3)).half(), dev(bd), dev(w2).half(), dev(b2), stride=stride, residual=res)
+    got, ref16 = to_host(y), h(ref)
+    # three chained layers: a different fp32 summation order can flip the rounding of a hidden value, which moves an output by up to an
+    # fp16 ulp of the LARGEST magnitude in play -> per-element bound of 2 ulp + one ulp of max|ref|
+    assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
+    assert np.mean(got != ref16) < 0.2                                  # the vast majority of the elements is bit-identical
