@@ -101,6 +101,13 @@ int sm_conv2d_uses_tile_config(const sm_conv_desc* d);
 int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias,
                       const void* residual, void* y, void* workspace, size_t workspace_bytes, sm_stream_t stream);
 
+/* MPSCNNConvolutionNode (3x3 / stride 1 / pad 1, Cin, Cout in {32, 64}) + the MPSCNNPoolingMaxNode (2x2 / stride 2, Converters.swift:662)
+ * that consumes it, in ONE launch; both the full-resolution tensor `y` (the U-Net's skip connection) and the pooled one are written.
+ * W % 32 == 0, H even.  cfg < 0 picks a configuration. */
+int sm_conv2d_pool_supported(const sm_conv_desc* d);
+int sm_conv2d_pool_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias, void* y,
+                           void* y_pool, int32_t pool_ld, sm_stream_t stream);
+
 /* Two MPSCNNConvolutionNodes in a row, both 1x1 / stride 1 (Converters.swift:253), in ONE launch:
  *   y = act(x * w1 + bias1 + residual)   [d: Cin = 64 -> Cout = 256]      z = act2(y * w2 + bias2)   [256 -> N2 in {64, 128}]
  * Both tensors are stored (y is the next residual); y is rounded to fp16 once, exactly as the separate launches would store it.

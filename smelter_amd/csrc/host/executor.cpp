@@ -313,6 +313,27 @@ int Executor::plan(ONNXGraph& g, int batch) {
         steps_.push_back(std::move(st));
     }
 
+    // ---- 3a. Conv 3x3 -> MaxPool 2x2 / 2: the pooled tensor is a second output of the weight-stationary convolution kernel (the
+    // window is the two fragments of a lane and its neighbour lane); the full-resolution tensor is still written (skip connection).
+    if (cfg_.fuse && !cfg_.keepIntermediates) {
+        for (size_t t = 0; t < steps_.size(); t++) {
+            Step& c = steps_[t];
+            if (c.op.kind != OpKind::Conv || c.stem || c.op.grid_h || c.op.residual >= 0 || c.op.output == output_value_) continue;
+            const Value& ov = values_[c.op.output];
+            sm_conv_desc d{}; d.N = batch; d.H = d.Ho = ov.h; d.W = d.Wo = ov.w; d.Cin = c.op.cin; d.Cout = c.op.cout; d.kH = c.op.kh; d.kW = c.op.kw; d.sH = c.op.sh; d.sW = c.op.sw;
+            d.dH = c.op.dh; d.dW = c.op.dw; d.pt = c.op.pt; d.pl = c.op.pl; d.pb = c.op.pb; d.pr = c.op.pr; d.groups = c.op.groups; d.act = c.op.act; d.x_ups = c.op.x_ups ? 1 : 0;
+            if (!sm_conv2d_pool_supported(&d)) continue;
+            for (size_t u = t + 1; u < steps_.size(); u++) {
+                Step& m = steps_[u];
+                if (m.op.kind != OpKind::MaxPool || m.op.inputs[0] != c.op.output || m.op.kh != 2 || m.op.kw != 2 || m.op.sh != 2 || m.op.sw != 2 || m.op.y0 || m.op.x0 ||
+                    values_[m.op.output].h * 2 != ov.h || values_[m.op.output].w * 2 != ov.w) continue;
+                c.pool_out = m.op.output;
+                steps_.erase(steps_.begin() + u);
+                break;
+            }
+        }
+    }
+
     // ---- 3b. pointwise pairs: a 1x1 expand (64 -> 256, + residual + ReLU) whose output feeds a 1x1 reduce (256 -> 64 | 128) runs together
     // with it in one persistent launch (conv1x1_pair.hpp): the 256-channel tensor is written once and never read back by the reduce.
     // The reduce moves up to the expand's position — legal, its only operand is produced there.
@@ -375,6 +396,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         if (op.residual >= 0) { touch(op.residual, t); touch(op.residual, until); }
         touch(op.output, t);
         if (steps_[t].has_pair) touch(steps_[t].pair.output, t);
+        if (steps_[t].pool_out >= 0) touch(steps_[t].pool_out, t);
     }
     touch(output_value_, ns);                               // result image must survive until read back
     if (cfg_.keepIntermediates) for (int v = 0; v < nv; v++) if (last[v] >= 0) { first[v] = -1; last[v] = ns; }
@@ -436,6 +458,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                      st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem ? " stem" : op.grid_h ? " convT-phase" : op.x_ups ? " +ups2x" : "");
         else snprintf(buf, sizeof buf, "%s %s pixels=%d C=%d%s", kindName(op.kind), op.name.c_str(), st.M, values_[op.output].c, op.act ? " +act" : "");
         st.desc = buf;
+        if (st.pool_out >= 0) { st.desc += " >> MaxPool 2x2/2 (same launch)"; alg_bytes_ += 2.0 * (double)(st.M / 4) * values_[st.pool_out].c; }
         if (st.has_pair) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.pair.name.c_str(), st.pair.cout, st.pair.cin, st.pair.act ? " +act" : ""); st.desc += buf; }
         if (st.join >= 0) st.desc += " side-stream";
     }
@@ -445,6 +468,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     for (auto& st : steps_) {
         if (st.op.kind != OpKind::Concat && materialized_.back() != values_[st.op.output].name) materialized_.push_back(values_[st.op.output].name);
         if (st.has_pair) materialized_.push_back(values_[st.pair.output].name);
+        if (st.pool_out >= 0) materialized_.push_back(values_[st.pool_out].name);
     }
     return SM_OK;
 }
@@ -537,6 +561,9 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
     switch (op.kind) {
     case OpKind::Conv: case OpKind::FullyConnected: {
         const sm_conv_desc d = convDesc(st);
+        if (st.pool_out >= 0)
+            return sm_conv2d_pool_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, y,
+                                          valuePtr(st.pool_out), valueLd(st.pool_out), ss);
         if (st.has_pair)
             return sm_conv1x1_pair_fwd(&d, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
                                        op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, st.pair.cout, arena_ + st.w2_off, st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr,

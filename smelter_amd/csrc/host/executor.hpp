@@ -37,6 +37,7 @@ struct Step {                // one op after fusion, with everything resolved
     bool waits_side = false; // this step is the join of an earlier side step
     // pointwise pair (executor.cpp pass 3b): `pair` is the 1x1 convolution that consumes this step's output, run in the same launch
     // (sm_conv1x1_pair_fwd); both outputs are materialised
+    int pool_out = -1;       // >= 0: value id of the 2x2 / stride-2 max-pool of this conv's output, written by the same launch (sm_conv2d_pool_fwd_cfg)
     bool has_pair = false; Op pair; size_t w2_off = 0, b2_off = 0; bool has_bias2 = false;
     std::string desc;
 };

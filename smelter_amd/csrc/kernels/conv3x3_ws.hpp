@@ -132,6 +132,27 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     u32x4 outv[TN][TM][2];                                            // packed results of the PREVIOUS tile: [a][b][j] = couts a*32 + 16j + 8*hi .. +7 of pixel b
     int pn = 0, py0 = 0, px0 = 0; bool pending = false;
     auto store_prev = [&]() {
+        if constexpr (TM == 2) {
+            // fused 2x2 / stride-2 max-pool of the output (p.y2; launcher: TW == 32, even H and W, so a wave's two fragments are image rows
+            // 2k and 2k+1 of the SAME columns and lanes 2i, 2i+1 are neighbouring columns): max over the two fragments, then over the lane
+            // pair (DPP quad_perm [1,0,3,2]); even lanes store.  Max of fp16 values is exact and commutes with the ReLU-family activation.
+            if (p.y2) {
+                const int oy = py0 + (int)(tyx[0] >> 16), ox = px0 + (int)(tyx[0] & 0xffff);
+                const bool live = oy < p.H && ox < p.W && (int)(tyx[0] >> 16) < TH && !(l31 & 1);
+                half_t* dst = p.y2 + (((long)pn * (p.H >> 1) + (oy >> 1)) * (p.W >> 1) + (ox >> 1)) * p.y2_ld + 8 * hi;
+#pragma unroll
+                for (int a = 0; a < TN; a++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        half8_t m = __builtin_elementwise_max(__builtin_bit_cast(half8_t, outv[a][0][j]), __builtin_bit_cast(half8_t, outv[a][1][j]));
+                        u32x4 mu = __builtin_bit_cast(u32x4, m), nb;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) nb[k] = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mu[k], 0xB1, 0xf, 0xf, false);
+                        m = __builtin_elementwise_max(m, __builtin_bit_cast(half8_t, nb));
+                        if (live) *(half8_t*)(dst + a * 32 + 16 * j) = m;
+                    }
+            }
+        }
 #pragma unroll
         for (int b = 0; b < TM; b++) {
             const int oy = py0 + (int)(tyx[b] >> 16), ox = px0 + (int)(tyx[b] & 0xffff);

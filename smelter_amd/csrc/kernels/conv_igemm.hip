@@ -44,6 +44,7 @@ struct ConvParams {
     unsigned ws_pw_mul, ws_pw_sh, ws_tw_mul, ws_tw_sh, ws_txy_mul, ws_txy_sh, ws_ty_mul, ws_ty_sh;
     // nine-tap patch kernel (conv3x3_p9.hpp): geometry chosen by p9_setup(); ups = the input is read through a fused nearest 2x upsampling
     int p9_TW, p9_tiles_per_band, p9_patch_bytes, p9_patch_px, ups;
+    half_t* y2; int y2_ld;           // conv3x3_ws only: second output = 2x2 / stride-2 max-pool of y (nullptr = none)
     unsigned p9_pw_mul, p9_pw_sh, p9_h2_mul, p9_h2_sh;
 };
 
@@ -721,7 +722,8 @@ size_t ws_setup(ConvParams& p, const TileCfg& c) {
     const size_t fixed = (size_t)9 * p.Cout * cin * 2 + (size_t)p.Cout * 4 + WS_DUMMY;
     const int nic = cin == 64 ? 12 : 6;                              // the kernels' NIC
     int best_th = 0; long best_tiles = 0; size_t best_lds = 0, best_patch = 0;
-    for (int th = p.ups ? 2 : 1; th * TW <= c.BM && th <= p.H; th += p.ups ? 2 : 1) {
+    const int thstep = (p.ups || p.y2) ? 2 : 1;                        // fused upsampling / pooling: even tile origins
+    for (int th = thstep; th * TW <= c.BM && th <= p.H; th += thstep) {
         const size_t slots = (size_t)(th + 2) * (TW + 2) * cp, patch = (slots * 16 + 1023) / 1024 * 1024;
         if (sm_ceil_div((long)slots, nt) > nic) break;
         const size_t stride = (size_t)ws_pstride((int)fixed);         // distance between the two patch buffers (compile-time in the kernel)
@@ -771,13 +773,17 @@ size_t p9_setup(ConvParams& p, const TileCfg& c) {
 // kind 2 = single LDS stage: only for K == 64 (one K tile)
 // kinds 1/2 (conv_igemm64.hpp): Cin % 64 == 0 and a tap mask of <= 32 bits
 bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
-    if (c.kind == 0) return true;
+    if (c.kind == 0) return p.y2 == nullptr;
     const bool same3x3 = p.kH == 3 && p.kW == 3 && p.sH == 1 && p.sW == 1 && p.dH == 1 && p.dW == 1 && p.pt == 1 && p.pl == 1 && p.Ho == p.H && p.Wo == p.W;
     if (c.kind == 4) {   // weight-stationary: the template's Cin / Cout exactly, no residual, dense 16-byte rows on both sides, ReLU family
         ConvParams q = p;
-        return same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
+        const bool ok = same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
                ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && p.Cout == c.BN && ws_setup(q, c) > 0;
+        // fused max-pool: two fragments per wave that are the image rows 2k, 2k+1 of one 32-pixel column band
+        if (ok && p.y2) return c.BM / (c.threads / 64) == 64 && q.ws_TW == 32 && (q.ws_TH & 1) == 0 && (p.H & 1) == 0 && (p.W & 1) == 0 && (p.y2_ld & 7) == 0 && ((((uintptr_t)p.y2) & 15) == 0);
+        return ok;
     }
+    if (p.y2) return false;                                          // only the weight-stationary kernel writes the pooled second output
     if (c.kind == 5) {   // nine-tap patch kernel: no residual, dense 16-byte rows, ReLU family
         ConvParams q = p;
         return same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 &&
@@ -822,7 +828,7 @@ int fill_params(const sm_conv_desc* d, const void* x, const void* w, const float
     p->x_ld = d->x_ld ? d->x_ld : d->Cin; p->y_ld = d->y_ld ? d->y_ld : d->Cout; p->res_ld = d->res_ld ? d->res_ld : d->Cout;
     p->act = d->act; p->slope = d->act == SM_ACT_RELU ? 0.f : d->slope;
     p->M = d->N * d->Ho * d->Wo; p->K = d->kH * d->kW * (d->Cin / d->groups);
-    p->splitk = 1; p->mt = p->nt = 0; p->ktiles_per_split = 0; p->ups = d->x_ups ? 1 : 0;
+    p->splitk = 1; p->mt = p->nt = 0; p->ktiles_per_split = 0; p->ups = d->x_ups ? 1 : 0; p->y2 = nullptr; p->y2_ld = 0;
     SM_REQUIRE(!d->x_ups || ((d->H & 1) == 0 && (d->W & 1) == 0 && d->groups == 1), "sm_conv2d_fwd: x_ups needs even H and W");
     SM_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "sm_conv2d_fwd: more than 2^31 output pixels");
     SM_REQUIRE((long)d->N * d->H * d->W < (1L << 31) - (1L << 24), "sm_conv2d_fwd: more than 2^31 input pixels");
@@ -986,6 +992,24 @@ int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void*
                       void* ws, size_t ws_bytes, sm_stream_t stream) {
     ConvParams p; int rc = fill_params(d, x, w, bias, res, y, &p); if (rc) return rc;
     return launch(d, p, cfg, ws, ws_bytes, sm_s(stream));
+}
+
+// 3x3 convolution + the 2x2 / stride-2 max-pool of its output in one launch (both tensors are written: the U-Net's skip + pooled pair)
+int sm_conv2d_pool_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w, const float* bias, void* y, void* y_pool, int32_t pool_ld, sm_stream_t stream) {
+    SM_REQUIRE(y_pool, "sm_conv2d_pool_fwd_cfg: null pooled output");
+    ConvParams p; int rc = fill_params(d, x, w, bias, nullptr, y, &p); if (rc) return rc;
+    p.y2 = (half_t*)y_pool; p.y2_ld = pool_ld ? pool_ld : d->Cout;
+    if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) cfg = i; }
+    if (cfg < 0) { sm_set_error("sm_conv2d_pool_fwd_cfg: no kernel takes this shape with a fused max-pool (3x3 / s1 / p1, Cin, Cout in {32, 64}, W %% 32 == 0, even H)"); return SM_ERR_INVALID_ARGUMENT; }
+    return launch(d, p, cfg, nullptr, 0, sm_s(stream));
+}
+int sm_conv2d_pool_supported(const sm_conv_desc* d) {
+    if (!d) return 0;
+    alignas(16) static char dummy[16];
+    ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
+    p.y2 = (half_t*)dummy; p.y2_ld = d->Cout;
+    for (int i = 0; i < kNumCfgs; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) return 1;
+    return 0;
 }
 
 int sm_conv_transpose2d_fwd(const sm_conv_desc* d, const void* x, const void* w, const float* bias, void* y, sm_stream_t stream) {

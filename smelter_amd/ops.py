@@ -85,6 +85,17 @@ def conv2d(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0)
     return out
 
 
+def conv2d_pool(x, w_ohwi, bias, act=ACT_RELU, slope=0.0, cfg=-1):
+    """3x3 / s1 / p1 convolution + 2x2 / s2 max-pool of its output in one launch (sm_conv2d_pool_fwd_cfg); returns (y, pooled)"""
+    n, h, w, cin, x_ld = _check_nhwc(x)
+    cout = w_ohwi.shape[0]
+    y = torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device)
+    yp = torch.empty((n, h // 2, w // 2, cout), dtype=torch.float16, device=x.device)
+    d = ConvDesc(n, h, w, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, h, w, act, slope, x_ld, _ld(y), 0)
+    check(lib().sm_conv2d_pool_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(y), _ptr(yp), _ld(yp), _stream()))
+    return y, yp
+
+
 def conv1x1_pair(x, w1, b1, residual, w2, b2, act1=ACT_RELU, act2=ACT_RELU, out_y=None, out_z=None):
     """y = act1(conv1x1(x, w1) + b1 + residual), z = act2(conv1x1(y, w2) + b2) in one launch (sm_conv1x1_pair_fwd)"""
     n, h, w, cin, x_ld = _check_nhwc(x)

@@ -98,6 +98,18 @@ def test_pointwise_pairs_experiment_is_the_same_function(monkeypatch):
     assert nerr(a, b) <= 1e-3
 
 
+def test_unet_fuses_upsample_and_maxpool_into_their_convolutions():
+    """executor passes 1b / 3a: nearest 2x Upsample -> Conv and Conv -> MaxPool 2x2/2 run as one launch each; same function as the unfused graph"""
+    model = zoo.unet(hw=(64, 64))
+    x = zoo.synthetic_images(2, 3, (64, 64))
+    ex, got = run_hip(model, x)
+    descs = [ex.opDesc(i) for i in range(ex.numOps)]
+    assert sum("+ups2x" in d for d in descs) == 4 and not any(d.startswith("Upsample") for d in descs)
+    assert sum(">> MaxPool" in d for d in descs) == 2             # the 32- and 64-channel levels (weight-stationary kernel); deeper levels keep their pool launch
+    _, plain = run_hip(model, x, fuse=False, useHipGraph=False)
+    assert nerr(got, plain) <= 2e-3
+
+
 def test_unet_concat_is_zero_copy():
     ex, _ = run_hip(zoo.unet(hw=(64, 64)), zoo.synthetic_images(1, 3, (64, 64)))
     assert not any(ex.opDesc(i).startswith("Concat") for i in range(ex.numOps))          # all 4 concats placed, no copy kernel

@@ -601,3 +601,25 @@ def test_mbconv_fused_block_equals_the_three_layers(n, hw, cin, ch, cout, stride
     # fp16 ulp of the LARGEST magnitude in play -> per-element bound of 2 ulp + one ulp of max|ref|
     assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
     assert np.mean(got != ref16) < 0.2                                  # the vast majority of the elements is bit-identical
+
+
+@pytest.mark.parametrize("n,hw,cin,cout,act", [(2, (64, 64), 32, 32, 1), (1, (32, 96), 64, 32, 2), (2, (20, 32), 64, 64, 1), (1, (16, 128), 32, 64, 0)])
+@pytest.mark.parametrize("cfg", [-1, 61, 62, 63, 64, 66, 67])
+def test_conv3x3_with_fused_maxpool(n, hw, cin, cout, act, cfg):
+    """sm_conv2d_pool_fwd_cfg: y bit-identical to the plain launch of the same config, pooled == max-pool of y (exact)"""
+    rng = np.random.default_rng(cin + cout + hw[1])
+    x = h(rng.standard_normal((n, cin, hw[0], hw[1])))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * np.sqrt(2.0 / (cin * 9))); b = rng.standard_normal(cout).astype(np.float32)
+    slope = 0.25 if act == 2 else 0.0
+    from smelter_amd._native import SmelterError
+    try:
+        y, yp = ops.conv2d_pool(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), act=act, slope=slope, cfg=cfg)
+    except SmelterError as e:
+        if cfg >= 0 and "does not apply" in e.detail:
+            pytest.skip(e.detail)
+        raise
+    ref = O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1))
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    assert_close(to_host(y), ref, cin * 9)
+    assert np.array_equal(to_host(yp), O.maxpool(to_host(y), (2, 2), (2, 2), (0, 0)))
