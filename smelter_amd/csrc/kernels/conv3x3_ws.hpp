@@ -45,11 +45,21 @@ constexpr int WS_DUMMY = 1024;                                        // LDS sin
 
 // NIC = LDS-DMA instructions per thread per patch (the launcher picks a tile geometry that needs no more)
 // ABL (tools/conv_bench.py, SM_ABLATION builds only): bit 0 = no DMA after the first patch, bit 1 = no MFMAs, bit 2 = no fragment reads, bit 3 = no stores
-template <int CIN, int NOUT, int NW, int TM, int NIC = (CIN == 64 ? 12 : 6), int ABL = 0>
+//
+// STEM > 0 (with CIN = 64): the image-stem form.  The input is the ROW-PAIR image (layout.hip: pixel = [row y | row y+1] x 4 channels =
+// 16 bytes, zero halo instead of padding) and the layer is a Cin = 64, kH' = STEM, kW' = 1, row-dilation-2, stride s convolution: "input
+// pixel" (y, x) = the 8 consecutive row-pair pixels (y, x .. x+7), so neighbouring pixels OVERLAP (x_ld = 8).  The patch holds plain
+// 16-byte row-pair pixels — ((TH-1)s + 2(STEM-1) + 1) x ((TW-1)s + 8) of them — and the A fragment of k step ks of tap j is row-pair pixel
+// (ty*s + 2j, tx*s + 2ks + hi): lanes of a half-wave read 16 (s = 1) or 32 (s = 2) bytes apart, no swizzle needed or possible.
+// PSB = distance between the two patch buffers (0: as large as the weights allow) — small patches leave room for a second block per CU.
+template <int CIN, int NOUT, int NW, int TM, int NIC = (CIN == 64 ? 12 : 6), int ABL = 0, int STEM = 0, int PSB = 0>
 __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
+    constexpr bool ST = STEM > 0;
+    constexpr int NTAP = ST ? STEM : 9;
+    static_assert(!ST || (CIN == 64 && STEM <= 4), "stem form: 64 = 8 row-pair pixels x 8 halfs");
     constexpr int NT = NW * 64, CP = CIN / 8, TN = NOUT / 32, KS = CIN / 16;
     constexpr int ROWB = CP * 16;                                     // bytes per pixel / per weight row of one tap
-    constexpr int W_BYTES = 9 * NOUT * ROWB, BIAS_BYTES = NOUT * 4;
+    constexpr int W_BYTES = NTAP * NOUT * ROWB, BIAS_BYTES = NOUT * 4;
     static_assert(TN >= 1 && TN <= 2 && TM >= 1 && TM <= 4, "wave tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char ws_smem[];
     unsigned char* const wl = ws_smem;                                // weights [tap][cout][CP chunks], chunk c of row n stored at c ^ swz(n)
@@ -58,23 +68,25 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     unsigned char* const patch0 = dummy + WS_DUMMY;
     // the second patch buffer sits a COMPILE-TIME distance behind the first, so that the buffer choice is an instruction offset of the
     // fragment reads (ds_read offset field: 16 bits), not an address computation
-    constexpr int WS_PSTRIDE = ws_pstride(W_BYTES + BIAS_BYTES + WS_DUMMY);
+    constexpr int WS_PSTRIDE = PSB ? PSB : ws_pstride(W_BYTES + BIAS_BYTES + WS_DUMMY);
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const half_t* zero = (const half_t*)g_zero_page;
-    const int TH = p.ws_TH, TW = p.ws_TW, PW = TW + 2, PH = TH + 2;
-    const int patch_slots = PH * PW * CP, NI = (patch_slots + NT - 1) / NT;
+    const int TH = p.ws_TH, TW = p.ws_TW, SS = ST ? p.sH : 1;
+    const int PW = ST ? (TW - 1) * SS + 8 : TW + 2, PH = ST ? (TH - 1) * SS + 2 * (NTAP - 1) + 1 : TH + 2;
+    const int OH = ST ? p.Ho : p.H, OW = ST ? p.Wo : p.W;             // output image (the plain form is "same" size)
+    const int patch_slots = PH * PW * (ST ? 1 : CP), NI = (patch_slots + NT - 1) / NT;
 
     // ---- weights + bias -> LDS (once per block) -------------------------------------------------------------------------
     {
-        constexpr int WSLOTS = 9 * NOUT * CP;
+        constexpr int WSLOTS = NTAP * NOUT * CP;
         static_assert((NOUT * CP) % 64 == 0, "a wave instruction stays inside the weight image");
 #pragma unroll 1
         for (int s0 = wave * 64; s0 < WSLOTS; s0 += NT) {
             const int s = s0 + lane, row = s / CP, c = s & (CP - 1);  // row = tap * NOUT + n
             const int tap = row / NOUT, n = row - tap * NOUT;
-            SM_GLDS16(p.w + (long)n * (9 * CIN) + tap * CIN + ((c ^ ws_swz<CP>(n)) << 3), wl + s0 * 16);
+            SM_GLDS16(p.w + (long)n * (NTAP * CIN) + tap * CIN + ((c ^ ws_swz<CP>(n)) << 3), wl + s0 * 16);
         }
         for (int i = tid; i < NOUT; i += NT) bl[i] = p.bias ? p.bias[i] : 0.f;
     }
@@ -82,11 +94,12 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     int rel[NIC]; unsigned prpc[NIC];
 #pragma unroll
     for (int i = 0; i < NIC; i++) {
-        const int s = i * NT + tid, ps = s / CP, c = s & (CP - 1);
+        const int s = i * NT + tid, ps = ST ? s : s / CP, c = ST ? 0 : s & (CP - 1);
         const int pr = (int)sm_fastdiv((unsigned)ps, p.ws_pw_mul, p.ws_pw_sh), pc = ps - pr * PW;
         // (p.ups: the patch is gathered from the half-resolution tensor; tile origins are even, so input pixel (y0-1+pr, x0-1+pc) of
         //  the upsampled image is low-resolution pixel (y0/2 + ((pr-1)>>1), x0/2 + ((pc-1)>>1)) — tile-invariant like the plain case)
-        rel[i] = (p.ups ? ((pr - 1) >> 1) * (p.W >> 1) + ((pc - 1) >> 1) : pr * p.W + pc) * p.x_ld + ((c ^ ws_swz<CP>(ps)) << 3);
+        if constexpr (ST) rel[i] = (pr * p.W + pc) * 8;
+        else rel[i] = (p.ups ? ((pr - 1) >> 1) * (p.W >> 1) + ((pc - 1) >> 1) : pr * p.W + pc) * p.x_ld + ((c ^ ws_swz<CP>(ps)) << 3);
         prpc[i] = s < patch_slots ? ((unsigned)pr << 16) | (unsigned)pc : 0x7fff0000u;        // beyond the patch: never inside the image -> zero page
     }
     // ---- per-lane fragment rows: tile pixel i = (wave*TM + b)*32 + (lane & 31) -> (ty, tx) ------------------------------
@@ -96,7 +109,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
         const int i = (wave * TM + b) * 32 + l31;
         const int ty = (int)sm_fastdiv((unsigned)i, p.ws_tw_mul, p.ws_tw_sh), tx = i - ty * TW;
         const bool in = i < TH * TW;
-        slot0[b] = in ? ty * PW + tx : 0;
+        slot0[b] = in ? (ty * PW + tx) * SS : 0;
         tyx[b] = in ? ((unsigned)ty << 16) | (unsigned)tx : 0x7fff7fffu;                        // outside the tile: fails every bounds check
     }
     int swn[TN];
@@ -114,14 +127,15 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     };
     auto issue_patch = [&](int buf, int t) {
         int n, y0, x0; tile_origin(t, n, y0, x0);
+        const int iy0 = ST ? y0 * SS : y0 - 1, ix0 = ST ? x0 * SS : x0 - 1;      // input pixel of patch pixel (0, 0)
         const half_t* xb = p.ups ? p.x + (((long)n * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1)) * p.x_ld
-                                 : p.x + (((long)n * p.H + (y0 - 1)) * p.W + (x0 - 1)) * p.x_ld;   // patch pixel (0,0); dereferenced only inside the image
+                                 : p.x + (((long)n * p.H + iy0) * p.W + ix0) * p.x_ld;             // dereferenced only inside the image
         unsigned char* dst = patch0 + buf * WS_PSTRIDE + wave * 1024;
 #pragma unroll
         for (int i = 0; i < NIC; i++) {
             if (i < NI && i * NT + wave * 64 < patch_slots) {         // wave-uniform
                 const int pr = (int)(prpc[i] >> 16), pc = (int)(prpc[i] & 0xffff);
-                const bool in = (unsigned)(y0 - 1 + pr) < (unsigned)p.H && (unsigned)(x0 - 1 + pc) < (unsigned)p.W;
+                const bool in = (unsigned)(iy0 + pr) < (unsigned)p.H && (unsigned)(ix0 + pc) < (unsigned)p.W;
                 SM_GLDS16(in ? xb + rel[i] : zero, dst + i * NT * 16);
             }
         }
@@ -132,7 +146,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     u32x4 outv[TN][TM][2];                                            // packed results of the PREVIOUS tile: [a][b][j] = couts a*32 + 16j + 8*hi .. +7 of pixel b
     int pn = 0, py0 = 0, px0 = 0; bool pending = false;
     auto store_prev = [&]() {
-        if constexpr (TM == 2) {
+        if constexpr (TM == 2 && !ST) {
             // fused 2x2 / stride-2 max-pool of the output (p.y2; launcher: TW == 32, even H and W, so a wave's two fragments are image rows
             // 2k and 2k+1 of the SAME columns and lanes 2i, 2i+1 are neighbouring columns): max over the two fragments, then over the lane
             // pair (DPP quad_perm [1,0,3,2]); even lanes store.  Max of fp16 values is exact and commutes with the ReLU-family activation.
@@ -156,8 +170,8 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
 #pragma unroll
         for (int b = 0; b < TM; b++) {
             const int oy = py0 + (int)(tyx[b] >> 16), ox = px0 + (int)(tyx[b] & 0xffff);
-            if (oy < p.H && ox < p.W && (int)(tyx[b] >> 16) < TH) {
-                half_t* dst = p.y + (((long)pn * p.H + oy) * p.W + ox) * p.y_ld + 8 * hi;
+            if (oy < OH && ox < OW && (int)(tyx[b] >> 16) < TH) {
+                half_t* dst = p.y + (((long)pn * OH + oy) * OW + ox) * p.y_ld + 8 * hi;
 #pragma unroll
                 for (int a = 0; a < TN; a++)
 #pragma unroll
@@ -168,15 +182,16 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
 
     // ---- fragment addresses: tile-invariant, computed once.  A: byte offset inside a patch of (fragment b, tap, k step) for this lane;
     // B: the weight image never moves — one register per k step, the tap is an instruction offset.
-    constexpr int NS = 9 * KS;                                        // k steps of 16 per tile
+    constexpr int NS = NTAP * KS;                                     // k steps of 16 per tile
     unsigned aoff[TM][NS];
 #pragma unroll
     for (int b = 0; b < TM; b++)
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
-            const int q = slot0[b] + (tap / 3) * PW + (tap % 3);
+        for (int tap = 0; tap < NTAP; tap++) {
+            const int q = ST ? slot0[b] + 2 * tap * PW : slot0[b] + (tap / 3) * PW + (tap % 3);
 #pragma unroll
-            for (int ks = 0; ks < KS; ks++) aoff[b][tap * KS + ks] = ws_lds_addr(patch0) + (unsigned)(q * ROWB + (((ks * 2 + hi) ^ ws_swz<CP>(q)) << 4));
+            for (int ks = 0; ks < KS; ks++)
+                aoff[b][tap * KS + ks] = ws_lds_addr(patch0) + (ST ? (unsigned)((q + ks * 2 + hi) << 4) : (unsigned)(q * ROWB + (((ks * 2 + hi) ^ ws_swz<CP>(q)) << 4)));
         }
     // (ds_read offsets are 16 bits: taps 0..4 are addressed from the first base, taps 5..8 from a second one)
     constexpr int TAPB = NOUT * ROWB;
@@ -187,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
 #pragma unroll
         for (int ks = 0; ks < KS; ks++) {
             boff[0][a][ks] = ws_lds_addr(wl) + (unsigned)(((a * 32 + l31) * CP + ((ks * 2 + hi) ^ swn[a])) * 16);
-            boff[1][a][ks] = boff[0][a][ks] + 5 * TAPB;
+            boff[1][a][ks] = boff[0][a][ks] + (NTAP > 5 ? 5 : 0) * TAPB;
         }
 
     // one tile: DMA pieces of the NEXT patch spread between the k steps (a VMEM instruction stalls its wave while the address queue
@@ -200,13 +215,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
         // the NEXT patch (the last tile of the range re-fetches itself: no branch anywhere in the k loop — behind a join hipcc waits
         // lgkmcnt(0) for fragment reads it has just issued).  A wave without slots in piece i sends it to the dummy sink.
         int nn, ny0, nx0; tile_origin(t + 1 < t_end ? t + 1 : t, nn, ny0, nx0);
+        const int iy0 = ST ? ny0 * SS : ny0 - 1, ix0 = ST ? nx0 * SS : nx0 - 1;
         const half_t* xb = p.ups ? p.x + (((long)nn * (p.H >> 1) + (ny0 >> 1)) * (p.W >> 1) + (nx0 >> 1)) * p.x_ld
-                                 : p.x + (((long)nn * p.H + (ny0 - 1)) * p.W + (nx0 - 1)) * p.x_ld;
+                                 : p.x + (((long)nn * p.H + iy0) * p.W + ix0) * p.x_ld;
         const unsigned dst_a = ws_lds_addr(patch0) + (BUF ^ 1) * WS_PSTRIDE + wave * 1024, dummy_a = ws_lds_addr(dummy);
         auto piece = [&](int i) {
             const bool mine = i * NT + wave * 64 < patch_slots;       // wave-uniform
             const int pr = (int)(prpc[i] >> 16), pc = (int)(prpc[i] & 0xffff);
-            const bool in = (unsigned)(ny0 - 1 + pr) < (unsigned)p.H && (unsigned)(nx0 - 1 + pc) < (unsigned)p.W;
+            const bool in = (unsigned)(iy0 + pr) < (unsigned)p.H && (unsigned)(ix0 + pc) < (unsigned)p.W;
             ws_glds16(in ? xb + rel[i] : zero, (unsigned)__builtin_amdgcn_readfirstlane((int)(mine ? dst_a + i * NT * 16 : dummy_a)));
         };
         floatx16 acc[TN][TM];

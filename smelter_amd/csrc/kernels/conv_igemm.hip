@@ -486,6 +486,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 #include "pw_thin.hpp"
 #include "conv3x3_ws.hpp"
 #include "conv3x3_p9.hpp"
+#include "conv1x1_ps.hpp"
 #include "conv1x1_pair.hpp"
 
 // 3x3 depthwise through LDS (the MobileNet-v2 path): the register-strip kernel above re-reads every input pixel 4.5x through
@@ -667,6 +668,32 @@ const TileCfg kCfgs[] = {
     {224, 64, 4, 448, conv3x3_ws_kernel<64, 64, 7, 1>, "ws:64->64 w7x1"},                             // 65  (56x56: 8 x 28 = 224-pixel tiles, no idle fragment)
     {512, 32, 4, 512, conv3x3_ws_kernel<64, 32, 8, 2>, "ws:64->32 w8x2"},                             // 66
     {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2>, "ws:32->32 w8x2"},                             // 67
+    // kind 5 (conv3x3_p9.hpp): 3x3 / stride 1 / pad 1, Cin % 64 == 0: one patch per cin block serves all nine taps, weights ring as kind 1
+    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 3>, "p9:256x128 s3"},                        // 68
+    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 2>, "p9:256x128 s2"},                        // 69
+    {128, 128, 5, 512, conv3x3_p9_kernel<128, 128, 4, 2, 3>, "p9:128x128(32x64) s3"},                 // 70
+    {128, 128, 5, 512, conv3x3_p9_kernel<128, 128, 2, 4, 3>, "p9:128x128(64x32) s3"},                 // 71
+    {256, 64, 5, 512, conv3x3_p9_kernel<256, 64, 4, 2, 3>, "p9:256x64 s3"},                           // 72
+    {128, 64, 5, 512, conv3x3_p9_kernel<128, 64, 4, 2, 3>, "p9:128x64 s3"},                           // 73
+    // kind 6 (conv3x3_ws.hpp, STEM form): the image stem on the row-pair image (Cin = 64 = 8 overlapping 16-byte pixels, kH' = 2 | 4 taps,
+    // kW' = 1, row dilation 2, stride 1 | 2); name = "wst:<taps>-><cout> ... [p<KB between the two patch buffers>]"
+    {256, 64, 6, 256, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 23 * 1024>, "wst:4->64 w4x2 p23"},     // 74  (ResNet-50 7x7/2: two blocks per CU)
+    {512, 64, 6, 512, conv3x3_ws_kernel<64, 64, 8, 2, 6, 0, 4>, "wst:4->64 w8x2"},                    // 75
+    {256, 64, 6, 256, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 2, 20 * 1024>, "wst:2->64 w4x2 p20"},     // 76  (U-Net 3x3/1)
+    {256, 32, 6, 256, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024>, "wst:2->32 w4x2 p20"},     // 77  (MobileNet-v2 3x3/2)
+    {256, 32, 6, 256, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 4, 24 * 1024>, "wst:4->32 w4x2 p24"},     // 78
+    {512, 64, 6, 512, conv3x3_ws_kernel<64, 64, 8, 2, 6, 0, 2>, "wst:2->64 w8x2"},                    // 79
+    {512, 32, 6, 512, conv3x3_ws_kernel<64, 32, 8, 2, 6, 0, 2>, "wst:2->32 w8x2"},                    // 80
+    // kind 7 (conv1x1_ps.hpp): persistent pointwise GEMM, 8 MFMA waves + 4 loader waves, one block per CU
+    {128, 128, 7, 768, conv1x1_ps_kernel<128, 128, 4, 2, 4>, "ps:128x128(32x64) s4"},                 // 81
+    {128, 128, 7, 768, conv1x1_ps_kernel<128, 128, 2, 4, 4>, "ps:128x128(64x32) s4"},                 // 82
+    {128, 64, 7, 768, conv1x1_ps_kernel<128, 64, 4, 2, 4>, "ps:128x64 s4"},                           // 83
+    {256, 128, 7, 768, conv1x1_ps_kernel<256, 128, 4, 2, 3, false>, "ps:256x128 s3"},                        // 84
+    {128, 256, 7, 768, conv1x1_ps_kernel<128, 256, 2, 4, 3, false>, "ps:128x256 s3"},                        // 85
+    {128, 128, 7, 768, conv1x1_ps_kernel<128, 128, 4, 2, 3>, "ps:128x128(32x64) s3"},                 // 86
+    // 256x256 (kind 1): for layers with <= 256 such tiles (ResNet-50 layer 3, N = 1024: 196) one round of blocks moves half the L1 bytes of 128x128
+    {256, 256, 1, 512, conv_igemm64_kernel<256, 256, 4, 2, 2, 0, 0, 0, 1, 1, true>, "k64w8:256x256(64x128)"},    // 87
+    {256, 256, 1, 512, conv_igemm64_kernel<256, 256, 4, 2, 2, 0, 1, 0, 1, 1, true>, "k64w8i:256x256(64x128)"},   // 88
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
@@ -676,13 +703,6 @@ const TileCfg kCfgs[] = {
     {128, 64, 3, 256, conv3x3_strip_kernel<128, 64, 2, 2, 2, 1>, "strip lean w4:128x64"},
     {128, 64, 3, 512, conv3x3_strip_kernel<128, 64, 4, 2, 2, 1>, "strip lean w8:128x64"},
 #endif
-    // kind 5 (conv3x3_p9.hpp): 3x3 / stride 1 / pad 1, Cin % 64 == 0: one patch per cin block serves all nine taps, weights ring as kind 1
-    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 3>, "p9:256x128 s3"},                        // 68
-    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 2>, "p9:256x128 s2"},                        // 69
-    {128, 128, 5, 512, conv3x3_p9_kernel<128, 128, 4, 2, 3>, "p9:128x128(32x64) s3"},                 // 70
-    {128, 128, 5, 512, conv3x3_p9_kernel<128, 128, 2, 4, 3>, "p9:128x128(64x32) s3"},                 // 71
-    {256, 64, 5, 512, conv3x3_p9_kernel<256, 64, 4, 2, 3>, "p9:256x64 s3"},                           // 72
-    {128, 64, 5, 512, conv3x3_p9_kernel<128, 64, 4, 2, 3>, "p9:128x64 s3"},                           // 73
 #ifdef SM_ABLATION   // conv3x3_ws ablations (64->32, 4 waves x 2 fragments)
     {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 0>, "ws:64->32 abl ref"},
     {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 1>, "ws:64->32 abl noDMA"},
@@ -742,6 +762,38 @@ size_t ws_setup(ConvParams& p, const TileCfg& c) {
     return best_lds;
 }
 
+// Dynamic LDS of the persistent pointwise kernel: ring ("... s<stages>") + the layer's bias vector
+size_t ps_lds_bytes(const ConvParams& p, const TileCfg& c) {
+    const char* sk = strstr(c.name, " s");
+    return (size_t)(sk ? atoi(sk + 2) : 3) * (c.BM + c.BN) * 128 + ((size_t)p.Cout * 4 + 15) / 16 * 16;
+}
+
+// Geometry of the stem form of the weight-stationary kernel (kind 6): the same search over the OUTPUT image; a patch is
+// ((TH-1)s + 2(taps-1) + 1) x ((TW-1)s + 8) 16-byte row-pair pixels.  Returns the dynamic LDS size in bytes, 0 if the config does not fit.
+size_t wst_setup(ConvParams& p, const TileCfg& c) {
+    const int taps = atoi(c.name + 4), s = p.sH, nt = c.threads, nic = 6;
+    if (p.kH != taps || p.Cin != 64) return 0;
+    const char* pk = strstr(c.name, " p");
+    const size_t fixed = (size_t)taps * p.Cout * 128 + (size_t)p.Cout * 4 + WS_DUMMY;
+    const size_t stride = pk ? (size_t)atoi(pk + 2) * 1024 : (size_t)ws_pstride((int)fixed);
+    const int bands = sm_ceil_div(p.Wo, 32), TW = sm_ceil_div(p.Wo, bands), PW = (TW - 1) * s + 8;
+    int best_th = 0; long best_tiles = 0; size_t best_patch = 0;
+    for (int th = 1; th * TW <= c.BM && th <= p.Ho; th++) {
+        const size_t slots = (size_t)((th - 1) * s + 2 * (taps - 1) + 1) * PW, patch = (slots * 16 + 1023) / 1024 * 1024;
+        if (sm_ceil_div((long)slots, nt) > nic || patch > stride) break;
+        const long tiles = (long)sm_ceil_div(p.Ho, th) * sm_ceil_div(p.Wo, TW);
+        if (!best_th || tiles < best_tiles) { best_th = th; best_tiles = tiles; best_patch = patch; }
+    }
+    if (!best_th) return 0;
+    p.ws_TH = best_th; p.ws_TW = TW; p.ws_tiles_x = sm_ceil_div(p.Wo, TW); p.ws_tiles_y = sm_ceil_div(p.Ho, best_th);
+    const long nt_all = (long)p.N * p.ws_tiles_x * p.ws_tiles_y;
+    if (nt_all >= (1L << 31)) return 0;
+    p.ws_ntiles = (int)nt_all; p.ws_patch_bytes = (int)best_patch;
+    sm_fastdiv_make((unsigned)PW, &p.ws_pw_mul, &p.ws_pw_sh); sm_fastdiv_make((unsigned)TW, &p.ws_tw_mul, &p.ws_tw_sh);
+    sm_fastdiv_make((unsigned)(p.ws_tiles_x * p.ws_tiles_y), &p.ws_txy_mul, &p.ws_txy_sh); sm_fastdiv_make((unsigned)p.ws_tiles_y, &p.ws_ty_mul, &p.ws_ty_sh);
+    return fixed + stride + best_patch;
+}
+
 // Geometry of the nine-tap patch kernel for tile config `c`: the column-band width TW (the whole row for small images, else ~32)
 // that moves the fewest patch pixels per tile while two patches + the weight ring fit 160 KiB and a patch needs at most NIC*NT
 // 16-byte DMA slots.  Returns the dynamic LDS size in bytes, 0 if the config does not fit the layer.
@@ -784,6 +836,18 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
         return ok;
     }
     if (p.y2) return false;                                          // only the weight-stationary kernel writes the pooled second output
+    if (c.kind == 7)     // persistent pointwise GEMM: 1x1, no padding, one square stride, dense 16-byte rows, ReLU family, bias vector beside the ring
+        return p.kH == 1 && p.kW == 1 && p.pt == 0 && p.pl == 0 && p.sH == p.sW && (p.sH == 1 || p.sH == 2) && (p.Cin % 64) == 0 && !p.ups && !p.yplace &&
+               p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
+               ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0)) &&
+               (long)(p.Ho - 1) * p.sH < p.H && (long)(p.Wo - 1) * p.sW < p.W && ps_lds_bytes(p, c) <= 160 * 1024;
+    if (c.kind == 6) {   // stem form: overlapping 64-half pixels of a row-pair image (x_ld = 8), one kernel column, rows two apart, no padding
+        ConvParams q = p;
+        return p.Cin == 64 && p.x_ld == 8 && p.kW == 1 && p.dH == 2 && p.pt == 0 && p.pl == 0 && p.sH == p.sW && (p.sH == 1 || p.sH == 2) && !p.ups &&
+               (long)(p.Ho - 1) * p.sH + 2 * (p.kH - 1) < p.H && (long)(p.Wo - 1) * p.sW + 8 <= p.W &&
+               !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
+               ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && p.Cout == c.BN && wst_setup(q, c) > 0;
+    }
     if (c.kind == 5) {   // nine-tap patch kernel: no residual, dense 16-byte rows, ReLU family
         ConvParams q = p;
         return same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 &&
@@ -911,12 +975,20 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     const TileCfg& c = kCfgs[cfg];
     if (p.ups && c.kind != 5 && c.kind != 4) { sm_set_error("conv tile config %d (%s) does not apply to an upsampled input", cfg, c.name); return SM_ERR_INVALID_ARGUMENT; }
     if (!cfg_eligible(c, p)) { sm_set_error("conv tile config %d (%s) does not apply to Cin=%d", cfg, c.name, p.Cin); return SM_ERR_INVALID_ARGUMENT; }
-    if (c.kind == 4) {                                               // persistent: one block per CU (two when the LDS allows), contiguous tile ranges
-        const size_t lds = ws_setup(p, c);
+    if (c.kind == 4 || c.kind == 6) {                                // persistent: one block per CU (two when the LDS allows), contiguous tile ranges
+        const size_t lds = c.kind == 4 ? ws_setup(p, c) : wst_setup(p, c);
         const int per_cu = lds * 2 <= 160 * 1024 ? 2 : 1;
         const int grid = std::min(p.ws_ntiles, SM_NUM_CU * per_cu);
         typedef void (*WsFn)(ConvParams);
         hipLaunchKernelGGL((WsFn)c.fn, dim3(grid), dim3(c.threads), lds, s, p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
+    if (c.kind == 7) {                                               // persistent: one block per CU, tiles dealt per XCD inside the kernel
+        p.mt = sm_ceil_div(p.M, c.BM); p.nt = sm_ceil_div(p.Cout, c.BN); p.splitk = 1;
+        sm_fastdiv_make((unsigned)p.nt, &p.nt_mul, &p.nt_sh);
+        const long tiles = (long)p.mt * p.nt;
+        // (a whole number of blocks per XCD: XCD x owns tiles [xT/8, (x+1)T/8), at most ceil(T/8) of them)
+        hipLaunchKernelGGL(c.fn, dim3((unsigned)std::min<long>((tiles + SM_NUM_XCD - 1) / SM_NUM_XCD * SM_NUM_XCD, SM_NUM_CU)), dim3(c.threads), ps_lds_bytes(p, c), s, p);
         SM_LAUNCH_CHECK(); return SM_OK;
     }
     if (c.kind == 5) {
@@ -1089,6 +1161,7 @@ int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w,
         static unsigned long long h[8192 * 16];
         memset(h, 0, sizeof h);
         SM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl), h, sizeof h));
+        if (getenv("SM_TIME_COLD")) { static char* scratch2 = nullptr; if (!scratch2) SM_HIP_CHECK(hipMalloc((void**)&scratch2, (size_t)768 << 20)); SM_HIP_CHECK(hipMemsetAsync(scratch2, 1, (size_t)768 << 20, s)); }
         rc = launch(d, p, cfg, ws, ws_bytes, s); SM_HIP_CHECK(hipStreamSynchronize(s));
         SM_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tl), sizeof h));
         static const char* names[8] = {"map_block", "rows", "brow+cursor", "prologue issue", "res+bias+init", "first tile", "main loop", "epilogue"};

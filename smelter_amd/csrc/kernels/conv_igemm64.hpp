@@ -68,7 +68,9 @@ constexpr int sm_pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; retur
 // buffers of the epilogue (one region per group, summed by the store pass in a fixed order).
 // KT = K tiles per ring stage (default KS).  KS = 1, KT = 2: every wave multiplies both tiles of a stage — BK = 128 per barrier: half
 // the barriers / counted waits per K tile for the one-block-per-CU layers, at twice the stage size.
-template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0, int NLW = 0, int KS = 1, int KT = KS>
+// LATE_RES: the residual operand is requested by the epilogue pass that adds it instead of before the main loop — for the 256x256 tile,
+// whose prefetched residual would be 64 registers per thread beside 128 accumulators.
+template <int BM, int BN, int WGM, int WGN, int NSTAGE = 2, int ABL = 0, int ILV = 0, int NLW = 0, int KS = 1, int KT = KS, bool LATE_RES = false>
 __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kernel(ConvParams p) {
     static_assert(WGM * WGN == 4 || WGM * WGN == 8, "4 or 8 MFMA waves per group");
     static_assert(NSTAGE >= 1 && NSTAGE <= 4, "1..4 stages");
@@ -238,7 +240,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
     //    main loop needs comes from an ordinary load, so it starts as soon as tile 0 has landed (bias-initialised
     //    accumulators made every block wait for bias AND residual, the youngest loads, before its first MFMA).
     constexpr int CHUNKS = BN / 8, ITEMS = EP_ROWS * CHUNKS, IPT = (ITEMS + NT - 1) / NT;
-    constexpr int EXTRA = 2 + EP_PASSES * IPT;
+    constexpr int EXTRA = 2 + (LATE_RES ? 0 : EP_PASSES * IPT);
     static_assert(NT % CHUNKS == 0, "a thread keeps its channel chunk across items");
     static_assert((NSTAGE - 1) * LOADS + EXTRA <= 63, "vmcnt range");
     const bool vec_ok = ((p.y_ld & 7) == 0) && ((((uintptr_t)p.y) & 15) == 0) && ((p.Cout & 7) == 0) &&
@@ -249,18 +251,20 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
         const float* bp = (fastep && p.bias) ? p.bias + min(ntile * BN + (tid % CHUNKS) * 8, p.Cout - 8) : (const float*)g_zero_page;
         eb0 = *(const floatx4*)bp; eb1 = *(const floatx4*)(bp + 4);
     }
-    half8_t rres[EP_PASSES][IPT];
-    {
-        const bool use_res = p.res && vec_ok && p.splitk == 1;
+    half8_t rres[LATE_RES ? 1 : EP_PASSES][IPT];
+    const bool use_res = p.res && vec_ok && p.splitk == 1;
+    auto load_res = [&](int pw) {
 #pragma unroll
-        for (int pw = 0; pw < EP_PASSES; pw++)
+        for (int k2 = 0; k2 < IPT; k2++) {
+            int it = tid + k2 * NT; if (ITEMS % NT != 0 && it >= ITEMS) it = ITEMS - 1;
+            const int row = it / CHUNKS, ch = it - row * CHUNKS;
+            const int m = min(mtile * BM + pw * EP_ROWS + row, p.M - 1), co = min(ntile * BN + ch * 8, p.Cout - 8);
+            rres[LATE_RES ? 0 : pw][k2] = *(const half8_t*)(use_res ? p.res + (long)m * p.res_ld + co : zero);
+        }
+    };
+    if (!LATE_RES) {
 #pragma unroll
-            for (int k2 = 0; k2 < IPT; k2++) {
-                int it = tid + k2 * NT; if (ITEMS % NT != 0 && it >= ITEMS) it = ITEMS - 1;
-                const int row = it / CHUNKS, ch = it - row * CHUNKS;
-                const int m = min(mtile * BM + pw * EP_ROWS + row, p.M - 1), co = min(ntile * BN + ch * 8, p.Cout - 8);
-                rres[pw][k2] = *(const half8_t*)(use_res ? p.res + (long)m * p.res_ld + co : zero);
-            }
+        for (int pw = 0; pw < EP_PASSES; pw++) load_res(pw);
     }
     __builtin_amdgcn_sched_barrier(0);
 
@@ -373,6 +377,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
     float* stg = (float*)smem_raw;
 #pragma unroll
     for (int pw = 0; pw < EP_PASSES; pw++) {
+        if (LATE_RES && use_res) load_res(pw);                  // in flight across the staging writes and the barrier
         if (is_consumer && wm / WPP == pw) {
             const int wrow = (wm % WPP) * WROWS + kgrp * EP_ROWS;   // K group g stages into region g (EP_ROWS*EP_LD floats each)
 #pragma unroll
@@ -409,7 +414,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
                     const int m = m0 + rowi[k2], co = co0 + chi[k2] * 8;
                     float v[8] = {s0[k2][0] + eb0[0], s0[k2][1] + eb0[1], s0[k2][2] + eb0[2], s0[k2][3] + eb0[3],
                                   s1[k2][0] + eb1[0], s1[k2][1] + eb1[1], s1[k2][2] + eb1[2], s1[k2][3] + eb1[3]};
-                    if (has_res) { const half8_t rr = rres[pw][k2];
+                    if (has_res) { const half8_t rr = rres[LATE_RES ? 0 : pw][k2];
 #pragma unroll
                         for (int j = 0; j < 8; j++) v[j] += (float)rr[j]; }
                     half8_t o;
@@ -441,7 +446,7 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
                 continue;
             }
             if (vec_ok) {
-                if (p.res) { const half8_t rr = rres[pw][k2];     // prefetched before the main loop
+                if (p.res) { const half8_t rr = rres[LATE_RES ? 0 : pw][k2];     // prefetched before the main loop
 #pragma unroll
                     for (int j = 0; j < 8; j++) v[j] += (float)rr[j]; }
                 half8_t o;

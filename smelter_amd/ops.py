@@ -85,6 +85,33 @@ def conv2d(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0)
     return out
 
 
+def stem_conv(x_nchw, w_ohwi_f32, bias=None, stride=1, pads=(0, 0, 0, 0), act=ACT_NONE, slope=0.0, cfg=None):
+    """First-layer convolution of a C <= 4 fp32 NCHW image the way the executor runs it (executor.cpp "image stem"): row-pair image
+    (sm_nchw_f32_to_rowpair_f16) + weights repacked to [Cout][ceil(kH/2)][8 pixels][2 rows][4 channels], launched as a Cin = 64, kW = 1,
+    row-dilation-2 convolution with x_ld = 8.  Returns NHWC fp16."""
+    assert x_nchw.is_cuda and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    n, c, h, w = x_nchw.shape
+    cout, kh, kw, c2 = w_ohwi_f32.shape
+    assert c == c2 and c <= 4 and kw <= 8
+    s, P = stride, (kh + 1) // 2
+    ho, wo = conv_out_size(h, w, kh, kw, s, s, pads)
+    hs, ws = (ho - 1) * s + 2 * (P - 1) + 1, (wo - 1) * s + 8
+    img = torch.empty((n, hs, ws, 8), dtype=torch.float16, device=x_nchw.device)
+    check(lib().sm_nchw_f32_to_rowpair_f16(_ptr(x_nchw), _ptr(img), n, c, h, w, hs, ws, pads[0], pads[1], _stream()))
+    wp = torch.zeros((cout, P, 8, 2, 4), dtype=torch.float32)
+    wc = w_ohwi_f32.detach().cpu().float()
+    for r in range(kh):
+        wp[:, r // 2, :kw, r & 1, :c] = wc[:, r]
+    wp = wp.reshape(cout, P, 1, 64).to(torch.float16).to(x_nchw.device).contiguous()
+    out = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x_nchw.device)
+    d = ConvDesc(n, hs, ws, 64, cout, P, 1, s, s, 2, 1, 0, 0, 0, 0, 1, ho, wo, act, slope, 8, cout, 0)
+    if cfg is None:
+        check(lib().sm_conv2d_fwd(C.byref(d), _ptr(img), _ptr(wp), _ptr(bias), None, _ptr(out), _stream()))
+    else:
+        check(lib().sm_conv2d_fwd_cfg(C.byref(d), cfg, _ptr(img), _ptr(wp), _ptr(bias), None, _ptr(out), None, 0, _stream()))
+    return out
+
+
 def conv2d_pool(x, w_ohwi, bias, act=ACT_RELU, slope=0.0, cfg=-1):
     """3x3 / s1 / p1 convolution + 2x2 / s2 max-pool of its output in one launch (sm_conv2d_pool_fwd_cfg); returns (y, pooled)"""
     n, h, w, cin, x_ld = _check_nhwc(x)

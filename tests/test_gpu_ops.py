@@ -56,7 +56,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg", [None] + list(range(80)))
+@pytest.mark.parametrize("cfg", [None] + list(range(92)))
 def test_conv2d(case, cfg):
     n, hh, ww, cin, cout, k, s, p, res, act = case
     if cfg is not None and (cin % 8 or cfg >= ops.num_conv_configs() or (cfg >= 6 and cin % 64)):
@@ -117,7 +117,7 @@ def test_pointwise_thin_kernel(cin, cout, res, act, monkeypatch):
     assert_close(to_host(y), ref, cin)
 
 
-@pytest.mark.parametrize("cfg", list(range(80)))
+@pytest.mark.parametrize("cfg", list(range(92)))
 def test_conv2d_generic_epilogue_every_config(cfg):
     """Tanh is not a ReLU-family activation, so every kernel takes its GENERIC epilogue (bias-initialised accumulators, per-element
     activation) instead of the straight-line fast path the ResNet cases exercise; Cin % 64 == 0 so that all BK=64 configs apply.
@@ -155,7 +155,7 @@ def test_conv2d_split_k_workspace():
     assert_close(to_host(y), O.conv2d(x, w, b), cin)
 
 
-@pytest.mark.parametrize("cfg", list(range(80)))
+@pytest.mark.parametrize("cfg", list(range(92)))
 def test_conv2d_split_k_every_config(cfg):
     """few tiles + long K + a workspace: the launcher splits K across blocks (fp32 partials + reduce kernel) for every tile config
     that has a split-K form; residual + ReLU are then applied by the reduce kernel"""
@@ -623,3 +623,89 @@ def test_conv3x3_with_fused_maxpool(n, hw, cin, cout, act, cfg):
         ref = np.where(ref >= 0, ref, ref * slope)
     assert_close(to_host(y), ref, cin * 9)
     assert np.array_equal(to_host(yp), O.maxpool(to_host(y), (2, 2), (2, 2), (0, 0)))
+
+
+@pytest.mark.parametrize("shape", [
+    # n, C, H, W, cout, k, stride, pads
+    (2, 3, 64, 64, 64, 7, 2, (3, 3, 3, 3)),      # ResNet-50 class
+    (1, 3, 75, 91, 64, 7, 2, (3, 3, 3, 3)),      # ragged tiles on both axes
+    (2, 3, 40, 72, 64, 3, 1, (1, 1, 1, 1)),      # U-Net class
+    (2, 3, 66, 66, 32, 3, 2, (1, 1, 1, 1)),      # MobileNet-v2 class
+    (1, 1, 33, 47, 32, 3, 1, (1, 1, 1, 1)),      # one channel, ragged
+    (1, 4, 50, 38, 32, 7, 2, (2, 3, 3, 2)),      # asymmetric padding, 4 channels
+    (1, 3, 9, 9, 64, 3, 1, (0, 0, 0, 0)),        # image smaller than a tile
+])
+@pytest.mark.parametrize("cfg", [None] + list(range(74, 81)))
+def test_stem_on_the_weight_stationary_kernel(shape, cfg):
+    """Image stem through the row-pair image (ops.stem_conv = executor's lowering): every stem configuration of conv3x3_ws.hpp that takes
+    the shape agrees with the oracle convolution, and with the default pick"""
+    n, C, H, W, cout, k, s, pads = shape
+    rng = np.random.default_rng(H * W + cout + k)
+    x = rng.standard_normal((n, C, H, W)).astype(np.float32)
+    w = h(rng.standard_normal((cout, k, k, C)) * np.sqrt(2.0 / (C * k * k))); b = rng.standard_normal(cout).astype(np.float32)
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.stem_conv(torch.from_numpy(x).cuda(), torch.from_numpy(w), torch.from_numpy(b).cuda(), stride=s, pads=pads, act=1, cfg=cfg)
+    except SmelterError as e:
+        if cfg is not None and "does not apply" in e.detail:
+            pytest.skip(e.detail)
+        raise
+    ref = np.maximum(O.conv2d(h(x), w, b, stride=(s, s), pads=pads), 0)
+    assert_close(to_host(y), ref, C * k * k)
+
+
+PS_CASES = [
+    # n, h, w, cin, cout, stride, residual, act        -- what the case exercises
+    (2, 14, 14, 256, 1024, 1, True, 1),                # ResNet layer-3 expand: 4 K tiles, residual
+    (1, 28, 28, 512, 128, 1, False, 1),                # reduce: 8 K tiles, one n tile
+    (3, 9, 11, 64, 200, 1, True, 2),                   # one K tile per output tile, ragged M (297) and ragged N (200), PReLU
+    (2, 14, 14, 512, 1024, 2, True, 1),                # stride-2 projection shortcut (+ residual)
+    (1, 7, 7, 2048, 512, 1, False, 0),                 # 32 K tiles, fewer tiles than CUs, no activation
+    (64, 14, 14, 256, 1024, 1, True, 1),               # full size: 784 tiles of 128x128 on 256 CUs (3..4 tiles per block)
+    (4, 56, 56, 64, 64, 1, False, 1),                  # 98 m tiles x 1 n tile, K = 64
+]
+
+
+@pytest.mark.parametrize("case", PS_CASES)
+@pytest.mark.parametrize("cfg", list(range(81, 88)))
+def test_persistent_pointwise_kernel(case, cfg):
+    """conv1x1_ps.hpp: every configuration that takes the shape agrees with the oracle and is bit-identical to conv_igemm64 (config 6)"""
+    if cfg >= ops.num_conv_configs():
+        pytest.skip("no such config")
+    n, hh, ww, cin, cout, s, res, act = case
+    rng = np.random.default_rng(cin * 7 + cout + hh)
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, 1, 1, cin)) * np.sqrt(2.0 / cin)); b = rng.standard_normal(cout).astype(np.float32)
+    ho, wo = (hh - 1) // s + 1, (ww - 1) // s + 1
+    r = h(rng.standard_normal((n, cout, ho, wo))) if res else None
+    slope = 0.25 if act == 2 else 0.0
+    xd, wd, bd, rd = to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), to_dev(r) if res else None
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(xd, wd, bd, residual=rd, stride=(s, s), act=act, slope=slope, cfg=cfg)
+    except SmelterError as e:
+        if "does not apply" in e.detail:
+            pytest.skip(e.detail)
+        raise
+    y6 = ops.conv2d(xd, wd, bd, residual=rd, stride=(s, s), act=act, slope=slope, cfg=6)
+    assert torch.equal(y, y6)
+    if n * ho * wo <= 4096:
+        ref = O.conv2d(x, w, b, stride=(s, s))
+        if res:
+            ref = ref + r
+        if act:
+            ref = np.where(ref >= 0, ref, ref * slope)
+        assert_close(to_host(y), ref, cin)
+
+
+def test_persistent_pointwise_kernel_into_a_channel_slice():
+    """output and residual rows wider than Cout (concat placement): only the slice is written"""
+    rng = np.random.default_rng(5)
+    n, hh, ww, cin, cout = 2, 13, 17, 128, 64
+    x = h(rng.standard_normal((n, cin, hh, ww))); w = h(rng.standard_normal((cout, 1, 1, cin)) * 0.1); b = rng.standard_normal(cout).astype(np.float32)
+    big = torch.full((n, hh, ww, 160), 7.0, dtype=torch.float16, device="cuda")
+    out = big[..., 32:96]
+    ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), act=1, out=out, cfg=81)
+    ref = np.maximum(O.conv2d(x, w, b), 0)
+    assert_close(to_host(out.contiguous()), ref, cin)
+    assert (big[..., :32] == 7).all() and (big[..., 96:] == 7).all()
