@@ -361,6 +361,38 @@ int Executor::plan(ONNXGraph& g, int batch) {
         }
     }
 
+    // ---- 3c. inverted-residual blocks (MobileNet-v2): 1x1 expand (+act) -> depthwise 3x3 / stride 1|2 / pad 1 (+act) -> 1x1 project
+    // (+ the block input as residual) run as ONE launch (mbconv.hip) when the two hidden tensors have no other reader: they are 6x the block's
+    // input and are otherwise written once and read once.  Domain = the all-in-LDS kernel's (Cin <= 32, Ch <= 192, Cout <= 64), where the fused
+    // launch measured faster than the three separate ones; SMELTER_MBCONV=0 keeps the layers apart.
+    {
+        const char* mb_env = getenv("SMELTER_MBCONV");
+        auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; if (q.has_pair) for (int u : q.pair.inputs) if (u == v) n++; } return n; };
+        auto pointwise = [&](const Step& q) { const Op& o = q.op; return o.kind == OpKind::Conv && o.kh == 1 && o.kw == 1 && o.sh == 1 && o.sw == 1 && !o.pt && !o.pl && !o.pb && !o.pr && o.groups == 1 &&
+                                                     o.act <= SM_ACT_PRELU && !q.stem && !o.grid_h && !o.x_ups && !q.has_pair && q.pool_out < 0 && !q.has_mb; };
+        if (!(mb_env && mb_env[0] == '0') && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency)
+            for (size_t t = 0; t < steps_.size(); t++) {
+                Step& e = steps_[t];
+                if (!pointwise(e) || e.op.residual >= 0 || readers(e.op.output) != 1) continue;
+                size_t ud = 0, up = 0;
+                for (size_t u = t + 1; u < steps_.size() && !ud; u++) if (!steps_[u].op.inputs.empty() && steps_[u].op.inputs[0] == e.op.output) ud = u;
+                if (!ud) continue;
+                const Op& dw = steps_[ud].op;
+                if (dw.kind != OpKind::Conv || dw.groups != dw.cin || dw.cin != dw.cout || dw.cin != e.op.cout || dw.kh != 3 || dw.kw != 3 || dw.dh != 1 || dw.dw != 1 || dw.sh != dw.sw ||
+                    (dw.sh != 1 && dw.sh != 2) || dw.pt != 1 || dw.pl != 1 || dw.residual >= 0 || dw.act > SM_ACT_PRELU || steps_[ud].has_pair || steps_[ud].pool_out >= 0 || readers(dw.output) != 1) continue;
+                for (size_t u = ud + 1; u < steps_.size() && !up; u++) if (!steps_[u].op.inputs.empty() && steps_[u].op.inputs[0] == dw.output) up = u;
+                if (!up || !pointwise(steps_[up])) continue;
+                const Op& pj = steps_[up].op;
+                if (pj.cin != dw.cout || (pj.residual >= 0 && pj.residual != e.op.inputs[0])) continue;
+                const Value& iv = values_[e.op.inputs[0]]; const Value& ov = values_[pj.output];
+                sm_mbconv_desc d{}; d.N = batch; d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.stride = dw.sh; d.Cin = e.op.cin; d.Ch = e.op.cout; d.Cout = pj.cout; d.expand = 1;
+                d.residual = pj.residual >= 0 ? 1 : 0; d.act1 = e.op.act; d.act2 = dw.act; d.act3 = pj.act;
+                if (d.Cin > 32 || d.Ch > 192 || d.Cout > 64 || !sm_mbconv_supported(&d)) continue;
+                e.has_mb = true; e.mb_dw = steps_[ud].op; e.mb_proj = steps_[up].op;
+                steps_.erase(steps_.begin() + up); steps_.erase(steps_.begin() + ud);
+            }
+    }
+
     // ---- 4. memory plan ------------------------------------------------------------------------------------
     const int ns = (int)steps_.size();
     std::vector<int> first(nv, INT32_MAX), last(nv, -1);   // per ROOT value: live step interval
@@ -394,6 +426,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         const int until = steps_[t].join >= 0 ? steps_[t].join : t;   // a side step may still be reading its operands at the join
         for (int u : op.inputs) { touch(u, t); touch(u, until); }
         if (op.residual >= 0) { touch(op.residual, t); touch(op.residual, until); }
+        if (steps_[t].has_mb) { touch(steps_[t].mb_proj.output, t); continue; }      // (the hidden tensors exist in LDS only; the residual is the step's own input)
         touch(op.output, t);
         if (steps_[t].has_pair) touch(steps_[t].pair.output, t);
         if (steps_[t].pool_out >= 0) touch(steps_[t].pool_out, t);
@@ -427,6 +460,19 @@ int Executor::plan(ONNXGraph& g, int batch) {
             st.w_off = off; off = alignUp(off + op.weight.size() * 2);
             st.has_bias = !op.bias.empty();
             if (st.has_bias) { st.b_off = off; off = alignUp(off + op.bias.size() * 4); }
+            if (st.has_mb) {
+                st.wd_off = off; off = alignUp(off + st.mb_dw.weight.size() * 2);
+                st.has_biasd = !st.mb_dw.bias.empty();
+                if (st.has_biasd) { st.bd_off = off; off = alignUp(off + st.mb_dw.bias.size() * 4); }
+                st.w2_off = off; off = alignUp(off + st.mb_proj.weight.size() * 2);
+                st.has_bias2 = !st.mb_proj.bias.empty();
+                if (st.has_bias2) { st.b2_off = off; off = alignUp(off + st.mb_proj.bias.size() * 4); }
+                // accounted as the three layers the graph holds (flops and algorithmic bytes do not depend on the fusion)
+                const Value& dv = values_[st.mb_dw.output]; const Value& pv = values_[st.mb_proj.output];
+                const double Md = (double)batch * dv.h * dv.w;
+                flops_ += 2.0 * Md * dv.c * 9.0 + 2.0 * Md * pv.c * (double)dv.c;
+                alg_bytes_ += 2.0 * ((double)st.M * op.cout + Md * dv.c + dv.c * 9.0) + 2.0 * (Md * dv.c + Md * pv.c * (st.mb_proj.residual >= 0 ? 2.0 : 1.0) + (double)pv.c * dv.c);
+            }
             if (st.has_pair) {
                 st.w2_off = off; off = alignUp(off + st.pair.weight.size() * 2);
                 st.has_bias2 = !st.pair.bias.empty();
@@ -460,12 +506,15 @@ int Executor::plan(ONNXGraph& g, int batch) {
         st.desc = buf;
         if (st.pool_out >= 0) { st.desc += " >> MaxPool 2x2/2 (same launch)"; alg_bytes_ += 2.0 * (double)(st.M / 4) * values_[st.pool_out].c; }
         if (st.has_pair) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.pair.name.c_str(), st.pair.cout, st.pair.cin, st.pair.act ? " +act" : ""); st.desc += buf; }
+        if (st.has_mb) { snprintf(buf, sizeof buf, " >> Conv %s k=3x3 s=%d g=%d%s >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.mb_dw.name.c_str(), st.mb_dw.sh, st.mb_dw.groups, st.mb_dw.act ? " +act" : "",
+                                  st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.residual >= 0 ? " +res" : "", st.mb_proj.act ? " +act" : ""); st.desc += buf; }
         if (st.join >= 0) st.desc += " side-stream";
     }
     arena_bytes_ = std::max(off, (size_t)kAlign);
     value_names_.resize(nv); for (int v = 0; v < nv; v++) value_names_[v] = values_[v].name;
     materialized_.clear(); materialized_.push_back(values_[input_value_].name);
     for (auto& st : steps_) {
+        if (st.has_mb) { materialized_.push_back(values_[st.mb_proj.output].name); continue; }
         if (st.op.kind != OpKind::Concat && materialized_.back() != values_[st.op.output].name) materialized_.push_back(values_[st.op.output].name);
         if (st.has_pair) materialized_.push_back(values_[st.pair.output].name);
         if (st.pool_out >= 0) materialized_.push_back(values_[st.pool_out].name);
@@ -490,6 +539,12 @@ int Executor::packWeights(std::vector<uint8_t>* host) const {
                 sm_float_to_half(op.weight.data(), dst, op.weight.size());   // fp16 cast, RNE (ONNX2MPS.py:27 numpy astype(float16))
             }
             if (st.has_bias) memcpy(host->data() + st.b_off, op.bias.data(), op.bias.size() * 4);
+            if (st.has_mb) {
+                sm_float_to_half(st.mb_dw.weight.data(), (uint16_t*)(host->data() + st.wd_off), st.mb_dw.weight.size());
+                if (st.has_biasd) memcpy(host->data() + st.bd_off, st.mb_dw.bias.data(), st.mb_dw.bias.size() * 4);
+                sm_float_to_half(st.mb_proj.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.mb_proj.weight.size());
+                if (st.has_bias2) memcpy(host->data() + st.b2_off, st.mb_proj.bias.data(), st.mb_proj.bias.size() * 4);
+            }
             if (st.has_pair) {
                 sm_float_to_half(st.pair.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.pair.weight.size());
                 if (st.has_bias2) memcpy(host->data() + st.b2_off, st.pair.bias.data(), st.pair.bias.size() * 4);
@@ -542,7 +597,8 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     const Value& ov = e->values_[e->output_value_];
     e->out_f32_count_ = std::max(sm_float_array_count(batch, ov.c, ov.h, ov.w), (size_t)batch * ov.c * ov.h * ov.w);
     SM_HIP_CHECK(hipMalloc((void**)&e->out_f32_, e->out_f32_count_ * 4));
-    for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit(); st.pair.weight.clear(); st.pair.weight.shrink_to_fit(); }   // host masters no longer needed
+    for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit(); st.pair.weight.clear(); st.pair.weight.shrink_to_fit();
+                                 st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
     if (e->cfg_.autotune) {   // with an external arena and upload == 0 the caller filled it before compiling
         hipStream_t s; SM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         rc = e->autotune(s);
@@ -560,6 +616,15 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
     sm_stream_t ss = (sm_stream_t)s;
     switch (op.kind) {
     case OpKind::Conv: case OpKind::FullyConnected: {
+        if (st.has_mb) {
+            const Value& iv = values_[op.inputs[0]]; const Value& pv = values_[st.mb_proj.output];
+            sm_mbconv_desc m{}; m.N = batch_; m.H = iv.h; m.W = iv.w; m.Ho = pv.h; m.Wo = pv.w; m.stride = st.mb_dw.sh; m.Cin = op.cin; m.Ch = op.cout; m.Cout = st.mb_proj.cout; m.expand = 1;
+            m.residual = st.mb_proj.residual >= 0 ? 1 : 0; m.act1 = op.act; m.slope1 = op.slope; m.act2 = st.mb_dw.act; m.slope2 = st.mb_dw.slope; m.act3 = st.mb_proj.act; m.slope3 = st.mb_proj.slope;
+            m.x_ld = valueLd(op.inputs[0]); m.y_ld = valueLd(st.mb_proj.output);
+            return sm_mbconv_fwd(&m, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, arena_ + st.wd_off,
+                                 st.has_biasd ? (const float*)(arena_ + st.bd_off) : nullptr, arena_ + st.w2_off, st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr,
+                                 valuePtr(st.mb_proj.output), ss);
+        }
         const sm_conv_desc d = convDesc(st);
         if (st.pool_out >= 0)
             return sm_conv2d_pool_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, y,
@@ -770,7 +835,7 @@ int Executor::autotune(hipStream_t s) {
     int rc = SM_OK;
     for (size_t i = 0; i < steps_.size() && !rc; i++) {
         Step& st = steps_[i];
-        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8) || st.has_pair) continue;
+        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8) || st.has_pair || st.has_mb) continue;
         if (st.op.kind != OpKind::ConvTranspose) { const sm_conv_desc cd = convDesc(st); if (!sm_conv2d_uses_tile_config(&cd)) continue; }   // dedicated kernel, nothing to tune
         // one config: `reps` timed launches after an untimed first one (code fetch); returns false if the config does not apply
         auto timeCfg = [&](int c, int reps, std::vector<float>& samples) -> bool {

@@ -39,6 +39,9 @@ struct Step {                // one op after fusion, with everything resolved
     // (sm_conv1x1_pair_fwd); both outputs are materialised
     int pool_out = -1;       // >= 0: value id of the 2x2 / stride-2 max-pool of this conv's output, written by the same launch (sm_conv2d_pool_fwd_cfg)
     bool has_pair = false; Op pair; size_t w2_off = 0, b2_off = 0; bool has_bias2 = false;
+    // inverted-residual block (executor.cpp pass 3c): this step is the 1x1 EXPAND; `mb_dw` (depthwise 3x3) and `mb_proj` (1x1 project, optional
+    // residual = this step's input) run in the same launch (sm_mbconv_fwd) and the two hidden tensors are never materialised
+    bool has_mb = false; Op mb_dw, mb_proj; size_t wd_off = 0, bd_off = 0; bool has_biasd = false;
     std::string desc;
 };
 

@@ -18,6 +18,13 @@
 
 #include "common.hpp"
 
+#ifdef SM_TIMELINE   // diagnostic build: clock64() spent per phase by thread 0 of block 0, summed over its tiles (sm_mbconv_debug_timeline)
+__device__ unsigned long long g_mb_tl[8];
+#define MB_TL(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now = clock64(); g_mb_tl[i] += now - mb_t0; mb_t0 = now; } } while (0)
+#else
+#define MB_TL(i)
+#endif
+
 namespace {
 
 struct MbParams {
@@ -33,6 +40,13 @@ struct MbParams {
 inline void fastdiv_make(unsigned d, unsigned* mul, unsigned* sh) { unsigned s = 0; while ((1ull << s) < d) s++; *mul = (unsigned)(((1ull << (31 + s)) / d) + 1); *sh = 31 + s; }
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned mul, unsigned sh) { return (unsigned)(((unsigned long long)n * mul) >> sh); }
 __device__ __forceinline__ float relu_family(float v, float sl) { return v < 0.f ? v * sl : v; }
+// Barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0): inside the tile loop that made every barrier wait for the
+// X-patch prefetch of the NEXT tile (a full HBM round trip) and for the previous tile's output stores.
+__device__ __forceinline__ void mb_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 
 // TH x TW output pixels per tile (TH*TW = 32 or 64); S = depthwise stride
 template <int TH, int TW, int S>
@@ -41,7 +55,10 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
     constexpr int MFA = (HP + 31) / 32, MFC = OP / 32;
     static_assert(OP % 32 == 0, "whole MFMA row blocks per tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
-    const int ChP = p.ChP, hs = p.hstride, KP1 = (p.Cin + 15) & ~15, CoP = (p.Cout + 31) & ~31;
+    // KP1: the expand GEMM's K = Cin + 2 rounded up to 16.  Columns Cin, Cin+1 of an X-patch row are 1 inside the image (0 outside) and meet
+    // hi(b1), lo(b1) = b1 split into two halfs in W1: the bias enters through the MFMA, a pixel outside the image comes out as exactly 0 (what the
+    // depthwise layer's zero padding of the HIDDEN tensor needs) and the epilogue has no bias add and no select.
+    const int ChP = p.ChP, hs = p.hstride, KP1 = (p.Cin + (p.expand ? 2 : 0) + 15) & ~15, CoP = (p.Cout + 31) & ~31;
     // LDS: X patch [2][MFA*32][KP1] (expand) | hidden patch [HP][hs] (x2 without expand: it IS the X patch) | hidden tile [OP][hs] |
     //      W1 [ChP][KP1] | Wd [9][ChP] | W2 [CoP][hs] | b1[ChP] bd[ChP] b2[CoP]
     // The X patch of tile t+1 is fetched (one 16-byte load per thread) at the START of tile t and written to LDS at its end: no global
@@ -61,7 +78,15 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
     // ---- weights -> LDS once per block, zero-padded (Ch -> ChP, Cin -> KP1, Cout -> CoP) so that padded lanes multiply zeros --------
-    if (p.expand) for (int i = tid; i < ChP * KP1; i += NT) { const int n = i / KP1, k = i - n * KP1; w1l[i] = (n < p.Ch && k < p.Cin) ? p.w1[(long)n * p.Cin + k] : (half_t)0.f; }
+    if (p.expand) for (int i = tid; i < ChP * KP1; i += NT) {
+        const int n = i / KP1, k = i - n * KP1;
+        half_t v = (half_t)0.f;
+        if (n < p.Ch) {
+            if (k < p.Cin) v = p.w1[(long)n * p.Cin + k];
+            else if (k < p.Cin + 2 && p.b1) { const float b = p.b1[n]; const half_t bh = (half_t)b; v = k == p.Cin ? bh : (half_t)(b - (float)bh); }
+        }
+        w1l[i] = v;
+    }
     for (int i = tid; i < 9 * ChP; i += NT) { const int t = i / ChP, c = i - t * ChP; wdl[i] = c < p.Ch ? p.wd[(long)c * 9 + t] : (half_t)0.f; }
     for (int i = tid; i < CoP * (hs / 2); i += NT) { const int n = i / (hs / 2), k = i - n * (hs / 2); ((half_t*)w2l)[i] = (n < p.Cout && k < p.Ch) ? p.w2[(long)n * p.Ch + k] : (half_t)0.f; }
     for (int i = tid; i < ChP; i += NT) { b1l[i] = (p.expand && p.b1 && i < p.Ch) ? p.b1[i] : 0.f; bdl[i] = (p.bd && i < p.Ch) ? p.bd[i] : 0.f; }
@@ -69,6 +94,7 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
     for (int i = tid; i < OP * (hs / 2); i += NT) ((half_t*)hid2)[i] = (half_t)0.f;      // (the pad channels / pad slot of the hidden tile stay zero for good)
     if (!p.expand) for (int i = tid; i < 2 * HIDB / 2; i += NT) ((half_t*)hid0)[i] = (half_t)0.f;   // (pad channels of the copied patch)
 
+    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;            // block-uniform: plain ReLU takes the packed-max path
     const int T = p.ntiles, G = gridDim.x;
     const int t_begin = (int)((long)blockIdx.x * T / G), t_end = (int)((long)(blockIdx.x + 1) * T / G);
     const int nfa = ChP >> 5, ks1 = KP1 >> 4, ks2 = ChP >> 4, nfc = CoP >> 5, cvn = p.Ch >> 3;
@@ -85,8 +111,10 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
         int n, oy0, ox0; tile_origin(t, n, oy0, ox0);
         const int iy = oy0 * S - 1 + xs_py, ix = ox0 * S - 1 + xs_px;
         half8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (xs_mine && xs_pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && xs_c * 8 < p.Cin)
-            v = *(const half8_t*)(p.x + (((long)n * p.H + iy) * p.W + ix) * p.x_ld + xs_c * 8);
+        if (xs_mine && xs_pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+            if (xs_c * 8 < p.Cin) v = *(const half8_t*)(p.x + (((long)n * p.H + iy) * p.W + ix) * p.x_ld + xs_c * 8);
+            else if (p.expand && xs_c * 8 == p.Cin) { v[0] = (half_t)1.f; v[1] = (half_t)1.f; }        // the two bias columns
+        }
         return v;
     };
     auto store_patch = [&](int buf, half8_t v) {
@@ -98,11 +126,14 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
     if (t_begin < t_end) store_patch(0, fetch_patch(t_begin));
     __syncthreads();
 
+#ifdef SM_TIMELINE
+    unsigned long long mb_t0 = clock64();
+#endif
 #pragma unroll 1
     for (int t = t_begin; t < t_end; t++) {
+        MB_TL(0);
         const int buf = (t - t_begin) & 1;
         int n, oy0, ox0; tile_origin(t, n, oy0, ox0);
-        const int iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
         half8_t xnext = {0, 0, 0, 0, 0, 0, 0, 0};
         if (t + 1 < t_end) xnext = fetch_patch(t + 1);               // in flight for the whole tile
         const unsigned char* const xp_l = xpl + buf * XPB;
@@ -112,47 +143,46 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
         for (int item = wave; item < (p.expand ? MFA * nfa : 0); item += NW) {
             const int mf = item / nfa, nf = item - mf * nfa;
             const int pp = mf * 32 + l31;
-            const int py = (int)fastdiv((unsigned)pp, p.pw_mul, p.pw_sh), px = pp - py * PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            const bool inimg = pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             floatx16 acc;
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[i] = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 2; ks++)
+            for (int ks = 0; ks < 3; ks++)
                 if (ks < ks1) {
                     const int k = ks * 16 + hi * 8;
                     const half8_t fx = *(const half8_t*)(xp_l + (pp * KP1 + k) * 2);     // (zero outside the image and beyond Cin)
                     const half8_t fw = *(const half8_t*)(w1l + (nf * 32 + l31) * KP1 + k);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw, fx, acc, 0, 0, 0);
                 }
-            // register 4q+r <-> hidden channel nf*32 + 8q + 4*hi + r of patch pixel pp; pixels outside the image must be ZERO
-            floatx4 bq[4];
+            // register 4q+r <-> hidden channel nf*32 + 8q + 4*hi + r of patch pixel pp (bias included, exactly 0 outside the image): round to
+            // fp16, activation on the packed halfs (ReLU: v_pk_max_f16 — max commutes with the rounding), four 8-byte LDS stores
 #pragma unroll
-            for (int q = 0; q < 4; q++) bq[q] = *(const floatx4*)(b1l + nf * 32 + 8 * q + 4 * hi);
+            for (int q = 0; q < 4; q++) {
+                half4_t o;
+                if (relu1) {
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                float o[8];
+                    for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[4 * q + r2];
+                    o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                } else {
 #pragma unroll
-                for (int r2 = 0; r2 < 4; r2++) {
-                    unsigned ua = __builtin_bit_cast(unsigned, acc[4 * (2 * j) + r2] + bq[2 * j][r2]), ub = __builtin_bit_cast(unsigned, acc[4 * (2 * j + 1) + r2] + bq[2 * j + 1][r2]);
-                    sm_permlane32_swap(ua, ub);
-                    o[r2] = __builtin_bit_cast(float, ua); o[4 + r2] = __builtin_bit_cast(float, ub);
+                    for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[4 * q + r2], p.sl1);
                 }
-                half8_t ov;
-#pragma unroll
-                for (int r2 = 0; r2 < 8; r2++) ov[r2] = inimg ? (half_t)relu_family(o[r2], p.sl1) : (half_t)0.f;
-                *(half8_t*)(hid + pp * hs + (nf * 4 + 2 * j + hi) * 16) = ov;
+                *(half4_t*)(hid + pp * hs + (nf * 32 + 8 * q + 4 * hi) * 2) = o;
             }
         }
-        __syncthreads();
+        MB_TL(1);
+        mb_lds_barrier();
+        MB_TL(2);
 
         // ---- phase B: depthwise 3x3, one thread = one output pixel x 8 channels --------------------------------------------------
         for (int it = tid; it < OP * cvn; it += NT) {
             const int op = it / cvn, cv = it - op * cvn, oy = op / TW, ox = op - oy * TW;
             float a[8];
+            {
+                const floatx4 b0 = *(const floatx4*)(bdl + cv * 8), b1v = *(const floatx4*)(bdl + cv * 8 + 4);
 #pragma unroll
-            for (int j = 0; j < 8; j++) a[j] = bdl[cv * 8 + j];
+                for (int j = 0; j < 4; j++) { a[j] = b0[j]; a[4 + j] = b1v[j]; }
+            }
 #pragma unroll
             for (int kh = 0; kh < 3; kh++)
 #pragma unroll
@@ -169,11 +199,19 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
                     }
                 }
             half8_t ov;
+            if (relu2) {
 #pragma unroll
-            for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+                for (int j = 0; j < 8; j++) ov[j] = (half_t)a[j];
+                ov = __builtin_elementwise_max(ov, half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+            }
             *(half8_t*)(hid2 + op * hs + cv * 16) = ov;
         }
-        __syncthreads();
+        MB_TL(3);
+        mb_lds_barrier();
+        MB_TL(4);
 
         // ---- phase C: project.  (row block, cout block) pairs over the waves ------------------------------------------------------
         for (int item = wave; item < MFC * nfc; item += NW) {
@@ -214,7 +252,191 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
             }
         }
         if (t + 1 < t_end) store_patch(buf ^ 1, xnext);              // the other buffer: nobody reads it during this tile
-        __syncthreads();                                              // next tile's patch visible; this tile's reads of the hidden tile are over
+        MB_TL(5);
+        mb_lds_barrier();                                              // next tile's patch visible; this tile's reads of the hidden tile are over
+        MB_TL(6);
+    }
+}
+
+
+// ---- v2: the same block CHUNKED over the hidden channels, in 4-wave blocks ------------------------------------------------------------------
+// The v1 kernel above keeps the whole hidden patch (all Ch channels) and every weight in LDS: 60..105 KB, i.e. one or two 16-wave blocks per
+// CU, and a tile is a dependent chain (patch -> MFMA -> LDS -> barrier -> FMA -> LDS -> barrier -> MFMA -> store) that those one or two blocks
+// cannot hide: 14 k clk per tile for ~2.5 k clk of work.  Here the hidden tensor exists 32 channels at a time:
+//     for each chunk c:  hidden[patch][32] = act1(Xpatch * W1[c]^T + b1[c])    (MFMA; X patch in LDS for the whole tile)
+//                        dw[tile][32]      = act2(depthwise3x3(hidden) + bd[c]) (one thread = 8 channels of one output pixel)
+//                        acc[tile][Cout]  += dw * W2[:, c]^T                    (MFMA; accumulators live across the chunks)
+// so a block needs ~20..27 KB of LDS whatever Ch is, 6..7 blocks share a CU and hide each other's chains, weights are read as MFMA
+// fragments straight from global memory (L2-resident, a few KB per block), and Ch is unbounded.  Numerics as v1: hidden and depthwise
+// outputs rounded to fp16 once; the projection sums k in ascending order (chunks in order, k inside a chunk ascending) in fp32.
+template <int TH, int TW, int S>
+__global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
+    constexpr int NT = 256, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, HP = PH * PW, OP = TH * TW;
+    constexpr int MFA = (HP + 31) / 32, MFC = OP / 32, HS = 80;          // HS: bytes per pixel of a 32-channel chunk (+16: conflict-free 8/16-byte columns)
+    static_assert(OP % 32 == 0 && MFC <= 4, "whole MFMA row blocks per tile, one (row block, cout block) pair per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
+    const int ChP = p.ChP, KP1 = (p.Cin + 15) & ~15, NC = ChP >> 5, ks1 = KP1 >> 4, nfc = (p.Cout + 31) >> 5;
+    unsigned char* const xpl = mb_smem;                                  // X patch [MFA*32][KP1] halfs (expand only)
+    unsigned char* const hid = xpl + (p.expand ? MFA * 32 * KP1 * 2 : 0);// hidden chunk [MFA*32][HS]
+    unsigned char* const dwo = hid + MFA * 32 * HS;                      // depthwise output chunk [OP][HS]
+    half_t* const wdl = (half_t*)(dwo + OP * HS);                        // depthwise weights [9][ChP]
+
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 9 * ChP; i += NT) { const int t = i / ChP, c = i - t * ChP; wdl[i] = c < p.Ch ? p.wd[(long)c * 9 + t] : (half_t)0.f; }
+
+    const int T = p.ntiles, G = gridDim.x;
+    const int t_begin = (int)((long)blockIdx.x * T / G), t_end = (int)((long)(blockIdx.x + 1) * T / G);
+    // projection: wave -> (row block mf, cout block nf)
+    const int c_mf = wave % MFC, c_nf = wave / MFC;
+    const bool c_mine = c_nf < nfc;
+    const half8_t hz = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef SM_TIMELINE
+    unsigned long long mb_t0 = clock64();
+#endif
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; t++) {
+        const int n = (int)fastdiv((unsigned)t, p.txy_mul, p.txy_sh);
+        const int r = t - n * (p.tiles_x * p.tiles_y), by = (int)fastdiv((unsigned)r, p.tx_mul, p.tx_sh);
+        const int oy0 = by * TH, ox0 = (r - by * p.tiles_x) * TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+        const half_t* const xim = p.x + (long)n * p.H * p.W * p.x_ld;
+        mb_lds_barrier();                                                // the previous tile's last readers of xpl / dwo are done (first tile: wdl is written)
+        if (p.expand) {
+            // X patch -> LDS, zero outside the image and beyond Cin
+            const int xchunks = KP1 >> 3;
+            for (int sl = tid; sl < MFA * 32 * xchunks; sl += NT) {
+                const int pp = sl / xchunks, c8 = sl - pp * xchunks, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px;
+                half8_t v = hz;
+                if (pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && c8 * 8 < p.Cin) v = *(const half8_t*)(xim + ((long)iy * p.W + ix) * p.x_ld + c8 * 8);
+                *(half8_t*)(xpl + (pp * KP1 + c8 * 8) * 2) = v;
+            }
+        }
+        floatx16 acc2;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc2[i] = 0.f;
+        MB_TL(0);
+#pragma unroll 1
+        for (int c = 0; c < NC; c++) {
+            // projection weights of this chunk: requested now, used after two barriers
+            half8_t fw2[2] = {hz, hz};
+            if (c_mine) {
+                const int co = c_nf * 32 + l31;
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) { const int k = c * 32 + ks * 16 + hi * 8; if (co < p.Cout && k < p.Ch) fw2[ks] = *(const half8_t*)(p.w2 + (long)co * p.Ch + k); }
+            }
+            if (p.expand) {
+                if (c == 0) mb_lds_barrier();                            // X patch complete
+                // ---- phase A: hidden chunk = act1(X patch * W1[c]^T + b1[c]); patch row blocks over the waves ----------------------------------
+                const int hch = c * 32 + l31;
+                half8_t fw1[4] = {hz, hz, hz, hz};
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) { const int k = ks * 16 + hi * 8; if (ks < ks1 && hch < p.Ch && k < p.Cin) fw1[ks] = *(const half8_t*)(p.w1 + (long)hch * p.Cin + k); }
+                floatx4 bq[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int ch = c * 32 + 8 * q + 4 * hi; bq[q] = (p.b1 && ch < p.Ch) ? *(const floatx4*)(p.b1 + ch) : floatx4{0.f, 0.f, 0.f, 0.f}; }
+                for (int mf = wave; mf < MFA; mf += 4) {
+                    const int pp = mf * 32 + l31, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px;
+                    const bool inimg = pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                    floatx16 acc;
+#pragma unroll
+                    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ks++)
+                        if (ks < ks1) {
+                            const half8_t fx = *(const half8_t*)(xpl + (pp * KP1 + ks * 16 + hi * 8) * 2);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1[ks], fx, acc, 0, 0, 0);
+                        }
+                    // register 4q+r <-> hidden channel 8q + 4hi + r of the chunk, patch pixel pp; pixels outside the image are ZERO (the depthwise layer pads the hidden tensor)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        half4_t o;
+#pragma unroll
+                        for (int r2 = 0; r2 < 4; r2++) o[r2] = inimg ? (half_t)relu_family(acc[4 * q + r2] + bq[q][r2], p.sl1) : (half_t)0.f;
+                        *(half4_t*)(hid + pp * HS + (8 * q + 4 * hi) * 2) = o;
+                    }
+                }
+            } else {
+                // no expand layer: the hidden chunk IS channels c*32 .. +31 of the X patch
+                for (int sl = tid; sl < MFA * 32 * 4; sl += NT) {
+                    const int pp = sl >> 2, c8 = sl & 3, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px, ch = c * 32 + c8 * 8;
+                    half8_t v = hz;
+                    if (pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Ch) v = *(const half8_t*)(xim + ((long)iy * p.W + ix) * p.x_ld + ch);
+                    *(half8_t*)(hid + pp * HS + c8 * 16) = v;
+                }
+            }
+            MB_TL(1);
+            mb_lds_barrier();
+            MB_TL(2);
+            // ---- phase B: depthwise 3x3 on the chunk, one thread = one output pixel x 8 channels ----------------------------------------------
+            for (int it = tid; it < OP * 4; it += NT) {
+                const int op = it >> 2, cv = it & 3, oy = op / TW, ox = op - oy * TW, ch = c * 32 + cv * 8;
+                float a[8];
+                {
+                    const bool hb = p.bd && ch < p.Ch;
+                    const floatx4 b0 = hb ? *(const floatx4*)(p.bd + ch) : floatx4{0.f, 0.f, 0.f, 0.f}, b1v = hb ? *(const floatx4*)(p.bd + ch + 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { a[j] = b0[j]; a[4 + j] = b1v[j]; }
+                }
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                    for (int kw = 0; kw < 3; kw++) {
+                        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                        const u32x4 xu = *(const u32x4*)(hid + ((oy * S + kh) * PW + ox * S + kw) * HS + cv * 16);
+                        const u32x4 wu = *(const u32x4*)(wdl + (kh * 3 + kw) * ChP + ch);
+#pragma unroll
+                        for (int d2 = 0; d2 < 4; d2++) {
+                            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2]) : "v"(xu[d2]), "v"(wu[d2]));
+                            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2 + 1]) : "v"(xu[d2]), "v"(wu[d2]));
+                        }
+                    }
+                half8_t ov;
+#pragma unroll
+                for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+                *(half8_t*)(dwo + op * HS + cv * 16) = ov;
+            }
+            MB_TL(3);
+            mb_lds_barrier();
+            MB_TL(4);
+            // ---- phase C: acc2 += dw chunk * W2[:, chunk]^T ---------------------------------------------------------------------------
+            if (c_mine) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ks++) {
+                    const half8_t fy = *(const half8_t*)(dwo + (c_mf * 32 + l31) * HS + (ks * 2 + hi) * 16);
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw2[ks], fy, acc2, 0, 0, 0);
+                }
+            }
+            MB_TL(5);
+        }
+        // ---- epilogue: + b2 (+ X), act3, 16-byte stores ------------------------------------------------------------------------------
+        if (c_mine) {
+            const int op = c_mf * 32 + l31, oy = oy0 + op / TW, ox = ox0 + op % TW;
+            const bool pin = oy < p.Ho && ox < p.Wo;
+            const long opix = ((long)n * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                float o[8];
+#pragma unroll
+                for (int r2 = 0; r2 < 4; r2++) {
+                    const int ca = c_nf * 32 + 8 * (2 * j) + 4 * hi + r2, cb = ca + 8;
+                    unsigned ua = __builtin_bit_cast(unsigned, acc2[4 * (2 * j) + r2] + ((p.b2 && ca < p.Cout) ? p.b2[ca] : 0.f));
+                    unsigned ub = __builtin_bit_cast(unsigned, acc2[4 * (2 * j + 1) + r2] + ((p.b2 && cb < p.Cout) ? p.b2[cb] : 0.f));
+                    sm_permlane32_swap(ua, ub);
+                    o[r2] = __builtin_bit_cast(float, ua); o[4 + r2] = __builtin_bit_cast(float, ub);
+                }
+                const int co = c_nf * 32 + 16 * j + 8 * hi;
+                if (pin && co < p.Cout) {
+                    if (p.res) { const half8_t rv = *(const half8_t*)(xpl + (((op / TW + 1) * PW + op % TW + 1) * KP1 + co) * 2);   // the block input at the same pixel: the patch centre
+#pragma unroll
+                        for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
+                    half8_t ov;
+#pragma unroll
+                    for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                    *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
+                }
+            }
+        }
+        MB_TL(6);
     }
 }
 
@@ -222,24 +444,51 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
 
 extern "C" {
 
-size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d) {
-    if (!d) return 0;
-    const int ChP = (d->Ch + 31) & ~31, hs = ChP * 2 + 16, KP1 = (d->Cin + 15) & ~15, CoP = (d->Cout + 31) & ~31;
+#ifdef SM_TIMELINE
+int sm_mbconv_debug_timeline(unsigned long long* out8, int reset) {
+    static unsigned long long z[8];
+    if (reset) { SM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_mb_tl), z, sizeof z)); return SM_OK; }
+    SM_HIP_CHECK(hipDeviceSynchronize());
+    SM_HIP_CHECK(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_mb_tl), 8 * sizeof(unsigned long long)));
+    return SM_OK;
+}
+#endif
+
+static size_t mb_v1_lds(const sm_mbconv_desc* d) {
+    const int ChP = (d->Ch + 31) & ~31, hs = ChP * 2 + 16, KP1 = (d->Cin + (d->expand ? 2 : 0) + 15) & ~15, CoP = (d->Cout + 31) & ~31;
     const int TH = d->stride == 1 ? 8 : 4, TW = 8, PH = (TH - 1) * d->stride + 3, PW = (TW - 1) * d->stride + 3, MFA = (PH * PW + 31) / 32;
     return (size_t)(d->expand ? 2 * MFA * 32 * KP1 * 2 + MFA * 32 * hs : 2 * MFA * 32 * hs) + (size_t)TH * TW * hs + (size_t)ChP * KP1 * 2 + (size_t)9 * ChP * 2 + (size_t)CoP * hs +
            (size_t)(2 * ChP + CoP) * 4;
 }
-
-int sm_mbconv_supported(const sm_mbconv_desc* d) {
-    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0) return 0;
-    if (d->stride != 1 && d->stride != 2) return 0;
-    if ((d->Cin & 7) || d->Cin > 32 || (d->Ch & 7) || d->Ch > 192 || (d->Cout & 7) || d->Cout > 64) return 0;
-    if (!d->expand && d->Ch != d->Cin) return 0;
-    if (d->residual && (d->stride != 1 || d->Cin != d->Cout)) return 0;
-    if (d->act1 > SM_ACT_PRELU || d->act2 > SM_ACT_PRELU || d->act3 > SM_ACT_PRELU) return 0;
-    if (d->Ho != (d->H + 2 - 3) / d->stride + 1 || d->Wo != (d->W + 2 - 3) / d->stride + 1) return 0;
-    return sm_mbconv_lds_bytes(d) <= 160 * 1024;
+static size_t mb_v2_lds(const sm_mbconv_desc* d) {
+    const int ChP = (d->Ch + 31) & ~31, KP1 = (d->Cin + 15) & ~15;
+    const int TH = d->stride == 1 ? 8 : 4, TW = 8, PH = (TH - 1) * d->stride + 3, PW = (TW - 1) * d->stride + 3, MFA = (PH * PW + 31) / 32;
+    return (size_t)(d->expand ? MFA * 32 * KP1 * 2 : 0) + (size_t)MFA * 32 * 80 + (size_t)TH * TW * 80 + (size_t)9 * ChP * 2;
 }
+static bool mb_common_ok(const sm_mbconv_desc* d) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0) return false;
+    if (d->stride != 1 && d->stride != 2) return false;
+    if ((d->Cin & 7) || (d->Ch & 7) || (d->Cout & 7) || d->Cin <= 0 || d->Ch <= 0 || d->Cout <= 0) return false;
+    if (!d->expand && d->Ch != d->Cin) return false;
+    if (d->residual && (d->stride != 1 || d->Cin != d->Cout)) return false;
+    if (d->act1 > SM_ACT_PRELU || d->act2 > SM_ACT_PRELU || d->act3 > SM_ACT_PRELU) return false;
+    return d->Ho == (d->H + 2 - 3) / d->stride + 1 && d->Wo == (d->W + 2 - 3) / d->stride + 1;
+}
+static bool mb_v1_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && d->Cin <= 32 && d->Ch <= 192 && d->Cout <= 64 && mb_v1_lds(d) <= 160 * 1024; }
+// v2 (chunked): any Ch; Cin <= 64 when there is an expand layer (X patch in LDS, <= 4 k steps); Cout <= 64 (stride 1) / 128 (stride 2): one
+// (row block, cout block) pair per wave; the residual is read from the X patch, i.e. needs the expand form
+static bool mb_v2_ok(const sm_mbconv_desc* d) {
+    return mb_common_ok(d) && (!d->expand || d->Cin <= 64) && d->Cout <= (d->stride == 1 ? 64 : 128) && (!d->residual || d->expand) && d->Ch <= 4096 && mb_v2_lds(d) <= 64 * 1024;
+}
+// v1 (everything in LDS) wherever it applies — it is the faster of the two today; the chunked v2 takes the shapes beyond it (SMELTER_MBCONV_V2=1: everywhere it can)
+static bool mb_use_v1(const sm_mbconv_desc* d) { static const bool force2 = getenv("SMELTER_MBCONV_V2") != nullptr; return mb_v1_ok(d) && !(force2 && mb_v2_ok(d)); }
+
+size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d) {
+    if (!d) return 0;
+    return mb_use_v1(d) ? mb_v1_lds(d) : mb_v2_lds(d);
+}
+
+int sm_mbconv_supported(const sm_mbconv_desc* d) { return (mb_v1_ok(d) || mb_v2_ok(d)) ? 1 : 0; }
 
 int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const float* b1, const void* wd, const float* bd, const void* w2, const float* b2, void* y,
                   sm_stream_t stream) {
@@ -262,6 +511,14 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
     p.ntiles = (int)nt;
     fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh); fastdiv_make((unsigned)PW, &p.pw_mul, &p.pw_sh);
     const size_t lds = sm_mbconv_lds_bytes(d);
+    if (!mb_use_v1(d)) {                                             // v2: 4-wave blocks, as many per CU as the LDS holds (<= 8)
+        SM_REQUIRE(((((uintptr_t)b1) | ((uintptr_t)bd) | ((uintptr_t)b2) | ((uintptr_t)w1) | ((uintptr_t)w2)) & 15) == 0, "sm_mbconv_fwd: weights and biases must be 16-byte aligned");
+        const int per_cu2 = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));
+        const int grid2 = (int)std::min<long>(nt, (long)SM_NUM_CU * per_cu2);
+        if (d->stride == 1) hipLaunchKernelGGL((mbconv2_kernel<8, 8, 1>), dim3(grid2), dim3(256), lds, sm_s(stream), p);
+        else hipLaunchKernelGGL((mbconv2_kernel<4, 8, 2>), dim3(grid2), dim3(256), lds, sm_s(stream), p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(3, (size_t)(160 * 1024) / lds));
     const int grid = (int)std::min<long>(nt, (long)SM_NUM_CU * std::min(per_cu, 2));      // 16-wave blocks: at most two per CU
     if (d->stride == 1) hipLaunchKernelGGL((mbconv_kernel<8, 8, 1>), dim3(grid), dim3(1024), lds, sm_s(stream), p);
