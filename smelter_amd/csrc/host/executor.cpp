@@ -514,7 +514,9 @@ int Executor::plan(ONNXGraph& g, int batch) {
     value_names_.resize(nv); for (int v = 0; v < nv; v++) value_names_[v] = values_[v].name;
     materialized_.clear(); materialized_.push_back(values_[input_value_].name);
     for (auto& st : steps_) {
-        if (st.has_mb) { materialized_.push_back(values_[st.mb_proj.output].name); continue; }
+        if (st.has_mb) {   // (the two hidden tensors live in LDS only, but are rounded to fp16 there exactly as a stored tensor would be: listed for the parity oracle)
+            materialized_.push_back(values_[st.op.output].name); materialized_.push_back(values_[st.mb_dw.output].name); materialized_.push_back(values_[st.mb_proj.output].name); continue;
+        }
         if (st.op.kind != OpKind::Concat && materialized_.back() != values_[st.op.output].name) materialized_.push_back(values_[st.op.output].name);
         if (st.has_pair) materialized_.push_back(values_[st.pair.output].name);
         if (st.pool_out >= 0) materialized_.push_back(values_[st.pool_out].name);
