@@ -440,6 +440,194 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
     }
 }
 
+
+// ---- v3: every WAVE is its own pipeline -----------------------------------------------------------------------------------------------
+// PMC and timeline of v1 after its VALU diet: the tile is a chain of short dependent phases separated by block-wide barriers, and the one
+// or two 16-wave blocks a CU holds cannot hide it (≈13 k clk per tile for ≈2 k clk of issue).  Here nothing in the tile loop is shared
+// between waves: a wave owns a 4x8 output tile, the hidden patch chunk (32 channels) and the depthwise output chunk live in LDS regions
+// private to the wave, so the phases need no barrier at all (LDS operations of one wave execute in order) and the 8 waves of a CU are 8
+// independent chains for the scheduler to interleave.  Block-shared and read-only after the prologue: W1 (+ the two bias columns), Wd,
+// W2, bd, b2.  The X patch never touches LDS: its MFMA B fragments (patch pixel = lane, 16 bytes of channels) are loaded straight from
+// global memory once per tile and stay in registers for all chunks; the bias columns (1, 1 inside the image) are made in registers.
+// Hidden channels are processed 32 at a time with the projection accumulating across chunks, so Ch is limited only by the weights' LDS.
+// KS1 = k steps of the expand GEMM (K = Cin + 2 rounded up to 16), NW = waves per block (they share only the weights), WREG = depthwise
+// weights of the lane's channel vector in registers for the chunk (36 registers: only where the occupancy survives it)
+template <int S, int KS1, int NW, bool WREG>
+__global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
+    constexpr int TH = 4, TW = 8, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, HP = PH * PW, MFA = (HP + 31) / 32, HS = 80, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
+    constexpr int KP1 = KS1 * 16;
+    const int ChP = p.ChP, NC = ChP >> 5, nfc = (p.Cout + 31) >> 5, CoP = nfc * 32, hs2 = ChP * 2 + 16;
+    half_t* const w1l = (half_t*)mb_smem;                                // [ChP][KP1]
+    half_t* const wdl = w1l + ChP * KP1;                                 // [9][ChP]
+    unsigned char* const w2l = (unsigned char*)(wdl + 9 * ChP);          // [CoP] rows of hs2 bytes
+    float* const bdl = (float*)(w2l + CoP * hs2);                        // [ChP]
+    float* const b2l = bdl + ChP;                                        // [CoP]
+    unsigned char* const wave_base = (unsigned char*)(b2l + CoP);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* const hid = wave_base + wave * ((MFA * 32 + 32) * HS);// hidden chunk [MFA*32][HS] | depthwise output chunk [32][HS]
+    unsigned char* const dwo = hid + MFA * 32 * HS;
+
+    for (int i = tid; i < ChP * KP1; i += NT) {
+        const int n = i / KP1, k = i - n * KP1;
+        half_t v = (half_t)0.f;
+        if (n < p.Ch) {
+            if (k < p.Cin) v = p.w1[(long)n * p.Cin + k];
+            else if (k < p.Cin + 2 && p.b1) { const float b = p.b1[n]; const half_t bh = (half_t)b; v = k == p.Cin ? bh : (half_t)(b - (float)bh); }
+        }
+        w1l[i] = v;
+    }
+    for (int i = tid; i < 9 * ChP; i += NT) { const int t = i / ChP, c = i - t * ChP; wdl[i] = c < p.Ch ? p.wd[(long)c * 9 + t] : (half_t)0.f; }
+    for (int i = tid; i < CoP * (hs2 / 2); i += NT) { const int n = i / (hs2 / 2), k = i - n * (hs2 / 2); ((half_t*)w2l)[i] = (n < p.Cout && k < p.Ch) ? p.w2[(long)n * p.Ch + k] : (half_t)0.f; }
+    for (int i = tid; i < ChP; i += NT) bdl[i] = (p.bd && i < p.Ch) ? p.bd[i] : 0.f;
+    for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
+    __syncthreads();                                                     // the only barrier of the kernel
+
+    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;
+    const long T = p.ntiles, GW = (long)gridDim.x * NW, gw = (long)blockIdx.x * NW + wave;
+    const int t_begin = (int)(gw * T / GW), t_end = (int)((gw + 1) * T / GW);
+    const half8_t hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    half8_t ones = hz; ones[0] = (half_t)1.f; ones[1] = (half_t)1.f;
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; t++) {
+        const int n = (int)fastdiv((unsigned)t, p.txy_mul, p.txy_sh);
+        const int r = t - n * (p.tiles_x * p.tiles_y), by = (int)fastdiv((unsigned)r, p.tx_mul, p.tx_sh);
+        const int oy0 = by * TH, ox0 = (r - by * p.tiles_x) * TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+        const half_t* const xim = p.x + (long)n * p.H * p.W * p.x_ld;
+        // ---- X fragments of the whole patch: [row block][k step], 16 bytes per lane, kept for all chunks ------------------------------
+        half8_t fx[MFA][KS1];
+#pragma unroll
+        for (int mf = 0; mf < MFA; mf++) {
+            const int pp = mf * 32 + l31, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px;
+            const bool inimg = pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const half_t* src = xim + ((long)iy * p.W + ix) * p.x_ld;
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) {
+                const int k = ks * 16 + hi * 8;
+                half8_t v = hz;
+                if (inimg) { if (k < p.Cin) v = *(const half8_t*)(src + k); else if (k == p.Cin) v = ones; }
+                fx[mf][ks] = v;
+            }
+        }
+        floatx16 acc2[2];
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc2[a][i] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < NC; c++) {
+            // ---- phase A: hidden chunk = act1(W1[c] (incl. bias columns) x patch) -> wave-private LDS ------------------------------------
+            half8_t fw1[KS1];
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) fw1[ks] = *(const half8_t*)(w1l + (c * 32 + l31) * KP1 + ks * 16 + hi * 8);
+#pragma unroll
+            for (int mf = 0; mf < MFA; mf++) {
+                floatx16 acc;
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1[ks], fx[mf][ks], acc, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    half4_t o;
+                    if (relu1) {
+#pragma unroll
+                        for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[4 * q + r2];
+                        o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                    } else {
+#pragma unroll
+                        for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[4 * q + r2], p.sl1);
+                    }
+                    *(half4_t*)(hid + (mf * 32 + l31) * HS + (8 * q + 4 * hi) * 2) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (one wave: its LDS operations execute in order; this orders the compiler)
+            // ---- phase B: depthwise 3x3 on the chunk: 32 pixels x 4 channel vectors = two items per lane ----------------------------------
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            u32x4 wreg[WREG ? 9 : 1];                                    // a lane keeps its channel vector (lane & 3) for both items: nine taps in registers
+            floatx4 bd0, bd1;
+            const int chl = c * 32 + (lane & 3) * 8;
+            if (WREG) {
+#pragma unroll
+                for (int tp = 0; tp < 9; tp++) wreg[WREG ? tp : 0] = *(const u32x4*)(wdl + tp * ChP + chl);
+            }
+            bd0 = *(const floatx4*)(bdl + chl); bd1 = *(const floatx4*)(bdl + chl + 4);
+#pragma unroll
+            for (int i2 = 0; i2 < 2; i2++) {
+                const int it = lane + 64 * i2, op = it >> 2, cv = it & 3, oy = op / TW, ox = op - oy * TW;
+                float a[8];
+#pragma unroll
+                for (int j = 0; j < 4; j++) { a[j] = bd0[j]; a[4 + j] = bd1[j]; }
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                    for (int kw = 0; kw < 3; kw++) {
+                        const u32x4 xu = *(const u32x4*)(hid + ((oy * S + kh) * PW + ox * S + kw) * HS + cv * 16);
+                        const u32x4 wu = WREG ? wreg[WREG ? kh * 3 + kw : 0] : *(const u32x4*)(wdl + (kh * 3 + kw) * ChP + chl);
+#pragma unroll
+                        for (int d2 = 0; d2 < 4; d2++) {
+                            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2]) : "v"(xu[d2]), "v"(wu[d2]));
+                            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2 + 1]) : "v"(xu[d2]), "v"(wu[d2]));
+                        }
+                    }
+                half8_t ov;
+                if (relu2) {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) ov[j] = (half_t)a[j];
+                    ov = __builtin_elementwise_max(ov, hz);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+                }
+                *(half8_t*)(dwo + op * HS + cv * 16) = ov;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            // ---- phase C: acc2 += W2[:, chunk] x depthwise chunk ---------------------------------------------------------------------
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const half8_t fy = *(const half8_t*)(dwo + l31 * HS + (ks * 2 + hi) * 16);
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+                    if (a < nfc) {
+                        const half8_t fw2 = *(const half8_t*)(w2l + (a * 32 + l31) * hs2 + (c * 32 + ks * 16 + hi * 8) * 2);
+                        acc2[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw2, fy, acc2[a], 0, 0, 0);
+                    }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the chunk's readers are done before the next chunk overwrites hid / dwo
+        }
+        // ---- epilogue: + b2 (+ X), act3, 16-byte stores; lane = output pixel l31 of the tile ------------------------------------------
+        const int oy = oy0 + l31 / TW, ox = ox0 + l31 % TW;
+        const bool pin = oy < p.Ho && ox < p.Wo;
+        const long opix = ((long)n * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+        for (int a = 0; a < 2; a++)
+            if (a < nfc) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    float o[8];
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; r2++) {
+                        unsigned ua = __builtin_bit_cast(unsigned, acc2[a][4 * (2 * j) + r2] + b2l[a * 32 + 8 * (2 * j) + 4 * hi + r2]);
+                        unsigned ub = __builtin_bit_cast(unsigned, acc2[a][4 * (2 * j + 1) + r2] + b2l[a * 32 + 8 * (2 * j + 1) + 4 * hi + r2]);
+                        sm_permlane32_swap(ua, ub);
+                        o[r2] = __builtin_bit_cast(float, ua); o[4 + r2] = __builtin_bit_cast(float, ub);
+                    }
+                    const int co = a * 32 + 16 * j + 8 * hi;
+                    if (pin && co < p.Cout) {
+                        if (p.res) { const half8_t rv = *(const half8_t*)(xim + ((long)oy * p.W + ox) * p.x_ld + co);   // stride 1, Cin == Cout: the block input at the same pixel
+#pragma unroll
+                            for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
+                        half8_t ov;
+#pragma unroll
+                        for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                        *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
+                    }
+                }
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -465,6 +653,17 @@ static size_t mb_v2_lds(const sm_mbconv_desc* d) {
     const int TH = d->stride == 1 ? 8 : 4, TW = 8, PH = (TH - 1) * d->stride + 3, PW = (TW - 1) * d->stride + 3, MFA = (PH * PW + 31) / 32;
     return (size_t)(d->expand ? MFA * 32 * KP1 * 2 : 0) + (size_t)MFA * 32 * 80 + (size_t)TH * TW * 80 + (size_t)9 * ChP * 2;
 }
+static size_t mb_v3_lds_nw(const sm_mbconv_desc* d, int nw) {
+    const int ChP = (d->Ch + 31) & ~31, KP1 = (d->Cin + 2 + 15) & ~15, CoP = (d->Cout + 31) & ~31;
+    const int PH = 3 * d->stride + 3, PW = 7 * d->stride + 3, MFA = (PH * PW + 31) / 32;
+    return (size_t)ChP * KP1 * 2 + (size_t)9 * ChP * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)nw * (MFA * 32 + 32) * 80;
+}
+// waves per block: stride 1 — 16 (one block per CU; its 128-register budget holds) when the LDS takes it, else 8, else 4; stride 2 — 4 (two blocks per CU)
+static int mb_v3_waves(const sm_mbconv_desc* d) {
+    if (d->stride == 1) { if (mb_v3_lds_nw(d, 16) <= 160 * 1024) return 16; if (mb_v3_lds_nw(d, 8) <= 160 * 1024) return 8; }
+    return 4;
+}
+static size_t mb_v3_lds(const sm_mbconv_desc* d) { return mb_v3_lds_nw(d, mb_v3_waves(d)); }
 static bool mb_common_ok(const sm_mbconv_desc* d) {
     if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0) return false;
     if (d->stride != 1 && d->stride != 2) return false;
@@ -480,15 +679,29 @@ static bool mb_v1_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && d->Cin
 static bool mb_v2_ok(const sm_mbconv_desc* d) {
     return mb_common_ok(d) && (!d->expand || d->Cin <= 64) && d->Cout <= (d->stride == 1 ? 64 : 128) && (!d->residual || d->expand) && d->Ch <= 4096 && mb_v2_lds(d) <= 64 * 1024;
 }
-// v1 (everything in LDS) wherever it applies — it is the faster of the two today; the chunked v2 takes the shapes beyond it (SMELTER_MBCONV_V2=1: everywhere it can)
-static bool mb_use_v1(const sm_mbconv_desc* d) { static const bool force2 = getenv("SMELTER_MBCONV_V2") != nullptr; return mb_v1_ok(d) && !(force2 && mb_v2_ok(d)); }
+// v3 (wave pipelines): the expand form with K = Cin + 2 <= 48 (three k steps of X fragments in registers), Cout <= 64, weights + four wave regions in LDS
+static bool mb_v3_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && d->expand && d->Cin <= 46 && d->Cout <= 64 && mb_v3_lds(d) <= 160 * 1024; }
+static int mb_pick(const sm_mbconv_desc* d) {                         // 3, 1 or 2; SMELTER_MBCONV_KERNEL=1|2|3 forces one where it applies
+    static const int force = getenv("SMELTER_MBCONV_KERNEL") ? atoi(getenv("SMELTER_MBCONV_KERNEL")) : 0;
+    const bool ok1 = d && mb_v1_ok(d), ok2 = d && mb_v2_ok(d), ok3 = d && mb_v3_ok(d);
+    if (force == 1 && ok1) return 1;
+    if (force == 2 && ok2) return 2;
+    if (force == 3 && ok3) return 3;
+    // measured on MobileNet-v2 bs = 256 (tools/mbconv_bench.py): the wave pipelines win on the large maps (112^2 -> 56^2: 169 vs 307 us, 56^2: 205 vs
+    // 245), the all-in-LDS blocks on 28^2 and smaller, where 4x8 tiles leave ragged edges and one or two tiles per wave
+    if (ok3 && (ok1 ? (long)d->Ho * d->Wo >= 3136 : true)) return 3;
+    return ok1 ? 1 : ok2 ? 2 : 0;
+}
+
+
 
 size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d) {
     if (!d) return 0;
-    return mb_use_v1(d) ? mb_v1_lds(d) : mb_v2_lds(d);
+    const int k = mb_pick(d);
+    return k == 3 ? mb_v3_lds(d) : k == 1 ? mb_v1_lds(d) : mb_v2_lds(d);
 }
 
-int sm_mbconv_supported(const sm_mbconv_desc* d) { return (mb_v1_ok(d) || mb_v2_ok(d)) ? 1 : 0; }
+int sm_mbconv_supported(const sm_mbconv_desc* d) { return mb_pick(d) ? 1 : 0; }
 
 int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const float* b1, const void* wd, const float* bd, const void* w2, const float* b2, void* y,
                   sm_stream_t stream) {
@@ -511,7 +724,24 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
     p.ntiles = (int)nt;
     fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh); fastdiv_make((unsigned)PW, &p.pw_mul, &p.pw_sh);
     const size_t lds = sm_mbconv_lds_bytes(d);
-    if (!mb_use_v1(d)) {                                             // v2: 4-wave blocks, as many per CU as the LDS holds (<= 8)
+    const int kernel = mb_pick(d);
+    if (kernel == 3) {                                               // wave pipelines: 4-wave blocks, tiles dealt to waves
+        const long nt3 = (long)d->N * sm_ceil_div(d->Ho, 4) * sm_ceil_div(d->Wo, 8);
+        SM_REQUIRE(nt3 < (1L << 31), "sm_mbconv_fwd: too many tiles");
+        p.tiles_x = sm_ceil_div(d->Wo, 8); p.tiles_y = sm_ceil_div(d->Ho, 4); p.ntiles = (int)nt3;
+        fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
+        const int nw = mb_v3_waves(d), ks1 = ((d->Cin + 2 + 15) & ~15) >> 4;
+        const int per_cu3 = (int)std::max<size_t>(1, std::min<size_t>(16 / nw, (size_t)(160 * 1024) / lds));
+        const int grid3 = (int)std::min<long>((nt3 + nw - 1) / nw, (long)SM_NUM_CU * per_cu3);
+        void (*fn)(MbParams) = nullptr;
+        if (d->stride == 2) fn = ks1 <= 2 ? mbconv3_kernel<2, 2, 4, false> : mbconv3_kernel<2, 3, 4, false>;
+        else if (nw == 16) fn = ks1 <= 2 ? mbconv3_kernel<1, 2, 16, false> : mbconv3_kernel<1, 3, 16, false>;
+        else if (nw == 8) fn = ks1 <= 2 ? mbconv3_kernel<1, 2, 8, true> : mbconv3_kernel<1, 3, 8, true>;
+        else fn = ks1 <= 2 ? mbconv3_kernel<1, 2, 4, true> : mbconv3_kernel<1, 3, 4, true>;
+        hipLaunchKernelGGL(fn, dim3(grid3), dim3(nw * 64), lds, sm_s(stream), p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
+    if (kernel == 2) {                                               // v2: 4-wave blocks, as many per CU as the LDS holds (<= 8)
         SM_REQUIRE(((((uintptr_t)b1) | ((uintptr_t)bd) | ((uintptr_t)b2) | ((uintptr_t)w1) | ((uintptr_t)w2)) & 15) == 0, "sm_mbconv_fwd: weights and biases must be 16-byte aligned");
         const int per_cu2 = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));
         const int grid2 = (int)std::min<long>(nt, (long)SM_NUM_CU * per_cu2);
