@@ -391,6 +391,23 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 e.has_mb = true; e.mb_dw = steps_[ud].op; e.mb_proj = steps_[up].op;
                 steps_.erase(steps_.begin() + up); steps_.erase(steps_.begin() + ud);
             }
+        // the block without an expand layer (MobileNet-v2's first: depthwise 3x3 on the stem output -> 1x1 project)
+        if (!(mb_env && mb_env[0] == '0') && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency)
+            for (size_t t = 0; t < steps_.size(); t++) {
+                Step& e = steps_[t];
+                const Op& dw = e.op;
+                if (e.has_mb || e.has_pair || e.pool_out >= 0 || e.stem || dw.kind != OpKind::Conv || dw.groups != dw.cin || dw.cin != dw.cout || dw.groups < 8 || dw.kh != 3 || dw.kw != 3 || dw.dh != 1 ||
+                    dw.dw != 1 || dw.sh != dw.sw || (dw.sh != 1 && dw.sh != 2) || dw.pt != 1 || dw.pl != 1 || dw.residual >= 0 || dw.act > SM_ACT_PRELU || dw.grid_h || dw.x_ups || readers(dw.output) != 1) continue;
+                size_t up = 0;
+                for (size_t u = t + 1; u < steps_.size() && !up; u++) if (!steps_[u].op.inputs.empty() && steps_[u].op.inputs[0] == dw.output) up = u;
+                if (!up || !pointwise(steps_[up]) || steps_[up].op.residual >= 0 || steps_[up].op.cin != dw.cout) continue;
+                const Value& iv = values_[dw.inputs[0]]; const Value& ov = values_[steps_[up].op.output];
+                sm_mbconv_desc d{}; d.N = batch; d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.stride = dw.sh; d.Cin = dw.cin; d.Ch = dw.cin; d.Cout = steps_[up].op.cout; d.expand = 0;
+                d.act2 = dw.act; d.act3 = steps_[up].op.act;
+                if (d.Ch > 32 || d.Cout > 64 || !sm_mbconv_supported(&d)) continue;      // (one chunk of hidden channels: where the fused launch measured faster)
+                e.has_mb = true; e.mb_noexp = true; e.mb_dw = e.op; e.mb_proj = steps_[up].op;
+                steps_.erase(steps_.begin() + up);
+            }
     }
 
     // ---- 4. memory plan ------------------------------------------------------------------------------------
@@ -470,8 +487,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 // accounted as the three layers the graph holds (flops and algorithmic bytes do not depend on the fusion)
                 const Value& dv = values_[st.mb_dw.output]; const Value& pv = values_[st.mb_proj.output];
                 const double Md = (double)batch * dv.h * dv.w;
-                flops_ += 2.0 * Md * dv.c * 9.0 + 2.0 * Md * pv.c * (double)dv.c;
-                alg_bytes_ += 2.0 * ((double)st.M * op.cout + Md * dv.c + dv.c * 9.0) + 2.0 * (Md * dv.c + Md * pv.c * (st.mb_proj.residual >= 0 ? 2.0 : 1.0) + (double)pv.c * dv.c);
+                flops_ += (st.mb_noexp ? 0.0 : 2.0 * Md * dv.c * 9.0) + 2.0 * Md * pv.c * (double)dv.c;         // (no expand layer: the depthwise layer is this step's own op, counted below)
+                alg_bytes_ += (st.mb_noexp ? 0.0 : 2.0 * ((double)st.M * op.cout + Md * dv.c + dv.c * 9.0)) + 2.0 * (Md * dv.c + Md * pv.c * (st.mb_proj.residual >= 0 ? 2.0 : 1.0) + (double)pv.c * dv.c);
             }
             if (st.has_pair) {
                 st.w2_off = off; off = alignUp(off + st.pair.weight.size() * 2);
@@ -506,7 +523,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
         st.desc = buf;
         if (st.pool_out >= 0) { st.desc += " >> MaxPool 2x2/2 (same launch)"; alg_bytes_ += 2.0 * (double)(st.M / 4) * values_[st.pool_out].c; }
         if (st.has_pair) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.pair.name.c_str(), st.pair.cout, st.pair.cin, st.pair.act ? " +act" : ""); st.desc += buf; }
-        if (st.has_mb) { snprintf(buf, sizeof buf, " >> Conv %s k=3x3 s=%d g=%d%s >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.mb_dw.name.c_str(), st.mb_dw.sh, st.mb_dw.groups, st.mb_dw.act ? " +act" : "",
+        if (st.has_mb && st.mb_noexp) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.act ? " +act" : ""); st.desc += buf; }
+        else if (st.has_mb) { snprintf(buf, sizeof buf, " >> Conv %s k=3x3 s=%d g=%d%s >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.mb_dw.name.c_str(), st.mb_dw.sh, st.mb_dw.groups, st.mb_dw.act ? " +act" : "",
                                   st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.residual >= 0 ? " +res" : "", st.mb_proj.act ? " +act" : ""); st.desc += buf; }
         if (st.join >= 0) st.desc += " side-stream";
     }
@@ -515,7 +533,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
     materialized_.clear(); materialized_.push_back(values_[input_value_].name);
     for (auto& st : steps_) {
         if (st.has_mb) {   // (the two hidden tensors live in LDS only, but are rounded to fp16 there exactly as a stored tensor would be: listed for the parity oracle)
-            materialized_.push_back(values_[st.op.output].name); materialized_.push_back(values_[st.mb_dw.output].name); materialized_.push_back(values_[st.mb_proj.output].name); continue;
+            if (!st.mb_noexp) materialized_.push_back(values_[st.op.output].name);
+            materialized_.push_back(values_[st.mb_dw.output].name); materialized_.push_back(values_[st.mb_proj.output].name); continue;
         }
         if (st.op.kind != OpKind::Concat && materialized_.back() != values_[st.op.output].name) materialized_.push_back(values_[st.op.output].name);
         if (st.has_pair) materialized_.push_back(values_[st.pair.output].name);
@@ -620,10 +639,10 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
     case OpKind::Conv: case OpKind::FullyConnected: {
         if (st.has_mb) {
             const Value& iv = values_[op.inputs[0]]; const Value& pv = values_[st.mb_proj.output];
-            sm_mbconv_desc m{}; m.N = batch_; m.H = iv.h; m.W = iv.w; m.Ho = pv.h; m.Wo = pv.w; m.stride = st.mb_dw.sh; m.Cin = op.cin; m.Ch = op.cout; m.Cout = st.mb_proj.cout; m.expand = 1;
-            m.residual = st.mb_proj.residual >= 0 ? 1 : 0; m.act1 = op.act; m.slope1 = op.slope; m.act2 = st.mb_dw.act; m.slope2 = st.mb_dw.slope; m.act3 = st.mb_proj.act; m.slope3 = st.mb_proj.slope;
+            sm_mbconv_desc m{}; m.N = batch_; m.H = iv.h; m.W = iv.w; m.Ho = pv.h; m.Wo = pv.w; m.stride = st.mb_dw.sh; m.Cin = op.cin; m.Ch = op.cout; m.Cout = st.mb_proj.cout; m.expand = st.mb_noexp ? 0 : 1;
+            m.residual = st.mb_proj.residual >= 0 ? 1 : 0; m.act1 = st.mb_noexp ? SM_ACT_NONE : op.act; m.slope1 = op.slope; m.act2 = st.mb_dw.act; m.slope2 = st.mb_dw.slope; m.act3 = st.mb_proj.act; m.slope3 = st.mb_proj.slope;
             m.x_ld = valueLd(op.inputs[0]); m.y_ld = valueLd(st.mb_proj.output);
-            return sm_mbconv_fwd(&m, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, arena_ + st.wd_off,
+            return sm_mbconv_fwd(&m, valuePtr(op.inputs[0]), st.mb_noexp ? nullptr : arena_ + st.w_off, (st.has_bias && !st.mb_noexp) ? (const float*)(arena_ + st.b_off) : nullptr, arena_ + st.wd_off,
                                  st.has_biasd ? (const float*)(arena_ + st.bd_off) : nullptr, arena_ + st.w2_off, st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr,
                                  valuePtr(st.mb_proj.output), ss);
         }

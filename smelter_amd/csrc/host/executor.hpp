@@ -42,6 +42,7 @@ struct Step {                // one op after fusion, with everything resolved
     // inverted-residual block (executor.cpp pass 3c): this step is the 1x1 EXPAND; `mb_dw` (depthwise 3x3) and `mb_proj` (1x1 project, optional
     // residual = this step's input) run in the same launch (sm_mbconv_fwd) and the two hidden tensors are never materialised
     bool has_mb = false; Op mb_dw, mb_proj; size_t wd_off = 0, bd_off = 0; bool has_biasd = false;
+    bool mb_noexp = false;   // the block has no expand layer: this step IS the depthwise convolution (mb_dw is a copy of it), mb_proj follows
     std::string desc;
 };
 

@@ -450,7 +450,8 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
 // W2, bd, b2.  The X patch never touches LDS: its MFMA B fragments (patch pixel = lane, 16 bytes of channels) are loaded straight from
 // global memory once per tile and stay in registers for all chunks; the bias columns (1, 1 inside the image) are made in registers.
 // Hidden channels are processed 32 at a time with the projection accumulating across chunks, so Ch is limited only by the weights' LDS.
-// KS1 = k steps of the expand GEMM (K = Cin + 2 rounded up to 16), NW = waves per block (they share only the weights), WREG = depthwise
+// KS1 = k steps of the expand GEMM (K = Cin + 2 rounded up to 16; 0 = no expand layer: the hidden chunk is a channel slice of the X patch, copied
+// into the wave's region by the wave itself), NW = waves per block (they share only the weights), WREG = depthwise
 // weights of the lane's channel vector in registers for the chunk (36 registers: only where the occupancy survives it)
 template <int S, int KS1, int NW, bool WREG>
 __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
@@ -469,7 +470,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     unsigned char* const hid = wave_base + wave * ((MFA * 32 + 32) * HS);// hidden chunk [MFA*32][HS] | depthwise output chunk [32][HS]
     unsigned char* const dwo = hid + MFA * 32 * HS;
 
-    for (int i = tid; i < ChP * KP1; i += NT) {
+    if constexpr (KS1 > 0) for (int i = tid; i < ChP * KP1; i += NT) {
         const int n = i / KP1, k = i - n * KP1;
         half_t v = (half_t)0.f;
         if (n < p.Ch) {
@@ -496,9 +497,9 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
         const int oy0 = by * TH, ox0 = (r - by * p.tiles_x) * TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
         const half_t* const xim = p.x + (long)n * p.H * p.W * p.x_ld;
         // ---- X fragments of the whole patch: [row block][k step], 16 bytes per lane, kept for all chunks ------------------------------
-        half8_t fx[MFA][KS1];
+        half8_t fx[MFA][KS1 ? KS1 : 1];
 #pragma unroll
-        for (int mf = 0; mf < MFA; mf++) {
+        for (int mf = 0; mf < (KS1 ? MFA : 0); mf++) {
             const int pp = mf * 32 + l31, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px;
             const bool inimg = pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const half_t* src = xim + ((long)iy * p.W + ix) * p.x_ld;
@@ -518,11 +519,21 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 #pragma unroll 1
         for (int c = 0; c < NC; c++) {
             // ---- phase A: hidden chunk = act1(W1[c] (incl. bias columns) x patch) -> wave-private LDS ------------------------------------
-            half8_t fw1[KS1];
+            if (KS1 == 0) {
+                // no expand layer: channels c*32 .. +31 of the zero-padded X patch, 16 bytes per (pixel, channel vector) slot
+#pragma unroll
+                for (int i2 = 0; i2 < MFA * 2; i2++) {
+                    const int sl = lane + 64 * i2, pp = sl >> 2, c8 = sl & 3, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px, ch = c * 32 + c8 * 8;
+                    half8_t v = hz;
+                    if (pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W && ch < p.Ch) v = *(const half8_t*)(xim + ((long)iy * p.W + ix) * p.x_ld + ch);
+                    *(half8_t*)(hid + pp * HS + c8 * 16) = v;
+                }
+            }
+            half8_t fw1[KS1 ? KS1 : 1];
 #pragma unroll
             for (int ks = 0; ks < KS1; ks++) fw1[ks] = *(const half8_t*)(w1l + (c * 32 + l31) * KP1 + ks * 16 + hi * 8);
 #pragma unroll
-            for (int mf = 0; mf < MFA; mf++) {
+            for (int mf = 0; mf < (KS1 ? MFA : 0); mf++) {
                 floatx16 acc;
 #pragma unroll
                 for (int i = 0; i < 16; i++) acc[i] = 0.f;
@@ -654,12 +665,14 @@ static size_t mb_v2_lds(const sm_mbconv_desc* d) {
     return (size_t)(d->expand ? MFA * 32 * KP1 * 2 : 0) + (size_t)MFA * 32 * 80 + (size_t)TH * TW * 80 + (size_t)9 * ChP * 2;
 }
 static size_t mb_v3_lds_nw(const sm_mbconv_desc* d, int nw) {
-    const int ChP = (d->Ch + 31) & ~31, KP1 = (d->Cin + 2 + 15) & ~15, CoP = (d->Cout + 31) & ~31;
+    const int ChP = (d->Ch + 31) & ~31, KP1 = d->expand ? (d->Cin + 2 + 15) & ~15 : 0, CoP = (d->Cout + 31) & ~31;
     const int PH = 3 * d->stride + 3, PW = 7 * d->stride + 3, MFA = (PH * PW + 31) / 32;
     return (size_t)ChP * KP1 * 2 + (size_t)9 * ChP * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)nw * (MFA * 32 + 32) * 80;
 }
 // waves per block: stride 1 — 16 (one block per CU; its 128-register budget holds) when the LDS takes it, else 8, else 4; stride 2 — 4 (two blocks per CU)
 static int mb_v3_waves(const sm_mbconv_desc* d) {
+    static const int force = getenv("SMELTER_MBCONV_WAVES") ? atoi(getenv("SMELTER_MBCONV_WAVES")) : 0;      // experiment switch: 4 | 8 | 16 where the LDS takes it
+    if (d->stride == 1 && (force == 4 || force == 8 || force == 16) && mb_v3_lds_nw(d, force) <= 160 * 1024) return force;
     if (d->stride == 1) { if (mb_v3_lds_nw(d, 16) <= 160 * 1024) return 16; if (mb_v3_lds_nw(d, 8) <= 160 * 1024) return 8; }
     return 4;
 }
@@ -680,16 +693,16 @@ static bool mb_v2_ok(const sm_mbconv_desc* d) {
     return mb_common_ok(d) && (!d->expand || d->Cin <= 64) && d->Cout <= (d->stride == 1 ? 64 : 128) && (!d->residual || d->expand) && d->Ch <= 4096 && mb_v2_lds(d) <= 64 * 1024;
 }
 // v3 (wave pipelines): the expand form with K = Cin + 2 <= 48 (three k steps of X fragments in registers), Cout <= 64, weights + four wave regions in LDS
-static bool mb_v3_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && d->expand && d->Cin <= 46 && d->Cout <= 64 && mb_v3_lds(d) <= 160 * 1024; }
+static bool mb_v3_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && (d->expand ? d->Cin <= 46 : !d->residual) && d->Cout <= 64 && mb_v3_lds(d) <= 160 * 1024; }
 static int mb_pick(const sm_mbconv_desc* d) {                         // 3, 1 or 2; SMELTER_MBCONV_KERNEL=1|2|3 forces one where it applies
     static const int force = getenv("SMELTER_MBCONV_KERNEL") ? atoi(getenv("SMELTER_MBCONV_KERNEL")) : 0;
     const bool ok1 = d && mb_v1_ok(d), ok2 = d && mb_v2_ok(d), ok3 = d && mb_v3_ok(d);
     if (force == 1 && ok1) return 1;
     if (force == 2 && ok2) return 2;
     if (force == 3 && ok3) return 3;
-    // measured on MobileNet-v2 bs = 256 (tools/mbconv_bench.py): the wave pipelines win on the large maps (112^2 -> 56^2: 169 vs 307 us, 56^2: 205 vs
-    // 245), the all-in-LDS blocks on 28^2 and smaller, where 4x8 tiles leave ragged edges and one or two tiles per wave
-    if (ok3 && (ok1 ? (long)d->Ho * d->Wo >= 3136 : true)) return 3;
+    // measured on MobileNet-v2 bs = 256 (tools/mbconv_bench.py): the wave pipelines win on the large maps (112^2 -> 56^2: 163 vs 307 us, 56^2: 144 vs
+    // 245) and on the block without an expand layer, the all-in-LDS blocks on 28^2 and smaller, where 4x8 tiles leave ragged edges and one or two tiles per wave
+    if (ok3 && (ok1 && d->expand ? (long)d->Ho * d->Wo >= 3136 : true)) return 3;
     return ok1 ? 1 : ok2 ? 2 : 0;
 }
 
@@ -730,11 +743,12 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
         SM_REQUIRE(nt3 < (1L << 31), "sm_mbconv_fwd: too many tiles");
         p.tiles_x = sm_ceil_div(d->Wo, 8); p.tiles_y = sm_ceil_div(d->Ho, 4); p.ntiles = (int)nt3;
         fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
-        const int nw = mb_v3_waves(d), ks1 = ((d->Cin + 2 + 15) & ~15) >> 4;
+        const int nw = mb_v3_waves(d), ks1 = d->expand ? ((d->Cin + 2 + 15) & ~15) >> 4 : 0;
         const int per_cu3 = (int)std::max<size_t>(1, std::min<size_t>(16 / nw, (size_t)(160 * 1024) / lds));
         const int grid3 = (int)std::min<long>((nt3 + nw - 1) / nw, (long)SM_NUM_CU * per_cu3);
         void (*fn)(MbParams) = nullptr;
-        if (d->stride == 2) fn = ks1 <= 2 ? mbconv3_kernel<2, 2, 4, false> : mbconv3_kernel<2, 3, 4, false>;
+        if (ks1 == 0) fn = d->stride == 2 ? mbconv3_kernel<2, 0, 4, false> : nw == 16 ? mbconv3_kernel<1, 0, 16, false> : nw == 8 ? mbconv3_kernel<1, 0, 8, true> : mbconv3_kernel<1, 0, 4, true>;
+        else if (d->stride == 2) fn = ks1 <= 2 ? mbconv3_kernel<2, 2, 4, false> : mbconv3_kernel<2, 3, 4, false>;
         else if (nw == 16) fn = ks1 <= 2 ? mbconv3_kernel<1, 2, 16, false> : mbconv3_kernel<1, 3, 16, false>;
         else if (nw == 8) fn = ks1 <= 2 ? mbconv3_kernel<1, 2, 8, true> : mbconv3_kernel<1, 3, 8, true>;
         else fn = ks1 <= 2 ? mbconv3_kernel<1, 2, 4, true> : mbconv3_kernel<1, 3, 4, true>;

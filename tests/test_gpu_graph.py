@@ -112,16 +112,16 @@ def test_unet_fuses_upsample_and_maxpool_into_their_convolutions():
 
 def test_mobilenet_runs_its_expand_blocks_as_one_launch_each(monkeypatch):
     """executor pass 3c: 1x1 expand -> depthwise 3x3 -> 1x1 project (+ block input) = one sm_mbconv_fwd step where the all-in-LDS kernel takes the
-    shape (Cin <= 32, Ch <= 192, Cout <= 64: six blocks of MobileNet-v2); same function as the three separate launches, and as the oracle"""
+    shape (Cin <= 32, Ch <= 192, Cout <= 64: six blocks of MobileNet-v2, plus the depthwise-first block); same function as the three separate launches, and as the oracle"""
     model = zoo.mobilenet_v2(hw=(96, 96))
     x = zoo.synthetic_images(2, 3, (96, 96))
     ex, got = run_hip(model, x)
     descs = [ex.opDesc(i) for i in range(ex.numOps)]
     fused = [d for d in descs if "(same launch)" in d and "k=3x3" in d]
-    assert len(fused) == 6 and sum("+res" in d for d in fused) == 3 and sum(" s=2 g=" in d for d in fused) == 3
+    assert len(fused) == 7 and sum("+res" in d for d in fused) == 3 and sum(" s=2 g=" in d for d in fused) == 3      # 6 expand blocks + the depthwise-first block
     monkeypatch.setenv("SMELTER_MBCONV", "0")
     ex0, plain = run_hip(model, x)
-    assert ex0.numOps == ex.numOps + 12 and not any("(same launch)" in ex0.opDesc(i) for i in range(ex0.numOps))
+    assert ex0.numOps == ex.numOps + 13 and not any("(same launch)" in ex0.opDesc(i) for i in range(ex0.numOps))
     assert nerr(got, plain) <= 2e-3
     ref = O.Graph(model).run(x)
     assert nerr(got, ref) <= 5e-3
