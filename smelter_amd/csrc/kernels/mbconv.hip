@@ -453,9 +453,11 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
 // KS1 = k steps of the expand GEMM (K = Cin + 2 rounded up to 16; 0 = no expand layer: the hidden chunk is a channel slice of the X patch, copied
 // into the wave's region by the wave itself), NW = waves per block (they share only the weights), WREG = depthwise
 // weights of the lane's channel vector in registers for the chunk (36 registers: only where the occupancy survives it)
-template <int S, int KS1, int NW, bool WREG>
+// TH x 8 output pixels per tile: 4 x 8 for stride 1; 2 x 8 for stride 2 (5 x 17 patch = 3 row blocks instead of 9 x 17 = 5: 9 KB of LDS per wave
+// instead of 15, i.e. 16 waves per CU instead of 8; half of the projection MFMA's pixel columns are idle, which costs nothing that matters)
+template <int S, int KS1, int NW, bool WREG, int TH = (S == 1 ? 4 : 2)>
 __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
-    constexpr int TH = 4, TW = 8, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, HP = PH * PW, MFA = (HP + 31) / 32, HS = 80, NT = NW * 64;
+    constexpr int TW = 8, OPX = TH * TW, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, HP = PH * PW, MFA = (HP + 31) / 32, HS = 80, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
     constexpr int KP1 = KS1 * 16;
     const int ChP = p.ChP, NC = ChP >> 5, nfc = (p.Cout + 31) >> 5, CoP = nfc * 32, hs2 = ChP * 2 + 16;
@@ -467,7 +469,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     unsigned char* const wave_base = (unsigned char*)(b2l + CoP);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char* const hid = wave_base + wave * ((MFA * 32 + 32) * HS);// hidden chunk [MFA*32][HS] | depthwise output chunk [32][HS]
+    unsigned char* const hid = wave_base + wave * ((MFA * 32 + OPX) * HS);// hidden chunk [MFA*32][HS] | depthwise output chunk [OPX][HS]
     unsigned char* const dwo = hid + MFA * 32 * HS;
 
     if constexpr (KS1 > 0) for (int i = tid; i < ChP * KP1; i += NT) {
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
             }
             bd0 = *(const floatx4*)(bdl + chl); bd1 = *(const floatx4*)(bdl + chl + 4);
 #pragma unroll
-            for (int i2 = 0; i2 < 2; i2++) {
+            for (int i2 = 0; i2 < OPX * 4 / 64; i2++) {
                 const int it = lane + 64 * i2, op = it >> 2, cv = it & 3, oy = op / TW, ox = op - oy * TW;
                 float a[8];
 #pragma unroll
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
         }
         // ---- epilogue: + b2 (+ X), act3, 16-byte stores; lane = output pixel l31 of the tile ------------------------------------------
         const int oy = oy0 + l31 / TW, ox = ox0 + l31 % TW;
-        const bool pin = oy < p.Ho && ox < p.Wo;
+        const bool pin = l31 < OPX && oy < p.Ho && ox < p.Wo;               // (2 x 8 tiles: lanes 16..31 of a half-wave carry no pixel)
         const long opix = ((long)n * p.Ho + oy) * p.Wo + ox;
 #pragma unroll
         for (int a = 0; a < 2; a++)
@@ -666,14 +668,15 @@ static size_t mb_v2_lds(const sm_mbconv_desc* d) {
 }
 static size_t mb_v3_lds_nw(const sm_mbconv_desc* d, int nw) {
     const int ChP = (d->Ch + 31) & ~31, KP1 = d->expand ? (d->Cin + 2 + 15) & ~15 : 0, CoP = (d->Cout + 31) & ~31;
-    const int PH = 3 * d->stride + 3, PW = 7 * d->stride + 3, MFA = (PH * PW + 31) / 32;
-    return (size_t)ChP * KP1 * 2 + (size_t)9 * ChP * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)nw * (MFA * 32 + 32) * 80;
+    const int TH = d->stride == 1 ? 4 : 2, PH = (TH - 1) * d->stride + 3, PW = 7 * d->stride + 3, MFA = (PH * PW + 31) / 32;
+    return (size_t)ChP * KP1 * 2 + (size_t)9 * ChP * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)nw * (MFA * 32 + TH * 8) * 80;
 }
-// waves per block: stride 1 — 16 (one block per CU; its 128-register budget holds) when the LDS takes it, else 8, else 4; stride 2 — 4 (two blocks per CU)
+// waves per block: 16 (one block per CU; its 128-register budget holds) when the LDS takes it, else 8, else 4
 static int mb_v3_waves(const sm_mbconv_desc* d) {
     static const int force = getenv("SMELTER_MBCONV_WAVES") ? atoi(getenv("SMELTER_MBCONV_WAVES")) : 0;      // experiment switch: 4 | 8 | 16 where the LDS takes it
-    if (d->stride == 1 && (force == 4 || force == 8 || force == 16) && mb_v3_lds_nw(d, force) <= 160 * 1024) return force;
-    if (d->stride == 1) { if (mb_v3_lds_nw(d, 16) <= 160 * 1024) return 16; if (mb_v3_lds_nw(d, 8) <= 160 * 1024) return 8; }
+    if ((force == 4 || force == 8 || force == 16) && mb_v3_lds_nw(d, force) <= 160 * 1024) return force;
+    if (mb_v3_lds_nw(d, 16) <= 160 * 1024) return 16;
+    if (mb_v3_lds_nw(d, 8) <= 160 * 1024) return 8;
     return 4;
 }
 static size_t mb_v3_lds(const sm_mbconv_desc* d) { return mb_v3_lds_nw(d, mb_v3_waves(d)); }
@@ -700,9 +703,9 @@ static int mb_pick(const sm_mbconv_desc* d) {                         // 3, 1 or
     if (force == 1 && ok1) return 1;
     if (force == 2 && ok2) return 2;
     if (force == 3 && ok3) return 3;
-    // measured on MobileNet-v2 bs = 256 (tools/mbconv_bench.py): the wave pipelines win on the large maps (112^2 -> 56^2: 163 vs 307 us, 56^2: 144 vs
-    // 245) and on the block without an expand layer, the all-in-LDS blocks on 28^2 and smaller, where 4x8 tiles leave ragged edges and one or two tiles per wave
-    if (ok3 && (ok1 && d->expand ? (long)d->Ho * d->Wo >= 3136 : true)) return 3;
+    // measured on MobileNet-v2 bs = 256 (tools/mbconv_bench.py): the wave pipelines win everywhere (112^2 -> 56^2: 125 vs 307 us, 56^2: 143 vs 245,
+    // 56^2 -> 28^2: 92 vs 122, 28^2: 60 vs 93) except on the 28^2 -> 14^2 block (58 vs 53: one or two ragged tiles per wave)
+    if (ok3 && !(ok1 && d->stride == 2 && (long)d->Ho * d->Wo <= 196)) return 3;
     return ok1 ? 1 : ok2 ? 2 : 0;
 }
 
@@ -739,16 +742,20 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
     const size_t lds = sm_mbconv_lds_bytes(d);
     const int kernel = mb_pick(d);
     if (kernel == 3) {                                               // wave pipelines: 4-wave blocks, tiles dealt to waves
-        const long nt3 = (long)d->N * sm_ceil_div(d->Ho, 4) * sm_ceil_div(d->Wo, 8);
+        const int th3 = d->stride == 1 ? 4 : 2;
+        const long nt3 = (long)d->N * sm_ceil_div(d->Ho, th3) * sm_ceil_div(d->Wo, 8);
         SM_REQUIRE(nt3 < (1L << 31), "sm_mbconv_fwd: too many tiles");
-        p.tiles_x = sm_ceil_div(d->Wo, 8); p.tiles_y = sm_ceil_div(d->Ho, 4); p.ntiles = (int)nt3;
+        p.tiles_x = sm_ceil_div(d->Wo, 8); p.tiles_y = sm_ceil_div(d->Ho, th3); p.ntiles = (int)nt3;
         fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
         const int nw = mb_v3_waves(d), ks1 = d->expand ? ((d->Cin + 2 + 15) & ~15) >> 4 : 0;
         const int per_cu3 = (int)std::max<size_t>(1, std::min<size_t>(16 / nw, (size_t)(160 * 1024) / lds));
         const int grid3 = (int)std::min<long>((nt3 + nw - 1) / nw, (long)SM_NUM_CU * per_cu3);
         void (*fn)(MbParams) = nullptr;
-        if (ks1 == 0) fn = d->stride == 2 ? mbconv3_kernel<2, 0, 4, false> : nw == 16 ? mbconv3_kernel<1, 0, 16, false> : nw == 8 ? mbconv3_kernel<1, 0, 8, true> : mbconv3_kernel<1, 0, 4, true>;
-        else if (d->stride == 2) fn = ks1 <= 2 ? mbconv3_kernel<2, 2, 4, false> : mbconv3_kernel<2, 3, 4, false>;
+        if (ks1 == 0) fn = d->stride == 2 ? (nw == 16 ? mbconv3_kernel<2, 0, 16, false> : nw == 8 ? mbconv3_kernel<2, 0, 8, false> : mbconv3_kernel<2, 0, 4, false>)
+                                          : nw == 16 ? mbconv3_kernel<1, 0, 16, false> : nw == 8 ? mbconv3_kernel<1, 0, 8, true> : mbconv3_kernel<1, 0, 4, true>;
+        else if (d->stride == 2) fn = nw == 16 ? (ks1 <= 2 ? mbconv3_kernel<2, 2, 16, false> : mbconv3_kernel<2, 3, 16, false>)
+                                    : nw == 8 ? (ks1 <= 2 ? mbconv3_kernel<2, 2, 8, false> : mbconv3_kernel<2, 3, 8, false>)
+                                              : (ks1 <= 2 ? mbconv3_kernel<2, 2, 4, false> : mbconv3_kernel<2, 3, 4, false>);
         else if (nw == 16) fn = ks1 <= 2 ? mbconv3_kernel<1, 2, 16, false> : mbconv3_kernel<1, 3, 16, false>;
         else if (nw == 8) fn = ks1 <= 2 ? mbconv3_kernel<1, 2, 8, true> : mbconv3_kernel<1, 3, 8, true>;
         else fn = ks1 <= 2 ? mbconv3_kernel<1, 2, 4, true> : mbconv3_kernel<1, 3, 4, true>;
