@@ -455,16 +455,19 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
 // weights of the lane's channel vector in registers for the chunk (36 registers: only where the occupancy survives it)
 // TH x 8 output pixels per tile: 4 x 8 for stride 1; 2 x 8 for stride 2 (5 x 17 patch = 3 row blocks instead of 9 x 17 = 5: 9 KB of LDS per wave
 // instead of 15, i.e. 16 waves per CU instead of 8; half of the projection MFMA's pixel columns are idle, which costs nothing that matters)
-template <int S, int KS1, int NW, bool WREG, int TH = (S == 1 ? 4 : 2)>
+// WG: W1 and W2 do not fit the LDS (Ch = 384 / 576): their MFMA fragments are read from global memory (L2-resident) — W1's for chunk c+1
+// right behind the MFMAs that consumed chunk c's, W2's at the top of the chunk that multiplies them two phases later; the bias columns of W1
+// are made in registers from b1.  NF = cout blocks of 32 (accumulator sets).
+template <int S, int KS1, int NW, bool WREG, int TH = (S == 1 ? 4 : 2), bool WG = false, int NF = 2>
 __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     constexpr int TW = 8, OPX = TH * TW, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, HP = PH * PW, MFA = (HP + 31) / 32, HS = 80, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
     constexpr int KP1 = KS1 * 16;
     const int ChP = p.ChP, NC = ChP >> 5, nfc = (p.Cout + 31) >> 5, CoP = nfc * 32, hs2 = ChP * 2 + 16;
-    half_t* const w1l = (half_t*)mb_smem;                                // [ChP][KP1]
-    half_t* const wdl = w1l + ChP * KP1;                                 // [9][ChP]
-    unsigned char* const w2l = (unsigned char*)(wdl + 9 * ChP);          // [CoP] rows of hs2 bytes
-    float* const bdl = (float*)(w2l + CoP * hs2);                        // [ChP]
+    half_t* const w1l = (half_t*)mb_smem;                                // [ChP][KP1]   (absent with WG)
+    half_t* const wdl = w1l + (WG ? 0 : ChP * KP1);                      // [9][ChP]
+    unsigned char* const w2l = (unsigned char*)(wdl + 9 * ChP);          // [CoP] rows of hs2 bytes   (absent with WG)
+    float* const bdl = (float*)(w2l + (WG ? 0 : CoP * hs2));             // [ChP]
     float* const b2l = bdl + ChP;                                        // [CoP]
     unsigned char* const wave_base = (unsigned char*)(b2l + CoP);
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -472,7 +475,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     unsigned char* const hid = wave_base + wave * ((MFA * 32 + OPX) * HS);// hidden chunk [MFA*32][HS] | depthwise output chunk [OPX][HS]
     unsigned char* const dwo = hid + MFA * 32 * HS;
 
-    if constexpr (KS1 > 0) for (int i = tid; i < ChP * KP1; i += NT) {
+    if constexpr (KS1 > 0 && !WG) for (int i = tid; i < ChP * KP1; i += NT) {
         const int n = i / KP1, k = i - n * KP1;
         half_t v = (half_t)0.f;
         if (n < p.Ch) {
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
         w1l[i] = v;
     }
     for (int i = tid; i < 9 * ChP; i += NT) { const int t = i / ChP, c = i - t * ChP; wdl[i] = c < p.Ch ? p.wd[(long)c * 9 + t] : (half_t)0.f; }
-    for (int i = tid; i < CoP * (hs2 / 2); i += NT) { const int n = i / (hs2 / 2), k = i - n * (hs2 / 2); ((half_t*)w2l)[i] = (n < p.Cout && k < p.Ch) ? p.w2[(long)n * p.Ch + k] : (half_t)0.f; }
+    if constexpr (!WG) for (int i = tid; i < CoP * (hs2 / 2); i += NT) { const int n = i / (hs2 / 2), k = i - n * (hs2 / 2); ((half_t*)w2l)[i] = (n < p.Cout && k < p.Ch) ? p.w2[(long)n * p.Ch + k] : (half_t)0.f; }
     for (int i = tid; i < ChP; i += NT) bdl[i] = (p.bd && i < p.Ch) ? p.bd[i] : 0.f;
     for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
     __syncthreads();                                                     // the only barrier of the kernel
@@ -492,6 +495,22 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     const int t_begin = (int)(gw * T / GW), t_end = (int)((gw + 1) * T / GW);
     const half8_t hz = {0, 0, 0, 0, 0, 0, 0, 0};
     half8_t ones = hz; ones[0] = (half_t)1.f; ones[1] = (half_t)1.f;
+    half8_t fw1[KS1 ? KS1 : 1];
+    auto load_w1 = [&](int c) {                                          // A fragments of W1's rows c*32 .. +31 (incl. the two bias columns)
+#pragma unroll
+        for (int ks = 0; ks < KS1; ks++) {
+            if constexpr (!WG) fw1[ks] = *(const half8_t*)(w1l + (c * 32 + l31) * KP1 + ks * 16 + hi * 8);
+            else {
+                const int ch = c * 32 + l31, k = ks * 16 + hi * 8;
+                half8_t v = hz;
+                if (ch < p.Ch) {
+                    if (k < p.Cin) v = *(const half8_t*)(p.w1 + (long)ch * p.Cin + k);
+                    else if (k == p.Cin && p.b1) { const float b = p.b1[ch]; const half_t bh = (half_t)b; v[0] = bh; v[1] = (half_t)(b - (float)bh); }
+                }
+                fw1[ks] = v;
+            }
+        }
+    };
 #pragma unroll 1
     for (int t = t_begin; t < t_end; t++) {
         const int n = (int)fastdiv((unsigned)t, p.txy_mul, p.txy_sh);
@@ -513,13 +532,24 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
                 fx[mf][ks] = v;
             }
         }
-        floatx16 acc2[2];
+        floatx16 acc2[NF];
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+        for (int a = 0; a < NF; a++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc2[a][i] = 0.f;
+        if constexpr (KS1 > 0 && WG) load_w1(0);
 #pragma unroll 1
         for (int c = 0; c < NC; c++) {
+            half8_t fw2g[WG ? NF : 1][2];                                // WG: this chunk's W2 fragments, in flight across phases A and B
+            if constexpr (WG) {
+#pragma unroll
+                for (int a = 0; a < NF; a++)
+#pragma unroll
+                    for (int ks = 0; ks < 2; ks++) {
+                        const int co = a * 32 + l31, k = c * 32 + ks * 16 + hi * 8;
+                        fw2g[a][ks] = (co < p.Cout && k < p.Ch) ? *(const half8_t*)(p.w2 + (long)co * p.Ch + k) : hz;
+                    }
+            }
             // ---- phase A: hidden chunk = act1(W1[c] (incl. bias columns) x patch) -> wave-private LDS ------------------------------------
             if (KS1 == 0) {
                 // no expand layer: channels c*32 .. +31 of the zero-padded X patch, 16 bytes per (pixel, channel vector) slot
@@ -531,16 +561,28 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
                     *(half8_t*)(hid + pp * HS + c8 * 16) = v;
                 }
             }
-            half8_t fw1[KS1 ? KS1 : 1];
+            // WG: all row blocks multiplied first, so that the next chunk's W1 fragments can be requested behind the MFMAs that read this chunk's
+            floatx16 accA[(KS1 && WG) ? MFA : 1];
+            if constexpr (KS1 > 0 && WG) {
 #pragma unroll
-            for (int ks = 0; ks < KS1; ks++) fw1[ks] = *(const half8_t*)(w1l + (c * 32 + l31) * KP1 + ks * 16 + hi * 8);
+                for (int mf = 0; mf < MFA; mf++) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) accA[mf][i] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < KS1; ks++) accA[mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1[ks], fx[mf][ks], accA[mf], 0, 0, 0);
+                }
+                if (c + 1 < NC) load_w1(c + 1);
+            } else if constexpr (KS1 > 0) load_w1(c);
 #pragma unroll
             for (int mf = 0; mf < (KS1 ? MFA : 0); mf++) {
                 floatx16 acc;
+                if constexpr (WG) acc = accA[mf];
+                else {
 #pragma unroll
-                for (int i = 0; i < 16; i++) acc[i] = 0.f;
+                    for (int i = 0; i < 16; i++) acc[i] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS1; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1[ks], fx[mf][ks], acc, 0, 0, 0);
+                    for (int ks = 0; ks < KS1; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw1[ks], fx[mf][ks], acc, 0, 0, 0);
+                }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     half4_t o;
@@ -601,9 +643,10 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
             for (int ks = 0; ks < 2; ks++) {
                 const half8_t fy = *(const half8_t*)(dwo + l31 * HS + (ks * 2 + hi) * 16);
 #pragma unroll
-                for (int a = 0; a < 2; a++)
+                for (int a = 0; a < NF; a++)
                     if (a < nfc) {
-                        const half8_t fw2 = *(const half8_t*)(w2l + (a * 32 + l31) * hs2 + (c * 32 + ks * 16 + hi * 8) * 2);
+                        half8_t fw2;
+                        if constexpr (WG) fw2 = fw2g[a][ks]; else fw2 = *(const half8_t*)(w2l + (a * 32 + l31) * hs2 + (c * 32 + ks * 16 + hi * 8) * 2);
                         acc2[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw2, fy, acc2[a], 0, 0, 0);
                     }
             }
@@ -614,7 +657,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
         const bool pin = l31 < OPX && oy < p.Ho && ox < p.Wo;               // (2 x 8 tiles: lanes 16..31 of a half-wave carry no pixel)
         const long opix = ((long)n * p.Ho + oy) * p.Wo + ox;
 #pragma unroll
-        for (int a = 0; a < 2; a++)
+        for (int a = 0; a < NF; a++)
             if (a < nfc) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
@@ -666,20 +709,24 @@ static size_t mb_v2_lds(const sm_mbconv_desc* d) {
     const int TH = d->stride == 1 ? 8 : 4, TW = 8, PH = (TH - 1) * d->stride + 3, PW = (TW - 1) * d->stride + 3, MFA = (PH * PW + 31) / 32;
     return (size_t)(d->expand ? MFA * 32 * KP1 * 2 : 0) + (size_t)MFA * 32 * 80 + (size_t)TH * TW * 80 + (size_t)9 * ChP * 2;
 }
-static size_t mb_v3_lds_nw(const sm_mbconv_desc* d, int nw) {
+static size_t mb_v3_lds_nw(const sm_mbconv_desc* d, int nw, bool wg = false) {
     const int ChP = (d->Ch + 31) & ~31, KP1 = d->expand ? (d->Cin + 2 + 15) & ~15 : 0, CoP = (d->Cout + 31) & ~31;
     const int TH = d->stride == 1 ? 4 : 2, PH = (TH - 1) * d->stride + 3, PW = 7 * d->stride + 3, MFA = (PH * PW + 31) / 32;
-    return (size_t)ChP * KP1 * 2 + (size_t)9 * ChP * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)nw * (MFA * 32 + TH * 8) * 80;
+    return (wg ? 0 : (size_t)ChP * KP1 * 2 + (size_t)CoP * (ChP * 2 + 16)) + (size_t)9 * ChP * 2 + (size_t)(ChP + CoP) * 4 + (size_t)nw * (MFA * 32 + TH * 8) * 80;
 }
+// W1 / W2 as fragments from global memory (8-wave blocks): the expand form whose weights leave no room for 8 wave regions; instantiated for
+// K = Cin + 2 <= 80 | 112 (5 | 7 k steps) and Cout <= 64 | 96 | 160 — MobileNet-v2's 14 x 14 blocks
+static bool mb_v3_wg(const sm_mbconv_desc* d) { return d->expand && mb_v3_lds_nw(d, 8) > 160 * 1024; }
 // waves per block: 16 (one block per CU; its 128-register budget holds) when the LDS takes it, else 8, else 4
 static int mb_v3_waves(const sm_mbconv_desc* d) {
-    static const int force = getenv("SMELTER_MBCONV_WAVES") ? atoi(getenv("SMELTER_MBCONV_WAVES")) : 0;      // experiment switch: 4 | 8 | 16 where the LDS takes it
+    if (mb_v3_wg(d)) return 8;
+    const char* fe = getenv("SMELTER_MBCONV_WAVES"); const int force = fe ? atoi(fe) : 0;            // experiment switch: 4 | 8 | 16 where the LDS takes it
     if ((force == 4 || force == 8 || force == 16) && mb_v3_lds_nw(d, force) <= 160 * 1024) return force;
     if (mb_v3_lds_nw(d, 16) <= 160 * 1024) return 16;
     if (mb_v3_lds_nw(d, 8) <= 160 * 1024) return 8;
     return 4;
 }
-static size_t mb_v3_lds(const sm_mbconv_desc* d) { return mb_v3_lds_nw(d, mb_v3_waves(d)); }
+static size_t mb_v3_lds(const sm_mbconv_desc* d) { return mb_v3_lds_nw(d, mb_v3_waves(d), mb_v3_wg(d)); }
 static bool mb_common_ok(const sm_mbconv_desc* d) {
     if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0) return false;
     if (d->stride != 1 && d->stride != 2) return false;
@@ -696,9 +743,13 @@ static bool mb_v2_ok(const sm_mbconv_desc* d) {
     return mb_common_ok(d) && (!d->expand || d->Cin <= 64) && d->Cout <= (d->stride == 1 ? 64 : 128) && (!d->residual || d->expand) && d->Ch <= 4096 && mb_v2_lds(d) <= 64 * 1024;
 }
 // v3 (wave pipelines): the expand form with K = Cin + 2 <= 48 (three k steps of X fragments in registers), Cout <= 64, weights + four wave regions in LDS
-static bool mb_v3_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && (d->expand ? d->Cin <= 46 : !d->residual) && d->Cout <= 64 && mb_v3_lds(d) <= 160 * 1024; }
+static bool mb_v3_ok(const sm_mbconv_desc* d) {
+    if (!mb_common_ok(d)) return false;
+    if (mb_v3_wg(d)) return d->Cin <= 110 && d->Cout <= 96 && mb_v3_lds(d) <= 160 * 1024;      // (five accumulator sets, Cout = 160, spill)
+    return (d->expand ? d->Cin <= 46 : !d->residual) && d->Cout <= 64 && mb_v3_lds(d) <= 160 * 1024;
+}
 static int mb_pick(const sm_mbconv_desc* d) {                         // 3, 1 or 2; SMELTER_MBCONV_KERNEL=1|2|3 forces one where it applies
-    static const int force = getenv("SMELTER_MBCONV_KERNEL") ? atoi(getenv("SMELTER_MBCONV_KERNEL")) : 0;
+    const char* fe = getenv("SMELTER_MBCONV_KERNEL"); const int force = fe ? atoi(fe) : 0;          // (read per call: the tests switch it)
     const bool ok1 = d && mb_v1_ok(d), ok2 = d && mb_v2_ok(d), ok3 = d && mb_v3_ok(d);
     if (force == 1 && ok1) return 1;
     if (force == 2 && ok2) return 2;
@@ -751,7 +802,11 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
         const int per_cu3 = (int)std::max<size_t>(1, std::min<size_t>(16 / nw, (size_t)(160 * 1024) / lds));
         const int grid3 = (int)std::min<long>((nt3 + nw - 1) / nw, (long)SM_NUM_CU * per_cu3);
         void (*fn)(MbParams) = nullptr;
-        if (ks1 == 0) fn = d->stride == 2 ? (nw == 16 ? mbconv3_kernel<2, 0, 16, false> : nw == 8 ? mbconv3_kernel<2, 0, 8, false> : mbconv3_kernel<2, 0, 4, false>)
+        if (mb_v3_wg(d)) {
+            const int nf = (d->Cout + 31) / 32;
+            if (d->stride == 1) fn = ks1 <= 5 ? (nf <= 2 ? mbconv3_kernel<1, 5, 8, false, 4, true, 2> : mbconv3_kernel<1, 5, 8, false, 4, true, 3>) : mbconv3_kernel<1, 7, 8, false, 4, true, 3>;
+            else fn = ks1 <= 5 ? mbconv3_kernel<2, 5, 8, false, 2, true, 3> : mbconv3_kernel<2, 7, 8, false, 2, true, 3>;
+        } else if (ks1 == 0) fn = d->stride == 2 ? (nw == 16 ? mbconv3_kernel<2, 0, 16, false> : nw == 8 ? mbconv3_kernel<2, 0, 8, false> : mbconv3_kernel<2, 0, 4, false>)
                                           : nw == 16 ? mbconv3_kernel<1, 0, 16, false> : nw == 8 ? mbconv3_kernel<1, 0, 8, true> : mbconv3_kernel<1, 0, 4, true>;
         else if (d->stride == 2) fn = nw == 16 ? (ks1 <= 2 ? mbconv3_kernel<2, 2, 16, false> : mbconv3_kernel<2, 3, 16, false>)
                                     : nw == 8 ? (ks1 <= 2 ? mbconv3_kernel<2, 2, 8, false> : mbconv3_kernel<2, 3, 8, false>)

@@ -582,9 +582,22 @@ def test_conv1x1_pair_equals_two_launches(n, hw, n2, res):
     (3, (29, 27), 32, 192, 64, 2, False, True),    # stride 2 on odd sizes, Cout = 64 (two cout blocks)
     (2, (19, 21), 32, 32, 16, 1, False, False),    # block 1: no expand (depthwise reads the input), ragged tiles
     (1, (9, 9), 24, 144, 32, 2, False, True),      # image barely larger than a tile
+    (1, (14, 14), 64, 384, 64, 1, True, True),     # 14x14 blocks: W1 / W2 read as fragments from global memory (five k steps, two cout blocks)
+    (2, (14, 14), 96, 576, 96, 1, True, True),     # seven k steps, three cout blocks, 18 chunks
+    (1, (15, 13), 64, 384, 96, 2, False, True),    # the same path at stride 2, odd sizes
 ])
-def test_mbconv_fused_block_equals_the_three_layers(n, hw, cin, ch, cout, stride, res, expand):
-    """sm_mbconv_fwd against the oracle's three convolutions with the hidden tensors rounded to fp16 where the separate launches store them"""
+@pytest.mark.parametrize("kernel", [None, 1, 2, 3])
+def test_mbconv_fused_block_equals_the_three_layers(n, hw, cin, ch, cout, stride, res, expand, kernel, monkeypatch):
+    """sm_mbconv_fwd against the oracle's three convolutions with the hidden tensors rounded to fp16 where the separate launches store them;
+    kernel = the launcher's own choice, or one of the three implementations forced (mbconv.hip: all-in-LDS blocks, chunked blocks, wave pipelines)"""
+    if kernel is not None:
+        monkeypatch.setenv("SMELTER_MBCONV_KERNEL", str(kernel))
+        v1 = cin <= 32 and ch <= 192 and cout <= 64
+        v2 = (not expand or cin <= 64) and cout <= (64 if stride == 1 else 128) and (not res or expand)
+        v3 = (cin <= 46 and cout <= 64 and ch <= 192) if expand else True
+        v3 = v3 or (expand and ch >= 384 and cin <= 110 and cout <= 96)
+        if not (v1, v2, v3)[kernel - 1]:
+            pytest.skip("outside this kernel's domain (the launcher falls back to another one)")
     rng = np.random.default_rng(cin * 7 + ch + stride)
     x = h(rng.standard_normal((n, cin, hw[0], hw[1])))
     w1 = h(rng.standard_normal((ch, 1, 1, cin)) * np.sqrt(2.0 / cin)) if expand else None
