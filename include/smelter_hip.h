@@ -108,6 +108,14 @@ int sm_conv2d_pool_supported(const sm_conv_desc* d);
 int sm_conv2d_pool_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias, void* y,
                            void* y_pool, int32_t pool_ld, sm_stream_t stream);
 
+/* ConvolutionConverter (Converters.swift:253) x 2: a 3x3 / stride 1 / pad 1 convolution (Cin, Cout in {32, 64}) whose output feeds a 1x1
+ * convolution to n3 <= 32 channels (n3 % 8 == 0) — a segmentation head — in ONE launch: y3 = act3(w3 . act(conv3x3(x)) + b3), the 3x3 output
+ * tile being rounded to fp16 exactly as the stored tensor would be.  w3 = [n3][Cout] fp16 (OHWI of a 1x1), b3 fp32 or NULL.  y may be NULL:
+ * the 3x3 output is then not stored at all. */
+int sm_conv2d_head_supported(const sm_conv_desc* d, int32_t n3);
+int sm_conv2d_head_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias, void* y, const void* w3,
+                           const float* b3, int32_t n3, int32_t act3, float slope3, void* y3, int32_t y3_ld, sm_stream_t stream);
+
 /* Two MPSCNNConvolutionNodes in a row, both 1x1 / stride 1 (Converters.swift:253), in ONE launch:
  *   y = act(x * w1 + bias1 + residual)   [d: Cin = 64 -> Cout = 256]      z = act2(y * w2 + bias2)   [256 -> N2 in {64, 128}]
  * Both tensors are stored (y is the next residual); y is rounded to fp16 once, exactly as the separate launches would store it.

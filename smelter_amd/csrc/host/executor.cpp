@@ -410,6 +410,30 @@ int Executor::plan(ONNXGraph& g, int batch) {
             }
     }
 
+    // ---- 3d. 3x3 convolution -> 1x1 head (a segmentation net's last two layers): when the 3x3 runs on the weight-stationary kernel and the 1x1 is
+    // the only reader of its output, the 1x1 is one more MFMA on the output tile while it is still in registers (conv3x3_ws.hpp HEAD): the
+    // full-resolution intermediate tensor is neither written nor read.  U-Net 512^2 bs=16: 145 + 110 us -> one launch.
+    if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency) {
+        auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
+        for (size_t t = 0; t < steps_.size(); t++) {
+            Step& c = steps_[t];
+            if (c.op.kind != OpKind::Conv || c.stem || c.op.grid_h || c.op.residual >= 0 || c.pool_out >= 0 || c.has_pair || c.has_mb || c.op.kh != 3 || readers(c.op.output) != 1) continue;
+            const Value& ov = values_[c.op.output];
+            sm_conv_desc d{}; d.N = batch; d.H = d.Ho = ov.h; d.W = d.Wo = ov.w; d.Cin = c.op.cin; d.Cout = c.op.cout; d.kH = c.op.kh; d.kW = c.op.kw; d.sH = c.op.sh; d.sW = c.op.sw;
+            d.dH = c.op.dh; d.dW = c.op.dw; d.pt = c.op.pt; d.pl = c.op.pl; d.pb = c.op.pb; d.pr = c.op.pr; d.groups = c.op.groups; d.act = c.op.act; d.x_ups = c.op.x_ups ? 1 : 0;
+            for (size_t u = t + 1; u < steps_.size(); u++) {
+                Step& h = steps_[u];
+                if (h.op.inputs.empty() || h.op.inputs[0] != c.op.output) continue;
+                const Op& o = h.op;
+                if (o.kind != OpKind::Conv || o.kh != 1 || o.kw != 1 || o.sh != 1 || o.sw != 1 || o.pt || o.pl || o.pb || o.pr || o.groups != 1 || o.residual >= 0 || o.act > SM_ACT_PRELU || o.grid_h ||
+                    o.x_ups || h.has_pair || h.has_mb || h.pool_out >= 0 || o.cin != c.op.cout || !sm_conv2d_head_supported(&d, o.cout)) break;
+                c.has_head = true; c.head = std::move(h.op);
+                steps_.erase(steps_.begin() + u);
+                break;
+            }
+        }
+    }
+
     // ---- 4. memory plan ------------------------------------------------------------------------------------
     const int ns = (int)steps_.size();
     std::vector<int> first(nv, INT32_MAX), last(nv, -1);   // per ROOT value: live step interval
@@ -443,7 +467,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
         const int until = steps_[t].join >= 0 ? steps_[t].join : t;   // a side step may still be reading its operands at the join
         for (int u : op.inputs) { touch(u, t); touch(u, until); }
         if (op.residual >= 0) { touch(op.residual, t); touch(op.residual, until); }
-        if (steps_[t].has_mb) { touch(steps_[t].mb_proj.output, t); continue; }      // (the hidden tensors exist in LDS only; the residual is the step's own input)
+        if (steps_[t].has_mb) { touch(steps_[t].mb_proj.output, t); continue; }
+        if (steps_[t].has_head) { touch(steps_[t].head.output, t); continue; }             // (the 3x3 output exists in registers only)      // (the hidden tensors exist in LDS only; the residual is the step's own input)
         touch(op.output, t);
         if (steps_[t].has_pair) touch(steps_[t].pair.output, t);
         if (steps_[t].pool_out >= 0) touch(steps_[t].pool_out, t);
@@ -490,6 +515,13 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 flops_ += (st.mb_noexp ? 0.0 : 2.0 * Md * dv.c * 9.0) + 2.0 * Md * pv.c * (double)dv.c;         // (no expand layer: the depthwise layer is this step's own op, counted below)
                 alg_bytes_ += (st.mb_noexp ? 0.0 : 2.0 * ((double)st.M * op.cout + Md * dv.c + dv.c * 9.0)) + 2.0 * (Md * dv.c + Md * pv.c * (st.mb_proj.residual >= 0 ? 2.0 : 1.0) + (double)pv.c * dv.c);
             }
+            if (st.has_head) {
+                st.w2_off = off; off = alignUp(off + st.head.weight.size() * 2);
+                st.has_bias2 = !st.head.bias.empty();
+                if (st.has_bias2) { st.b2_off = off; off = alignUp(off + st.head.bias.size() * 4); }
+                flops_ += 2.0 * st.M * st.head.cout * (double)st.head.cin;
+                alg_bytes_ += 2.0 * ((double)st.M * st.head.cin + (double)st.M * st.head.cout + (double)st.head.cout * st.head.cin);      // (accounted as the layer the graph holds)
+            }
             if (st.has_pair) {
                 st.w2_off = off; off = alignUp(off + st.pair.weight.size() * 2);
                 st.has_bias2 = !st.pair.bias.empty();
@@ -523,6 +555,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         st.desc = buf;
         if (st.pool_out >= 0) { st.desc += " >> MaxPool 2x2/2 (same launch)"; alg_bytes_ += 2.0 * (double)(st.M / 4) * values_[st.pool_out].c; }
         if (st.has_pair) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.pair.name.c_str(), st.pair.cout, st.pair.cin, st.pair.act ? " +act" : ""); st.desc += buf; }
+        if (st.has_head) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.head.name.c_str(), st.head.cout, st.head.cin, st.head.act ? " +act" : ""); st.desc += buf; }
         if (st.has_mb && st.mb_noexp) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.act ? " +act" : ""); st.desc += buf; }
         else if (st.has_mb) { snprintf(buf, sizeof buf, " >> Conv %s k=3x3 s=%d g=%d%s >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.mb_dw.name.c_str(), st.mb_dw.sh, st.mb_dw.groups, st.mb_dw.act ? " +act" : "",
                                   st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.residual >= 0 ? " +res" : "", st.mb_proj.act ? " +act" : ""); st.desc += buf; }
@@ -532,6 +565,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     value_names_.resize(nv); for (int v = 0; v < nv; v++) value_names_[v] = values_[v].name;
     materialized_.clear(); materialized_.push_back(values_[input_value_].name);
     for (auto& st : steps_) {
+        if (st.has_head) { materialized_.push_back(values_[st.op.output].name); materialized_.push_back(values_[st.head.output].name); continue; }   // (rounded to fp16 in registers)
         if (st.has_mb) {   // (the two hidden tensors live in LDS only, but are rounded to fp16 there exactly as a stored tensor would be: listed for the parity oracle)
             if (!st.mb_noexp) materialized_.push_back(values_[st.op.output].name);
             materialized_.push_back(values_[st.mb_dw.output].name); materialized_.push_back(values_[st.mb_proj.output].name); continue;
@@ -565,6 +599,10 @@ int Executor::packWeights(std::vector<uint8_t>* host) const {
                 if (st.has_biasd) memcpy(host->data() + st.bd_off, st.mb_dw.bias.data(), st.mb_dw.bias.size() * 4);
                 sm_float_to_half(st.mb_proj.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.mb_proj.weight.size());
                 if (st.has_bias2) memcpy(host->data() + st.b2_off, st.mb_proj.bias.data(), st.mb_proj.bias.size() * 4);
+            }
+            if (st.has_head) {
+                sm_float_to_half(st.head.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.head.weight.size());
+                if (st.has_bias2) memcpy(host->data() + st.b2_off, st.head.bias.data(), st.head.bias.size() * 4);
             }
             if (st.has_pair) {
                 sm_float_to_half(st.pair.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.pair.weight.size());
@@ -619,7 +657,7 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     e->out_f32_count_ = std::max(sm_float_array_count(batch, ov.c, ov.h, ov.w), (size_t)batch * ov.c * ov.h * ov.w);
     SM_HIP_CHECK(hipMalloc((void**)&e->out_f32_, e->out_f32_count_ * 4));
     for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit(); st.pair.weight.clear(); st.pair.weight.shrink_to_fit();
-                                 st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
+                                 st.head.weight.clear(); st.head.weight.shrink_to_fit(); st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
     if (e->cfg_.autotune) {   // with an external arena and upload == 0 the caller filled it before compiling
         hipStream_t s; SM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         rc = e->autotune(s);
@@ -647,6 +685,9 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
                                  valuePtr(st.mb_proj.output), ss);
         }
         const sm_conv_desc d = convDesc(st);
+        if (st.has_head)
+            return sm_conv2d_head_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, nullptr, arena_ + st.w2_off,
+                                          st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr, st.head.cout, st.head.act, st.head.slope, valuePtr(st.head.output), valueLd(st.head.output), ss);
         if (st.pool_out >= 0)
             return sm_conv2d_pool_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, y,
                                           valuePtr(st.pool_out), valueLd(st.pool_out), ss);

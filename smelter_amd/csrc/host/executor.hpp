@@ -42,6 +42,9 @@ struct Step {                // one op after fusion, with everything resolved
     // inverted-residual block (executor.cpp pass 3c): this step is the 1x1 EXPAND; `mb_dw` (depthwise 3x3) and `mb_proj` (1x1 project, optional
     // residual = this step's input) run in the same launch (sm_mbconv_fwd) and the two hidden tensors are never materialised
     bool has_mb = false; Op mb_dw, mb_proj; size_t wd_off = 0, bd_off = 0; bool has_biasd = false;
+    // 3x3 convolution -> 1x1 "head" (executor.cpp pass 3d): `head` is the pointwise convolution that is the only reader of this step's output; it
+    // runs in the same launch (sm_conv2d_head_fwd_cfg; weights at w2_off / b2_off) and the 3x3 output is never stored
+    bool has_head = false; Op head;
     bool mb_noexp = false;   // the block has no expand layer: this step IS the depthwise convolution (mb_dw is a copy of it), mb_proj follows
     std::string desc;
 };

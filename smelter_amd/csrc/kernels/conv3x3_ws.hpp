@@ -52,7 +52,9 @@ constexpr int WS_DUMMY = 1024;                                        // LDS sin
 // 16-byte row-pair pixels — ((TH-1)s + 2(STEM-1) + 1) x ((TW-1)s + 8) of them — and the A fragment of k step ks of tap j is row-pair pixel
 // (ty*s + 2j, tx*s + 2ks + hi): lanes of a half-wave read 16 (s = 1) or 32 (s = 2) bytes apart, no swizzle needed or possible.
 // PSB = distance between the two patch buffers (0: as large as the weights allow) — small patches leave room for a second block per CU.
-template <int CIN, int NOUT, int NW, int TM, int NIC = (CIN == 64 ? 12 : 6), int ABL = 0, int STEM = 0, int PSB = 0>
+// HEAD: instantiated with the fused 1x1 head (p.y3) — a separate instantiation because the extra MFMA epilogue costs the plain kernels 30-40
+// registers (one resident block instead of two on the 64 -> 32 layers)
+template <int CIN, int NOUT, int NW, int TM, int NIC = (CIN == 64 ? 12 : 6), int ABL = 0, int STEM = 0, int PSB = 0, bool HEAD = false>
 __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     constexpr bool ST = STEM > 0;
     constexpr int NTAP = ST ? STEM : 9;
@@ -145,7 +147,39 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 outv[TN][TM][2];                                            // packed results of the PREVIOUS tile: [a][b][j] = couts a*32 + 16j + 8*hi .. +7 of pixel b
     int pn = 0, py0 = 0, px0 = 0; bool pending = false;
-    auto store_prev = [&]() {
+    auto store_prev = [&]() __attribute__((always_inline)) {          // (three call sites: left out of line, its captured arrays would live in scratch)
+        if constexpr (!ST && HEAD) {
+            // 1x1 head: outv[a][b][j] (couts a*32 + 16j + 8hi .. +7 of pixel lane & 31, already activated and rounded) IS the MFMA B fragment of
+            // k step 2a + j, so y3 = w3 . y costs NOUT/16 MFMAs per fragment and no memory; register 4q + r <-> head channel 8q + 4hi + r
+            if (p.y3) {
+                // A fragments of w3 [n3][NOUT] (row = lane & 31, zero beyond n3), one per 16 input channels: re-read per tile (L1-resident, <= 2 KB) so
+                // that layers without a head carry no registers for it
+                half8_t w3f[NOUT / 16];
+                const half8_t hz8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int ks = 0; ks < NOUT / 16; ks++) w3f[ks] = l31 < p.n3 ? *(const half8_t*)(p.w3 + l31 * NOUT + ks * 16 + hi * 8) : hz8;
+#pragma unroll
+                for (int b = 0; b < TM; b++) {
+                    floatx16 a3;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) a3[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < NOUT / 16; ks++) a3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3f[ks], __builtin_bit_cast(half8_t, outv[ks / 2][b][ks % 2]), a3, 0, 0, 0);
+                    const int oy = py0 + (int)(tyx[b] >> 16), ox = px0 + (int)(tyx[b] & 0xffff);
+                    if (oy < p.H && ox < p.W && (int)(tyx[b] >> 16) < TH) {
+                        half_t* dst = p.y3 + (((long)pn * p.H + oy) * p.W + ox) * p.y3_ld + 4 * hi;
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            if (8 * q < p.n3) {
+                                half4_t o;
+#pragma unroll
+                                for (int r = 0; r < 4; r++) { float v = a3[4 * q + r] + (p.b3 ? p.b3[8 * q + 4 * hi + r] : 0.f); o[r] = (half_t)(v < 0.f ? v * p.sl3 : v); }
+                                *(half4_t*)(dst + 8 * q) = o;
+                            }
+                    }
+                }
+            }
+        }
         if constexpr (TM == 2 && !ST) {
             // fused 2x2 / stride-2 max-pool of the output (p.y2; launcher: TW == 32, even H and W, so a wave's two fragments are image rows
             // 2k and 2k+1 of the SAME columns and lanes 2i, 2i+1 are neighbouring columns): max over the two fragments, then over the lane
@@ -170,7 +204,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
 #pragma unroll
         for (int b = 0; b < TM; b++) {
             const int oy = py0 + (int)(tyx[b] >> 16), ox = px0 + (int)(tyx[b] & 0xffff);
-            if (oy < OH && ox < OW && (int)(tyx[b] >> 16) < TH) {
+            if (p.y && oy < OH && ox < OW && (int)(tyx[b] >> 16) < TH) {
                 half_t* dst = p.y + (((long)pn * OH + oy) * OW + ox) * p.y_ld + 8 * hi;
 #pragma unroll
                 for (int a = 0; a < TN; a++)

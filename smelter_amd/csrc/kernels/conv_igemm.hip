@@ -45,6 +45,9 @@ struct ConvParams {
     // nine-tap patch kernel (conv3x3_p9.hpp): geometry chosen by p9_setup(); ups = the input is read through a fused nearest 2x upsampling
     int p9_TW, p9_tiles_per_band, p9_patch_bytes, p9_patch_px, ups;
     half_t* y2; int y2_ld;           // conv3x3_ws only: second output = 2x2 / stride-2 max-pool of y (nullptr = none)
+    // conv3x3_ws only: a 1x1 convolution applied to the output tile while it is still in registers ("head": w3 [n3][Cout] fp16, b3 fp32,
+    // y3 = act3(w3 . y + b3), n3 <= 32); y itself is stored only if p.y != nullptr
+    const half_t* w3; const float* b3; half_t* y3; int n3, y3_ld, act3; float sl3;
     unsigned p9_pw_mul, p9_pw_sh, p9_h2_mul, p9_h2_sh;
 };
 
@@ -694,6 +697,12 @@ const TileCfg kCfgs[] = {
     // 256x256 (kind 1): for layers with <= 256 such tiles (ResNet-50 layer 3, N = 1024: 196) one round of blocks moves half the L1 bytes of 128x128
     {256, 256, 1, 512, conv_igemm64_kernel<256, 256, 4, 2, 2, 0, 0, 0, 1, 1, true>, "k64w8:256x256(64x128)"},    // 87
     {256, 256, 1, 512, conv_igemm64_kernel<256, 256, 4, 2, 2, 0, 1, 0, 1, 1, true>, "k64w8i:256x256(64x128)"},   // 88
+    // kind 4 with the fused 1x1 head (sm_conv2d_head_fwd_cfg): separate instantiations, chosen only for launches that carry a head
+    {256, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 2, 12, 0, 0, 0, true>, "ws:64->64 w4x2 head"},     // 89
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 0, 0, 0, true>, "ws:64->32 w4x2 head"},     // 90
+    {256, 64, 4, 256, conv3x3_ws_kernel<32, 64, 4, 2, 6, 0, 0, 0, true>, "ws:32->64 w4x2 head"},      // 91
+    {256, 32, 4, 256, conv3x3_ws_kernel<32, 32, 4, 2, 6, 0, 0, 0, true>, "ws:32->32 w4x2 head"},      // 92
+    {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2, 6, 0, 0, 0, true>, "ws:32->32 w8x2 head"},      // 93
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
@@ -825,17 +834,19 @@ size_t p9_setup(ConvParams& p, const TileCfg& c) {
 // kind 2 = single LDS stage: only for K == 64 (one K tile)
 // kinds 1/2 (conv_igemm64.hpp): Cin % 64 == 0 and a tap mask of <= 32 bits
 bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
-    if (c.kind == 0) return p.y2 == nullptr;
+    if (c.kind == 0) return p.y2 == nullptr && p.y3 == nullptr;
     const bool same3x3 = p.kH == 3 && p.kW == 3 && p.sH == 1 && p.sW == 1 && p.dH == 1 && p.dW == 1 && p.pt == 1 && p.pl == 1 && p.Ho == p.H && p.Wo == p.W;
     if (c.kind == 4) {   // weight-stationary: the template's Cin / Cout exactly, no residual, dense 16-byte rows on both sides, ReLU family
         ConvParams q = p;
         const bool ok = same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
                ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && p.Cout == c.BN && ws_setup(q, c) > 0;
         // fused max-pool: two fragments per wave that are the image rows 2k, 2k+1 of one 32-pixel column band
+        if (ok && (p.y3 != nullptr) != (strstr(c.name, " head") != nullptr)) return false;      // head launches <-> head instantiations
+        if (ok && p.y3 && !(p.n3 > 0 && p.n3 <= 32 && (p.n3 & 7) == 0 && (p.y3_ld & 3) == 0 && ((((uintptr_t)p.y3) & 7) == 0) && ((((uintptr_t)p.w3) & 15) == 0) && p.act3 <= SM_ACT_PRELU && !p.y2)) return false;
         if (ok && p.y2) return c.BM / (c.threads / 64) == 64 && q.ws_TW == 32 && (q.ws_TH & 1) == 0 && (p.H & 1) == 0 && (p.W & 1) == 0 && (p.y2_ld & 7) == 0 && ((((uintptr_t)p.y2) & 15) == 0);
         return ok;
     }
-    if (p.y2) return false;                                          // only the weight-stationary kernel writes the pooled second output
+    if (p.y2 || p.y3) return false;                                  // only the weight-stationary kernel writes the pooled second output / applies a head
     if (c.kind == 7)     // persistent pointwise GEMM: 1x1, no padding, one square stride, dense 16-byte rows, ReLU family, bias vector beside the ring
         return p.kH == 1 && p.kW == 1 && p.pt == 0 && p.pl == 0 && p.sH == p.sW && (p.sH == 1 || p.sH == 2) && (p.Cin % 64) == 0 && !p.ups && !p.yplace &&
                p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
@@ -893,6 +904,7 @@ int fill_params(const sm_conv_desc* d, const void* x, const void* w, const float
     p->act = d->act; p->slope = d->act == SM_ACT_RELU ? 0.f : d->slope;
     p->M = d->N * d->Ho * d->Wo; p->K = d->kH * d->kW * (d->Cin / d->groups);
     p->splitk = 1; p->mt = p->nt = 0; p->ktiles_per_split = 0; p->ups = d->x_ups ? 1 : 0; p->y2 = nullptr; p->y2_ld = 0;
+    p->w3 = nullptr; p->b3 = nullptr; p->y3 = nullptr; p->n3 = 0; p->y3_ld = 0; p->act3 = 0; p->sl3 = 0.f;
     SM_REQUIRE(!d->x_ups || ((d->H & 1) == 0 && (d->W & 1) == 0 && d->groups == 1), "sm_conv2d_fwd: x_ups needs even H and W");
     SM_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "sm_conv2d_fwd: more than 2^31 output pixels");
     SM_REQUIRE((long)d->N * d->H * d->W < (1L << 31) - (1L << 24), "sm_conv2d_fwd: more than 2^31 input pixels");
@@ -1080,6 +1092,28 @@ int sm_conv2d_pool_supported(const sm_conv_desc* d) {
     alignas(16) static char dummy[16];
     ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
     p.y2 = (half_t*)dummy; p.y2_ld = d->Cout;
+    for (int i = 0; i < kNumCfgs; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) return 1;
+    return 0;
+}
+
+// 3x3 / stride 1 / pad 1 convolution (Cin, Cout in {32, 64}) followed by a 1x1 convolution to n3 <= 32 channels, one launch: the 3x3 output
+// tile (bias, activation, rounded to fp16 as the stored tensor would be) is the B operand of one more MFMA while it is still in registers.
+// y == nullptr: the 3x3 output is not stored at all (it has no other reader).
+int sm_conv2d_head_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w, const float* bias, void* y, const void* w3, const float* b3, int32_t n3,
+                           int32_t act3, float slope3, void* y3, int32_t y3_ld, sm_stream_t stream) {
+    SM_REQUIRE(w3 && y3 && n3 > 0, "sm_conv2d_head_fwd_cfg: null head operand");
+    ConvParams p; int rc = fill_params(d, x, w, bias, nullptr, y ? y : y3, &p); if (rc) return rc;
+    if (!y) p.y = nullptr;
+    p.w3 = (const half_t*)w3; p.b3 = b3; p.y3 = (half_t*)y3; p.n3 = n3; p.y3_ld = y3_ld ? y3_ld : n3; p.act3 = act3; p.sl3 = act3 == SM_ACT_RELU ? 0.f : act3 == SM_ACT_NONE ? 1.f : slope3;
+    if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) cfg = i; }
+    if (cfg < 0) { sm_set_error("sm_conv2d_head_fwd_cfg: no kernel takes this shape with a fused 1x1 head (3x3 / s1 / p1, Cin, Cout in {32, 64}, n3 <= 32, n3 %% 8 == 0)"); return SM_ERR_INVALID_ARGUMENT; }
+    return launch(d, p, cfg, nullptr, 0, sm_s(stream));
+}
+int sm_conv2d_head_supported(const sm_conv_desc* d, int32_t n3) {
+    if (!d) return 0;
+    alignas(16) static char dummy[16];
+    ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
+    p.w3 = (const half_t*)dummy; p.y3 = (half_t*)dummy; p.n3 = n3; p.y3_ld = n3;
     for (int i = 0; i < kNumCfgs; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) return 1;
     return 0;
 }

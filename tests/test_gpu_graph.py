@@ -106,6 +106,7 @@ def test_unet_fuses_upsample_and_maxpool_into_their_convolutions():
     descs = [ex.opDesc(i) for i in range(ex.numOps)]
     assert sum("+ups2x" in d for d in descs) == 4 and not any(d.startswith("Upsample") for d in descs)
     assert sum(">> MaxPool" in d for d in descs) == 2             # the 32- and 64-channel levels (weight-stationary kernel); deeper levels keep their pool launch
+    assert sum(">> Conv" in d and "k=1x1" in d and "(same launch)" in d for d in descs) == 1      # pass 3d: the last 3x3 and the 1x1 head behind it
     _, plain = run_hip(model, x, fuse=False, useHipGraph=False)
     assert nerr(got, plain) <= 2e-3
 

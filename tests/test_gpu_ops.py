@@ -56,7 +56,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg", [None] + list(range(92)))
+@pytest.mark.parametrize("cfg", [None] + list(range(96)))
 def test_conv2d(case, cfg):
     n, hh, ww, cin, cout, k, s, p, res, act = case
     if cfg is not None and (cin % 8 or cfg >= ops.num_conv_configs() or (cfg >= 6 and cin % 64)):
@@ -117,7 +117,7 @@ def test_pointwise_thin_kernel(cin, cout, res, act, monkeypatch):
     assert_close(to_host(y), ref, cin)
 
 
-@pytest.mark.parametrize("cfg", list(range(92)))
+@pytest.mark.parametrize("cfg", list(range(96)))
 def test_conv2d_generic_epilogue_every_config(cfg):
     """Tanh is not a ReLU-family activation, so every kernel takes its GENERIC epilogue (bias-initialised accumulators, per-element
     activation) instead of the straight-line fast path the ResNet cases exercise; Cin % 64 == 0 so that all BK=64 configs apply.
@@ -155,7 +155,7 @@ def test_conv2d_split_k_workspace():
     assert_close(to_host(y), O.conv2d(x, w, b), cin)
 
 
-@pytest.mark.parametrize("cfg", list(range(92)))
+@pytest.mark.parametrize("cfg", list(range(96)))
 def test_conv2d_split_k_every_config(cfg):
     """few tiles + long K + a workspace: the launcher splits K across blocks (fp32 partials + reduce kernel) for every tile config
     that has a split-K form; residual + ReLU are then applied by the reduce kernel"""
@@ -722,3 +722,37 @@ def test_persistent_pointwise_kernel_into_a_channel_slice():
     ref = np.maximum(O.conv2d(x, w, b), 0)
     assert_close(to_host(out.contiguous()), ref, cin)
     assert (big[..., :32] == 7).all() and (big[..., 96:] == 7).all()
+
+
+@pytest.mark.parametrize("n,hw,cin,cout,n3,act3,store_y", [
+    (2, (64, 64), 32, 32, 8, 0, False),      # U-Net's last two layers: 3x3 32->32 + ReLU -> 1x1 32->8, the 3x3 output not stored
+    (1, (40, 96), 64, 32, 16, 1, True),      # both outputs stored, ReLU on the head
+    (2, (24, 36), 64, 64, 32, 2, False),     # four k steps of head input, 32 head channels, PReLU, ragged tiles
+    (1, (16, 32), 32, 64, 24, 0, True),      # 24 head channels (three groups of 8)
+])
+@pytest.mark.parametrize("cfg", [-1, 89, 90, 91, 92, 93])
+def test_conv3x3_with_fused_pointwise_head(n, hw, cin, cout, n3, act3, store_y, cfg):
+    """sm_conv2d_head_fwd_cfg: y (when stored) bit-identical to the plain launch, y3 == the 1x1 convolution of the ROUNDED y (the stored tensor's
+    values), i.e. what the two separate launches compute"""
+    rng = np.random.default_rng(cin + cout + n3)
+    x = h(rng.standard_normal((n, cin, hw[0], hw[1])))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * np.sqrt(2.0 / (cin * 9))); b = rng.standard_normal(cout).astype(np.float32)
+    w3 = h(rng.standard_normal((n3, 1, 1, cout)) * np.sqrt(1.0 / cout)); b3 = rng.standard_normal(n3).astype(np.float32)
+    slope3 = 0.25 if act3 == 2 else 0.0
+    from smelter_amd._native import SmelterError
+    xd, wd, bd = to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda()
+    try:
+        y, y3 = ops.conv2d_head(xd, wd, bd, torch.from_numpy(w3).cuda().half(), torch.from_numpy(b3).cuda(), act3=act3, slope3=slope3, cfg=cfg, store_y=store_y)
+    except SmelterError as e:
+        if cfg >= 0 and "does not apply" in e.detail:
+            pytest.skip(e.detail)
+        raise
+    yplain = ops.conv2d(xd, wd, bd, pads=(1, 1, 1, 1), act=1)
+    if store_y:
+        assert torch.equal(y, yplain)
+    z = ops.conv2d(yplain, torch.from_numpy(w3).cuda().half(), torch.from_numpy(b3).cuda(), act=act3, slope=slope3)      # the separate second launch
+    assert torch.equal(y3, z)
+    ref = O.conv2d(to_host(yplain), w3, b3)
+    if act3:
+        ref = np.where(ref >= 0, ref, ref * slope3)
+    assert_close(to_host(y3), ref, cout)
