@@ -773,6 +773,7 @@ int Executor::convertInput(hipStream_t s, const float* in) const {
 }
 
 int Executor::launchAll(hipStream_t s, const float* in) const {
+    static const bool debug_sync = getenv("SMELTER_DEBUG_SYNC") != nullptr;   // debugging switch, read once
     int rc = convertInput(s, in);
     if (rc) return rc;
     for (auto& st : steps_) {
@@ -785,6 +786,10 @@ int Executor::launchAll(hipStream_t s, const float* in) const {
         }
         if (st.waits_side && side_) SM_HIP_CHECK(hipStreamWaitEvent(s, ev_join_, 0));
         rc = launchStep(st, s); if (rc) return rc;
+        if (debug_sync && !cfg_.useHipGraph) {                  // fault localisation: name the step before its kernel's fault aborts the process
+            fprintf(stderr, "[sync] %s\n", st.desc.c_str()); fflush(stderr);
+            SM_HIP_CHECK(hipStreamSynchronize(s));
+        }
     }
     return SM_OK;
 }

@@ -1081,6 +1081,7 @@ int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void*
 // 3x3 convolution + the 2x2 / stride-2 max-pool of its output in one launch (both tensors are written: the U-Net's skip + pooled pair)
 int sm_conv2d_pool_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w, const float* bias, void* y, void* y_pool, int32_t pool_ld, sm_stream_t stream) {
     SM_REQUIRE(y_pool, "sm_conv2d_pool_fwd_cfg: null pooled output");
+    SM_REQUIRE(d && d->groups == 1, "sm_conv2d_pool_fwd_cfg: grouped convolutions have no fused max-pool");
     ConvParams p; int rc = fill_params(d, x, w, bias, nullptr, y, &p); if (rc) return rc;
     p.y2 = (half_t*)y_pool; p.y2_ld = pool_ld ? pool_ld : d->Cout;
     if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) cfg = i; }
@@ -1088,7 +1089,7 @@ int sm_conv2d_pool_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const 
     return launch(d, p, cfg, nullptr, 0, sm_s(stream));
 }
 int sm_conv2d_pool_supported(const sm_conv_desc* d) {
-    if (!d) return 0;
+    if (!d || d->groups != 1) return 0;
     alignas(16) static char dummy[16];
     ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
     p.y2 = (half_t*)dummy; p.y2_ld = d->Cout;
@@ -1102,6 +1103,7 @@ int sm_conv2d_pool_supported(const sm_conv_desc* d) {
 int sm_conv2d_head_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w, const float* bias, void* y, const void* w3, const float* b3, int32_t n3,
                            int32_t act3, float slope3, void* y3, int32_t y3_ld, sm_stream_t stream) {
     SM_REQUIRE(w3 && y3 && n3 > 0, "sm_conv2d_head_fwd_cfg: null head operand");
+    SM_REQUIRE(d && d->groups == 1, "sm_conv2d_head_fwd_cfg: grouped convolutions have no fused head");   // (launch() would route a depthwise layer past the head kernels)
     ConvParams p; int rc = fill_params(d, x, w, bias, nullptr, y ? y : y3, &p); if (rc) return rc;
     if (!y) p.y = nullptr;
     p.w3 = (const half_t*)w3; p.b3 = b3; p.y3 = (half_t*)y3; p.n3 = n3; p.y3_ld = y3_ld ? y3_ld : n3; p.act3 = act3; p.sl3 = act3 == SM_ACT_RELU ? 0.f : act3 == SM_ACT_NONE ? 1.f : slope3;
@@ -1110,7 +1112,7 @@ int sm_conv2d_head_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const 
     return launch(d, p, cfg, nullptr, 0, sm_s(stream));
 }
 int sm_conv2d_head_supported(const sm_conv_desc* d, int32_t n3) {
-    if (!d) return 0;
+    if (!d || d->groups != 1) return 0;
     alignas(16) static char dummy[16];
     ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
     p.w3 = (const half_t*)dummy; p.y3 = (half_t*)dummy; p.n3 = n3; p.y3_ld = n3;

@@ -285,3 +285,15 @@ def test_matmul_weight_is_packed_transposed_to_out_in():
     b.add_output(b.add_node("MatMul", ["input", b.add_init("w", w)]), [1, 4])
     arena = ONNXGraph(b.to_model()).packWeights(1)
     assert np.array_equal(arena[:48].view(np.float16).astype(np.float32).reshape(4, 6), w.T)   # MPSCNNFullyConnected weights are [out, in]
+
+
+def test_fused_pool_and_head_predicates_reject_grouped_convolutions():
+    """sm_conv2d_pool_supported / sm_conv2d_head_supported are host-only predicates the planner (executor passes 3a / 3d) relies on: a depthwise
+    3x3 with 32 channels has the weight-stationary kernel's Cin / Cout but must not be taken (it runs on the depthwise kernel, which has no second output)"""
+    L = N.lib()
+    L.sm_conv2d_head_supported.argtypes = [C.c_void_p, C.c_int32]
+    L.sm_conv2d_pool_supported.argtypes = [C.c_void_p]
+    for groups, want in ((1, 1), (32, 0)):
+        d = N.ConvDesc(2, 64, 64, 32, 32, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, groups, 64, 64, 1, 0.0, 32, 32, 0)
+        assert L.sm_conv2d_head_supported(C.byref(d), 16) == want
+        assert L.sm_conv2d_pool_supported(C.byref(d)) == want
