@@ -116,6 +116,15 @@ int sm_conv2d_head_supported(const sm_conv_desc* d, int32_t n3);
 int sm_conv2d_head_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias, void* y, const void* w3,
                            const float* b3, int32_t n3, int32_t act3, float slope3, void* y3, int32_t y3_ld, sm_stream_t stream);
 
+/* ConvolutionConverter (Converters.swift:253) x 2 + the MPSNNAdditionNode (:440) and MPSCNNNeuronReLUNode (:351) behind them — the last two
+ * layers of a ResNet bottleneck block: 3x3 / stride 1 / pad 1 convolution (Cin = Cout = 64) -> 1x1 convolution to n3 = 32 .. 256 channels
+ * (n3 % 32 == 0) + optional residual `res3` ([N,H,W,n3] fp16, row stride res3_ld) + activation, ONE launch:
+ * y3 = act3((w3 . act(conv3x3(x)) + b3) + res3), the 3x3 output rounded to fp16 exactly as the stored tensor would be.  y may be NULL. */
+int sm_conv2d_xhead_supported(const sm_conv_desc* d, int32_t n3, int32_t has_res);
+int sm_conv2d_xhead_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias, void* y, const void* w3,
+                            const float* b3, int32_t n3, int32_t act3, float slope3, const void* res3, int32_t res3_ld, void* y3, int32_t y3_ld,
+                            sm_stream_t stream);
+
 /* Two MPSCNNConvolutionNodes in a row, both 1x1 / stride 1 (Converters.swift:253), in ONE launch:
  *   y = act(x * w1 + bias1 + residual)   [d: Cin = 64 -> Cout = 256]      z = act2(y * w2 + bias2)   [256 -> N2 in {64, 128}]
  * Both tensors are stored (y is the next residual); y is rounded to fp16 once, exactly as the separate launches would store it.

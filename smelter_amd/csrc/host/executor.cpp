@@ -387,7 +387,11 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 const Value& iv = values_[e.op.inputs[0]]; const Value& ov = values_[pj.output];
                 sm_mbconv_desc d{}; d.N = batch; d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.stride = dw.sh; d.Cin = e.op.cin; d.Ch = e.op.cout; d.Cout = pj.cout; d.expand = 1;
                 d.residual = pj.residual >= 0 ? 1 : 0; d.act1 = e.op.act; d.act2 = dw.act; d.act3 = pj.act;
-                if (d.Cin > 32 || d.Ch > 192 || d.Cout > 64 || !sm_mbconv_supported(&d)) continue;
+                // (experiment switch: SMELTER_MBCONV_DOMAIN="cin,ch,cout" widens / narrows the domain; "32,192,64" = the all-in-LDS kernel's only)
+                const char* dom_env = getenv("SMELTER_MBCONV_DOMAIN");
+                int max_cin = 96, max_ch = 576, max_cout = 160;
+                if (dom_env) sscanf(dom_env, "%d,%d,%d", &max_cin, &max_ch, &max_cout);
+                if (d.Cin > max_cin || d.Ch > max_ch || d.Cout > max_cout || !sm_mbconv_supported(&d)) continue;
                 e.has_mb = true; e.mb_dw = steps_[ud].op; e.mb_proj = steps_[up].op;
                 steps_.erase(steps_.begin() + up); steps_.erase(steps_.begin() + ud);
             }
@@ -425,9 +429,37 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 Step& h = steps_[u];
                 if (h.op.inputs.empty() || h.op.inputs[0] != c.op.output) continue;
                 const Op& o = h.op;
-                if (o.kind != OpKind::Conv || o.kh != 1 || o.kw != 1 || o.sh != 1 || o.sw != 1 || o.pt || o.pl || o.pb || o.pr || o.groups != 1 || o.residual >= 0 || o.act > SM_ACT_PRELU || o.grid_h ||
-                    o.x_ups || h.has_pair || h.has_mb || h.pool_out >= 0 || o.cin != c.op.cout || !sm_conv2d_head_supported(&d, o.cout)) break;
-                c.has_head = true; c.head = std::move(h.op);
+                if (o.kind != OpKind::Conv || o.kh != 1 || o.kw != 1 || o.sh != 1 || o.sw != 1 || o.pt || o.pl || o.pb || o.pr || o.groups != 1 || o.act > SM_ACT_PRELU || o.grid_h ||
+                    o.x_ups || h.has_pair || h.has_mb || h.pool_out >= 0 || o.cin != c.op.cout) break;
+                // narrow head without residual: the HEAD instantiations; a bottleneck's tail (1x1 expand to <= 256 channels + block input + ReLU): the
+                // expand head (conv3x3_ws.hpp HX), SMELTER_XHEAD=0 keeps the two launches
+                const bool xhead_on = !(getenv("SMELTER_XHEAD") && getenv("SMELTER_XHEAD")[0] == '0');      // (plan time, not the launch path)
+                const bool narrow = o.residual < 0 && sm_conv2d_head_supported(&d, o.cout);
+                if (!narrow && !(xhead_on && sm_conv2d_xhead_supported(&d, o.cout, o.residual >= 0 ? 1 : 0))) break;
+                if (o.residual >= 0) {
+                    // the head runs where the 3x3 runs, so its residual operand has to exist by then: a producer between the two steps (the projection
+                    // shortcut of a first block) moves in front of the 3x3 when its own operands allow it
+                    auto producer = [&](int v) -> long {
+                        for (size_t q = 0; q < steps_.size(); q++)
+                            if (steps_[q].op.output == v || steps_[q].pool_out == v || (steps_[q].has_pair && steps_[q].pair.output == v) || (steps_[q].has_mb && steps_[q].mb_proj.output == v) ||
+                                (steps_[q].has_head && steps_[q].head.output == v)) return (long)q;
+                        return -1L;
+                    };
+                    const long pr = producer(rootOf(o.residual));
+                    if (pr > (long)u) break;
+                    if (pr > (long)t) {
+                        const Step& ps = steps_[pr];
+                        bool movable = !ps.has_pair && ps.pool_out < 0 && !ps.has_mb && !ps.has_head && ps.op.output == rootOf(o.residual);
+                        for (int v : ps.op.inputs) { const long q = producer(rootOf(v)); if (q >= (long)t) movable = false; }
+                        if (ps.op.residual >= 0 && producer(rootOf(ps.op.residual)) >= (long)t) movable = false;
+                        if (!movable) break;
+                        Step moved = std::move(steps_[pr]);
+                        steps_.erase(steps_.begin() + pr); steps_.insert(steps_.begin() + t, std::move(moved));
+                        t++;                                           // (c and h are re-fetched below: the vector moved)
+                    }
+                }
+                Step& c2 = steps_[t]; Step& h2 = steps_[u];
+                c2.has_head = true; c2.head = std::move(h2.op);
                 steps_.erase(steps_.begin() + u);
                 break;
             }
@@ -468,7 +500,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         for (int u : op.inputs) { touch(u, t); touch(u, until); }
         if (op.residual >= 0) { touch(op.residual, t); touch(op.residual, until); }
         if (steps_[t].has_mb) { touch(steps_[t].mb_proj.output, t); continue; }
-        if (steps_[t].has_head) { touch(steps_[t].head.output, t); continue; }             // (the 3x3 output exists in registers only)      // (the hidden tensors exist in LDS only; the residual is the step's own input)
+        if (steps_[t].has_head) { touch(steps_[t].head.output, t); if (steps_[t].head.residual >= 0) touch(steps_[t].head.residual, t); continue; }             // (the 3x3 output exists in registers only)      // (the hidden tensors exist in LDS only; the residual is the step's own input)
         touch(op.output, t);
         if (steps_[t].has_pair) touch(steps_[t].pair.output, t);
         if (steps_[t].pool_out >= 0) touch(steps_[t].pool_out, t);
@@ -520,7 +552,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 st.has_bias2 = !st.head.bias.empty();
                 if (st.has_bias2) { st.b2_off = off; off = alignUp(off + st.head.bias.size() * 4); }
                 flops_ += 2.0 * st.M * st.head.cout * (double)st.head.cin;
-                alg_bytes_ += 2.0 * ((double)st.M * st.head.cin + (double)st.M * st.head.cout + (double)st.head.cout * st.head.cin);      // (accounted as the layer the graph holds)
+                alg_bytes_ += 2.0 * ((double)st.M * st.head.cin + (double)st.M * st.head.cout * (st.head.residual >= 0 ? 2 : 1) + (double)st.head.cout * st.head.cin);      // (accounted as the layer the graph holds)
             }
             if (st.has_pair) {
                 st.w2_off = off; off = alignUp(off + st.pair.weight.size() * 2);
@@ -555,7 +587,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         st.desc = buf;
         if (st.pool_out >= 0) { st.desc += " >> MaxPool 2x2/2 (same launch)"; alg_bytes_ += 2.0 * (double)(st.M / 4) * values_[st.pool_out].c; }
         if (st.has_pair) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.pair.name.c_str(), st.pair.cout, st.pair.cin, st.pair.act ? " +act" : ""); st.desc += buf; }
-        if (st.has_head) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.head.name.c_str(), st.head.cout, st.head.cin, st.head.act ? " +act" : ""); st.desc += buf; }
+        if (st.has_head) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.head.name.c_str(), st.head.cout, st.head.cin, st.head.residual >= 0 ? " +res" : "", st.head.act ? " +act" : ""); st.desc += buf; }
         if (st.has_mb && st.mb_noexp) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.act ? " +act" : ""); st.desc += buf; }
         else if (st.has_mb) { snprintf(buf, sizeof buf, " >> Conv %s k=3x3 s=%d g=%d%s >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.mb_dw.name.c_str(), st.mb_dw.sh, st.mb_dw.groups, st.mb_dw.act ? " +act" : "",
                                   st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.residual >= 0 ? " +res" : "", st.mb_proj.act ? " +act" : ""); st.desc += buf; }
@@ -685,6 +717,11 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
                                  valuePtr(st.mb_proj.output), ss);
         }
         const sm_conv_desc d = convDesc(st);
+        if (st.has_head && (st.head.residual >= 0 || st.head.cout > 32))
+            return sm_conv2d_xhead_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, nullptr, arena_ + st.w2_off,
+                                           st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr, st.head.cout, st.head.act, st.head.slope,
+                                           st.head.residual >= 0 ? valuePtr(st.head.residual) : nullptr, st.head.residual >= 0 ? valueLd(st.head.residual) : 0,
+                                           valuePtr(st.head.output), valueLd(st.head.output), ss);
         if (st.has_head)
             return sm_conv2d_head_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, nullptr, arena_ + st.w2_off,
                                           st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr, st.head.cout, st.head.act, st.head.slope, valuePtr(st.head.output), valueLd(st.head.output), ss);

@@ -54,23 +54,32 @@ constexpr int WS_DUMMY = 1024;                                        // LDS sin
 // PSB = distance between the two patch buffers (0: as large as the weights allow) — small patches leave room for a second block per CU.
 // HEAD: instantiated with the fused 1x1 head (p.y3) — a separate instantiation because the extra MFMA epilogue costs the plain kernels 30-40
 // registers (one resident block instead of two on the 64 -> 32 layers)
-template <int CIN, int NOUT, int NW, int TM, int NIC = (CIN == 64 ? 12 : 6), int ABL = 0, int STEM = 0, int PSB = 0, bool HEAD = false>
+// HX: the EXPAND head (ResNet bottleneck tail): y3 = act3(w3 . y + b3 + res3) with n3 = 32 .. 256 channels.  w3 [n3][NOUT] and b3 live in LDS
+// beside the 3x3 weights (the launcher shrinks the tiles accordingly), the residual rows of a tile are requested when its k loop starts and
+// consumed with the deferred stores one tile later (TM = 1: 64 registers), so neither the 3x3 output nor any operand latency is exposed.
+constexpr int WS_HX_N3 = 256;                                         // LDS is reserved for this many head channels
+constexpr int ws_hx_bytes(int nout) { return WS_HX_N3 * nout * 2 + WS_HX_N3 * 4; }
+template <int CIN, int NOUT, int NW, int TM, int NIC = (CIN == 64 ? 12 : 6), int ABL = 0, int STEM = 0, int PSB = 0, bool HEAD = false, bool HX = false>
 __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     constexpr bool ST = STEM > 0;
     constexpr int NTAP = ST ? STEM : 9;
     static_assert(!ST || (CIN == 64 && STEM <= 4), "stem form: 64 = 8 row-pair pixels x 8 halfs");
+    static_assert(!HX || (!ST && !HEAD && TM == 1 && NOUT == 64), "expand head: plain form, one fragment per wave");
     constexpr int NT = NW * 64, CP = CIN / 8, TN = NOUT / 32, KS = CIN / 16;
     constexpr int ROWB = CP * 16;                                     // bytes per pixel / per weight row of one tap
     constexpr int W_BYTES = NTAP * NOUT * ROWB, BIAS_BYTES = NOUT * 4;
+    constexpr int HX_BYTES = HX ? ws_hx_bytes(NOUT) : 0, CP3 = NOUT / 8, ROWB3 = NOUT * 2, HXC = WS_HX_N3 / 32;
     static_assert(TN >= 1 && TN <= 2 && TM >= 1 && TM <= 4, "wave tile");
     extern __shared__ __attribute__((aligned(16))) unsigned char ws_smem[];
     unsigned char* const wl = ws_smem;                                // weights [tap][cout][CP chunks], chunk c of row n stored at c ^ swz(n)
     float* const bl = (float*)(ws_smem + W_BYTES);
-    unsigned char* const dummy = ws_smem + W_BYTES + BIAS_BYTES;
+    unsigned char* const w3l = ws_smem + W_BYTES + BIAS_BYTES;       // HX: head weights [n3][CP3 chunks], same swizzle; then the head bias
+    float* const b3l = (float*)(w3l + WS_HX_N3 * ROWB3);
+    unsigned char* const dummy = ws_smem + W_BYTES + BIAS_BYTES + HX_BYTES;
     unsigned char* const patch0 = dummy + WS_DUMMY;
     // the second patch buffer sits a COMPILE-TIME distance behind the first, so that the buffer choice is an instruction offset of the
     // fragment reads (ds_read offset field: 16 bits), not an address computation
-    constexpr int WS_PSTRIDE = PSB ? PSB : ws_pstride(W_BYTES + BIAS_BYTES + WS_DUMMY);
+    constexpr int WS_PSTRIDE = PSB ? PSB : ws_pstride(W_BYTES + BIAS_BYTES + HX_BYTES + WS_DUMMY);
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -91,6 +100,14 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
             SM_GLDS16(p.w + (long)n * (NTAP * CIN) + tap * CIN + ((c ^ ws_swz<CP>(n)) << 3), wl + s0 * 16);
         }
         for (int i = tid; i < NOUT; i += NT) bl[i] = p.bias ? p.bias[i] : 0.f;
+        if constexpr (HX) {
+#pragma unroll 1
+            for (int s0 = wave * 64; s0 < p.n3 * CP3; s0 += NT) {     // (n3 % 32 == 0: whole wave instructions)
+                const int s = s0 + lane, row = s / CP3, c = s & (CP3 - 1);
+                SM_GLDS16(p.w3 + (long)row * NOUT + ((c ^ ws_swz<CP3>(row)) << 3), w3l + s0 * 16);
+            }
+            for (int i = tid; i < p.n3; i += NT) b3l[i] = p.b3 ? p.b3[i] : 0.f;
+        }
     }
     // ---- per-thread patch DMA descriptors: slot s = i*NT + tid -> (patch row, patch column, source chunk) ---------------
     int rel[NIC]; unsigned prpc[NIC];
@@ -147,7 +164,106 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 outv[TN][TM][2];                                            // packed results of the PREVIOUS tile: [a][b][j] = couts a*32 + 16j + 8*hi .. +7 of pixel b
     int pn = 0, py0 = 0, px0 = 0; bool pending = false;
+    u32x4 rres[HX ? TM : 1][HX ? HXC : 1][2];                         // HX: residual rows of the PREVIOUS tile, [b][c][j] = head channels 32c + 16j + 8hi .. +7 of pixel b
+    const unsigned char* const aw3 = w3l + l31 * ROWB3;               // HX: A fragment of head row 32c + l31 = aw3 + c*32*ROWB3 + (((2ks + hi) ^ sw3) << 4)
+    const int sw3 = ws_swz<CP3>(l31);                                 // (rows 32c + l31: the key does not depend on c)
+    // HX addresses its two streams through buffer descriptors: a dead lane (pixel outside the image / the tile) carries an offset beyond
+    // num_records, so its loads return 0 and its stores are dropped — no branch anywhere in the head epilogue (one scheduling region
+    // for all chunks: the MFMAs of one chunk run beside the VALU work of its neighbours).  Launcher: both tensors < 2 GB.
+    constexpr unsigned HX_DEAD = 0x80000000u;
+    __amdgpu_buffer_rsrc_t rs_y3, rs_r3;
+    if constexpr (HX) {
+        const unsigned pix_all = (unsigned)p.N * (unsigned)p.H * (unsigned)p.W;
+        rs_y3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.y3, 0, (int)(pix_all * (unsigned)p.y3_ld * 2u), 0x00020000);
+        rs_r3 = __builtin_amdgcn_make_buffer_rsrc((void*)p.res3, 0, p.res3 ? (int)(pix_all * (unsigned)p.res3_ld * 2u) : 0, 0x00020000);
+    }
+    // one-hot A fragments: E_j[r][k] = (r == 16j + k), so that mfma(E_j, R_j, acc) adds the residual rows R_j (which arrive in the B layout:
+    // 8 consecutive channels per lane) to the accumulator tile — exact (1.0 x fp16, one nonzero product per element)
+    half8_t onehot[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int i = 0; i < 8; i++) onehot[j][i] = (half_t)((HX && l31 == 16 * j + 8 * hi + i) ? 1.f : 0.f);
+    auto load_res = [&](int n, int y0, int x0) __attribute__((always_inline)) {
+        if constexpr (HX) {
+#pragma unroll
+            for (int b = 0; b < TM; b++) {
+                const int oy = y0 + (int)(tyx[b] >> 16), ox = x0 + (int)(tyx[b] & 0xffff);
+                const bool live = oy < p.H && ox < p.W && (int)(tyx[b] >> 16) < TH;
+                const unsigned off = (live && !(p.hx_dbg & 2)) ? (unsigned)(((n * p.H + oy) * p.W + ox) * p.res3_ld + 8 * hi) * 2u : HX_DEAD;
+#pragma unroll
+                for (int c = 0; c < HXC; c++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        rres[b][c][j] = c * 32 < p.n3 ? __builtin_amdgcn_raw_buffer_load_b128(rs_r3, (int)(off + (unsigned)(c * 64 + 32 * j)), 0, 0) : u32x4{0, 0, 0, 0};   // (wave-uniform select)
+            }
+        }
+    };
+    auto hx_store = [&](auto relu0c) __attribute__((always_inline)) {
+        // expand head: outv[a][b][j] is the MFMA B fragment of k step 2a + j (see HEAD below); per 32 head channels 4 MFMAs, + the
+        // residual (two one-hot MFMAs), + b3 in fp32, activation, one rounding, lane swaps, 16-byte stores.
+        constexpr bool RELU0 = decltype(relu0c)::value;               // slope 0: ReLU as a packed fp16 max after the rounding (max commutes with it)
+#pragma unroll
+        for (int b = 0; b < TM; b++) {
+            const int oy = py0 + (int)(tyx[b] >> 16), ox = px0 + (int)(tyx[b] & 0xffff);
+            const bool live = oy < p.H && ox < p.W && (int)(tyx[b] >> 16) < TH;
+            const unsigned off = (live && !(p.hx_dbg & 1)) ? (unsigned)(((pn * p.H + oy) * p.W + ox) * p.y3_ld + 8 * hi) * 2u : HX_DEAD;
+            // four chunks (128 head channels) at a time: their MFMA chains are independent, so the matrix pipe never waits for its own result
+            // and the VALU work of one chunk runs under the MFMAs of the others (one wave per SIMD: nothing else would fill the gaps)
+#pragma unroll
+            for (int g = 0; g < HXC / 4; g++) {
+                if (g * 128 < p.n3 && !(p.hx_dbg & 4)) {              // wave-uniform (n3 = 256: both groups)
+                    floatx16 a3[4];
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) a3[cc][r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < NOUT / 16; ks++)
+#pragma unroll
+                        for (int cc = 0; cc < 4; cc++) {
+                            const half8_t wf = *(const half8_t*)(aw3 + (g * 4 + cc) * 32 * ROWB3 + (((ks * 2 + hi) ^ sw3) << 4));
+                            a3[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(half8_t, outv[ks / 2][b][ks % 2]), a3[cc], 0, 0, 0);
+                        }
+                    // (no residual: the rows were loaded through an empty descriptor and are 0 — adding them is exact, and cheaper than a branch here.
+                    //  The bias is added AFTER the residual, on the way out of the accumulators: between the two MFMA groups it would cost a round
+                    //  trip of all 64 accumulator registers through the VALU; without a residual the result is still the tiled kernels' acc + bias.)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int cc = 0; cc < 4; cc++) a3[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(onehot[j], __builtin_bit_cast(half8_t, rres[b][g * 4 + cc][j]), a3[cc], 0, 0, 0);
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) {
+                        const int c = g * 4 + cc;
+                        unsigned d[4][2];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const floatx4 bq = *(const floatx4*)(b3l + c * 32 + 8 * q + 4 * hi);
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; h2++) {
+                                float v0 = a3[cc][4 * q + 2 * h2] + bq[2 * h2], v1 = a3[cc][4 * q + 2 * h2 + 1] + bq[2 * h2 + 1];
+                                if constexpr (!RELU0) { v0 = v0 < 0.f ? v0 * p.sl3 : v0; v1 = v1 < 0.f ? v1 * p.sl3 : v1; }
+                                half2_t hv = {(half_t)v0, (half_t)v1};
+                                if constexpr (RELU0) hv = __builtin_elementwise_max(hv, half2_t{0, 0});
+                                d[q][h2] = __builtin_bit_cast(unsigned, hv);
+                            }
+                        }
+                        const unsigned offc = c * 32 < p.n3 ? off : HX_DEAD;      // (a group's chunks beyond n3 are computed on whatever the LDS holds and dropped)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            sm_permlane32_swap(d[2 * j][0], d[2 * j + 1][0]);
+                            sm_permlane32_swap(d[2 * j][1], d[2 * j + 1][1]);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]}, rs_y3, (int)(offc + (unsigned)(c * 64 + 32 * j)), 0, 0);
+                        }
+                    }
+                }
+            }
+        }
+    };
     auto store_prev = [&]() __attribute__((always_inline)) {          // (three call sites: left out of line, its captured arrays would live in scratch)
+        if constexpr (HX) {
+            if (p.sl3 == 0.f) hx_store(std::true_type()); else hx_store(std::false_type());
+        }
         if constexpr (!ST && HEAD) {
             // 1x1 head: outv[a][b][j] (couts a*32 + 16j + 8hi .. +7 of pixel lane & 31, already activated and rounded) IS the MFMA B fragment of
             // k step 2a + j, so y3 = w3 . y costs NOUT/16 MFMAs per fragment and no memory; register 4q + r <-> head channel 8q + 4hi + r
@@ -290,6 +406,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
         }
         if constexpr (!(ABL & 4)) sm_static_for<0, PF>([&](auto sc) { fetch(sc); });
         if (pending) store_prev();
+        load_res(n, y0, x0);                                          // HX: this tile's residual rows, a whole k loop ahead of their use
         sm_static_for<0, NS>([&](auto sc) {
             constexpr int S2 = decltype(sc)::value;
 #pragma unroll

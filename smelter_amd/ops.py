@@ -135,6 +135,20 @@ def conv2d_head(x, w_ohwi, bias, w3, b3, act=ACT_RELU, slope=0.0, act3=ACT_NONE,
     return y, y3
 
 
+def conv2d_xhead(x, w_ohwi, bias, w3, b3, residual=None, act=ACT_RELU, slope=0.0, act3=ACT_RELU, slope3=0.0, cfg=-1, store_y=False):
+    """3x3 / s1 / p1 convolution (64 -> 64) + the 1x1 expand convolution behind it (n3 <= 256) + residual + activation in one launch
+    (sm_conv2d_xhead_fwd_cfg); returns (y or None, y3)"""
+    n, h, w, cin, x_ld = _check_nhwc(x)
+    cout, n3 = w_ohwi.shape[0], w3.shape[0]
+    y = torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device) if store_y else None
+    y3 = torch.empty((n, h, w, n3), dtype=torch.float16, device=x.device)
+    res_ld = _check_nhwc(residual)[4] if residual is not None else 0
+    d = ConvDesc(n, h, w, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, h, w, act, slope, x_ld, cout, 0)
+    check(lib().sm_conv2d_xhead_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(y), _ptr(w3), _ptr(b3), n3, act3, slope3,
+                                        _ptr(residual), res_ld, _ptr(y3), _ld(y3), _stream()))
+    return y, y3
+
+
 def conv1x1_pair(x, w1, b1, residual, w2, b2, act1=ACT_RELU, act2=ACT_RELU, out_y=None, out_z=None):
     """y = act1(conv1x1(x, w1) + b1 + residual), z = act2(conv1x1(y, w2) + b2) in one launch (sm_conv1x1_pair_fwd)"""
     n, h, w, cin, x_ld = _check_nhwc(x)
