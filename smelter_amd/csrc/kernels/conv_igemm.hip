@@ -490,6 +490,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 #include "conv3x3_strip.hpp"
 #include "pw_thin.hpp"
 #include "conv3x3_ws.hpp"
+#include "conv3x3_wsx.hpp"
 #include "conv3x3_p9.hpp"
 #include "conv1x1_ps.hpp"
 #include "conv1x1_pair.hpp"
@@ -706,6 +707,7 @@ const TileCfg kCfgs[] = {
     {256, 32, 4, 256, conv3x3_ws_kernel<32, 32, 4, 2, 6, 0, 0, 0, true>, "ws:32->32 w4x2 head"},      // 92
     {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2, 6, 0, 0, 0, true>, "ws:32->32 w8x2 head"},      // 93
     {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead"},  // 94  expand head (bottleneck tail): + 1x1 to <= 256 channels + residual
+    {128, 64, 4, 512, conv3x3_wsx_kernel<6>, "ws:64->64 w4+4 xhead"},                                 // 95  ... with the two layers on different waves (conv3x3_wsx.hpp)
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
@@ -747,13 +749,14 @@ size_t ws_setup(ConvParams& p, const TileCfg& c) {
     if (cin != 32 && cin != 64) return 0;
     const char* nm = c.name;                                         // "ws:<cin>-><cout> ..."
     if (atoi(nm + 3) != cin) return 0;
-    const int cp = cin / 8, nt = c.threads;
+    const bool w44 = strstr(nm, "w4+4") != nullptr;                  // conv3x3_wsx.hpp: 4 of the 8 waves issue the patch DMA, 6 pieces per thread
+    const int cp = cin / 8, nt = w44 ? 256 : c.threads;
     const int bands = sm_ceil_div(p.W, 32);
     int TW = sm_ceil_div(p.W, bands);
     if (p.ups && (TW & 1)) TW++;                                       // fused upsampling: even tile origins
     const bool xhead = strstr(nm, " xhead") != nullptr;              // head weights + bias in LDS too (conv3x3_ws.hpp HX)
     const size_t fixed = (size_t)9 * p.Cout * cin * 2 + (size_t)p.Cout * 4 + WS_DUMMY + (xhead ? (size_t)ws_hx_bytes(p.Cout) : 0);
-    const int nic = cin == 64 ? 12 : 6;                              // the kernels' NIC
+    const int nic = w44 ? 6 : cin == 64 ? 12 : 6;                    // the kernels' NIC
     int best_th = 0; long best_tiles = 0; size_t best_lds = 0, best_patch = 0;
     const int thstep = (p.ups || p.y2) ? 2 : 1;                        // fused upsampling / pooling: even tile origins
     for (int th = thstep; th * TW <= c.BM && th <= p.H; th += thstep) {
@@ -849,6 +852,7 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
         const bool want_x = p.y3 && (p.n3 > 32 || p.res3);                                       // wide or residual heads: the expand-head instantiations
         if (ok && ((p.y3 != nullptr && !want_x) != is_head || want_x != is_xhead)) return false;   // head launches <-> head instantiations
         if (ok && p.y3 && !want_x && !(p.n3 > 0 && p.n3 <= 32 && (p.n3 & 7) == 0 && (p.y3_ld & 3) == 0 && ((((uintptr_t)p.y3) & 7) == 0) && ((((uintptr_t)p.w3) & 15) == 0) && p.act3 <= SM_ACT_PRELU && !p.y2)) return false;
+        if (ok && is_xhead && strstr(c.name, "w4+4") && (p.y || p.ups)) return false;            // the two-role kernel never stores the 3x3 output
         if (ok && want_x && !(p.n3 >= 32 && p.n3 <= WS_HX_N3 && (p.n3 & 31) == 0 && (p.y3_ld & 7) == 0 && ((((uintptr_t)p.y3) & 15) == 0) && ((((uintptr_t)p.w3) & 15) == 0) && p.act3 <= SM_ACT_PRELU && !p.y2 &&
                                 (!p.res3 || ((p.res3_ld & 7) == 0 && ((((uintptr_t)p.res3) & 15) == 0))) &&
                                 (long)p.N * p.H * p.W * std::max(p.y3_ld, p.res3 ? p.res3_ld : 0) * 2 < 0x7fff0000L)) return false;   // (both head streams go through 32-bit buffer offsets)

@@ -765,8 +765,9 @@ def test_conv3x3_with_fused_pointwise_head(n, hw, cin, cout, n3, act3, store_y, 
     (1, (9, 70), 32, 0, True, True),         # one chunk, no activation, a partial column band
     (2, (16, 16), 64, 1, False, False),      # wide head without residual
 ])
-def test_conv3x3_with_fused_expand_head(n, hw, n3, act3, with_res, store_y):
-    """sm_conv2d_xhead_fwd_cfg (config 94): y3 = the two separate launches (3x3, then 1x1 + residual + activation on the ROUNDED 3x3 output) —
+@pytest.mark.parametrize("cfg", [-1, 94, 95])
+def test_conv3x3_with_fused_expand_head(n, hw, n3, act3, with_res, store_y, cfg):
+    """sm_conv2d_xhead_fwd_cfg (config 94: one role per block; 95: producer / consumer waves): y3 = the two separate launches (3x3, then 1x1 + residual + activation on the ROUNDED 3x3 output) —
     bit-identical without a residual, within one fp16 ulp at a few values per million with one; y (when stored) bit-identical to the plain 3x3 launch"""
     cin = cout = 64
     rng = np.random.default_rng(n3 + hw[0] + hw[1])
@@ -778,7 +779,13 @@ def test_conv3x3_with_fused_expand_head(n, hw, n3, act3, with_res, store_y):
     xd, wd, bd = to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda()
     w3d, b3d = torch.from_numpy(w3).cuda().half(), torch.from_numpy(b3).cuda()
     resd = to_dev(res) if with_res else None
-    y, y3 = ops.conv2d_xhead(xd, wd, bd, w3d, b3d, residual=resd, act3=act3, slope3=slope3, store_y=store_y)
+    from smelter_amd._native import SmelterError
+    try:
+        y, y3 = ops.conv2d_xhead(xd, wd, bd, w3d, b3d, residual=resd, act3=act3, slope3=slope3, store_y=store_y, cfg=cfg)
+    except SmelterError as e:
+        if cfg == 95 and store_y and "does not apply" in e.detail:      # the two-role kernel (conv3x3_wsx.hpp) never stores the 3x3 output
+            pytest.skip(e.detail)
+        raise
     yplain = ops.conv2d(xd, wd, bd, pads=(1, 1, 1, 1), act=1)
     if store_y:
         assert torch.equal(y, yplain)

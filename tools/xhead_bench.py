@@ -21,9 +21,10 @@ def timed(fn, reps=8):
     ts.sort(); return ts[len(ts) // 2]
 t3 = {c: timed(lambda c=c: ops.conv2d(x, w, b, pads=(1, 1, 1, 1), act=1, cfg=c, out=y)) for c in (61, 65)}
 t1 = {c: timed(lambda c=c: ops.conv2d(y, w3, b3, residual=r, act=1, cfg=c, out=z)) for c in (6, 7, 9, 13, 14, 18, 24, 25, 26, 27, 29)}
-tx = timed(lambda: ops.conv2d_xhead(x, w, b, w3, b3, residual=r))
-tn = timed(lambda: ops.conv2d_xhead(x, w, b, w3, b3, residual=None))
+XC = int(os.environ.get("XCFG", "94"))
+tx = timed(lambda: ops.conv2d_xhead(x, w, b, w3, b3, residual=r, cfg=XC))
+tn = timed(lambda: ops.conv2d_xhead(x, w, b, w3, b3, residual=None, cfg=XC))
 print("3x3:", {k: round(v, 1) for k, v in t3.items()})
 print("1x1+res:", {k: round(v, 1) for k, v in t1.items()})
 byts = 2.0 * (x.numel() + r.numel() + z.numel())
-print("separate %.1f + %.1f = %.1f us ; xhead %.1f us (%.2f TB/s on %.0f MB) ; xhead without residual %.1f us" % (min(t3.values()), min(t1.values()), min(t3.values()) + min(t1.values()), tx, byts / tx / 1e6, byts / 1e6, tn))
+print("cfg", XC, "separate %.1f + %.1f = %.1f us ; xhead %.1f us (%.2f TB/s on %.0f MB) ; xhead without residual %.1f us" % (min(t3.values()), min(t1.values()), min(t3.values()) + min(t1.values()), tx, byts / tx / 1e6, byts / 1e6, tn))
