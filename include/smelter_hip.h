@@ -125,6 +125,14 @@ int sm_conv2d_xhead_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const
                             const float* b3, int32_t n3, int32_t act3, float slope3, const void* res3, int32_t res3_ld, void* y3, int32_t y3_ld,
                             sm_stream_t stream);
 
+/* ... the FIRST block of a stage, whose shortcut is a projection: three ConvolutionConverter nodes (3x3 64 -> 64; 1x1 expand; 1x1 projection of
+ * the block input `xs` [N,H,W,64]) + AddConverter + ReluConverter in ONE launch: y3 = act3(w3 . act(conv3x3(x)) + ws . xs + b3) with
+ * b3 = the sum of the two 1x1 layers' biases (added by the caller).  The expand layer's own output is never rounded or stored. */
+int sm_conv2d_xhead_proj_supported(const sm_conv_desc* d, int32_t n3);
+int sm_conv2d_xhead_proj_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias, const void* w3, const float* b3,
+                                 int32_t n3, int32_t act3, float slope3, const void* xs, int32_t xs_ld, const void* ws, void* y3, int32_t y3_ld,
+                                 sm_stream_t stream);
+
 /* Two MPSCNNConvolutionNodes in a row, both 1x1 / stride 1 (Converters.swift:253), in ONE launch:
  *   y = act(x * w1 + bias1 + residual)   [d: Cin = 64 -> Cout = 256]      z = act2(y * w2 + bias2)   [256 -> N2 in {64, 128}]
  * Both tensors are stored (y is the next residual); y is rounded to fp16 once, exactly as the separate launches would store it.

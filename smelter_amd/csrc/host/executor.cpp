@@ -466,6 +466,39 @@ int Executor::plan(ONNXGraph& g, int batch) {
         }
     }
 
+    // ---- 3e. ... + projection shortcut: in a stage's first block the Add sits in the epilogue of the shortcut convolution (1x1 on the 64-channel block
+    // input, residual = the expand layer's output).  When that expand layer is an expand head without activation and the shortcut is its only reader, the
+    // shortcut becomes the head's second GEMM: y = act(w3 . h + ws . x0 + (b3 + bs)) — three layers, one launch, and the expand layer's output (102.8 MB
+    // at 56^2 x 256 x bs 64, written once and read once) never exists.  SMELTER_XHEAD_PROJ=0 keeps the shortcut as its own launch.
+    if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && !(getenv("SMELTER_XHEAD_PROJ") && getenv("SMELTER_XHEAD_PROJ")[0] == '0')) {
+        auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
+        auto producer = [&](int v) -> long {
+            for (size_t q = 0; q < steps_.size(); q++)
+                if (steps_[q].op.output == v || steps_[q].pool_out == v || (steps_[q].has_pair && steps_[q].pair.output == v) || (steps_[q].has_mb && steps_[q].mb_proj.output == v) ||
+                    (steps_[q].has_head && steps_[q].head.output == v)) return (long)q;
+            return -1L;
+        };
+        for (size_t t = 0; t < steps_.size(); t++) {
+            Step& c = steps_[t];
+            if (!c.has_head || c.has_side || c.head.residual >= 0 || c.head.act != SM_ACT_NONE || readers(c.head.output) != 1) continue;
+            const Value& ov = values_[c.op.output];
+            sm_conv_desc d{}; d.N = batch; d.H = d.Ho = ov.h; d.W = d.Wo = ov.w; d.Cin = c.op.cin; d.Cout = c.op.cout; d.kH = c.op.kh; d.kW = c.op.kw; d.sH = c.op.sh; d.sW = c.op.sw;
+            d.dH = c.op.dh; d.dW = c.op.dw; d.pt = c.op.pt; d.pl = c.op.pl; d.pb = c.op.pb; d.pr = c.op.pr; d.groups = c.op.groups; d.act = c.op.act;
+            for (size_t u = t + 1; u < steps_.size(); u++) {
+                Step& sd = steps_[u];
+                if (sd.op.residual != c.head.output) continue;
+                const Op& o = sd.op;
+                if (o.kind != OpKind::Conv || o.kh != 1 || o.kw != 1 || o.sh != 1 || o.sw != 1 || o.pt || o.pl || o.pb || o.pr || o.groups != 1 || o.act > SM_ACT_PRELU || o.grid_h || o.x_ups ||
+                    sd.stem || sd.has_pair || sd.has_mb || sd.has_head || sd.pool_out >= 0 || o.cin != 64 || o.cout != c.head.cout || o.inputs.empty()) break;
+                const Value& sv = values_[o.inputs[0]];
+                if (sv.h != ov.h || sv.w != ov.w || producer(rootOf(o.inputs[0])) >= (long)t || !sm_conv2d_xhead_proj_supported(&d, o.cout)) break;
+                c.has_side = true; c.side = std::move(sd.op);
+                steps_.erase(steps_.begin() + u);
+                break;
+            }
+        }
+    }
+
     // ---- 4. memory plan ------------------------------------------------------------------------------------
     const int ns = (int)steps_.size();
     std::vector<int> first(nv, INT32_MAX), last(nv, -1);   // per ROOT value: live step interval
@@ -500,6 +533,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         for (int u : op.inputs) { touch(u, t); touch(u, until); }
         if (op.residual >= 0) { touch(op.residual, t); touch(op.residual, until); }
         if (steps_[t].has_mb) { touch(steps_[t].mb_proj.output, t); continue; }
+        if (steps_[t].has_side) { touch(steps_[t].side.output, t); touch(steps_[t].side.inputs[0], t); continue; }                    // (neither the 3x3 nor the expand output exists)
         if (steps_[t].has_head) { touch(steps_[t].head.output, t); if (steps_[t].head.residual >= 0) touch(steps_[t].head.residual, t); continue; }             // (the 3x3 output exists in registers only)      // (the hidden tensors exist in LDS only; the residual is the step's own input)
         touch(op.output, t);
         if (steps_[t].has_pair) touch(steps_[t].pair.output, t);
@@ -547,10 +581,15 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 flops_ += (st.mb_noexp ? 0.0 : 2.0 * Md * dv.c * 9.0) + 2.0 * Md * pv.c * (double)dv.c;         // (no expand layer: the depthwise layer is this step's own op, counted below)
                 alg_bytes_ += (st.mb_noexp ? 0.0 : 2.0 * ((double)st.M * op.cout + Md * dv.c + dv.c * 9.0)) + 2.0 * (Md * dv.c + Md * pv.c * (st.mb_proj.residual >= 0 ? 2.0 : 1.0) + (double)pv.c * dv.c);
             }
+            if (st.has_side) {
+                st.wd_off = off; off = alignUp(off + st.side.weight.size() * 2);
+                flops_ += 2.0 * st.M * st.side.cout * (double)st.side.cin;
+                alg_bytes_ += 2.0 * ((double)st.M * st.side.cin + (double)st.M * st.side.cout * 2 + (double)st.side.cout * st.side.cin);      // (the shortcut layer of the graph: input, residual, output, weights)
+            }
             if (st.has_head) {
                 st.w2_off = off; off = alignUp(off + st.head.weight.size() * 2);
-                st.has_bias2 = !st.head.bias.empty();
-                if (st.has_bias2) { st.b2_off = off; off = alignUp(off + st.head.bias.size() * 4); }
+                st.has_bias2 = !st.head.bias.empty() || (st.has_side && !st.side.bias.empty());
+                if (st.has_bias2) { st.b2_off = off; off = alignUp(off + (size_t)st.head.cout * 4); }
                 flops_ += 2.0 * st.M * st.head.cout * (double)st.head.cin;
                 alg_bytes_ += 2.0 * ((double)st.M * st.head.cin + (double)st.M * st.head.cout * (st.head.residual >= 0 ? 2 : 1) + (double)st.head.cout * st.head.cin);      // (accounted as the layer the graph holds)
             }
@@ -588,6 +627,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         if (st.pool_out >= 0) { st.desc += " >> MaxPool 2x2/2 (same launch)"; alg_bytes_ += 2.0 * (double)(st.M / 4) * values_[st.pool_out].c; }
         if (st.has_pair) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.pair.name.c_str(), st.pair.cout, st.pair.cin, st.pair.act ? " +act" : ""); st.desc += buf; }
         if (st.has_head) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.head.name.c_str(), st.head.cout, st.head.cin, st.head.residual >= 0 ? " +res" : "", st.head.act ? " +act" : ""); st.desc += buf; }
+        if (st.has_side) { snprintf(buf, sizeof buf, " + Conv %s N=%d K=%d k=1x1 projection%s (same launch)", st.side.name.c_str(), st.side.cout, st.side.cin, st.side.act ? " +act" : ""); st.desc += buf; }
         if (st.has_mb && st.mb_noexp) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.act ? " +act" : ""); st.desc += buf; }
         else if (st.has_mb) { snprintf(buf, sizeof buf, " >> Conv %s k=3x3 s=%d g=%d%s >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.mb_dw.name.c_str(), st.mb_dw.sh, st.mb_dw.groups, st.mb_dw.act ? " +act" : "",
                                   st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.residual >= 0 ? " +res" : "", st.mb_proj.act ? " +act" : ""); st.desc += buf; }
@@ -597,6 +637,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     value_names_.resize(nv); for (int v = 0; v < nv; v++) value_names_[v] = values_[v].name;
     materialized_.clear(); materialized_.push_back(values_[input_value_].name);
     for (auto& st : steps_) {
+        if (st.has_side) { materialized_.push_back(values_[st.op.output].name); materialized_.push_back(values_[st.side.output].name); continue; }   // (the expand output is summed in fp32, never rounded)
         if (st.has_head) { materialized_.push_back(values_[st.op.output].name); materialized_.push_back(values_[st.head.output].name); continue; }   // (rounded to fp16 in registers)
         if (st.has_mb) {   // (the two hidden tensors live in LDS only, but are rounded to fp16 there exactly as a stored tensor would be: listed for the parity oracle)
             if (!st.mb_noexp) materialized_.push_back(values_[st.op.output].name);
@@ -634,7 +675,11 @@ int Executor::packWeights(std::vector<uint8_t>* host) const {
             }
             if (st.has_head) {
                 sm_float_to_half(st.head.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.head.weight.size());
-                if (st.has_bias2) memcpy(host->data() + st.b2_off, st.head.bias.data(), st.head.bias.size() * 4);
+                if (st.has_bias2) {
+                    float* b2 = (float*)(host->data() + st.b2_off);
+                    for (int i = 0; i < st.head.cout; i++) b2[i] = (st.head.bias.empty() ? 0.f : st.head.bias[i]) + ((st.has_side && !st.side.bias.empty()) ? st.side.bias[i] : 0.f);
+                }
+                if (st.has_side) sm_float_to_half(st.side.weight.data(), (uint16_t*)(host->data() + st.wd_off), st.side.weight.size());
             }
             if (st.has_pair) {
                 sm_float_to_half(st.pair.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.pair.weight.size());
@@ -689,7 +734,7 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     e->out_f32_count_ = std::max(sm_float_array_count(batch, ov.c, ov.h, ov.w), (size_t)batch * ov.c * ov.h * ov.w);
     SM_HIP_CHECK(hipMalloc((void**)&e->out_f32_, e->out_f32_count_ * 4));
     for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit(); st.pair.weight.clear(); st.pair.weight.shrink_to_fit();
-                                 st.head.weight.clear(); st.head.weight.shrink_to_fit(); st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
+                                 st.head.weight.clear(); st.head.weight.shrink_to_fit(); st.side.weight.clear(); st.side.weight.shrink_to_fit(); st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
     if (e->cfg_.autotune) {   // with an external arena and upload == 0 the caller filled it before compiling
         hipStream_t s; SM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         rc = e->autotune(s);
@@ -717,6 +762,10 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
                                  valuePtr(st.mb_proj.output), ss);
         }
         const sm_conv_desc d = convDesc(st);
+        if (st.has_side)
+            return sm_conv2d_xhead_proj_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, arena_ + st.w2_off,
+                                                st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr, st.head.cout, st.side.act, st.side.slope, valuePtr(st.side.inputs[0]),
+                                                valueLd(st.side.inputs[0]), arena_ + st.wd_off, valuePtr(st.side.output), valueLd(st.side.output), ss);
         if (st.has_head && (st.head.residual >= 0 || st.head.cout > 32))
             return sm_conv2d_xhead_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, nullptr, arena_ + st.w2_off,
                                            st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr, st.head.cout, st.head.act, st.head.slope,

@@ -45,6 +45,10 @@ struct Step {                // one op after fusion, with everything resolved
     // 3x3 convolution -> 1x1 "head" (executor.cpp pass 3d): `head` is the pointwise convolution that is the only reader of this step's output; it
     // runs in the same launch (sm_conv2d_head_fwd_cfg; weights at w2_off / b2_off) and the 3x3 output is never stored
     bool has_head = false; Op head;
+    // ... and the projection shortcut of a first bottleneck block: `side` is the 1x1 convolution of the 64-channel block input whose fused residual operand
+    // is the head's output; it becomes the head's second GEMM (sm_conv2d_xhead_proj_fwd_cfg; weights at wd_off, the two biases summed at b2_off) and the
+    // head's own output is never materialised
+    bool has_side = false; Op side;
     bool mb_noexp = false;   // the block has no expand layer: this step IS the depthwise convolution (mb_dw is a copy of it), mb_proj follows
     std::string desc;
 };

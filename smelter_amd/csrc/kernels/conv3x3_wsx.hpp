@@ -18,7 +18,11 @@
 // Numerics = conv3x3_ws.hpp HX: (acc + residual) + b3 in fp32, one rounding; without a residual bit-identical to the two separate launches.
 #pragma once
 
-template <int NIC = 6>
+// SIDE: the head has a second GEMM instead of a residual tensor — y3 = act3(w3 . y + ws . xs + b3), xs = a 64-channel tensor of the same
+// spatial size (the block input) and ws [n3][64] (the projection shortcut of a bottleneck's first block: three layers, one launch).  The
+// "residual" registers then hold xs rows: a 64-channel row in the store layout IS the B operand of the four k steps, so the loads, their
+// refill and the register budget are the residual's; ws sits in 32 more registers per consumer.
+template <int NIC = 6, bool SIDE = false>
 __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
     constexpr int CIN = 64, NOUT = 64, NWP = 4, NTP = NWP * 64, NT = 512, CP = 8, TN = 2, KS = 4, NTAP = 9;
     constexpr int ROWB = CP * 16, W_BYTES = NTAP * NOUT * ROWB, BIAS_BYTES = NOUT * 4, B3_BYTES = WS_HX_N3 * 4, HO_BYTES = NWP * 32 * NOUT * 2;
@@ -210,7 +214,17 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int i = 0; i < 8; i++) onehot[j][i] = (half_t)((l31 == 16 * j + 8 * hi + i) ? 1.f : 0.f);
+            for (int i = 0; i < 8; i++) onehot[j][i] = (half_t)((!SIDE && l31 == 16 * j + 8 * hi + i) ? 1.f : 0.f);
+        half8_t wsr[SIDE ? 2 : 1][NOUT / 16];                             // SIDE: my 64 rows of the second GEMM's weights
+        if constexpr (SIDE) {
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++)
+#pragma unroll
+                for (int ks = 0; ks < NOUT / 16; ks++) {
+                    const int row = (2 * jw + cc) * 32 + l31;
+                    wsr[cc][ks] = row < p.n3 ? *(const half8_t*)(p.w3s + (long)row * NOUT + ks * 16 + hi * 8) : hz8;
+                }
+        }
         unsigned tyx[NWP];                                                // tile pixel of (fragment f, lane & 31)
 #pragma unroll
         for (int f = 0; f < NWP; f++) {
@@ -225,11 +239,13 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
             const bool live = on && t < t_end && oy < p.H && ox < p.W && ty < TH;
             return live ? (unsigned)(((n * p.H + oy) * p.W + ox) * ld + 64 * jw + 8 * hi) * 2u : DEAD;
         };
+        // (SIDE: every consumer reads the SAME 64 channels of xs — no 64 jw)
+        const unsigned r_sub = SIDE ? (unsigned)(64 * jw) * 2u : 0u;
         u32x4 rres[NWP][2][2];                                            // residual rows [fragment][chunk][j] of the tile whose head runs next
         const bool res_on = p.res3 != nullptr && !(p.hx_dbg & 2);
 #pragma unroll
         for (int f = 0; f < NWP; f++) {
-            const unsigned off = pixel_off(t_begin, f, p.res3_ld, res_on);
+            unsigned off = pixel_off(t_begin, f, p.res3_ld, res_on); if (off != DEAD) off -= r_sub;
 #pragma unroll
             for (int cc = 0; cc < 2; cc++)
 #pragma unroll
@@ -248,7 +264,8 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
                     half8_t h2[NOUT / 16];
 #pragma unroll
                     for (int ks = 0; ks < NOUT / 16; ks++) h2[ks] = *(const half8_t*)(hb + ((f * 4 + ks) * 64 + lane) * 16);
-                    const unsigned offy = pixel_off(t, f, p.y3_ld, !(p.hx_dbg & 1)), offr = pixel_off(t + 1, f, p.res3_ld, res_on);
+                    const unsigned offy = pixel_off(t, f, p.y3_ld, !(p.hx_dbg & 1));
+                    unsigned offr = pixel_off(t + 1, f, p.res3_ld, res_on); if (offr != DEAD) offr -= r_sub;
                     floatx16 a3[2];
 #pragma unroll
                     for (int cc = 0; cc < 2; cc++) {
@@ -256,12 +273,19 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
                         for (int r = 0; r < 16; r++) a3[cc][r] = 0.f;
 #pragma unroll
                         for (int ks = 0; ks < NOUT / 16; ks++) a3[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3r[cc][ks], h2[ks], a3[cc], 0, 0, 0);
+                        if constexpr (SIDE) {
 #pragma unroll
-                        for (int j = 0; j < 2; j++) a3[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(onehot[j], __builtin_bit_cast(half8_t, rres[f][cc][j]), a3[cc], 0, 0, 0);
-                        // these registers are free again: the NEXT tile's rows of the same (fragment, chunk) — a whole tile of flight time
+                            for (int ks = 0; ks < NOUT / 16; ks++) a3[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wsr[cc][ks], __builtin_bit_cast(half8_t, rres[f][ks / 2][ks % 2]), a3[cc], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 2; j++) a3[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(onehot[j], __builtin_bit_cast(half8_t, rres[f][cc][j]), a3[cc], 0, 0, 0);
+                        }
+                    }
+                    // these registers are free again: the NEXT tile's rows of the same fragment — a whole tile of flight time
+#pragma unroll
+                    for (int cc = 0; cc < 2; cc++)
 #pragma unroll
                         for (int j = 0; j < 2; j++) rres[f][cc][j] = __builtin_amdgcn_raw_buffer_load_b128(rs_r3, (int)(offr + (unsigned)(cc * 64 + 32 * j)), 0, 0);
-                    }
 #pragma unroll
                     for (int cc = 0; cc < 2; cc++) {
                         const int c = 2 * jw + cc;

@@ -49,6 +49,7 @@ struct ConvParams {
     // y3 = act3(w3 . y + b3), n3 <= 32); y itself is stored only if p.y != nullptr
     const half_t* w3; const float* b3; half_t* y3; int n3, y3_ld, act3; float sl3;
     // ... the EXPAND head (" xhead" instantiations): n3 = 32 .. 256 (multiple of 32), w3 / b3 in LDS, optional residual added to the head's output
+    const half_t* w3s;               // conv3x3_wsx.hpp SIDE: weights [n3][64] of the head's second GEMM; res3 / res3_ld then name its 64-channel input tensor
     const half_t* res3; int res3_ld; int hx_dbg;   // hx_dbg: SM_HX_DEBUG ablation bits (1 = no stores, 2 = no residual loads, 4 = no head at all)
     unsigned p9_pw_mul, p9_pw_sh, p9_h2_mul, p9_h2_sh;
 };
@@ -708,6 +709,7 @@ const TileCfg kCfgs[] = {
     {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2, 6, 0, 0, 0, true>, "ws:32->32 w8x2 head"},      // 93
     {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead"},  // 94  expand head (bottleneck tail): + 1x1 to <= 256 channels + residual
     {128, 64, 4, 512, conv3x3_wsx_kernel<6>, "ws:64->64 w4+4 xhead"},                                 // 95  ... with the two layers on different waves (conv3x3_wsx.hpp)
+    {128, 64, 4, 512, conv3x3_wsx_kernel<6, true>, "ws:64->64 w4+4 xhead side"},                      // 96  ... and a second GEMM (the projection shortcut) instead of the residual tensor
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
@@ -849,10 +851,12 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
                ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && p.Cout == c.BN && ws_setup(q, c) > 0;
         // fused max-pool: two fragments per wave that are the image rows 2k, 2k+1 of one 32-pixel column band
         const bool is_head = strstr(c.name, " head") != nullptr, is_xhead = strstr(c.name, " xhead") != nullptr;
-        const bool want_x = p.y3 && (p.n3 > 32 || p.res3);                                       // wide or residual heads: the expand-head instantiations
+        const bool want_x = p.y3 && (p.n3 > 32 || p.res3 || p.w3s);                                       // wide or residual heads: the expand-head instantiations
         if (ok && ((p.y3 != nullptr && !want_x) != is_head || want_x != is_xhead)) return false;   // head launches <-> head instantiations
         if (ok && p.y3 && !want_x && !(p.n3 > 0 && p.n3 <= 32 && (p.n3 & 7) == 0 && (p.y3_ld & 3) == 0 && ((((uintptr_t)p.y3) & 7) == 0) && ((((uintptr_t)p.w3) & 15) == 0) && p.act3 <= SM_ACT_PRELU && !p.y2)) return false;
         if (ok && is_xhead && strstr(c.name, "w4+4") && (p.y || p.ups)) return false;            // the two-role kernel never stores the 3x3 output
+        if (ok && is_xhead && (strstr(c.name, " side") != nullptr) != (p.w3s != nullptr)) return false;
+        if (ok && p.w3s && !(p.res3 && ((((uintptr_t)p.w3s) & 15) == 0))) return false;
         if (ok && want_x && !(p.n3 >= 32 && p.n3 <= WS_HX_N3 && (p.n3 & 31) == 0 && (p.y3_ld & 7) == 0 && ((((uintptr_t)p.y3) & 15) == 0) && ((((uintptr_t)p.w3) & 15) == 0) && p.act3 <= SM_ACT_PRELU && !p.y2 &&
                                 (!p.res3 || ((p.res3_ld & 7) == 0 && ((((uintptr_t)p.res3) & 15) == 0))) &&
                                 (long)p.N * p.H * p.W * std::max(p.y3_ld, p.res3 ? p.res3_ld : 0) * 2 < 0x7fff0000L)) return false;   // (both head streams go through 32-bit buffer offsets)
@@ -917,7 +921,7 @@ int fill_params(const sm_conv_desc* d, const void* x, const void* w, const float
     p->act = d->act; p->slope = d->act == SM_ACT_RELU ? 0.f : d->slope;
     p->M = d->N * d->Ho * d->Wo; p->K = d->kH * d->kW * (d->Cin / d->groups);
     p->splitk = 1; p->mt = p->nt = 0; p->ktiles_per_split = 0; p->ups = d->x_ups ? 1 : 0; p->y2 = nullptr; p->y2_ld = 0;
-    p->w3 = nullptr; p->b3 = nullptr; p->y3 = nullptr; p->n3 = 0; p->y3_ld = 0; p->act3 = 0; p->sl3 = 0.f; p->res3 = nullptr; p->res3_ld = 0; p->hx_dbg = 0;
+    p->w3 = nullptr; p->b3 = nullptr; p->y3 = nullptr; p->n3 = 0; p->y3_ld = 0; p->act3 = 0; p->sl3 = 0.f; p->res3 = nullptr; p->res3_ld = 0; p->hx_dbg = 0; p->w3s = nullptr;
     SM_REQUIRE(!d->x_ups || ((d->H & 1) == 0 && (d->W & 1) == 0 && d->groups == 1), "sm_conv2d_fwd: x_ups needs even H and W");
     SM_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "sm_conv2d_fwd: more than 2^31 output pixels");
     SM_REQUIRE((long)d->N * d->H * d->W < (1L << 31) - (1L << 24), "sm_conv2d_fwd: more than 2^31 input pixels");
@@ -1149,6 +1153,29 @@ int sm_conv2d_xhead_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const
     if (small || cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) cfg = i; }
     if (cfg < 0) { sm_set_error("sm_conv2d_xhead_fwd_cfg: no kernel takes this shape with a fused expand head (3x3 / s1 / p1, Cin = Cout = 64, n3 <= 256, n3 %% 32 == 0)"); return SM_ERR_INVALID_ARGUMENT; }
     return launch(d, p, cfg, nullptr, 0, sm_s(stream));
+}
+// ... with a second GEMM in the head instead of the residual tensor: y3 = act3(w3 . y + ws . xs + b3), xs = [N,H,W,64] fp16 (row stride xs_ld), ws = [n3][64];
+// b3 = the SUM of the two layers' biases (the caller adds them).  A bottleneck's first block: 3x3, 1x1 expand, projection shortcut + Add + ReLU.
+int sm_conv2d_xhead_proj_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w, const float* bias, const void* w3, const float* b3, int32_t n3,
+                                 int32_t act3, float slope3, const void* xs, int32_t xs_ld, const void* ws, void* y3, int32_t y3_ld, sm_stream_t stream) {
+    SM_REQUIRE(w3 && y3 && n3 > 0 && xs && ws, "sm_conv2d_xhead_proj_fwd_cfg: null head operand");
+    SM_REQUIRE(d && d->groups == 1, "sm_conv2d_xhead_proj_fwd_cfg: grouped convolutions have no fused head");
+    ConvParams p; int rc = fill_params(d, x, w, bias, nullptr, y3, &p); if (rc) return rc;
+    p.y = nullptr;
+    p.w3 = (const half_t*)w3; p.b3 = b3; p.y3 = (half_t*)y3; p.n3 = n3; p.y3_ld = y3_ld ? y3_ld : n3; p.act3 = act3; p.sl3 = act3 == SM_ACT_RELU ? 0.f : act3 == SM_ACT_NONE ? 1.f : slope3;
+    p.res3 = (const half_t*)xs; p.res3_ld = xs_ld ? xs_ld : 64; p.w3s = (const half_t*)ws;
+    { static const int dbg = getenv("SM_HX_DEBUG") ? atoi(getenv("SM_HX_DEBUG")) : 0; p.hx_dbg = dbg; }
+    if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) cfg = i; }
+    if (cfg < 0) { sm_set_error("sm_conv2d_xhead_proj_fwd_cfg: no kernel takes this shape (3x3 / s1 / p1, Cin = Cout = 64, n3 <= 256, n3 %% 32 == 0, 64-channel side input)"); return SM_ERR_INVALID_ARGUMENT; }
+    return launch(d, p, cfg, nullptr, 0, sm_s(stream));
+}
+int sm_conv2d_xhead_proj_supported(const sm_conv_desc* d, int32_t n3) {
+    if (!d || d->groups != 1) return 0;
+    alignas(16) static char dummy[16];
+    ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
+    p.y = nullptr; p.w3 = (const half_t*)dummy; p.y3 = (half_t*)dummy; p.n3 = n3; p.y3_ld = n3; p.res3 = (const half_t*)dummy; p.res3_ld = 64; p.w3s = (const half_t*)dummy;
+    for (int i = 0; i < kNumCfgs; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) return 1;
+    return 0;
 }
 int sm_conv2d_xhead_supported(const sm_conv_desc* d, int32_t n3, int32_t has_res) {
     if (!d || d->groups != 1) return 0;

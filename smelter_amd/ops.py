@@ -149,6 +149,18 @@ def conv2d_xhead(x, w_ohwi, bias, w3, b3, residual=None, act=ACT_RELU, slope=0.0
     return y, y3
 
 
+def conv2d_xhead_proj(x, w_ohwi, bias, w3, b3sum, xs, ws, act=ACT_RELU, slope=0.0, act3=ACT_RELU, slope3=0.0, cfg=-1):
+    """3x3 / s1 / p1 convolution (64 -> 64) + 1x1 expand (w3) + 1x1 projection of the 64-channel block input xs (ws) + Add + activation in one
+    launch (sm_conv2d_xhead_proj_fwd_cfg); b3sum = the two 1x1 biases added; returns y3"""
+    n, h, w, cin, x_ld = _check_nhwc(x)
+    cout, n3 = w_ohwi.shape[0], w3.shape[0]
+    y3 = torch.empty((n, h, w, n3), dtype=torch.float16, device=x.device)
+    d = ConvDesc(n, h, w, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, h, w, act, slope, x_ld, cout, 0)
+    check(lib().sm_conv2d_xhead_proj_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(w3), _ptr(b3sum), n3, act3, slope3,
+                                             _ptr(xs), _check_nhwc(xs)[4], _ptr(ws), _ptr(y3), _ld(y3), _stream()))
+    return y3
+
+
 def conv1x1_pair(x, w1, b1, residual, w2, b2, act1=ACT_RELU, act2=ACT_RELU, out_y=None, out_z=None):
     """y = act1(conv1x1(x, w1) + b1 + residual), z = act2(conv1x1(y, w2) + b2) in one launch (sm_conv1x1_pair_fwd)"""
     n, h, w, cin, x_ld = _check_nhwc(x)

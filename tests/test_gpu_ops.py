@@ -804,3 +804,32 @@ def test_conv3x3_with_fused_expand_head(n, hw, n3, act3, with_res, store_y, cfg)
     if act3:
         ref = np.where(ref >= 0, ref, ref * slope3)
     assert_close(to_host(y3), ref, cout)
+
+
+@pytest.mark.parametrize("n,hw,n3,act3", [
+    (2, (56, 56), 256, 1),       # ResNet-50's first bottleneck block: 3x3 64->64 -> 1x1 64->256, + projection 64->256 of the block input, ReLU
+    (3, (20, 37), 128, 2),       # ragged tiles, PReLU
+    (1, (9, 70), 64, 0),         # two chunks (consumers 2 and 3 idle), no activation
+])
+def test_conv3x3_with_fused_expand_head_and_projection(n, hw, n3, act3):
+    """sm_conv2d_xhead_proj_fwd_cfg (config 96): y3 = act3(w3 . y + ws . xs + b3 + bs).  The expand layer's output is never rounded, so the result is
+    compared with the fp32 evaluation on the ROUNDED 3x3 output (what the three separate launches compute, minus one rounding)"""
+    cin = cout = 64
+    rng = np.random.default_rng(n3 + hw[0] + hw[1] + 7)
+    x = h(rng.standard_normal((n, cin, hw[0], hw[1])))
+    xs = h(rng.standard_normal((n, 64, hw[0], hw[1])))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * np.sqrt(2.0 / (cin * 9))); b = rng.standard_normal(cout).astype(np.float32)
+    w3 = h(rng.standard_normal((n3, 1, 1, cout)) * np.sqrt(1.0 / cout)); b3 = rng.standard_normal(n3).astype(np.float32)
+    ws = h(rng.standard_normal((n3, 1, 1, 64)) * np.sqrt(1.0 / 64)); bs = rng.standard_normal(n3).astype(np.float32)
+    slope3 = 0.25 if act3 == 2 else 0.0
+    xd, wd, bd = to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda()
+    w3d, wsd, xsd = torch.from_numpy(w3).cuda().half(), torch.from_numpy(ws).cuda().half(), to_dev(xs)
+    y3 = ops.conv2d_xhead_proj(xd, wd, bd, w3d, torch.from_numpy(b3 + bs).cuda(), xsd, wsd, act3=act3, slope3=slope3)
+    yplain = ops.conv2d(xd, wd, bd, pads=(1, 1, 1, 1), act=1)
+    y27 = ops.conv2d(yplain, w3d, torch.from_numpy(b3).cuda())                                          # the three separate launches
+    z = ops.conv2d(xsd, wsd, torch.from_numpy(bs).cuda(), act=act3, slope=slope3, residual=y27)
+    ref = O.conv2d(to_host(yplain), w3, b3) + O.conv2d(xs, ws, bs)
+    if act3:
+        ref = np.where(ref >= 0, ref, ref * slope3)
+    assert_close(to_host(y3), ref, 2 * cout)
+    assert float((y3.float() - z.float()).abs().max()) <= 2e-2 * float(z.float().abs().max())
