@@ -102,7 +102,7 @@ def toy(seed: int = 1, hw=(64, 64), dtype=np.float32, with_bn: bool = True) -> b
 
 
 def resnet50(seed: int = 1, batch: int = 1, hw=(224, 224), classes: int = 1000, res_gamma: float = 0.25,
-             dtype=np.float32, layers=(3, 4, 6, 3), width: int = 64, return_macs: bool = False):
+             dtype=np.float32, layers=(3, 4, 6, 3), width: int = 64, return_macs: bool = False, shortcut_order: str = "last"):
     """Config 2/5: ResNet-50 v1.5 (stride on the 3x3), 53 Conv + 53 BN + 49 Relu + 16 Add + MaxPool +
     GlobalAveragePool + Flatten + Gemm = 175 nodes."""
     net = _Net("resnet50", seed, dtype)
@@ -115,10 +115,16 @@ def resnet50(seed: int = 1, batch: int = 1, hw=(224, 224), classes: int = 1000, 
         for b in range(nblocks):
             s = 2 if (b == 0 and stage > 0) else 1
             identity = x
+            # node order of the projection shortcut relative to the main branch: "last" = the usual export (the shortcut convolution runs last and
+            # carries the fused Add), "mid" = between the 3x3 and the expand layer, "first" = in front of the block (the expand layer carries the Add)
+            if b == 0 and shortcut_order == "first":
+                identity, _ = net.conv_bn(x, cur, cin, cout, 1, s=s, act=False)
             y, hw1 = net.conv_bn(x, cur, cin, mid, 1)
             y, hw2 = net.conv_bn(y, hw1, mid, mid, 3, s=s)
+            if b == 0 and shortcut_order == "mid":
+                identity, _ = net.conv_bn(x, cur, cin, cout, 1, s=s, act=False)
             y, hw3 = net.conv_bn(y, hw2, mid, cout, 1, act=False, gamma_scale=res_gamma)
-            if b == 0:
+            if b == 0 and shortcut_order == "last":
                 identity, _ = net.conv_bn(x, cur, cin, cout, 1, s=s, act=False)
             x = net.relu(net.g.add_node("Add", [y, identity]))
             cur, cin = hw3, cout

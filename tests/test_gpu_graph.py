@@ -118,6 +118,23 @@ def test_resnet50_runs_its_first_stage_bottleneck_tails_as_one_launch_each(monke
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3
 
 
+@pytest.mark.parametrize("order", ["mid", "first"])
+def test_resnet50_expand_head_with_the_shortcut_listed_elsewhere(order, monkeypatch):
+    """the same blocks with the projection shortcut listed between the 3x3 and the expand layer ("mid": pass 3d moves it in front of the 3x3, because
+    the head runs where the 3x3 runs and needs its residual operand by then) or in front of the block ("first"): the expand layer carries the Add and
+    every first-stage tail is an expand head WITH a residual"""
+    model = zoo.resnet50(hw=(64, 64), shortcut_order=order)
+    x = zoo.synthetic_images(2, 3, (64, 64))
+    ex, got = run_hip(model, x)
+    fused = [ex.opDesc(i) for i in range(ex.numOps) if "(same launch)" in ex.opDesc(i)]
+    assert len(fused) == 3 and sum("+res" in d.split(">>")[1] for d in fused) == 3 and not any("projection" in d for d in fused)
+    monkeypatch.setenv("SMELTER_XHEAD", "0")
+    ex0, plain = run_hip(model, x)
+    assert ex0.numOps == ex.numOps + 3
+    assert nerr(got, plain) <= 1e-3
+    assert nerr(got, O.Graph(model).run(x)) <= 5e-3
+
+
 def test_unet_fuses_upsample_and_maxpool_into_their_convolutions():
     """executor passes 1b / 3a: nearest 2x Upsample -> Conv and Conv -> MaxPool 2x2/2 run as one launch each; same function as the unfused graph"""
     model = zoo.unet(hw=(64, 64))
