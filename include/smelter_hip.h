@@ -133,6 +133,14 @@ int sm_conv2d_xhead_proj_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, 
                                  int32_t n3, int32_t act3, float slope3, const void* xs, int32_t xs_ld, const void* ws, void* y3, int32_t y3_ld,
                                  sm_stream_t stream);
 
+/* The image stem (first ConvolutionConverter of a network, Cin <= 4) with the texture -> MPSImage conversion INSIDE the launch: loader waves build
+ * the stem kernel's row-pair patches from the fp32 NCHW batch (`x_nchw`: [N, C, H_in, W_in]; zero outside the image = the padding (pt, pl)).
+ * `d` is the stem-form descriptor sm_conv2d_fwd takes for the same layer (row-pair geometry: Cin = 64, kW = 1, dH = 2, x_ld = 8), `w` the weights
+ * packed for it. */
+int sm_conv2d_stem_f32_supported(const sm_conv_desc* d, int32_t C, int32_t H_in, int32_t W_in);
+int sm_conv2d_stem_f32_fwd_cfg(const sm_conv_desc* d, int cfg, const float* x_nchw, int32_t C, int32_t H_in, int32_t W_in, int32_t pt, int32_t pl,
+                               const void* w_packed, const float* bias, void* y, sm_stream_t stream);
+
 /* Two MPSCNNConvolutionNodes in a row, both 1x1 / stride 1 (Converters.swift:253), in ONE launch:
  *   y = act(x * w1 + bias1 + residual)   [d: Cin = 64 -> Cout = 256]      z = act2(y * w2 + bias2)   [256 -> N2 in {64, 128}]
  * Both tensors are stored (y is the next residual); y is rounded to fp16 once, exactly as the separate launches would store it.

@@ -69,6 +69,8 @@ SYMBOLS = {
     "sm_conv2d_pool_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "sm_conv2d_head_supported": (_i32, [C.POINTER(ConvDesc), _i32]),
     "sm_conv2d_head_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _i32, _vp]),
+    "sm_conv2d_stem_f32_supported": (_i32, [C.POINTER(ConvDesc), _i32, _i32, _i32]),
+    "sm_conv2d_stem_f32_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sm_conv2d_xhead_supported": (_i32, [C.POINTER(ConvDesc), _i32, _i32]),
     "sm_conv2d_xhead_proj_supported": (_i32, [C.POINTER(ConvDesc), _i32]),
     "sm_conv2d_xhead_proj_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _i32, _vp, _vp, _i32, _vp]),

@@ -499,6 +499,16 @@ int Executor::plan(ONNXGraph& g, int batch) {
         }
     }
 
+    // ---- 3f. image stem: when a loader-wave instantiation of the stem kernel takes the layer, the input conversion happens inside its launch
+    // (conv3x3_ws.hpp NLW): the row-pair image is never written; SMELTER_STEM_F32=0 keeps the conversion launch.
+    stem_f32_ = false;
+    if (stem_ && cfg_.fuse && !cfg_.keepIntermediates && !(getenv("SMELTER_STEM_F32") && getenv("SMELTER_STEM_F32")[0] == '0'))
+        for (const Step& st : steps_) if (st.stem) {
+            const sm_conv_desc d = convDesc(st); const Value& iv = values_[input_value_];
+            stem_f32_ = sm_conv2d_stem_f32_supported(&d, iv.c, iv.h, iv.w) != 0;
+        }
+    if (stem_f32_) launches_ -= 1;
+
     // ---- 4. memory plan ------------------------------------------------------------------------------------
     const int ns = (int)steps_.size();
     std::vector<int> first(nv, INT32_MAX), last(nv, -1);   // per ROOT value: live step interval
@@ -546,7 +556,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     std::vector<Blk> blks;
     for (int v = 0; v < nv; v++) if (place_[v].root == v && last[v] >= 0) {
         size_t bytes = alignUp((size_t)batch * values_[v].h * values_[v].w * place_[v].ld * 2 + 64);
-        if (stem_ && v == input_value_) bytes = alignUp((size_t)batch * stem_h_ * stem_w_ * 16 + 64);
+        if (stem_ && v == input_value_) bytes = stem_f32_ ? alignUp(64) : alignUp((size_t)batch * stem_h_ * stem_w_ * 16 + 64);
         blks.push_back({v, bytes});
     }
     std::sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) { return a.bytes > b.bytes; });
@@ -762,6 +772,11 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
                                  valuePtr(st.mb_proj.output), ss);
         }
         const sm_conv_desc d = convDesc(st);
+        if (st.stem && stem_f32_) {
+            if (!cur_in_) { sm_set_error("stem step launched before any input was bound"); return SM_ERR_INCONSISTENT_STATE; }
+            const Value& iv = values_[input_value_];
+            return sm_conv2d_stem_f32_fwd_cfg(&d, st.conv_cfg, cur_in_, iv.c, iv.h, iv.w, stem_pt_, stem_pl_, arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, y, ss);
+        }
         if (st.has_side)
             return sm_conv2d_xhead_proj_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, arena_ + st.w2_off,
                                                 st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr, st.head.cout, st.side.act, st.side.slope, valuePtr(st.side.inputs[0]),
@@ -854,12 +869,14 @@ sm_conv_desc Executor::convDesc(const Step& st) const {
 // application image (NCHW fp32) -> the layout the first layer reads
 int Executor::convertInput(hipStream_t s, const float* in) const {
     const Value& iv = values_[input_value_];
+    if (stem_f32_) return SM_OK;                                     // the stem kernel reads `in` itself
     if (stem_) return sm_nchw_f32_to_rowpair_f16(in, valuePtr(input_value_), batch_, iv.c, iv.h, iv.w, stem_h_, stem_w_, stem_pt_, stem_pl_, (sm_stream_t)s);
     return sm_nchw_f32_to_nhwc_f16(in, valuePtr(input_value_), batch_, iv.c, iv.h, iv.w, input_ld_, 0, 0, 0, 0, (sm_stream_t)s);
 }
 
 int Executor::launchAll(hipStream_t s, const float* in) const {
     static const bool debug_sync = getenv("SMELTER_DEBUG_SYNC") != nullptr;   // debugging switch, read once
+    cur_in_ = in;
     int rc = convertInput(s, in);
     if (rc) return rc;
     for (auto& st : steps_) {
@@ -986,6 +1003,12 @@ int Executor::autotune(hipStream_t s) {
     if (hipMalloc((void**)&flush, flush_bytes) != hipSuccess) { flush = nullptr; (void)hipGetLastError(); }
     hipEvent_t a, b; SM_HIP_CHECK(hipEventCreate(&a)); SM_HIP_CHECK(hipEventCreate(&b));
     int rc = SM_OK;
+    float* tune_in = nullptr;                                        // the loader-wave stem reads the fp32 batch: a zero image while its configurations are timed
+    if (stem_f32_ && !cur_in_) {
+        const Value& iv = values_[input_value_]; const size_t bytes = (size_t)batch_ * iv.c * iv.h * iv.w * sizeof(float);
+        SM_HIP_CHECK(hipMalloc((void**)&tune_in, bytes)); SM_HIP_CHECK(hipMemsetAsync(tune_in, 0, bytes, s));
+        cur_in_ = tune_in;
+    }
     for (size_t i = 0; i < steps_.size() && !rc; i++) {
         Step& st = steps_[i];
         if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8) || st.has_pair || st.has_mb) continue;
@@ -1027,6 +1050,7 @@ int Executor::autotune(hipStream_t s) {
     }
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (tune_in) { (void)hipFree(tune_in); cur_in_ = nullptr; }
     if (flush) (void)hipFree(flush);
     return rc;
 }

@@ -107,6 +107,8 @@ class Executor {
     int input_value_ = -1, output_value_ = -1, input_ld_ = 0;
     float* resized_ = nullptr;       // forceInputScale: the resampled batch (NCHW fp32), allocated on first use
     bool stem_ = false; int stem_h_ = 0, stem_w_ = 0, stem_pt_ = 0, stem_pl_ = 0;   // row-pair image geometry
+    // the stem kernel's loader waves build its patches from the fp32 batch (sm_conv2d_stem_f32_fwd_cfg): no conversion launch, no row-pair image
+    bool stem_f32_ = false; mutable const float* cur_in_ = nullptr;
     std::vector<std::string> value_names_, materialized_;
 
     char* arena_ = nullptr; size_t arena_bytes_ = 0; bool own_arena_ = false;

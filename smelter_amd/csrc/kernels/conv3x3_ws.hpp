@@ -59,9 +59,14 @@ constexpr int WS_DUMMY = 1024;                                        // LDS sin
 // consumed with the deferred stores one tile later (TM = 1: 64 registers), so neither the 3x3 output nor any operand latency is exposed.
 constexpr int WS_HX_N3 = 256;                                         // LDS is reserved for this many head channels
 constexpr int ws_hx_bytes(int nout) { return WS_HX_N3 * nout * 2 + WS_HX_N3 * 4; }
-template <int CIN, int NOUT, int NW, int TM, int NIC = (CIN == 64 ? 12 : 6), int ABL = 0, int STEM = 0, int PSB = 0, bool HEAD = false, bool HX = false>
-__global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
+// NLW > 0 (stem form only): LOADER WAVES.  The block has NLW more waves that build the row-pair patches straight from the fp32 NCHW input
+// (p.xf: <= 4 planes per image, zero outside the image = the convolution's padding) — convert, pack [row y | row y+1] x 4 channels, one
+// ds_write_b128 per patch pixel — into the buffer the MFMA waves will read next, under the same one barrier per tile; the MFMA waves issue
+// no DMA at all.  The separate input-conversion launch (nchw_to_rowpair_kernel: the batch read once and written twice over) disappears.
+template <int CIN, int NOUT, int NW, int TM, int NIC = (CIN == 64 ? 12 : 6), int ABL = 0, int STEM = 0, int PSB = 0, bool HEAD = false, bool HX = false, int NLW = 0>
+__global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams p) {
     constexpr bool ST = STEM > 0;
+    static_assert(NLW == 0 || (ST && !HEAD && !HX), "loader waves: stem form");
     constexpr int NTAP = ST ? STEM : 9;
     static_assert(!ST || (CIN == 64 && STEM <= 4), "stem form: 64 = 8 row-pair pixels x 8 halfs");
     static_assert(!HX || (!ST && !HEAD && TM == 1 && NOUT == 64), "expand head: plain form, one fragment per wave");
@@ -90,7 +95,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
     const int patch_slots = PH * PW * (ST ? 1 : CP), NI = (patch_slots + NT - 1) / NT;
 
     // ---- weights + bias -> LDS (once per block) -------------------------------------------------------------------------
-    {
+    if (NLW == 0 || wave < NW) {
         constexpr int WSLOTS = NTAP * NOUT * CP;
         static_assert((NOUT * CP) % 64 == 0, "a wave instruction stays inside the weight image");
 #pragma unroll 1
@@ -144,7 +149,68 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
         const int bx = (int)sm_fastdiv((unsigned)r, p.ws_ty_mul, p.ws_ty_sh), by = r - bx * p.ws_tiles_y;
         y0 = by * TH; x0 = bx * TW;
     };
+    if constexpr (NLW > 0) {
+        if (wave >= NW) {
+            // =========================== LOADER WAVES ===========================
+            constexpr int NLT = NLW * 64, LNI = (NIC * NT + NLT - 1) / NLT;      // patch pixels per loader thread (launcher: patch_slots <= NIC * NT)
+            constexpr unsigned DEAD = 0x80000000u;
+            const int ltid = tid - NT;
+            const int C = p.in_C, IH = p.in_H, IW = p.in_W;
+            const unsigned plane = (unsigned)IH * (unsigned)IW;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xf, 0, (int)((unsigned)p.N * (unsigned)C * plane * 4u), 0x00020000);
+            int lpr[LNI], lpc[LNI];
+#pragma unroll
+            for (int i = 0; i < LNI; i++) {
+                const int sl = i * NLT + ltid;
+                const int pr = (int)sm_fastdiv((unsigned)sl, p.ws_pw_mul, p.ws_pw_sh);
+                lpr[i] = sl < patch_slots ? pr : -0x40000000; lpc[i] = sl - pr * PW;   // beyond the patch: a row far outside the image (nothing read, nothing written)
+            }
+            // the loads of a patch are issued a whole tile before they are converted and written (two register sets, alternating): what a loader
+            // wave waits for at the top of a tile was requested one tile ago, and the next request is already out before it writes
+            auto request = [&](float (&v)[LNI][2][4], int t) __attribute__((always_inline)) {
+                int n, y0, x0; tile_origin(t, n, y0, x0);
+                const int r0 = y0 * SS - p.in_pt, c0 = x0 * SS - p.in_pl;               // input pixel of patch pixel (0, 0), top row
+                const unsigned img = (unsigned)n * (unsigned)C * plane;
+#pragma unroll
+                for (int i = 0; i < LNI; i++) {
+                    const int r = r0 + lpr[i], c = c0 + lpc[i];
+                    const bool okc = (unsigned)c < (unsigned)IW && t < t_end;
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const bool ok = okc && (unsigned)(r + h) < (unsigned)IH;
+                        const unsigned off = (img + (unsigned)(r + h) * (unsigned)IW + (unsigned)c) * 4u;
+#pragma unroll
+                        for (int ch = 0; ch < 4; ch++) v[i][h][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)((ch < C && ok) ? off + (unsigned)ch * plane * 4u : DEAD), 0, 0));
+                    }
+                }
+            };
+            auto deposit = [&](const float (&v)[LNI][2][4], int buf) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < LNI; i++) {
+                    const half8_t o = {(half_t)v[i][0][0], (half_t)v[i][0][1], (half_t)v[i][0][2], (half_t)v[i][0][3], (half_t)v[i][1][0], (half_t)v[i][1][1], (half_t)v[i][1][2], (half_t)v[i][1][3]};
+                    if (lpr[i] >= 0) *(half8_t*)(patch0 + buf * WS_PSTRIDE + (i * NLT + ltid) * 16) = o;
+                }
+            };
+            float va[LNI][2][4], vb[LNI][2][4];
+            request(va, t_begin); deposit(va, 0);
+            request(va, t_begin + 1);                                 // (beyond the range: dead offsets, nothing is read)
+#pragma unroll 1
+            for (int t = t_begin; t < t_end; t += 2) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my share of patch t is in LDS
+                __builtin_amdgcn_s_barrier();                         // ... everybody's; the MFMA waves are done with the other buffer
+                request(vb, t + 2);
+                if (t + 1 < t_end) deposit(va, 1);
+                if (t + 1 >= t_end) break;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                request(va, t + 3);
+                if (t + 2 < t_end) deposit(vb, 0);
+            }
+            return;
+        }
+    }
     auto issue_patch = [&](int buf, int t) {
+        if constexpr (NLW > 0) return;
         int n, y0, x0; tile_origin(t, n, y0, x0);
         const int iy0 = ST ? y0 * SS : y0 - 1, ix0 = ST ? x0 * SS : x0 - 1;      // input pixel of patch pixel (0, 0)
         const half_t* xb = p.ups ? p.x + (((long)n * (p.H >> 1) + (y0 >> 1)) * (p.W >> 1) + (x0 >> 1)) * p.x_ld
@@ -410,7 +476,7 @@ __global__ __launch_bounds__(NW * 64) void conv3x3_ws_kernel(ConvParams p) {
         sm_static_for<0, NS>([&](auto sc) {
             constexpr int S2 = decltype(sc)::value;
 #pragma unroll
-            for (int i = 0; i < NIC; i++) if (i * NS / (3 * NIC) == S2 && !(ABL & 1)) piece(i);   // one piece per k step over the FIRST THIRD of the tile: the rest of the tile is their flight time
+            for (int i = 0; i < NIC; i++) if (i * NS / (3 * NIC) == S2 && !(ABL & 1) && NLW == 0) piece(i);   // one piece per k step over the FIRST THIRD of the tile: the rest of the tile is their flight time
             if constexpr (S2 + PF < NS && !(ABL & 4)) fetch(std::integral_constant<int, S2 + PF>());
             constexpr int AHEAD = (NS - 1 - S2 < PF ? NS - 1 - S2 : PF) * RD;
             asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"((ABL & 4) ? 15 : AHEAD) : "memory");

@@ -49,6 +49,7 @@ struct ConvParams {
     // y3 = act3(w3 . y + b3), n3 <= 32); y itself is stored only if p.y != nullptr
     const half_t* w3; const float* b3; half_t* y3; int n3, y3_ld, act3; float sl3;
     // ... the EXPAND head (" xhead" instantiations): n3 = 32 .. 256 (multiple of 32), w3 / b3 in LDS, optional residual added to the head's output
+    const float* xf; int in_C, in_H, in_W, in_pt, in_pl;   // stem form with loader waves (conv3x3_ws.hpp NLW): the fp32 NCHW input the patches are built from
     const half_t* w3s;               // conv3x3_wsx.hpp SIDE: weights [n3][64] of the head's second GEMM; res3 / res3_ld then name its 64-channel input tensor
     const half_t* res3; int res3_ld; int hx_dbg;   // hx_dbg: SM_HX_DEBUG ablation bits (1 = no stores, 2 = no residual loads, 4 = no head at all)
     unsigned p9_pw_mul, p9_pw_sh, p9_h2_mul, p9_h2_sh;
@@ -710,6 +711,13 @@ const TileCfg kCfgs[] = {
     {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead"},  // 94  expand head (bottleneck tail): + 1x1 to <= 256 channels + residual
     {128, 64, 4, 512, conv3x3_wsx_kernel<6>, "ws:64->64 w4+4 xhead"},                                 // 95  ... with the two layers on different waves (conv3x3_wsx.hpp)
     {128, 64, 4, 512, conv3x3_wsx_kernel<6, true>, "ws:64->64 w4+4 xhead side"},                      // 96  ... and a second GEMM (the projection shortcut) instead of the residual tensor
+    // stem form with loader waves (conv3x3_ws.hpp NLW): the patches are built from the fp32 NCHW input inside the launch (sm_conv2d_stem_f32_fwd_cfg)
+    {256, 64, 6, 512, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 0, false, false, 4>, "wst:4->64 w4x2 ld4"},            // 97  (ResNet-50 7x7/2)
+    {256, 32, 6, 384, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024, false, false, 2>, "wst:2->32 w4x2 p20 ld2"}, // 98  (MobileNet-v2 3x3/2, U-Net 3x3/1: two blocks per CU)
+    {256, 64, 6, 384, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 2, 20 * 1024, false, false, 2>, "wst:2->64 w4x2 p20 ld2"}, // 99
+    {256, 32, 6, 512, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 4, 0, false, false, 4>, "wst:4->32 w4x2 ld4"},            // 100
+    {256, 64, 6, 512, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 23 * 1024, false, false, 4>, "wst:4->64 w4x2 p23 ld4"},  // 101 (178 registers: still one resident block; forcing <= 170 for two blocks of 4 + 2 waves spilled and did not win)
+    {256, 32, 6, 512, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024, false, false, 4>, "wst:2->32 w4x2 p20 ld4"},  // 102
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
@@ -789,7 +797,9 @@ size_t ps_lds_bytes(const ConvParams& p, const TileCfg& c) {
 // Geometry of the stem form of the weight-stationary kernel (kind 6): the same search over the OUTPUT image; a patch is
 // ((TH-1)s + 2(taps-1) + 1) x ((TW-1)s + 8) 16-byte row-pair pixels.  Returns the dynamic LDS size in bytes, 0 if the config does not fit.
 size_t wst_setup(ConvParams& p, const TileCfg& c) {
-    const int taps = atoi(c.name + 4), s = p.sH, nt = c.threads, nic = 6;
+    const int taps = atoi(c.name + 4), s = p.sH, nic = 6;
+    const char* ld = strstr(c.name, " ld");                            // loader waves: c.threads counts them, the patch is sized for the MFMA waves' NIC * NT slots
+    const int nt = ld ? c.threads - atoi(ld + 3) * 64 : c.threads;
     if (p.kH != taps || p.Cin != 64) return 0;
     const char* pk = strstr(c.name, " p");
     const size_t fixed = (size_t)taps * p.Cout * 128 + (size_t)p.Cout * 4 + WS_DUMMY;
@@ -871,6 +881,8 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
                (long)(p.Ho - 1) * p.sH < p.H && (long)(p.Wo - 1) * p.sW < p.W && ps_lds_bytes(p, c) <= 160 * 1024;
     if (c.kind == 6) {   // stem form: overlapping 64-half pixels of a row-pair image (x_ld = 8), one kernel column, rows two apart, no padding
         ConvParams q = p;
+        if ((strstr(c.name, " ld") != nullptr) != (p.xf != nullptr)) return false;            // loader-wave instantiations <-> fp32 input
+        if (p.xf && !(p.in_C >= 1 && p.in_C <= 4 && (long)p.N * p.in_C * p.in_H * p.in_W * 4 < 0x7fff0000L)) return false;
         return p.Cin == 64 && p.x_ld == 8 && p.kW == 1 && p.dH == 2 && p.pt == 0 && p.pl == 0 && p.sH == p.sW && (p.sH == 1 || p.sH == 2) && !p.ups &&
                (long)(p.Ho - 1) * p.sH + 2 * (p.kH - 1) < p.H && (long)(p.Wo - 1) * p.sW + 8 <= p.W &&
                !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
@@ -921,7 +933,7 @@ int fill_params(const sm_conv_desc* d, const void* x, const void* w, const float
     p->act = d->act; p->slope = d->act == SM_ACT_RELU ? 0.f : d->slope;
     p->M = d->N * d->Ho * d->Wo; p->K = d->kH * d->kW * (d->Cin / d->groups);
     p->splitk = 1; p->mt = p->nt = 0; p->ktiles_per_split = 0; p->ups = d->x_ups ? 1 : 0; p->y2 = nullptr; p->y2_ld = 0;
-    p->w3 = nullptr; p->b3 = nullptr; p->y3 = nullptr; p->n3 = 0; p->y3_ld = 0; p->act3 = 0; p->sl3 = 0.f; p->res3 = nullptr; p->res3_ld = 0; p->hx_dbg = 0; p->w3s = nullptr;
+    p->w3 = nullptr; p->b3 = nullptr; p->y3 = nullptr; p->n3 = 0; p->y3_ld = 0; p->act3 = 0; p->sl3 = 0.f; p->res3 = nullptr; p->res3_ld = 0; p->hx_dbg = 0; p->w3s = nullptr; p->xf = nullptr; p->in_C = p->in_H = p->in_W = p->in_pt = p->in_pl = 0;
     SM_REQUIRE(!d->x_ups || ((d->H & 1) == 0 && (d->W & 1) == 0 && d->groups == 1), "sm_conv2d_fwd: x_ups needs even H and W");
     SM_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "sm_conv2d_fwd: more than 2^31 output pixels");
     SM_REQUIRE((long)d->N * d->H * d->W < (1L << 31) - (1L << 24), "sm_conv2d_fwd: more than 2^31 input pixels");
@@ -1175,6 +1187,27 @@ int sm_conv2d_xhead_proj_supported(const sm_conv_desc* d, int32_t n3) {
     ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
     p.y = nullptr; p.w3 = (const half_t*)dummy; p.y3 = (half_t*)dummy; p.n3 = n3; p.y3_ld = n3; p.res3 = (const half_t*)dummy; p.res3_ld = 64; p.w3s = (const half_t*)dummy;
     for (int i = 0; i < kNumCfgs; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) return 1;
+    return 0;
+}
+// Image stem with the input conversion inside the launch: `d` is the stem-form descriptor (the row-pair geometry sm_conv2d_fwd takes for the stem:
+// H x W = row-pair image, Cin = 64, kW = 1, dH = 2, x_ld = 8), x_nchw the fp32 [N, C <= 4, H_in, W_in] batch, (pt, pl) the convolution's top / left padding.
+int sm_conv2d_stem_f32_fwd_cfg(const sm_conv_desc* d, int cfg, const float* x_nchw, int32_t C, int32_t H_in, int32_t W_in, int32_t pt, int32_t pl, const void* w,
+                               const float* bias, void* y, sm_stream_t stream) {
+    SM_REQUIRE(x_nchw && C >= 1 && C <= 4 && H_in > 0 && W_in > 0 && pt >= 0 && pl >= 0, "sm_conv2d_stem_f32_fwd_cfg: bad input description");
+    ConvParams p; int rc = fill_params(d, x_nchw, w, bias, nullptr, y, &p); if (rc) return rc;
+    p.xf = x_nchw; p.in_C = C; p.in_H = H_in; p.in_W = W_in; p.in_pt = pt; p.in_pl = pl;
+    if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 6 && cfg_eligible(kCfgs[i], p)) cfg = i; }
+    if (cfg < 0) { sm_set_error("sm_conv2d_stem_f32_fwd_cfg: no loader-wave stem kernel takes this shape"); return SM_ERR_INVALID_ARGUMENT; }
+    // (the generic kernels would take the stem-form descriptor and read `x_nchw` as a row-pair image)
+    if (kCfgs[cfg].kind != 6) { sm_set_error("conv tile config %d (%s) does not apply to an fp32 NCHW input", cfg, kCfgs[cfg].name); return SM_ERR_INVALID_ARGUMENT; }
+    return launch(d, p, cfg, nullptr, 0, sm_s(stream));
+}
+int sm_conv2d_stem_f32_supported(const sm_conv_desc* d, int32_t C, int32_t H_in, int32_t W_in) {
+    if (!d || d->groups != 1) return 0;
+    alignas(16) static char dummy[16];
+    ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
+    p.xf = (const float*)dummy; p.in_C = C; p.in_H = H_in; p.in_W = W_in;
+    for (int i = 0; i < kNumCfgs; i++) if (kCfgs[i].kind == 6 && cfg_eligible(kCfgs[i], p)) return 1;
     return 0;
 }
 int sm_conv2d_xhead_supported(const sm_conv_desc* d, int32_t n3, int32_t has_res) {

@@ -96,8 +96,10 @@ def stem_conv(x_nchw, w_ohwi_f32, bias=None, stride=1, pads=(0, 0, 0, 0), act=AC
     s, P = stride, (kh + 1) // 2
     ho, wo = conv_out_size(h, w, kh, kw, s, s, pads)
     hs, ws = (ho - 1) * s + 2 * (P - 1) + 1, (wo - 1) * s + 8
-    img = torch.empty((n, hs, ws, 8), dtype=torch.float16, device=x_nchw.device)
-    check(lib().sm_nchw_f32_to_rowpair_f16(_ptr(x_nchw), _ptr(img), n, c, h, w, hs, ws, pads[0], pads[1], _stream()))
+    f32_path = cfg is not None and cfg >= 97          # loader-wave configurations: the kernel builds its patches from the fp32 batch itself
+    if not f32_path:
+        img = torch.empty((n, hs, ws, 8), dtype=torch.float16, device=x_nchw.device)
+        check(lib().sm_nchw_f32_to_rowpair_f16(_ptr(x_nchw), _ptr(img), n, c, h, w, hs, ws, pads[0], pads[1], _stream()))
     wp = torch.zeros((cout, P, 8, 2, 4), dtype=torch.float32)
     wc = w_ohwi_f32.detach().cpu().float()
     for r in range(kh):
@@ -105,7 +107,9 @@ def stem_conv(x_nchw, w_ohwi_f32, bias=None, stride=1, pads=(0, 0, 0, 0), act=AC
     wp = wp.reshape(cout, P, 1, 64).to(torch.float16).to(x_nchw.device).contiguous()
     out = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x_nchw.device)
     d = ConvDesc(n, hs, ws, 64, cout, P, 1, s, s, 2, 1, 0, 0, 0, 0, 1, ho, wo, act, slope, 8, cout, 0)
-    if cfg is None:
+    if f32_path:
+        check(lib().sm_conv2d_stem_f32_fwd_cfg(C.byref(d), cfg, _ptr(x_nchw), c, h, w, pads[0], pads[1], _ptr(wp), _ptr(bias), _ptr(out), _stream()))
+    elif cfg is None:
         check(lib().sm_conv2d_fwd(C.byref(d), _ptr(img), _ptr(wp), _ptr(bias), None, _ptr(out), _stream()))
     else:
         check(lib().sm_conv2d_fwd_cfg(C.byref(d), cfg, _ptr(img), _ptr(wp), _ptr(bias), None, _ptr(out), None, 0, _stream()))

@@ -84,7 +84,7 @@ def test_fusion_counts_resnet50():
     # 53 convs (BN folded, Add/Relu in epilogues) + MaxPool + GlobalAveragePool + FC = 56 ops, of which the three 1x1 expand convolutions of the
     # first stage run inside the 3x3 launch in front of them (pass 3d, expand head) and so does the first block's projection shortcut (pass 3e);
     # + input conversion
-    assert ex.numOps == 52 and ex.numLaunches in (53, 54)
+    assert ex.numOps == 52 and ex.numLaunches in (52, 53)         # (no input-conversion launch: the stem's loader waves read the fp32 batch, pass 3f)
     assert abs(ex.flops - 2 * 4089184256 * (64 * 64) / (224 * 224)) / ex.flops < 0.2      # scaled MAC count, FC unscaled
 
 

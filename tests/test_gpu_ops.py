@@ -648,10 +648,11 @@ def test_conv3x3_with_fused_maxpool(n, hw, cin, cout, act, cfg):
     (1, 4, 50, 38, 32, 7, 2, (2, 3, 3, 2)),      # asymmetric padding, 4 channels
     (1, 3, 9, 9, 64, 3, 1, (0, 0, 0, 0)),        # image smaller than a tile
 ])
-@pytest.mark.parametrize("cfg", [None] + list(range(74, 81)))
+@pytest.mark.parametrize("cfg", [None] + list(range(74, 81)) + list(range(97, 103)))
 def test_stem_on_the_weight_stationary_kernel(shape, cfg):
     """Image stem through the row-pair image (ops.stem_conv = executor's lowering): every stem configuration of conv3x3_ws.hpp that takes
-    the shape agrees with the oracle convolution, and with the default pick"""
+    the shape agrees with the oracle convolution, and with the default pick.  Configurations 97+ have loader waves that build the patches from
+    the fp32 batch inside the launch (sm_conv2d_stem_f32_fwd_cfg): bit-identical to the row-pair path"""
     n, C, H, W, cout, k, s, pads = shape
     rng = np.random.default_rng(H * W + cout + k)
     x = rng.standard_normal((n, C, H, W)).astype(np.float32)
@@ -665,6 +666,8 @@ def test_stem_on_the_weight_stationary_kernel(shape, cfg):
         raise
     ref = np.maximum(O.conv2d(h(x), w, b, stride=(s, s), pads=pads), 0)
     assert_close(to_host(y), ref, C * k * k)
+    if cfg is not None and cfg >= 97:
+        assert torch.equal(y, ops.stem_conv(torch.from_numpy(x).cuda(), torch.from_numpy(w), torch.from_numpy(b).cuda(), stride=s, pads=pads, act=1))
 
 
 PS_CASES = [
