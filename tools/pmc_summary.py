@@ -5,10 +5,16 @@ conv_igemm kernel family; writes the HBM traffic per launch that bench.py report
 
 gfx950 corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE is in KiB and reports HALF the bytes of a wide coalesced
 stream -> hbm_read_bytes = FETCH_SIZE * 1024 * 2; WRITE_SIZE (KiB) is used as reported (uncalibrated in the guide)."""
+import os
+import sys
 import argparse
 import collections
 import csv
 import json
+
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from rocprof_summary import step_starts  # noqa: E402
 
 
 def main():
@@ -29,7 +35,7 @@ def main():
             d = int(r["Dispatch_Id"])
             if d not in seen:
                 seen.add(d); ids.append((d, r["Kernel_Name"]))
-        starts = [i for i, (_, n) in enumerate(ids) if "nchw_to_" in n]
+        starts = step_starts([n for _, n in ids], 2)
         lo, hi = starts[-2], starts[-1]
         ordinal = {d: i - lo for i, (d, _) in enumerate(ids) if lo <= i < hi}
         for r in rows:

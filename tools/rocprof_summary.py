@@ -40,6 +40,28 @@ def short(name):
     return name
 
 
+def step_starts(names, steps):
+    """dispatch indices that open an encode() step.  Marker = the input-conversion kernel when the step has one; otherwise (the stem's loader
+    waves read the fp32 batch) any kernel that occurs once per step: its last steps + 1 occurrences are evenly spaced"""
+    starts = [i for i, n in enumerate(names) if "nchw_to_" in n]
+    if len(starts) >= steps + 1:
+        return starts
+    occ = collections.defaultdict(list)
+    for i, n in enumerate(names):
+        occ[n].append(i)
+    best, best_gap = [], 0
+    for n, idx in occ.items():
+        if len(idx) < steps + 1:
+            continue
+        tail = idx[-(steps + 1):]
+        gaps = {y - x for x, y in zip(tail, tail[1:])}
+        if len(gaps) == 1:
+            g = gaps.pop()
+            if g > best_gap or (g == best_gap and tail[0] < best[0]):
+                best, best_gap = tail, g
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("path")
@@ -47,7 +69,7 @@ def main():
     ap.add_argument("--flops-per-step", type=float, default=64 * 2 * 4089184256.0)
     a = ap.parse_args()
     rows = load(a.path)
-    starts = [i for i, r in enumerate(rows) if "nchw_to_" in r[2]]
+    starts = step_starts([r[2] for r in rows], a.steps)
     assert len(starts) >= a.steps + 1, "found %d encode() calls" % len(starts)
     lo = starts[-a.steps - 1]
     hi = starts[-1]                      # the last encode may be followed by read-back kernels: use complete segments only
