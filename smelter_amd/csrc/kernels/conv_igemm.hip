@@ -713,11 +713,11 @@ const TileCfg kCfgs[] = {
     {128, 64, 4, 512, conv3x3_wsx_kernel<6, true>, "ws:64->64 w4+4 xhead side"},                      // 96  ... and a second GEMM (the projection shortcut) instead of the residual tensor
     // stem form with loader waves (conv3x3_ws.hpp NLW): the patches are built from the fp32 NCHW input inside the launch (sm_conv2d_stem_f32_fwd_cfg)
     {256, 64, 6, 512, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 0, false, false, 4>, "wst:4->64 w4x2 ld4"},            // 97  (ResNet-50 7x7/2)
-    {256, 32, 6, 384, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024, false, false, 2>, "wst:2->32 w4x2 p20 ld2"}, // 98  (MobileNet-v2 3x3/2, U-Net 3x3/1: two blocks per CU)
+    {256, 32, 6, 512, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024, false, false, 4>, "wst:2->32 w4x2 p20 ld4"},  // 98  (MobileNet-v2 3x3/2, U-Net 3x3/1: the autotuner's pick, first = the default)
     {256, 64, 6, 384, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 2, 20 * 1024, false, false, 2>, "wst:2->64 w4x2 p20 ld2"}, // 99
     {256, 32, 6, 512, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 4, 0, false, false, 4>, "wst:4->32 w4x2 ld4"},            // 100
     {256, 64, 6, 512, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 23 * 1024, false, false, 4>, "wst:4->64 w4x2 p23 ld4"},  // 101 (178 registers: still one resident block; forcing <= 170 for two blocks of 4 + 2 waves spilled and did not win)
-    {256, 32, 6, 512, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024, false, false, 4>, "wst:2->32 w4x2 p20 ld4"},  // 102
+    {256, 32, 6, 384, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024, false, false, 2>, "wst:2->32 w4x2 p20 ld2"}, // 102 (two blocks of 4 + 2 waves per CU)
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
@@ -1162,7 +1162,11 @@ int sm_conv2d_xhead_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const
     p.res3 = (const half_t*)res3; p.res3_ld = res3_ld ? res3_ld : n3;
     { static const int dbg = getenv("SM_HX_DEBUG") ? atoi(getenv("SM_HX_DEBUG")) : 0; p.hx_dbg = dbg; }   // ablation switch, read once
     const bool small = n3 <= 32 && !res3;                            // (the narrow heads without residual run on the " head" instantiations)
-    if (small || cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) cfg = i; }
+    if (small || cfg < 0 || cfg >= kNumCfgs) {                       // default pick: the two-role kernel where it applies (the faster one), else the first that takes the shape
+        cfg = -1;
+        for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && strstr(kCfgs[i].name, "w4+4") && cfg_eligible(kCfgs[i], p)) cfg = i;
+        for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) cfg = i;
+    }
     if (cfg < 0) { sm_set_error("sm_conv2d_xhead_fwd_cfg: no kernel takes this shape with a fused expand head (3x3 / s1 / p1, Cin = Cout = 64, n3 <= 256, n3 %% 32 == 0)"); return SM_ERR_INVALID_ARGUMENT; }
     return launch(d, p, cfg, nullptr, 0, sm_s(stream));
 }
