@@ -167,6 +167,15 @@ size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d);
 int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const float* b1, const void* wd, const float* bd,
                   const void* w2, const float* b2, void* y, sm_stream_t stream);
 
+/* The same block directly behind an image stem, the stem included (MobileNet-v2's first three layers): 3x3 convolution of the fp32 NCHW batch
+ * (`C` = 3 planes of in_H x in_W, stride st_stride, padding st_pad, activation d->act1) -> depthwise 3x3 -> 1x1 project, ONE launch; neither the
+ * input conversion nor the stem's output tensor exists.  d->H x d->W = the stem's output image, d->Ch = its channels (<= 32), d->Cin ignored;
+ * w1 = the stem's weights [Ch][3][3][3] (OHWI) fp16.  Same roundings as the separate launches. */
+int sm_mbconv_stem_supported(const sm_mbconv_desc* d, int32_t C, int32_t in_H, int32_t in_W, int32_t st_stride, int32_t st_pad);
+int sm_mbconv_stem_fwd(const sm_mbconv_desc* d, const float* x_nchw, int32_t C, int32_t in_H, int32_t in_W, int32_t st_stride, int32_t st_pad,
+                       const void* w1, const float* b1, const void* wd, const float* bd, const void* w2, const float* b2, void* y,
+                       sm_stream_t stream);
+
 /* MPSCNNConvolutionTransposeNode (Converters.swift:277) + ONNX_ConvolutionPadding(isTranspose) (:66-71, :97-103).
  * `w_ohwi_flipped` is what ConvDataSource hands MPS: out[oc][kH-1-kh][kW-1-kw][ic] = W[ic][oc][kh][kw]
  * (Array+Extensions.swift:71-76).  y[n,oy,ox,oc] = act(bias[oc] + sum x[n,iy,ix,ic] * W[ic,oc,kh,kw]) over

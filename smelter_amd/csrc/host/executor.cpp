@@ -300,7 +300,9 @@ int Executor::plan(ONNXGraph& g, int batch) {
                             w[((size_t)co * P + kh / 2) * 64 + kw * 8 + (kh & 1) * 4 + c] = op.weight[(((size_t)co * op.kh + kh) * op.kw + kw) * C + c];
             stem_ = true; stem_pt_ = op.pt; stem_pl_ = op.pl;
             stem_h_ = (ov.h - 1) * op.sh + 2 * (P - 1) + 1; stem_w_ = (ov.w - 1) * op.sw + 8;
+            st.stem_s = op.sh; st.stem_p = (op.pt == op.pl && op.pt == op.pb && op.pt == op.pr && op.sh == op.sw && op.kh == 3 && op.kw == 3 && C == 3) ? op.pt : -1;   // (-1: not a form pass 3g takes)
             op.weight.swap(w); op.cin = 64; op.kh = P; op.kw = 1; op.dh = 2; op.dw = 1; op.pt = op.pl = op.pb = op.pr = 0;
+            st.stem_w = std::move(w);                                  // the original [Cout][kH][kW][C] weights
             st.stem = true; input_ld_ = 8; place_[input_value_].ld = 8;
         } else if (isConvLike(op.kind) && op.groups == 1 && op.kind == OpKind::Conv && rootOf(op.inputs[0]) == input_value_ && input_ld_ != op.cin) {
             // pad Cin (OHWI innermost) with zero columns up to the padded image stride
@@ -499,6 +501,33 @@ int Executor::plan(ONNXGraph& g, int batch) {
         }
     }
 
+    // ---- 3g. stem inside the first block: a 3x3 stem on 3 planes whose only reader is a depthwise-first block of pass 3c (MobileNet-v2's first three
+    // layers) becomes that block's "expand" layer — an im2col gather of the fp32 batch inside the block kernel (mbconv.hip IMC, sm_mbconv_stem_fwd): the
+    // input conversion, the stem launch and the stem's output tensor (205 MB at 112^2 x 32, bs 256: written once, read once) disappear.
+    // SMELTER_MBCONV_STEM=0 keeps the stem launch.
+    stem_in_block_ = false;
+    if (stem_ && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && !(getenv("SMELTER_MBCONV_STEM") && getenv("SMELTER_MBCONV_STEM")[0] == '0')) {
+        auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
+        for (size_t t = 0; t + 1 < steps_.size(); t++) {
+            Step& sc = steps_[t];
+            if (!sc.stem || sc.stem_p < 0 || sc.op.act > SM_ACT_PRELU || sc.op.residual >= 0 || readers(sc.op.output) != 1) continue;
+            size_t ub = 0;
+            for (size_t u = t + 1; u < steps_.size() && !ub; u++) if (!steps_[u].op.inputs.empty() && steps_[u].op.inputs[0] == sc.op.output) ub = u;
+            if (!ub || !steps_[ub].has_mb || !steps_[ub].mb_noexp) continue;
+            Step& bk = steps_[ub];
+            const Value& hv = values_[sc.op.output]; const Value& pv = values_[bk.mb_proj.output]; const Value& iv = values_[input_value_];
+            sm_mbconv_desc d{}; d.N = batch; d.H = hv.h; d.W = hv.w; d.Ho = pv.h; d.Wo = pv.w; d.stride = bk.mb_dw.sh; d.Cin = 27; d.Ch = sc.op.cout; d.Cout = bk.mb_proj.cout; d.expand = 1;
+            d.act1 = sc.op.act; d.act2 = bk.mb_dw.act; d.act3 = bk.mb_proj.act;
+            if (!sm_mbconv_stem_supported(&d, iv.c, iv.h, iv.w, sc.stem_s, sc.stem_p)) continue;
+            bk.mb_stem = true; bk.stem_w = std::move(sc.stem_w); bk.stem_b = sc.op.bias; bk.stem_oh = hv.h; bk.stem_ow = hv.w; bk.stem_s = sc.stem_s; bk.stem_p = sc.stem_p;
+            bk.stem_act = sc.op.act; bk.stem_slope = sc.op.slope; bk.stem_out = sc.op.output; bk.stem_name = sc.op.name;
+            bk.op.inputs[0] = input_value_; bk.mb_dw.inputs[0] = input_value_;
+            steps_.erase(steps_.begin() + t);
+            stem_in_block_ = true;
+            break;
+        }
+    }
+
     // ---- 3f. image stem: when a loader-wave instantiation of the stem kernel takes the layer, the input conversion happens inside its launch
     // (conv3x3_ws.hpp NLW): the row-pair image is never written; SMELTER_STEM_F32=0 keeps the conversion launch.
     stem_f32_ = false;
@@ -507,6 +536,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             const sm_conv_desc d = convDesc(st); const Value& iv = values_[input_value_];
             stem_f32_ = sm_conv2d_stem_f32_supported(&d, iv.c, iv.h, iv.w) != 0;
         }
+    if (stem_in_block_) stem_f32_ = true;                             // (no conversion launch, no row-pair image either)
     if (stem_f32_) launches_ -= 1;
 
     // ---- 4. memory plan ------------------------------------------------------------------------------------
@@ -578,6 +608,13 @@ int Executor::plan(ONNXGraph& g, int batch) {
             st.w_off = off; off = alignUp(off + op.weight.size() * 2);
             st.has_bias = !op.bias.empty();
             if (st.has_bias) { st.b_off = off; off = alignUp(off + op.bias.size() * 4); }
+            if (st.has_mb && st.mb_stem) {
+                st.ws_off = off; off = alignUp(off + st.stem_w.size() * 2);
+                if (!st.stem_b.empty()) { st.bs_off = off; off = alignUp(off + st.stem_b.size() * 4); }
+                const double Ms = (double)batch * st.stem_oh * st.stem_ow; const Value& iv = values_[input_value_];
+                flops_ += 2.0 * Ms * (double)st.stem_w.size();                                  // the stem layer of the graph: M x Cout x (kH kW C)
+                alg_bytes_ += 2.0 * ((double)batch * iv.c * iv.h * iv.w + Ms * (double)(st.stem_w.size() / 27) + (double)st.stem_w.size());
+            }
             if (st.has_mb) {
                 st.wd_off = off; off = alignUp(off + st.mb_dw.weight.size() * 2);
                 st.has_biasd = !st.mb_dw.bias.empty();
@@ -639,6 +676,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         if (st.has_head) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.head.name.c_str(), st.head.cout, st.head.cin, st.head.residual >= 0 ? " +res" : "", st.head.act ? " +act" : ""); st.desc += buf; }
         if (st.has_side) { snprintf(buf, sizeof buf, " + Conv %s N=%d K=%d k=1x1 projection%s (same launch)", st.side.name.c_str(), st.side.cout, st.side.cin, st.side.act ? " +act" : ""); st.desc += buf; }
         if (st.has_mb && st.mb_noexp) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.act ? " +act" : ""); st.desc += buf; }
+        if (st.has_mb && st.mb_stem) st.desc = "Conv " + st.stem_name + " k=3x3 stem (fp32 image, same launch) >> " + st.desc;
         else if (st.has_mb) { snprintf(buf, sizeof buf, " >> Conv %s k=3x3 s=%d g=%d%s >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.mb_dw.name.c_str(), st.mb_dw.sh, st.mb_dw.groups, st.mb_dw.act ? " +act" : "",
                                   st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.residual >= 0 ? " +res" : "", st.mb_proj.act ? " +act" : ""); st.desc += buf; }
         if (st.join >= 0) st.desc += " side-stream";
@@ -651,6 +689,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         if (st.has_head) { materialized_.push_back(values_[st.op.output].name); materialized_.push_back(values_[st.head.output].name); continue; }   // (rounded to fp16 in registers)
         if (st.has_mb) {   // (the two hidden tensors live in LDS only, but are rounded to fp16 there exactly as a stored tensor would be: listed for the parity oracle)
             if (!st.mb_noexp) materialized_.push_back(values_[st.op.output].name);
+            if (st.mb_stem) materialized_.push_back(values_[st.stem_out].name);                   // (the stem's output: the block's first hidden tensor)
             materialized_.push_back(values_[st.mb_dw.output].name); materialized_.push_back(values_[st.mb_proj.output].name); continue;
         }
         if (st.op.kind != OpKind::Concat && materialized_.back() != values_[st.op.output].name) materialized_.push_back(values_[st.op.output].name);
@@ -677,6 +716,10 @@ int Executor::packWeights(std::vector<uint8_t>* host) const {
                 sm_float_to_half(op.weight.data(), dst, op.weight.size());   // fp16 cast, RNE (ONNX2MPS.py:27 numpy astype(float16))
             }
             if (st.has_bias) memcpy(host->data() + st.b_off, op.bias.data(), op.bias.size() * 4);
+            if (st.has_mb && st.mb_stem) {
+                sm_float_to_half(st.stem_w.data(), (uint16_t*)(host->data() + st.ws_off), st.stem_w.size());
+                if (!st.stem_b.empty()) memcpy(host->data() + st.bs_off, st.stem_b.data(), st.stem_b.size() * 4);
+            }
             if (st.has_mb) {
                 sm_float_to_half(st.mb_dw.weight.data(), (uint16_t*)(host->data() + st.wd_off), st.mb_dw.weight.size());
                 if (st.has_biasd) memcpy(host->data() + st.bd_off, st.mb_dw.bias.data(), st.mb_dw.bias.size() * 4);
@@ -762,6 +805,15 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
     sm_stream_t ss = (sm_stream_t)s;
     switch (op.kind) {
     case OpKind::Conv: case OpKind::FullyConnected: {
+        if (st.has_mb && st.mb_stem) {
+            if (!cur_in_) { sm_set_error("stem block launched before any input was bound"); return SM_ERR_INCONSISTENT_STATE; }
+            const Value& iv = values_[input_value_]; const Value& pv = values_[st.mb_proj.output];
+            sm_mbconv_desc m{}; m.N = batch_; m.H = st.stem_oh; m.W = st.stem_ow; m.Ho = pv.h; m.Wo = pv.w; m.stride = st.mb_dw.sh; m.Cin = 27; m.Ch = op.cout; m.Cout = st.mb_proj.cout; m.expand = 1;
+            m.act1 = st.stem_act; m.slope1 = st.stem_slope; m.act2 = st.mb_dw.act; m.slope2 = st.mb_dw.slope; m.act3 = st.mb_proj.act; m.slope3 = st.mb_proj.slope; m.y_ld = valueLd(st.mb_proj.output);
+            return sm_mbconv_stem_fwd(&m, cur_in_, iv.c, iv.h, iv.w, st.stem_s, st.stem_p, arena_ + st.ws_off, st.stem_b.empty() ? nullptr : (const float*)(arena_ + st.bs_off), arena_ + st.wd_off,
+                                      st.has_biasd ? (const float*)(arena_ + st.bd_off) : nullptr, arena_ + st.w2_off, st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr,
+                                      valuePtr(st.mb_proj.output), ss);
+        }
         if (st.has_mb) {
             const Value& iv = values_[op.inputs[0]]; const Value& pv = values_[st.mb_proj.output];
             sm_mbconv_desc m{}; m.N = batch_; m.H = iv.h; m.W = iv.w; m.Ho = pv.h; m.Wo = pv.w; m.stride = st.mb_dw.sh; m.Cin = op.cin; m.Ch = op.cout; m.Cout = st.mb_proj.cout; m.expand = st.mb_noexp ? 0 : 1;

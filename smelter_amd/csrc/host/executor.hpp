@@ -49,6 +49,10 @@ struct Step {                // one op after fusion, with everything resolved
     // is the head's output; it becomes the head's second GEMM (sm_conv2d_xhead_proj_fwd_cfg; weights at wd_off, the two biases summed at b2_off) and the
     // head's own output is never materialised
     bool has_side = false; Op side;
+    // ... behind an image stem (executor.cpp pass 3g): the stem convolution is the block kernel's "expand" layer, gathered from the fp32 batch
+    // (sm_mbconv_stem_fwd): `stem_w` = the stem's weights [Ch][3][3][C] before the row-pair packing (kept for every stem step), at ws_off / bs_off
+    bool mb_stem = false; std::vector<float> stem_w, stem_b; size_t ws_off = 0, bs_off = 0; int stem_oh = 0, stem_ow = 0, stem_s = 1, stem_p = 0, stem_act = 0; float stem_slope = 0.f;
+    int stem_out = -1; std::string stem_name;
     bool mb_noexp = false;   // the block has no expand layer: this step IS the depthwise convolution (mb_dw is a copy of it), mb_proj follows
     std::string desc;
 };
@@ -109,6 +113,7 @@ class Executor {
     bool stem_ = false; int stem_h_ = 0, stem_w_ = 0, stem_pt_ = 0, stem_pl_ = 0;   // row-pair image geometry
     // the stem kernel's loader waves build its patches from the fp32 batch (sm_conv2d_stem_f32_fwd_cfg): no conversion launch, no row-pair image
     bool stem_f32_ = false; mutable const float* cur_in_ = nullptr;
+    bool stem_in_block_ = false;     // pass 3g: the stem runs inside the first block's launch
     std::vector<std::string> value_names_, materialized_;
 
     char* arena_ = nullptr; size_t arena_bytes_ = 0; bool own_arena_ = false;

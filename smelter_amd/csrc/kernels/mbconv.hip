@@ -35,6 +35,9 @@ struct MbParams {
     int ChP, hstride;                // Ch rounded up to 32; LDS bytes per hidden pixel = ChP*2 + 16 (an odd number of 16-byte slots: conflict-free b128 columns)
     int tiles_x, tiles_y, ntiles;
     unsigned tx_mul, tx_sh, txy_mul, txy_sh, pw_mul, pw_sh;
+    // v3 IMC (the block behind an image stem): the "expand" layer is the stem's 3x3 convolution of the fp32 NCHW image `xf` (3 planes of in_H x in_W,
+    // stride st_s, padding st_p): K = 27 taps (kh, kw, c) + the two bias columns, gathered per patch pixel; H x W above = the stem's OUTPUT image
+    const float* xf; int in_H, in_W, st_s, st_p;
 };
 
 inline void fastdiv_make(unsigned d, unsigned* mul, unsigned* sh) { unsigned s = 0; while ((1ull << s) < d) s++; *mul = (unsigned)(((1ull << (31 + s)) / d) + 1); *sh = 31 + s; }
@@ -458,8 +461,12 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
 // WG: W1 and W2 do not fit the LDS (Ch = 384 / 576): their MFMA fragments are read from global memory (L2-resident) — W1's for chunk c+1
 // right behind the MFMAs that consumed chunk c's, W2's at the top of the chunk that multiplies them two phases later; the bias columns of W1
 // are made in registers from b1.  NF = cout blocks of 32 (accumulator sets).
-template <int S, int KS1, int NW, bool WREG, int TH = (S == 1 ? 4 : 2), bool WG = false, int NF = 2>
+// IMC: the expand layer is an image stem (3x3, 3 input planes, fp32 NCHW): the patch's B fragments are an im2col gather — lane = patch pixel of
+// the stem's output, its 16 k values per k step = taps (kh, kw, c) = k / 3 / 3, k / 3 % 3, k % 3 read from the planes (zero outside the image:
+// the stem's padding), k = 27, 28 the bias columns.  The stem's output (32 channels at full resolution: written once and read once) never exists.
+template <int S, int KS1, int NW, bool WREG, int TH = (S == 1 ? 4 : 2), bool WG = false, int NF = 2, bool IMC = false>
 __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
+    static_assert(!IMC || (KS1 == 2 && !WG), "image-stem form: K = 27 + 2 -> two k steps");
     constexpr int TW = 8, OPX = TH * TW, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, HP = PH * PW, MFA = (HP + 31) / 32, HS = 80, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
     constexpr int KP1 = KS1 * 16;
@@ -519,8 +526,43 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
         const half_t* const xim = p.x + (long)n * p.H * p.W * p.x_ld;
         // ---- X fragments of the whole patch: [row block][k step], 16 bytes per lane, kept for all chunks ------------------------------
         half8_t fx[MFA][KS1 ? KS1 : 1];
+        if constexpr (IMC) {
+            constexpr unsigned DEAD = 0x80000000u;
+            const unsigned plane = (unsigned)p.in_H * (unsigned)p.in_W;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xf, 0, (int)((unsigned)p.N * 3u * plane * 4u), 0x00020000);
 #pragma unroll
-        for (int mf = 0; mf < (KS1 ? MFA : 0); mf++) {
+            for (int mf = 0; mf < MFA; mf++) {
+                const int pp = mf * 32 + l31, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px;
+                const bool inimg = pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const int r0 = iy * p.st_s - p.st_p, c0 = ix * p.st_s - p.st_p;
+                // (one k step at a time: 8 loads in flight per lane, not 16 — the 16-wave blocks live on a 128-register budget)
+#pragma unroll
+                for (int ks = 0; ks < KS1; ks++) {
+                    float g[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        // k = 16 ks + 8 hi + e: both candidates are compile-time constants, the lane's half-wave picks one
+                        const int k0 = ks * 16 + e, k1 = k0 + 8;
+                        const int kh = hi ? (k1 / 9) : (k0 / 9), kw = hi ? (k1 / 3 % 3) : (k0 / 3 % 3), c = hi ? (k1 % 3) : (k0 % 3);
+                        const bool tap = hi ? k1 < 27 : k0 < 27;
+                        const int row = r0 + kh, col = c0 + kw;
+                        const bool ok = inimg && tap && (unsigned)row < (unsigned)p.in_H && (unsigned)col < (unsigned)p.in_W;
+                        const unsigned off = ok ? (((unsigned)n * 3u + (unsigned)c) * plane + (unsigned)row * (unsigned)p.in_W + (unsigned)col) * 4u : DEAD;
+                        g[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+                    }
+                    half8_t v;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int k = ks * 16 + hi * 8 + e;
+                        v[e] = (k == 27 || k == 28) ? (half_t)(inimg ? 1.f : 0.f) : (half_t)g[e];
+                    }
+                    fx[mf][ks] = v;
+                    __builtin_amdgcn_sched_barrier(0);                // (keeps hipcc from computing all 32 addresses up front)
+                }
+            }
+        }
+#pragma unroll
+        for (int mf = 0; mf < ((KS1 && !IMC) ? MFA : 0); mf++) {
             const int pp = mf * 32 + l31, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px;
             const bool inimg = pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const half_t* src = xim + ((long)iy * p.W + ix) * p.x_ld;
@@ -829,6 +871,49 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
     const int grid = (int)std::min<long>(nt, (long)SM_NUM_CU * std::min(per_cu, 2));      // 16-wave blocks: at most two per CU
     if (d->stride == 1) hipLaunchKernelGGL((mbconv_kernel<8, 8, 1>), dim3(grid), dim3(1024), lds, sm_s(stream), p);
     else hipLaunchKernelGGL((mbconv_kernel<4, 8, 2>), dim3(grid), dim3(1024), lds, sm_s(stream), p);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
+
+// The block behind an image stem, stem included: 3x3 convolution of the fp32 NCHW image (3 planes, stride st_stride, padding st_pad, ReLU-family
+// activation d->act1) -> depthwise 3x3 (d->stride) -> 1x1 project, ONE launch (mbconv3_kernel IMC).  d->H x d->W = the stem's OUTPUT image,
+// d->Ch = the stem's output channels (<= 32: one hidden chunk), w1 = the stem's weights [Ch][3][3][3] (OHWI) fp16, d->Cin is ignored.
+int sm_mbconv_stem_supported(const sm_mbconv_desc* d, int32_t C, int32_t in_H, int32_t in_W, int32_t st_stride, int32_t st_pad) {
+    if (!d || C != 3 || d->Ch > 32 || (d->Ch & 7) || d->Cout > 64 || (d->Cout & 7) || d->residual || in_H <= 0 || in_W <= 0 || st_stride < 1 || st_stride > 2 || st_pad < 0 || st_pad > 1) return 0;
+    if (d->H != (in_H + 2 * st_pad - 3) / st_stride + 1 || d->W != (in_W + 2 * st_pad - 3) / st_stride + 1) return 0;
+    if ((long)d->N * 3 * in_H * in_W * 4 >= 0x7fff0000L) return 0;
+    sm_mbconv_desc dl = *d; dl.Cin = 24; dl.expand = 1;               // (K = 27 + 2 -> the LDS / wave budget of a Cin = 24 expand block)
+    return mb_common_ok(&dl) && !mb_v3_wg(&dl) && mb_v3_lds(&dl) <= 160 * 1024;
+}
+int sm_mbconv_stem_fwd(const sm_mbconv_desc* d, const float* x_nchw, int32_t C, int32_t in_H, int32_t in_W, int32_t st_stride, int32_t st_pad, const void* w1, const float* b1,
+                       const void* wd, const float* bd, const void* w2, const float* b2, void* y, sm_stream_t stream) {
+    SM_REQUIRE(sm_mbconv_stem_supported(d, C, in_H, in_W, st_stride, st_pad) && x_nchw && w1 && wd && w2 && y, "sm_mbconv_stem_fwd: unsupported geometry");
+    sm_mbconv_desc dl = *d; dl.Cin = 24; dl.expand = 1;
+    MbParams p{};
+    p.xf = x_nchw; p.in_H = in_H; p.in_W = in_W; p.st_s = st_stride; p.st_p = st_pad;
+    p.x = nullptr; p.y = (half_t*)y; p.w1 = (const half_t*)w1; p.wd = (const half_t*)wd; p.w2 = (const half_t*)w2; p.b1 = b1; p.bd = bd; p.b2 = b2;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo; p.s = d->stride; p.Cin = 27; p.Ch = d->Ch; p.Cout = d->Cout;
+    p.x_ld = 8; p.y_ld = d->y_ld ? d->y_ld : d->Cout; p.expand = 1; p.res = 0;
+    SM_REQUIRE((p.y_ld & 7) == 0 && (((uintptr_t)y) & 15) == 0, "sm_mbconv_stem_fwd: output must be 16-byte aligned, pixel stride % 8 == 0");
+    p.act1 = d->act1; p.act2 = d->act2; p.act3 = d->act3;
+    p.sl1 = d->act1 == SM_ACT_NONE ? 1.f : d->act1 == SM_ACT_RELU ? 0.f : d->slope1;
+    p.sl2 = d->act2 == SM_ACT_NONE ? 1.f : d->act2 == SM_ACT_RELU ? 0.f : d->slope2;
+    p.sl3 = d->act3 == SM_ACT_NONE ? 1.f : d->act3 == SM_ACT_RELU ? 0.f : d->slope3;
+    p.ChP = (d->Ch + 31) & ~31; p.hstride = p.ChP * 2 + 16;
+    const int th3 = d->stride == 1 ? 4 : 2;
+    const long nt3 = (long)d->N * sm_ceil_div(d->Ho, th3) * sm_ceil_div(d->Wo, 8);
+    SM_REQUIRE(nt3 < (1L << 31), "sm_mbconv_stem_fwd: too many tiles");
+    p.tiles_x = sm_ceil_div(d->Wo, 8); p.tiles_y = sm_ceil_div(d->Ho, th3); p.ntiles = (int)nt3;
+    fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
+    fastdiv_make((unsigned)(7 * d->stride + 3), &p.pw_mul, &p.pw_sh);
+    // (8-wave blocks at most: the gather's address arithmetic does not fit the 16-wave blocks' 128-register budget — 436 us spilling against 282)
+    const int nw = std::min(mb_v3_waves(&dl), 8);
+    const size_t lds = mb_v3_lds_nw(&dl, nw);
+    const int per_cu3 = (int)std::max<size_t>(1, std::min<size_t>(16 / nw, (size_t)(160 * 1024) / lds));
+    const int grid3 = (int)std::min<long>((nt3 + nw - 1) / nw, (long)SM_NUM_CU * per_cu3);
+    void (*fn)(MbParams) = nullptr;
+    if (d->stride == 2) fn = nw == 16 ? mbconv3_kernel<2, 2, 16, false, 2, false, 2, true> : nw == 8 ? mbconv3_kernel<2, 2, 8, false, 2, false, 2, true> : mbconv3_kernel<2, 2, 4, false, 2, false, 2, true>;
+    else fn = nw == 16 ? mbconv3_kernel<1, 2, 16, false, 4, false, 2, true> : nw == 8 ? mbconv3_kernel<1, 2, 8, true, 4, false, 2, true> : mbconv3_kernel<1, 2, 4, true, 4, false, 2, true>;
+    hipLaunchKernelGGL(fn, dim3(grid3), dim3(nw * 64), lds, sm_s(stream), p);
     SM_LAUNCH_CHECK(); return SM_OK;
 }
 

@@ -366,3 +366,18 @@ def nhwc_f16_to_float_array(x):
     out = torch.empty((lib().sm_float_array_count(n, c, h, w),), dtype=torch.float32, device=x.device)
     check(lib().sm_nhwc_f16_to_float_array(_ptr(x), _ptr(out), n, c, h, w, x_ld, _stream()))
     return out
+
+
+def mbconv_stem(x_nchw, w_stem_ohwi, b_stem, wd, bd, w2, b2, st_stride=2, st_pad=1, stride=1, acts=(ACT_RELU, ACT_RELU, ACT_NONE)):
+    """image stem (3x3 on the fp32 NCHW batch) -> depthwise 3x3 -> 1x1 project in one launch (sm_mbconv_stem_fwd); w_stem_ohwi [Ch,3,3,3] fp16"""
+    from ._native import MbConvDesc
+    assert x_nchw.is_cuda and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    n, c, ih, iw = x_nchw.shape
+    ch, cout = wd.shape[0], w2.shape[0]
+    h, w = (ih + 2 * st_pad - 3) // st_stride + 1, (iw + 2 * st_pad - 3) // st_stride + 1
+    ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x_nchw.device)
+    d = MbConvDesc(n, h, w, ho, wo, stride, 27, ch, cout, 1, 0, acts[0], 0.0, acts[1], 0.0, acts[2], 0.0, 0, _ld(y))
+    check(lib().sm_mbconv_stem_fwd(C.byref(d), _ptr(x_nchw), c, ih, iw, st_stride, st_pad, _ptr(w_stem_ohwi), _ptr(b_stem), _ptr(wd), _ptr(bd), _ptr(w2), _ptr(b2),
+                                   _ptr(y), _stream()))
+    return y

@@ -616,6 +616,31 @@ def test_mbconv_fused_block_equals_the_three_layers(n, hw, cin, ch, cout, stride
     assert np.mean(got != ref16) < 0.2                                  # the vast majority of the elements is bit-identical
 
 
+@pytest.mark.parametrize("n,hw,ch,cout,st_stride,stride", [
+    (2, (64, 64), 32, 16, 2, 1),      # MobileNet-v2's first three layers: 3x3/2 stem 3 -> 32, depthwise 3x3, project 32 -> 16
+    (1, (45, 51), 32, 16, 2, 1),      # odd image, ragged tiles
+    (2, (40, 24), 32, 24, 1, 2),      # stride-1 stem, stride-2 depthwise
+    (1, (30, 38), 16, 64, 2, 1),      # 16 stem channels, 64 outputs (two cout blocks)
+])
+def test_mbconv_with_the_image_stem_inside(n, hw, ch, cout, st_stride, stride):
+    """sm_mbconv_stem_fwd: stem (3x3 on the fp32 NCHW batch, padding 1, ReLU) -> depthwise 3x3 -> project in one launch, against the oracle's three
+    convolutions with the hidden tensors rounded to fp16 where the separate launches store them (the stem reads the fp16-rounded image, as
+    the conversion kernel would have produced it)"""
+    rng = np.random.default_rng(ch + cout + hw[0] + st_stride)
+    x = rng.standard_normal((n, 3, hw[0], hw[1])).astype(np.float32)
+    ws = h(rng.standard_normal((ch, 3, 3, 3)) * np.sqrt(2.0 / 27)); bs = rng.standard_normal(ch).astype(np.float32) * 0.1
+    wd = h(rng.standard_normal((ch, 3, 3, 1)) * np.sqrt(2.0 / 9)); bd = rng.standard_normal(ch).astype(np.float32) * 0.1
+    w2 = h(rng.standard_normal((cout, 1, 1, ch)) * np.sqrt(1.0 / ch)); b2 = rng.standard_normal(cout).astype(np.float32) * 0.1
+    hid = h(np.maximum(O.conv2d(h(x), ws, bs, stride=(st_stride, st_stride), pads=(1, 1, 1, 1)), 0))
+    hid2 = h(np.maximum(O.conv2d(hid, wd, bd, stride=(stride, stride), pads=(1, 1, 1, 1), groups=ch), 0))
+    ref = O.conv2d(hid2, w2, b2)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    y = ops.mbconv_stem(dev(x), dev(ws).half(), dev(bs), dev(wd.reshape(ch, 3, 3)).half(), dev(bd), dev(w2).half(), dev(b2), st_stride=st_stride, st_pad=1, stride=stride)
+    got, ref16 = to_host(y), h(ref)
+    assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
+    assert np.mean(got != ref16) < 0.2
+
+
 @pytest.mark.parametrize("n,hw,cin,cout,act", [(2, (64, 64), 32, 32, 1), (1, (32, 96), 64, 32, 2), (2, (20, 32), 64, 64, 1), (1, (16, 128), 32, 64, 0)])
 @pytest.mark.parametrize("cfg", [-1, 61, 62, 63, 64, 66, 67])
 def test_conv3x3_with_fused_maxpool(n, hw, cin, cout, act, cfg):
