@@ -614,6 +614,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 const double Ms = (double)batch * st.stem_oh * st.stem_ow; const Value& iv = values_[input_value_];
                 flops_ += 2.0 * Ms * (double)st.stem_w.size();                                  // the stem layer of the graph: M x Cout x (kH kW C)
                 alg_bytes_ += 2.0 * ((double)batch * iv.c * iv.h * iv.w + Ms * (double)(st.stem_w.size() / 27) + (double)st.stem_w.size());
+                // (the depthwise layer below is accounted with this step's input, which is now the image: charge it the stem's output it reads in the graph)
+                alg_bytes_ += 2.0 * (Ms * (double)(st.stem_w.size() / 27) - (double)batch * iv.c * iv.h * iv.w);
             }
             if (st.has_mb) {
                 st.wd_off = off; off = alignUp(off + st.mb_dw.weight.size() * 2);

@@ -535,19 +535,26 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
                 const int pp = mf * 32 + l31, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px;
                 const bool inimg = pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                 const int r0 = iy * p.st_s - p.st_p, c0 = ix * p.st_s - p.st_p;
-                // (one k step at a time: 8 loads in flight per lane, not 16 — the 16-wave blocks live on a 128-register budget)
+                // byte offset of tap (0, 0) of plane 0 (wraps when r0 / c0 are negative: only in-bounds taps use it), and one bit per tap that is inside the image
+                const unsigned base = (((unsigned)n * 3u) * plane + (unsigned)r0 * (unsigned)p.in_W + (unsigned)c0) * 4u;
+                unsigned okbits = 0;
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                    for (int kw = 0; kw < 3; kw++)
+                        okbits |= (unsigned)(inimg && (unsigned)(r0 + kh) < (unsigned)p.in_H && (unsigned)(c0 + kw) < (unsigned)p.in_W) << (kh * 3 + kw);
 #pragma unroll
                 for (int ks = 0; ks < KS1; ks++) {
                     float g[8];
 #pragma unroll
                     for (int e = 0; e < 8; e++) {
-                        // k = 16 ks + 8 hi + e: both candidates are compile-time constants, the lane's half-wave picks one
+                        // k = 16 ks + 8 hi + e = (kh*3 + kw)*3 + c: both candidates are compile-time constants (their plane / row / column offsets wave-uniform
+                        // scalars), the lane's half-wave picks one; k >= 27 (bias columns, padding) reads nothing
                         const int k0 = ks * 16 + e, k1 = k0 + 8;
-                        const int kh = hi ? (k1 / 9) : (k0 / 9), kw = hi ? (k1 / 3 % 3) : (k0 / 3 % 3), c = hi ? (k1 % 3) : (k0 % 3);
-                        const bool tap = hi ? k1 < 27 : k0 < 27;
-                        const int row = r0 + kh, col = c0 + kw;
-                        const bool ok = inimg && tap && (unsigned)row < (unsigned)p.in_H && (unsigned)col < (unsigned)p.in_W;
-                        const unsigned off = ok ? (((unsigned)n * 3u + (unsigned)c) * plane + (unsigned)row * (unsigned)p.in_W + (unsigned)col) * 4u : DEAD;
+                        const unsigned rel0 = (unsigned)(k0 % 3) * plane + (unsigned)(k0 / 9) * (unsigned)p.in_W + (unsigned)(k0 / 3 % 3);
+                        const unsigned rel1 = (unsigned)(k1 % 3) * plane + (unsigned)(k1 / 9 % 3) * (unsigned)p.in_W + (unsigned)(k1 / 3 % 3);
+                        const unsigned bit = hi ? (k1 < 27 ? 1u << (k1 / 3) : 0u) : (k0 < 27 ? 1u << (k0 / 3) : 0u);
+                        const unsigned off = (okbits & bit) ? base + (hi ? rel1 : rel0) * 4u : DEAD;
                         g[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
                     }
                     half8_t v;
@@ -557,7 +564,6 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
                         v[e] = (k == 27 || k == 28) ? (half_t)(inimg ? 1.f : 0.f) : (half_t)g[e];
                     }
                     fx[mf][ks] = v;
-                    __builtin_amdgcn_sched_barrier(0);                // (keeps hipcc from computing all 32 addresses up front)
                 }
             }
         }
@@ -906,7 +912,8 @@ int sm_mbconv_stem_fwd(const sm_mbconv_desc* d, const float* x_nchw, int32_t C, 
     fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
     fastdiv_make((unsigned)(7 * d->stride + 3), &p.pw_mul, &p.pw_sh);
     // (8-wave blocks at most: the gather's address arithmetic does not fit the 16-wave blocks' 128-register budget — 436 us spilling against 282)
-    const int nw = std::min(mb_v3_waves(&dl), 8);
+    static const int force16 = getenv("SMELTER_MBCONV_STEM_WAVES") ? atoi(getenv("SMELTER_MBCONV_STEM_WAVES")) : 0;   // experiment switch, read once
+    const int nw = (force16 == 16 && mb_v3_lds_nw(&dl, 16) <= 160 * 1024) ? 16 : std::min(mb_v3_waves(&dl), 8);
     const size_t lds = mb_v3_lds_nw(&dl, nw);
     const int per_cu3 = (int)std::max<size_t>(1, std::min<size_t>(16 / nw, (size_t)(160 * 1024) / lds));
     const int grid3 = (int)std::min<long>((nt3 + nw - 1) / nw, (long)SM_NUM_CU * per_cu3);
