@@ -861,3 +861,4 @@ def test_conv3x3_with_fused_expand_head_and_projection(n, hw, n3, act3):
         ref = np.where(ref >= 0, ref, ref * slope3)
     assert_close(to_host(y3), ref, 2 * cout)
     assert float((y3.float() - z.float()).abs().max()) <= 2e-2 * float(z.float().abs().max())
+
