@@ -73,7 +73,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     batch_ = batch; cfg_ = g.configuration;
     values_ = g.values(); input_value_ = g.inputValue(); output_value_ = g.outputValue();
     std::vector<Op> ops = g.ops();
-    const int nv = (int)values_.size(), no = (int)ops.size();
+    int nv = (int)values_.size(); const int no = (int)ops.size();
     std::vector<char> dead(no, 0);
 
     auto consumers = [&](int v) { int c = v == output_value_ ? 1 : 0; for (int i = 0; i < no; i++) if (!dead[i]) { for (int u : ops[i].inputs) c += u == v; c += ops[i].residual == v; } return c; };
@@ -501,6 +501,68 @@ int Executor::plan(ONNXGraph& g, int batch) {
         }
     }
 
+    // ---- 3h. projection shortcut concatenated along K: in the first block of a later stage (ResNet stages 2-4) the expand layer E (1x1, K1 -> N, no
+    // activation) is read only as the residual operand of the shortcut convolution S (1x1 / stride s on the block input, K2 -> N, + Add + ReLU).  The two
+    // are ONE GEMM over K1 + K2: y = act([W_E | W_S] . [h ; x_s] + (b_E + b_S)).  The producer of h writes its rows with pixel stride K1 + K2, a
+    // MaxPool 1x1 / stride s step (an exact strided copy) puts the block input's pixels beside them, and a single 1x1 convolution replaces both layers:
+    // E's output (51 MB at 28^2 x 512, bs 64) is neither written nor read back, and one launch per stage goes away.  SMELTER_KCAT=0 keeps the graph.
+    if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && !(getenv("SMELTER_KCAT") && getenv("SMELTER_KCAT")[0] == '0')) {
+        auto readers = [&](int v) {
+            int n = v == output_value_ ? 2 : 0;
+            for (const Step& q : steps_) {
+                for (int u : q.op.inputs) if (u == v) n++;
+                if (q.op.residual == v) n++;
+                if (q.has_head && q.head.residual == v) n++;
+                if (q.has_side) for (int u : q.side.inputs) if (u == v) n++;
+                if (q.has_pair) for (int u : q.pair.inputs) if (u == v) n++;
+            }
+            return n;
+        };
+        auto plainConv = [&](const Step& q) { return q.op.kind == OpKind::Conv && !q.stem && !q.has_pair && !q.has_mb && !q.has_head && !q.has_side && q.pool_out < 0 && !q.op.grid_h && !q.op.x_ups && q.join < 0; };
+        auto pointwise = [&](const Op& o) { return o.kh == 1 && o.kw == 1 && !o.pt && !o.pl && !o.pb && !o.pr && o.groups == 1 && o.dh == 1 && o.dw == 1 && o.sh == o.sw; };
+        for (size_t u = 0; u < steps_.size(); u++) {
+            if (!plainConv(steps_[u])) continue;
+            const Op& so = steps_[u].op;
+            if (!pointwise(so) || so.residual < 0 || so.act > SM_ACT_PRELU || (so.sh != 1 && so.sh != 2) || (so.cin & 7)) continue;
+            long ei = -1, pi = -1;
+            for (size_t q = 0; q < u; q++) if (steps_[q].op.output == so.residual) ei = (long)q;
+            if (ei < 0 || !plainConv(steps_[ei])) continue;
+            const Op& eo = steps_[ei].op;
+            if (!pointwise(eo) || eo.sh != 1 || eo.act != SM_ACT_NONE || eo.residual >= 0 || eo.cout != so.cout || (eo.cin & 7) || readers(eo.output) != 1) continue;
+            const int h2 = eo.inputs[0], xs = so.inputs[0];
+            if (h2 == input_value_ || h2 == output_value_ || alias_of[h2] >= 0 || placed_in[h2] >= 0 || place_[h2].root != h2 || place_[h2].c_off || readers(h2) != 1) continue;
+            for (size_t q = 0; q < (size_t)ei; q++) if (steps_[q].op.output == h2) pi = (long)q;
+            if (pi < 0 || !plainConv(steps_[pi]) || steps_[pi].op.residual == h2) continue;
+            const Value& hv = values_[h2]; const Value& ov = values_[so.output]; const Value& xv = values_[xs];
+            if (hv.h != ov.h || hv.w != ov.w || (xv.h - 1) / so.sh + 1 != ov.h || (xv.w - 1) / so.sw + 1 != ov.w || hv.c != eo.cin || xv.c != so.cin) continue;
+            const int K1 = eo.cin, K2 = so.cin, N = so.cout, oh = hv.h, ow = hv.w;        // (values_ grows below: no reference into it survives)
+            const double x_full = (double)batch * xv.c * xv.h * xv.w;
+            // two new values: the concatenated operand, and the strided copy of the block input inside it
+            Value cv; cv.name = values_[eo.output].name + "/kcat"; cv.c = K1 + K2; cv.h = oh; cv.w = ow;
+            Value gv; gv.name = values_[xs].name + "/strided"; gv.c = K2; gv.h = oh; gv.w = ow;
+            const int cat = (int)values_.size(); values_.push_back(cv); const int gq = (int)values_.size(); values_.push_back(gv);
+            Placement pc; pc.root = cat; pc.c_off = 0; pc.ld = K1 + K2; place_.push_back(pc);
+            Placement pg; pg.root = cat; pg.c_off = K1; pg.ld = K1 + K2; place_.push_back(pg);
+            alias_of.push_back(-1); alias_of.push_back(-1); placed_in.push_back(-1); placed_in.push_back(cat); nv += 2;
+            place_[h2] = pc; placed_in[h2] = cat;
+            // the merged convolution takes the shortcut's place
+            Step& S = steps_[u]; Op& mo = S.op;
+            std::vector<float> w((size_t)N * (K1 + K2));
+            for (int n = 0; n < N; n++) {
+                std::copy(eo.weight.begin() + (size_t)n * K1, eo.weight.begin() + (size_t)(n + 1) * K1, w.begin() + (size_t)n * (K1 + K2));
+                std::copy(mo.weight.begin() + (size_t)n * K2, mo.weight.begin() + (size_t)(n + 1) * K2, w.begin() + (size_t)n * (K1 + K2) + K1);
+            }
+            if (!eo.bias.empty()) { if (mo.bias.empty()) mo.bias.assign(N, 0.f); for (int n = 0; n < N; n++) mo.bias[n] += eo.bias[n]; }
+            Step G; G.op.kind = OpKind::MaxPool; G.op.name = gv.name; G.op.inputs = {xs}; G.op.output = gq; G.op.kh = G.op.kw = 1; G.op.sh = mo.sh; G.op.sw = mo.sw;
+            G.M = batch * oh * ow; G.launches = 1; G.gather = true;
+            mo.name = eo.name + "+" + mo.name; mo.weight.swap(w); mo.cin = K1 + K2; mo.inputs[0] = cat; mo.residual = -1; mo.sh = mo.sw = 1;
+            S.real_k = K1 + K2; S.kcat = true;
+            S.kcat_extra_elems = 2.0 * (double)S.M * N + (x_full - (double)S.M * K2);   // E's output written and read back; S accounted with its whole input tensor
+            steps_.insert(steps_.begin() + u, std::move(G));         // (u now names the gather, u + 1 the merged convolution)
+            steps_.erase(steps_.begin() + ei);                        // ei < u: the pair moves down by one
+        }
+    }
+
     // ---- 3g. stem inside the first block: a 3x3 stem on 3 planes whose only reader is a depthwise-first block of pass 3c (MobileNet-v2's first three
     // layers) becomes that block's "expand" layer — an im2col gather of the fp32 batch inside the block kernel (mbconv.hip IMC, sm_mbconv_stem_fwd): the
     // input conversion, the stem launch and the stem's output tensor (205 MB at 112^2 x 32, bs 256: written once, read once) disappear.
@@ -661,7 +723,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
             st.s_off = off; off = alignUp(off + op.scale.size() * 4);
             st.t_off = off; off = alignUp(off + op.shift.size() * 4);
         }
-        if (!isConvLike(op.kind)) {
+        if (st.kcat) alg_bytes_ += 2.0 * st.kcat_extra_elems;                                 // (accounted as the two layers the graph holds)
+        if (!isConvLike(op.kind) && !st.gather) {
             const Value& ov = values_[op.output]; double in_elems = 0;
             for (int u : op.inputs) in_elems += (double)batch * values_[u].c * values_[u].h * values_[u].w;
             alg_bytes_ += 2.0 * (in_elems + (double)batch * (op.kind == OpKind::Concat ? values_[op.inputs[0]].c : ov.c) * ov.h * ov.w);

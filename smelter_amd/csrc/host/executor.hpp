@@ -53,6 +53,10 @@ struct Step {                // one op after fusion, with everything resolved
     // (sm_mbconv_stem_fwd): `stem_w` = the stem's weights [Ch][3][3][C] before the row-pair packing (kept for every stem step), at ws_off / bs_off
     bool mb_stem = false; std::vector<float> stem_w, stem_b; size_t ws_off = 0, bs_off = 0; int stem_oh = 0, stem_ow = 0, stem_s = 1, stem_p = 0, stem_act = 0; float stem_slope = 0.f;
     int stem_out = -1; std::string stem_name;
+    // pass 3h: `kcat` = this 1x1 convolution is an expand layer and the projection shortcut that carried its Add, concatenated along K (its extra
+    // algorithmic bytes = the expand output the graph writes and reads back); `gather` = the strided copy of the block input placed beside the expand
+    // layer's input (a MaxPool 1x1 step the graph does not hold: not accounted)
+    bool kcat = false, gather = false; double kcat_extra_elems = 0;   // elements the two graph layers move beyond the merged layer's own operands
     bool mb_noexp = false;   // the block has no expand layer: this step IS the depthwise convolution (mb_dw is a copy of it), mb_proj follows
     std::string desc;
 };

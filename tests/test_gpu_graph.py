@@ -409,3 +409,20 @@ def test_reshape_net_materialises_exactly_the_order_changing_reshapes():
     kinds = [ex.opDesc(i).split()[0] for i in range(ex.numOps)]
     assert kinds.count("Reshape") == 3          # spatial -> spatial twice, 1x1x8 -> 2x2x2; 1x1 -> 1x1 aliases; Flatten -> MatMul permutes the weights
     assert kinds.count("FC") == 1 and "Alias" not in kinds
+
+
+def test_resnet50_projection_shortcuts_are_concatenated_along_k(monkeypatch):
+    """executor pass 3h: in the first block of stages 2-4 the 1x1 expand layer and the stride-2 shortcut convolution that carries its Add are ONE 1x1
+    convolution over [h ; x_strided] (a MaxPool 1x1 / stride 2 step copies the block input's pixels beside h); same function as the two layers"""
+    model = zoo.resnet50(hw=(64, 64))
+    x = zoo.synthetic_images(3, 3, (64, 64))
+    ex, got = run_hip(model, x)
+    descs = [ex.opDesc(i) for i in range(ex.numOps)]
+    assert sum("/strided" in d and d.startswith("MaxPool") for d in descs) == 3
+    merged = [d for d in descs if d.startswith("Conv") and "+conv" in d.split()[1]]
+    assert len(merged) == 3 and [int(d.split(" K=")[1].split()[0]) for d in merged] == [384, 768, 1536] and all("+res" not in d for d in merged)
+    monkeypatch.setenv("SMELTER_KCAT", "0")
+    ex0, plain = run_hip(model, x)
+    assert ex0.numOps == ex.numOps and abs(ex0.algorithmicBytes - ex.algorithmicBytes) <= 1e-6 * ex.algorithmicBytes
+    assert nerr(got, plain) <= 1e-3
+    assert nerr(got, O.Graph(model).run(x)) <= 5e-3
