@@ -426,3 +426,23 @@ def test_resnet50_projection_shortcuts_are_concatenated_along_k(monkeypatch):
     assert ex0.numOps == ex.numOps and abs(ex0.algorithmicBytes - ex.algorithmicBytes) <= 1e-6 * ex.algorithmicBytes
     assert nerr(got, plain) <= 1e-3
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3
+
+
+@pytest.mark.parametrize("env,make,shape,fewer_launches", [
+    ("SMELTER_XHEAD_PROJ", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 1),        # pass 3e: the first block's shortcut as the head's second GEMM
+    ("SMELTER_STEM_F32", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 1),          # pass 3f: no input-conversion launch
+    ("SMELTER_STEM_F32", lambda: zoo.unet(hw=(64, 48)), (2, 3, 64, 48), 1),
+    ("SMELTER_MBCONV_STEM", lambda: zoo.mobilenet_v2(hw=(96, 96)), (2, 3, 96, 96), 1),   # pass 3g: the stem inside the first block (the stem launch goes;
+])                                                                                          # the conversion launch is gone either way: loader-wave stem)
+def test_fusion_pass_switches_keep_the_function(env, make, shape, fewer_launches, monkeypatch):
+    """each of these passes removes exactly one launch and changes no result beyond the parity bar"""
+    model = make()
+    x = zoo.synthetic_images(shape[0], 3, shape[2:])
+    ex, got = run_hip(model, x)
+    monkeypatch.setenv(env, "0")
+    ex0, plain = run_hip(model, x)
+    assert ex0.numLaunches == ex.numLaunches + fewer_launches
+    # (MobileNet-v2: the stem's fp32 summation order differs between the two forms and a flipped fp16 rounding travels through 52 layers — the
+    #  bound of the block-fusion test above)
+    assert nerr(got, plain) <= (2e-3 if env == "SMELTER_MBCONV_STEM" else 1e-3)
+    assert nerr(got, O.Graph(model).run(x)) <= 5e-3
