@@ -95,6 +95,11 @@ int sm_conv2d_fwd_ws(const sm_conv_desc* d, const void* x, const void* w_ohwi, c
                      const void* residual, void* y, void* workspace, size_t workspace_bytes, sm_stream_t stream);
 /* force a tile configuration (tuning / tests); cfg < 0 restores the heuristic.  Returns the number of configs. */
 int sm_conv2d_num_configs(void);
+/* label of a tile configuration ("" outside 0 .. num_configs-1): for logs and profile tables only, nothing parses it */
+const char* sm_conv2d_config_name(int cfg);
+/* > 0 iff `cfg` is a stem-form configuration with loader waves, i.e. one sm_conv2d_stem_f32_fwd_cfg (fp32 NCHW input) takes and
+ * sm_conv2d_fwd_cfg (row-pair image input) does not */
+int sm_conv2d_config_loader_waves(int cfg);
 /* 1 if this shape runs through a tile configuration (so `cfg` of sm_conv2d_fwd_cfg matters and autotuning it makes sense), 0 if a
  * dedicated kernel takes it (depthwise, thin pointwise, direct).  Assumes 16-byte aligned operands. */
 int sm_conv2d_uses_tile_config(const sm_conv_desc* d);

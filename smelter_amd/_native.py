@@ -64,6 +64,8 @@ SYMBOLS = {
     "sm_conv2d_uses_tile_config": (_i32, [C.POINTER(ConvDesc)]),
     "sm_conv2d_fwd_ws": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sm_conv2d_num_configs": (_i32, []),
+    "sm_conv2d_config_name": (C.c_char_p, [_i32]),
+    "sm_conv2d_config_loader_waves": (_i32, [_i32]),
     "sm_conv2d_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sm_conv2d_pool_supported": (_i32, [C.POINTER(ConvDesc)]),
     "sm_conv2d_pool_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),

@@ -16,6 +16,7 @@
 #include "executor.hpp"
 #include <cstring>
 #include <cstdlib>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <functional>
@@ -43,6 +44,24 @@ const char* kindName(OpKind k) {
     }
     return "?";
 }
+
+// Optional trace ranges (SMELTER_ROCTX=1): every launch of a step is bracketed by roctxRangePush(<smelter_exec_op_desc>) / roctxRangePop, so a
+// `rocprofv3 --kernel-trace --marker-trace` run names its kernel rows by ONNX node — what the reference's node labels do for a Metal GPU
+// capture (Converters.swift:178, :787, :931, :1064).  libroctx64 is looked up at run time: the product library does not link against it.
+struct Roctx {
+    int (*push)(const char*) = nullptr; int (*pop)() = nullptr; bool on = false;
+    Roctx() {
+        const char* e = getenv("SMELTER_ROCTX");
+        if (!e || e[0] == '0') return;
+        void* h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);       // the library rocprofv3 --marker-trace intercepts
+        if (!h) h = dlopen("/opt/rocm/lib/librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { fprintf(stderr, "SMELTER_ROCTX: no roctx library found, ranges disabled\n"); return; }
+        push = (int (*)(const char*))dlsym(h, "roctxRangePushA"); pop = (int (*)())dlsym(h, "roctxRangePop");
+        on = push && pop;
+    }
+};
+const Roctx& roctx() { static const Roctx r; return r; }
 
 }  // namespace
 
@@ -142,6 +161,15 @@ int Executor::plan(ONNXGraph& g, int batch) {
             Op& cv = ops[c];
             if (cv.kind != OpKind::Conv || cv.groups != 1 || cv.kh != 3 || cv.kw != 3 || cv.sh != 1 || cv.sw != 1 || cv.dh != 1 || cv.dw != 1 || cv.pt != 1 || cv.pl != 1 ||
                 cv.pb != 1 || cv.pr != 1 || ((cv.cin % 64) && !(cv.cin == 32 && (cv.cout == 32 || cv.cout == 64))) || (cv.cout % 8) || cv.residual >= 0 || cv.act > SM_ACT_PRELU || up.inputs[0] == input_value_) continue;
+            // the fused read needs 16-byte channel vectors on both sides; placement happens later (pass 3), so be conservative here: neither tensor
+            // may sit in a Concat that has an operand whose channel count is not a multiple of 8 (it could then land on an odd channel offset)
+            bool odd_concat = (values_[up.inputs[0]].c & 7) != 0 || (cv.cout & 7) != 0;
+            for (int j = 0; j < no && !odd_concat; j++) if (!dead[j] && ops[j].kind == OpKind::Concat) {
+                bool member = false, odd = false;
+                for (int u : ops[j].inputs) { member |= u == up.inputs[0] || u == cv.output; odd |= (values_[u].c & 7) != 0; }
+                odd_concat = member && odd;
+            }
+            if (odd_concat) continue;
             cv.inputs[0] = up.inputs[0]; cv.x_ups = true; dead[i] = 1;
         }
     }
@@ -227,6 +255,10 @@ int Executor::plan(ONNXGraph& g, int batch) {
         if (placed_in[v] >= 0) { int b = placed_in[v]; resolve(b); int own = place_[v].c_off; place_[v].root = place_[b].root; place_[v].c_off = place_[b].c_off + own; place_[v].ld = place_[b].ld; return; }
     };
     for (int v = 0; v < nv; v++) resolve(v);
+    // every fused kernel moves 16-byte channel vectors: an operand placed inside a concat buffer qualifies only when its channel offset and the
+    // buffer's pixel stride are multiples of 8 halfs (arena blocks are 256-byte aligned, so this is the pointer's alignment as well).  The fusion
+    // passes ask this BEFORE they erase a step: a fused step has no unfused fallback at launch time.
+    auto vecOk = [&](int v) { return v >= 0 && (place_[v].c_off & 7) == 0 && (place_[v].ld & 7) == 0; };
 
     // ---- steps ---------------------------------------------------------------------------------------------
     steps_.clear(); launches_ = 1 /* input conversion */; flops_ = 0; alg_bytes_ = 0;
@@ -317,10 +349,11 @@ int Executor::plan(ONNXGraph& g, int batch) {
 
     // ---- 3a. Conv 3x3 -> MaxPool 2x2 / 2: the pooled tensor is a second output of the weight-stationary convolution kernel (the
     // window is the two fragments of a lane and its neighbour lane); the full-resolution tensor is still written (skip connection).
-    if (cfg_.fuse && !cfg_.keepIntermediates) {
+    // (not with branchConcurrency: the side-branch selection below knows nothing of a step's second output)
+    if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency) {
         for (size_t t = 0; t < steps_.size(); t++) {
             Step& c = steps_[t];
-            if (c.op.kind != OpKind::Conv || c.stem || c.op.grid_h || c.op.residual >= 0 || c.op.output == output_value_) continue;
+            if (c.op.kind != OpKind::Conv || c.stem || c.op.grid_h || c.op.residual >= 0 || c.op.output == output_value_ || !vecOk(c.op.inputs[0]) || !vecOk(c.op.output)) continue;
             const Value& ov = values_[c.op.output];
             sm_conv_desc d{}; d.N = batch; d.H = d.Ho = ov.h; d.W = d.Wo = ov.w; d.Cin = c.op.cin; d.Cout = c.op.cout; d.kH = c.op.kh; d.kW = c.op.kw; d.sH = c.op.sh; d.sW = c.op.sw;
             d.dH = c.op.dh; d.dW = c.op.dw; d.pt = c.op.pt; d.pl = c.op.pl; d.pb = c.op.pb; d.pr = c.op.pr; d.groups = c.op.groups; d.act = c.op.act; d.x_ups = c.op.x_ups ? 1 : 0;
@@ -328,7 +361,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             for (size_t u = t + 1; u < steps_.size(); u++) {
                 Step& m = steps_[u];
                 if (m.op.kind != OpKind::MaxPool || m.op.inputs[0] != c.op.output || m.op.kh != 2 || m.op.kw != 2 || m.op.sh != 2 || m.op.sw != 2 || m.op.y0 || m.op.x0 ||
-                    values_[m.op.output].h * 2 != ov.h || values_[m.op.output].w * 2 != ov.w) continue;
+                    values_[m.op.output].h * 2 != ov.h || values_[m.op.output].w * 2 != ov.w || !vecOk(m.op.output)) continue;
                 c.pool_out = m.op.output;
                 steps_.erase(steps_.begin() + u);
                 break;
@@ -393,7 +426,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 const char* dom_env = getenv("SMELTER_MBCONV_DOMAIN");
                 int max_cin = 96, max_ch = 576, max_cout = 160;
                 if (dom_env) sscanf(dom_env, "%d,%d,%d", &max_cin, &max_ch, &max_cout);
-                if (d.Cin > max_cin || d.Ch > max_ch || d.Cout > max_cout || !sm_mbconv_supported(&d)) continue;
+                if (d.Cin > max_cin || d.Ch > max_ch || d.Cout > max_cout || !vecOk(e.op.inputs[0]) || !vecOk(pj.output) || !sm_mbconv_supported(&d)) continue;
                 e.has_mb = true; e.mb_dw = steps_[ud].op; e.mb_proj = steps_[up].op;
                 steps_.erase(steps_.begin() + up); steps_.erase(steps_.begin() + ud);
             }
@@ -410,7 +443,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 const Value& iv = values_[dw.inputs[0]]; const Value& ov = values_[steps_[up].op.output];
                 sm_mbconv_desc d{}; d.N = batch; d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.stride = dw.sh; d.Cin = dw.cin; d.Ch = dw.cin; d.Cout = steps_[up].op.cout; d.expand = 0;
                 d.act2 = dw.act; d.act3 = steps_[up].op.act;
-                if (d.Ch > 32 || d.Cout > 64 || !sm_mbconv_supported(&d)) continue;      // (one chunk of hidden channels: where the fused launch measured faster)
+                if (d.Ch > 32 || d.Cout > 64 || !vecOk(dw.inputs[0]) || !vecOk(steps_[up].op.output) || !sm_mbconv_supported(&d)) continue;      // (one chunk of hidden channels: where the fused launch measured faster)
                 e.has_mb = true; e.mb_noexp = true; e.mb_dw = e.op; e.mb_proj = steps_[up].op;
                 steps_.erase(steps_.begin() + up);
             }
@@ -423,7 +456,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
         for (size_t t = 0; t < steps_.size(); t++) {
             Step& c = steps_[t];
-            if (c.op.kind != OpKind::Conv || c.stem || c.op.grid_h || c.op.residual >= 0 || c.pool_out >= 0 || c.has_pair || c.has_mb || c.op.kh != 3 || readers(c.op.output) != 1) continue;
+            if (c.op.kind != OpKind::Conv || c.stem || c.op.grid_h || c.op.residual >= 0 || c.pool_out >= 0 || c.has_pair || c.has_mb || c.op.kh != 3 || readers(c.op.output) != 1 || !vecOk(c.op.inputs[0])) continue;
             const Value& ov = values_[c.op.output];
             sm_conv_desc d{}; d.N = batch; d.H = d.Ho = ov.h; d.W = d.Wo = ov.w; d.Cin = c.op.cin; d.Cout = c.op.cout; d.kH = c.op.kh; d.kW = c.op.kw; d.sH = c.op.sh; d.sW = c.op.sw;
             d.dH = c.op.dh; d.dW = c.op.dw; d.pt = c.op.pt; d.pl = c.op.pl; d.pb = c.op.pb; d.pr = c.op.pr; d.groups = c.op.groups; d.act = c.op.act; d.x_ups = c.op.x_ups ? 1 : 0;
@@ -432,7 +465,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 if (h.op.inputs.empty() || h.op.inputs[0] != c.op.output) continue;
                 const Op& o = h.op;
                 if (o.kind != OpKind::Conv || o.kh != 1 || o.kw != 1 || o.sh != 1 || o.sw != 1 || o.pt || o.pl || o.pb || o.pr || o.groups != 1 || o.act > SM_ACT_PRELU || o.grid_h ||
-                    o.x_ups || h.has_pair || h.has_mb || h.pool_out >= 0 || o.cin != c.op.cout) break;
+                    o.x_ups || h.has_pair || h.has_mb || h.pool_out >= 0 || o.cin != c.op.cout || !vecOk(o.output) || (o.residual >= 0 && !vecOk(o.residual))) break;
                 // narrow head without residual: the HEAD instantiations; a bottleneck's tail (1x1 expand to <= 256 channels + block input + ReLU): the
                 // expand head (conv3x3_ws.hpp HX), SMELTER_XHEAD=0 keeps the two launches
                 const bool xhead_on = !(getenv("SMELTER_XHEAD") && getenv("SMELTER_XHEAD")[0] == '0');      // (plan time, not the launch path)
@@ -447,11 +480,14 @@ int Executor::plan(ONNXGraph& g, int batch) {
                                 (steps_[q].has_head && steps_[q].head.output == v)) return (long)q;
                         return -1L;
                     };
-                    const long pr = producer(rootOf(o.residual));
+                    long pr = producer(rootOf(o.residual));
+                    for (int v = 0; v < nv; v++) if (v != rootOf(o.residual) && place_[v].root == place_[rootOf(o.residual)].root && placed_in[v] >= 0) pr = std::max(pr, producer(v));   // a concat root is ready when its last member is
                     if (pr > (long)u) break;
                     if (pr > (long)t) {
                         const Step& ps = steps_[pr];
-                        bool movable = !ps.has_pair && ps.pool_out < 0 && !ps.has_mb && !ps.has_head && ps.op.output == rootOf(o.residual);
+                        // (one step must be the WHOLE producer: the phase steps of a ConvTranspose and the fallback copies of a Concat share an output)
+                        bool movable = !ps.has_pair && ps.pool_out < 0 && !ps.has_mb && !ps.has_head && ps.op.output == rootOf(o.residual) && !ps.op.grid_h && ps.op.kind != OpKind::Concat;
+                        for (size_t q = 0; q < steps_.size(); q++) if ((long)q != pr && steps_[q].op.output == ps.op.output) movable = false;
                         for (int v : ps.op.inputs) { const long q = producer(rootOf(v)); if (q >= (long)t) movable = false; }
                         if (ps.op.residual >= 0 && producer(rootOf(ps.op.residual)) >= (long)t) movable = false;
                         if (!movable) break;
@@ -493,7 +529,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 if (o.kind != OpKind::Conv || o.kh != 1 || o.kw != 1 || o.sh != 1 || o.sw != 1 || o.pt || o.pl || o.pb || o.pr || o.groups != 1 || o.act > SM_ACT_PRELU || o.grid_h || o.x_ups ||
                     sd.stem || sd.has_pair || sd.has_mb || sd.has_head || sd.pool_out >= 0 || o.cin != 64 || o.cout != c.head.cout || o.inputs.empty()) break;
                 const Value& sv = values_[o.inputs[0]];
-                if (sv.h != ov.h || sv.w != ov.w || producer(rootOf(o.inputs[0])) >= (long)t || !sm_conv2d_xhead_proj_supported(&d, o.cout)) break;
+                if (sv.h != ov.h || sv.w != ov.w || producer(rootOf(o.inputs[0])) >= (long)t || !vecOk(o.inputs[0]) || !vecOk(o.output) || !sm_conv2d_xhead_proj_supported(&d, o.cout)) break;
                 c.has_side = true; c.side = std::move(sd.op);
                 steps_.erase(steps_.begin() + u);
                 break;
@@ -531,6 +567,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
             if (!pointwise(eo) || eo.sh != 1 || eo.act != SM_ACT_NONE || eo.residual >= 0 || eo.cout != so.cout || (eo.cin & 7) || readers(eo.output) != 1) continue;
             const int h2 = eo.inputs[0], xs = so.inputs[0];
             if (h2 == input_value_ || h2 == output_value_ || alias_of[h2] >= 0 || placed_in[h2] >= 0 || place_[h2].root != h2 || place_[h2].c_off || readers(h2) != 1) continue;
+            bool aliased = rootOf(output_value_) == h2; for (int v = 0; v < nv && !aliased; v++) aliased = v != h2 && (alias_of[v] == h2 || place_[v].root == h2);   // a Dropout / same-shape Reshape of h2 kept a copy of its old placement
+            if (aliased) continue;
             for (size_t q = 0; q < (size_t)ei; q++) if (steps_[q].op.output == h2) pi = (long)q;
             if (pi < 0 || !plainConv(steps_[pi]) || steps_[pi].op.residual == h2) continue;
             const Value& hv = values_[h2]; const Value& ov = values_[so.output]; const Value& xv = values_[xs];
@@ -580,7 +618,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             const Value& hv = values_[sc.op.output]; const Value& pv = values_[bk.mb_proj.output]; const Value& iv = values_[input_value_];
             sm_mbconv_desc d{}; d.N = batch; d.H = hv.h; d.W = hv.w; d.Ho = pv.h; d.Wo = pv.w; d.stride = bk.mb_dw.sh; d.Cin = 27; d.Ch = sc.op.cout; d.Cout = bk.mb_proj.cout; d.expand = 1;
             d.act1 = sc.op.act; d.act2 = bk.mb_dw.act; d.act3 = bk.mb_proj.act;
-            if (!sm_mbconv_stem_supported(&d, iv.c, iv.h, iv.w, sc.stem_s, sc.stem_p)) continue;
+            if (!vecOk(bk.mb_proj.output) || !sm_mbconv_stem_supported(&d, iv.c, iv.h, iv.w, sc.stem_s, sc.stem_p)) continue;
             bk.mb_stem = true; bk.stem_w = std::move(sc.stem_w); bk.stem_b = sc.op.bias; bk.stem_oh = hv.h; bk.stem_ow = hv.w; bk.stem_s = sc.stem_s; bk.stem_p = sc.stem_p;
             bk.stem_act = sc.op.act; bk.stem_slope = sc.op.slope; bk.stem_out = sc.op.output; bk.stem_name = sc.op.name;
             bk.op.inputs[0] = input_value_; bk.mb_dw.inputs[0] = input_value_;
@@ -994,9 +1032,14 @@ int Executor::convertInput(hipStream_t s, const float* in) const {
 int Executor::launchAll(hipStream_t s, const float* in) const {
     static const bool debug_sync = getenv("SMELTER_DEBUG_SYNC") != nullptr;   // debugging switch, read once
     cur_in_ = in;
+    const Roctx& rx = roctx();
+    if (rx.on) rx.push("input NCHW f32 -> first-layer layout");
     int rc = convertInput(s, in);
+    if (rx.on) rx.pop();
     if (rc) return rc;
+    struct Range { const Roctx& r; Range(const Roctx& r_, const char* n) : r(r_) { if (r.on) r.push(n); } ~Range() { if (r.on) r.pop(); } };
     for (auto& st : steps_) {
+        Range range(rx, st.desc.c_str());
         if (st.join >= 0 && side_) {                            // fork: the side stream sees everything enqueued so far
             SM_HIP_CHECK(hipEventRecord(ev_fork_, s));
             SM_HIP_CHECK(hipStreamWaitEvent(side_, ev_fork_, 0));
@@ -1016,7 +1059,7 @@ int Executor::launchAll(hipStream_t s, const float* in) const {
 
 int Executor::encode(hipStream_t s, const float* in) {
     if (!in) { sm_set_error("smelter_exec_encode: null input"); return SM_ERR_INVALID_ARGUMENT; }
-    if (!cfg_.useHipGraph) return launchAll(s, in);
+    if (!cfg_.useHipGraph || roctx().on) return launchAll(s, in);      // (trace ranges bracket real launches, not a graph replay)
     if (!graph_exec_ || captured_in_ != in) {
         if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
         if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }

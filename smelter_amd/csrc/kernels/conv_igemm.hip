@@ -496,6 +496,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 #include "conv3x3_p9.hpp"
 #include "conv1x1_ps.hpp"
 #include "conv1x1_pair.hpp"
+#include "conv1x1_rw.hpp"
 
 // 3x3 depthwise through LDS (the MobileNet-v2 path): the register-strip kernel above re-reads every input pixel 4.5x through
 // L1/L2 and needs 227 VGPRs (1.2..2 TB/s of algorithmic bytes).  Here a block owns a tile of TH x TW output pixels x `cbv`
@@ -596,7 +597,13 @@ __global__ __launch_bounds__(256) void dwconv3x3_lds_kernel(ConvParams p, int cb
 }
 
 // kind 0: generic (Cin % 8 == 0, BK = 32, register staging); kind 1: Cin % 64 == 0 fast path (BK = 64, LDS-DMA)
-struct TileCfg { int BM, BN, kind, threads; void (*fn)(ConvParams); const char* name; };
+// flags / p0..p2 carry the geometry the launcher needs (never parsed out of `name`, which is a label only):
+//   kind 4: p0 = Cin of the instantiation; CF_HEAD / CF_XHEAD / CF_W44 (two-role kernel: 4 of the 8 waves issue the patch DMA) / CF_SIDE
+//   kind 6: p0 = taps (kH' of the row-pair form), p1 = KB between the two patch buffers (0 = as large as the weights allow), p2 = loader waves
+//   kinds 5, 7: p0 = ring stages
+//   kind 8: BM = pixels per step (32 FS), BN = channels per block, p0 = Cin of the instantiation; CF_RES = the instantiation that stages a residual tile
+enum { CF_HEAD = 1, CF_XHEAD = 2, CF_W44 = 4, CF_SIDE = 8, CF_RES = 16 };
+struct TileCfg { int BM, BN, kind, threads; void (*fn)(ConvParams); const char* name; int flags = 0, p0 = 0, p1 = 0, p2 = 0; };
 const TileCfg kCfgs[] = {
     {128, 128, 0, 256, conv_igemm_kernel<128, 128, 2, 2>, "128x128"},
     {128, 64, 0, 256, conv_igemm_kernel<128, 64, 2, 2>, "128x64"},
@@ -669,55 +676,69 @@ const TileCfg kCfgs[] = {
     {128, 128, 3, 256, conv3x3_strip_kernel<128, 128, 2, 2, 2>, "strip w4:128x128"},                  // 59
     {128, 32, 3, 256, conv3x3_strip_kernel<128, 32, 4, 1, 2>, "strip w4:128x32"},                     // 60  (59 KB: two blocks per CU)
     // kind 4 (conv3x3_ws.hpp): weight-stationary persistent 3x3 for Cin, Cout in {32, 64}; BM = pixels per tile, BN = Cout
-    {256, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 2>, "ws:64->64 w4x2"},                             // 61
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2>, "ws:64->32 w4x2"},                             // 62
-    {256, 64, 4, 256, conv3x3_ws_kernel<32, 64, 4, 2>, "ws:32->64 w4x2"},                             // 63
-    {256, 32, 4, 256, conv3x3_ws_kernel<32, 32, 4, 2>, "ws:32->32 w4x2"},                             // 64
-    {224, 64, 4, 448, conv3x3_ws_kernel<64, 64, 7, 1>, "ws:64->64 w7x1"},                             // 65  (56x56: 8 x 28 = 224-pixel tiles, no idle fragment)
-    {512, 32, 4, 512, conv3x3_ws_kernel<64, 32, 8, 2>, "ws:64->32 w8x2"},                             // 66
-    {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2>, "ws:32->32 w8x2"},                             // 67
+    {256, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 2>, "ws:64->64 w4x2", 0, 64},                             // 61
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2>, "ws:64->32 w4x2", 0, 64},                             // 62
+    {256, 64, 4, 256, conv3x3_ws_kernel<32, 64, 4, 2>, "ws:32->64 w4x2", 0, 32},                             // 63
+    {256, 32, 4, 256, conv3x3_ws_kernel<32, 32, 4, 2>, "ws:32->32 w4x2", 0, 32},                             // 64
+    {224, 64, 4, 448, conv3x3_ws_kernel<64, 64, 7, 1>, "ws:64->64 w7x1", 0, 64},                             // 65  (56x56: 8 x 28 = 224-pixel tiles, no idle fragment)
+    {512, 32, 4, 512, conv3x3_ws_kernel<64, 32, 8, 2>, "ws:64->32 w8x2", 0, 64},                             // 66
+    {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2>, "ws:32->32 w8x2", 0, 32},                             // 67
     // kind 5 (conv3x3_p9.hpp): 3x3 / stride 1 / pad 1, Cin % 64 == 0: one patch per cin block serves all nine taps, weights ring as kind 1
-    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 3>, "p9:256x128 s3"},                        // 68
-    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 2>, "p9:256x128 s2"},                        // 69
-    {128, 128, 5, 512, conv3x3_p9_kernel<128, 128, 4, 2, 3>, "p9:128x128(32x64) s3"},                 // 70
-    {128, 128, 5, 512, conv3x3_p9_kernel<128, 128, 2, 4, 3>, "p9:128x128(64x32) s3"},                 // 71
-    {256, 64, 5, 512, conv3x3_p9_kernel<256, 64, 4, 2, 3>, "p9:256x64 s3"},                           // 72
-    {128, 64, 5, 512, conv3x3_p9_kernel<128, 64, 4, 2, 3>, "p9:128x64 s3"},                           // 73
+    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 3>, "p9:256x128 s3", 0, 3},                        // 68
+    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 2>, "p9:256x128 s2", 0, 2},                        // 69
+    {128, 128, 5, 512, conv3x3_p9_kernel<128, 128, 4, 2, 3>, "p9:128x128(32x64) s3", 0, 3},                 // 70
+    {128, 128, 5, 512, conv3x3_p9_kernel<128, 128, 2, 4, 3>, "p9:128x128(64x32) s3", 0, 3},                 // 71
+    {256, 64, 5, 512, conv3x3_p9_kernel<256, 64, 4, 2, 3>, "p9:256x64 s3", 0, 3},                           // 72
+    {128, 64, 5, 512, conv3x3_p9_kernel<128, 64, 4, 2, 3>, "p9:128x64 s3", 0, 3},                           // 73
     // kind 6 (conv3x3_ws.hpp, STEM form): the image stem on the row-pair image (Cin = 64 = 8 overlapping 16-byte pixels, kH' = 2 | 4 taps,
     // kW' = 1, row dilation 2, stride 1 | 2); name = "wst:<taps>-><cout> ... [p<KB between the two patch buffers>]"
-    {256, 64, 6, 256, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 23 * 1024>, "wst:4->64 w4x2 p23"},     // 74  (ResNet-50 7x7/2: two blocks per CU)
-    {512, 64, 6, 512, conv3x3_ws_kernel<64, 64, 8, 2, 6, 0, 4>, "wst:4->64 w8x2"},                    // 75
-    {256, 64, 6, 256, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 2, 20 * 1024>, "wst:2->64 w4x2 p20"},     // 76  (U-Net 3x3/1)
-    {256, 32, 6, 256, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024>, "wst:2->32 w4x2 p20"},     // 77  (MobileNet-v2 3x3/2)
-    {256, 32, 6, 256, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 4, 24 * 1024>, "wst:4->32 w4x2 p24"},     // 78
-    {512, 64, 6, 512, conv3x3_ws_kernel<64, 64, 8, 2, 6, 0, 2>, "wst:2->64 w8x2"},                    // 79
-    {512, 32, 6, 512, conv3x3_ws_kernel<64, 32, 8, 2, 6, 0, 2>, "wst:2->32 w8x2"},                    // 80
+    {256, 64, 6, 256, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 23 * 1024>, "wst:4->64 w4x2 p23", 0, 4, 23},     // 74  (ResNet-50 7x7/2: two blocks per CU)
+    {512, 64, 6, 512, conv3x3_ws_kernel<64, 64, 8, 2, 6, 0, 4>, "wst:4->64 w8x2", 0, 4},                    // 75
+    {256, 64, 6, 256, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 2, 20 * 1024>, "wst:2->64 w4x2 p20", 0, 2, 20},     // 76  (U-Net 3x3/1)
+    {256, 32, 6, 256, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024>, "wst:2->32 w4x2 p20", 0, 2, 20},     // 77  (MobileNet-v2 3x3/2)
+    {256, 32, 6, 256, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 4, 24 * 1024>, "wst:4->32 w4x2 p24", 0, 4, 24},     // 78
+    {512, 64, 6, 512, conv3x3_ws_kernel<64, 64, 8, 2, 6, 0, 2>, "wst:2->64 w8x2", 0, 2},                    // 79
+    {512, 32, 6, 512, conv3x3_ws_kernel<64, 32, 8, 2, 6, 0, 2>, "wst:2->32 w8x2", 0, 2},                    // 80
     // kind 7 (conv1x1_ps.hpp): persistent pointwise GEMM, 8 MFMA waves + 4 loader waves, one block per CU
-    {128, 128, 7, 768, conv1x1_ps_kernel<128, 128, 4, 2, 4>, "ps:128x128(32x64) s4"},                 // 81
-    {128, 128, 7, 768, conv1x1_ps_kernel<128, 128, 2, 4, 4>, "ps:128x128(64x32) s4"},                 // 82
-    {128, 64, 7, 768, conv1x1_ps_kernel<128, 64, 4, 2, 4>, "ps:128x64 s4"},                           // 83
-    {256, 128, 7, 768, conv1x1_ps_kernel<256, 128, 4, 2, 3, false>, "ps:256x128 s3"},                        // 84
-    {128, 256, 7, 768, conv1x1_ps_kernel<128, 256, 2, 4, 3, false>, "ps:128x256 s3"},                        // 85
-    {128, 128, 7, 768, conv1x1_ps_kernel<128, 128, 4, 2, 3>, "ps:128x128(32x64) s3"},                 // 86
+    {128, 128, 7, 768, conv1x1_ps_kernel<128, 128, 4, 2, 4>, "ps:128x128(32x64) s4", 0, 4},                 // 81
+    {128, 128, 7, 768, conv1x1_ps_kernel<128, 128, 2, 4, 4>, "ps:128x128(64x32) s4", 0, 4},                 // 82
+    {128, 64, 7, 768, conv1x1_ps_kernel<128, 64, 4, 2, 4>, "ps:128x64 s4", 0, 4},                           // 83
+    {256, 128, 7, 768, conv1x1_ps_kernel<256, 128, 4, 2, 3, false>, "ps:256x128 s3", 0, 3},                        // 84
+    {128, 256, 7, 768, conv1x1_ps_kernel<128, 256, 2, 4, 3, false>, "ps:128x256 s3", 0, 3},                        // 85
+    {128, 128, 7, 768, conv1x1_ps_kernel<128, 128, 4, 2, 3>, "ps:128x128(32x64) s3", 0, 3},                 // 86
     // 256x256 (kind 1): for layers with <= 256 such tiles (ResNet-50 layer 3, N = 1024: 196) one round of blocks moves half the L1 bytes of 128x128
     {256, 256, 1, 512, conv_igemm64_kernel<256, 256, 4, 2, 2, 0, 0, 0, 1, 1, true>, "k64w8:256x256(64x128)"},    // 87
     {256, 256, 1, 512, conv_igemm64_kernel<256, 256, 4, 2, 2, 0, 1, 0, 1, 1, true>, "k64w8i:256x256(64x128)"},   // 88
     // kind 4 with the fused 1x1 head (sm_conv2d_head_fwd_cfg): separate instantiations, chosen only for launches that carry a head
-    {256, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 2, 12, 0, 0, 0, true>, "ws:64->64 w4x2 head"},     // 89
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 0, 0, 0, true>, "ws:64->32 w4x2 head"},     // 90
-    {256, 64, 4, 256, conv3x3_ws_kernel<32, 64, 4, 2, 6, 0, 0, 0, true>, "ws:32->64 w4x2 head"},      // 91
-    {256, 32, 4, 256, conv3x3_ws_kernel<32, 32, 4, 2, 6, 0, 0, 0, true>, "ws:32->32 w4x2 head"},      // 92
-    {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2, 6, 0, 0, 0, true>, "ws:32->32 w8x2 head"},      // 93
-    {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead"},  // 94  expand head (bottleneck tail): + 1x1 to <= 256 channels + residual
-    {128, 64, 4, 512, conv3x3_wsx_kernel<6>, "ws:64->64 w4+4 xhead"},                                 // 95  ... with the two layers on different waves (conv3x3_wsx.hpp)
-    {128, 64, 4, 512, conv3x3_wsx_kernel<6, true>, "ws:64->64 w4+4 xhead side"},                      // 96  ... and a second GEMM (the projection shortcut) instead of the residual tensor
+    {256, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 2, 12, 0, 0, 0, true>, "ws:64->64 w4x2 head", CF_HEAD, 64},     // 89
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 0, 0, 0, true>, "ws:64->32 w4x2 head", CF_HEAD, 64},     // 90
+    {256, 64, 4, 256, conv3x3_ws_kernel<32, 64, 4, 2, 6, 0, 0, 0, true>, "ws:32->64 w4x2 head", CF_HEAD, 32},      // 91
+    {256, 32, 4, 256, conv3x3_ws_kernel<32, 32, 4, 2, 6, 0, 0, 0, true>, "ws:32->32 w4x2 head", CF_HEAD, 32},      // 92
+    {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2, 6, 0, 0, 0, true>, "ws:32->32 w8x2 head", CF_HEAD, 32},      // 93
+    {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead", CF_XHEAD, 64},  // 94  expand head (bottleneck tail): + 1x1 to <= 256 channels + residual
+    {128, 64, 4, 512, conv3x3_wsx_kernel<6>, "ws:64->64 w4+4 xhead", CF_XHEAD | CF_W44, 64},                                 // 95  ... with the two layers on different waves (conv3x3_wsx.hpp)
+    {128, 64, 4, 512, conv3x3_wsx_kernel<6, true>, "ws:64->64 w4+4 xhead side", CF_XHEAD | CF_W44 | CF_SIDE, 64},                      // 96  ... and a second GEMM (the projection shortcut) instead of the residual tensor
     // stem form with loader waves (conv3x3_ws.hpp NLW): the patches are built from the fp32 NCHW input inside the launch (sm_conv2d_stem_f32_fwd_cfg)
-    {256, 64, 6, 512, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 0, false, false, 4>, "wst:4->64 w4x2 ld4"},            // 97  (ResNet-50 7x7/2)
-    {256, 32, 6, 512, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024, false, false, 4>, "wst:2->32 w4x2 p20 ld4"},  // 98  (MobileNet-v2 3x3/2, U-Net 3x3/1: the autotuner's pick, first = the default)
-    {256, 64, 6, 384, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 2, 20 * 1024, false, false, 2>, "wst:2->64 w4x2 p20 ld2"}, // 99
-    {256, 32, 6, 512, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 4, 0, false, false, 4>, "wst:4->32 w4x2 ld4"},            // 100
-    {256, 64, 6, 512, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 23 * 1024, false, false, 4>, "wst:4->64 w4x2 p23 ld4"},  // 101 (178 registers: still one resident block; forcing <= 170 for two blocks of 4 + 2 waves spilled and did not win)
-    {256, 32, 6, 384, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024, false, false, 2>, "wst:2->32 w4x2 p20 ld2"}, // 102 (two blocks of 4 + 2 waves per CU)
+    {256, 64, 6, 512, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 0, false, false, 4>, "wst:4->64 w4x2 ld4", 0, 4, 0, 4},            // 97  (ResNet-50 7x7/2)
+    {256, 32, 6, 512, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024, false, false, 4>, "wst:2->32 w4x2 p20 ld4", 0, 2, 20, 4},  // 98  (MobileNet-v2 3x3/2, U-Net 3x3/1: the autotuner's pick, first = the default)
+    {256, 64, 6, 384, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 2, 20 * 1024, false, false, 2>, "wst:2->64 w4x2 p20 ld2", 0, 2, 20, 2}, // 99
+    {256, 32, 6, 512, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 4, 0, false, false, 4>, "wst:4->32 w4x2 ld4", 0, 4, 0, 4},            // 100
+    {256, 64, 6, 512, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 23 * 1024, false, false, 4>, "wst:4->64 w4x2 p23 ld4", 0, 4, 23, 4},  // 101 (178 registers: still one resident block; forcing <= 170 for two blocks of 4 + 2 waves spilled and did not win)
+    {256, 32, 6, 384, conv3x3_ws_kernel<64, 32, 4, 2, 6, 0, 2, 20 * 1024, false, false, 2>, "wst:2->32 w4x2 p20 ld2", 0, 2, 20, 2}, // 102 (two blocks of 4 + 2 waves per CU)
+    // kind 8 (conv1x1_rw.hpp): pointwise convolution with Cin = 64 | 128 | 256, weights resident in registers, pixel steps streaming through two LDS buffer pairs
+    {64, 256, 8, 512, conv1x1_rw_kernel<16, 2, 4, 2, true>, "rw:k256 n256 s64 +res", CF_RES, 256},         // 103 (ResNet-50 256 -> 1024 + block input + ReLU at 14x14)
+    {128, 256, 8, 512, conv1x1_rw_kernel<16, 2, 4, 4, false>, "rw:k256 n256 s128", 0, 256},                // 104
+    {128, 128, 8, 512, conv1x1_rw_kernel<16, 2, 2, 4, false>, "rw:k256 n128 s128", 0, 256},                // 105 (256 -> 128 at 56x56)
+    {128, 64, 8, 512, conv1x1_rw_kernel<16, 1, 2, 4, false>, "rw:k256 n64 s128", 0, 256},                  // 106 (256 -> 64 at 56x56)
+    {64, 256, 8, 512, conv1x1_rw_kernel<8, 2, 4, 2, true>, "rw:k128 n256 s64 +res", CF_RES, 128},          // 107 (128 -> 512 + block input + ReLU at 28x28)
+    {128, 256, 8, 512, conv1x1_rw_kernel<8, 2, 4, 4, false>, "rw:k128 n256 s128", 0, 128},                 // 108
+    {256, 64, 8, 512, conv1x1_rw_kernel<4, 1, 2, 8, false>, "rw:k64 n64 s256", 0, 64},                     // 109 (64 -> 64 at 56x56)
+    {64, 256, 8, 512, conv1x1_rw_kernel<4, 2, 4, 2, true>, "rw:k64 n256 s64 +res", CF_RES, 64},            // 110 (64 -> 256 + block input + ReLU when the expand head is off)
+    // ... with 4 loader waves and a ring of NST stages (conv1x1_rwl_kernel): p1 = stages, BM = pixels per stage, 8 consumer waves x 32 channels = 256 per block
+    {32, 256, 8, 768, conv1x1_rwl_kernel<16, 1, 4, true>, "rwl:k256 n256 s32x4 +res", CF_RES, 256, 4},    // 111
+    {64, 256, 8, 768, conv1x1_rwl_kernel<8, 2, 3, true>, "rwl:k128 n256 s64x3 +res", CF_RES, 128, 3},     // 112
+    {32, 256, 8, 768, conv1x1_rwl_kernel<8, 1, 4, true>, "rwl:k128 n256 s32x4 +res", CF_RES, 128, 4},     // 113
+    {64, 256, 8, 768, conv1x1_rwl_kernel<16, 2, 4, false>, "rwl:k256 n256 s64x4", 0, 256, 4},             // 114
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
@@ -728,18 +749,18 @@ const TileCfg kCfgs[] = {
     {128, 64, 3, 512, conv3x3_strip_kernel<128, 64, 4, 2, 2, 1>, "strip lean w8:128x64"},
 #endif
 #ifdef SM_ABLATION   // conv3x3_ws ablations (64->32, 4 waves x 2 fragments)
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 0>, "ws:64->32 abl ref"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 1>, "ws:64->32 abl noDMA"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 2>, "ws:64->32 abl noMFMA"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 4>, "ws:64->32 abl noReads"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 8>, "ws:64->32 abl noStores"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 9>, "ws:64->32 abl noDMA noStores"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 15>, "ws:64->32 abl nothing"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 6>, "ws:64->32 abl DMA+stores only"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 13>, "ws:64->32 abl MFMA only"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 11>, "ws:64->32 abl reads only"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 14>, "ws:64->32 abl DMA only"},
-    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 7>, "ws:64->32 abl stores only"},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 0>, "ws:64->32 abl ref", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 1>, "ws:64->32 abl noDMA", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 2>, "ws:64->32 abl noMFMA", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 4>, "ws:64->32 abl noReads", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 8>, "ws:64->32 abl noStores", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 9>, "ws:64->32 abl noDMA noStores", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 15>, "ws:64->32 abl nothing", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 6>, "ws:64->32 abl DMA+stores only", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 13>, "ws:64->32 abl MFMA only", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 11>, "ws:64->32 abl reads only", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 14>, "ws:64->32 abl DMA only", 0, 64},
+    {256, 32, 4, 256, conv3x3_ws_kernel<64, 32, 4, 2, 12, 7>, "ws:64->32 abl stores only", 0, 64},
 #endif
 #ifdef SM_ABLATION   // tools/conv_bench.py only: never built into the product library
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 2, 1>, "abl:w8 noMFMA"},
@@ -757,14 +778,13 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 size_t ws_setup(ConvParams& p, const TileCfg& c) {
     const int cin = p.Cin;
     if (cin != 32 && cin != 64) return 0;
-    const char* nm = c.name;                                         // "ws:<cin>-><cout> ..."
-    if (atoi(nm + 3) != cin) return 0;
-    const bool w44 = strstr(nm, "w4+4") != nullptr;                  // conv3x3_wsx.hpp: 4 of the 8 waves issue the patch DMA, 6 pieces per thread
+    if (c.p0 != cin) return 0;
+    const bool w44 = (c.flags & CF_W44) != 0;                        // conv3x3_wsx.hpp: 4 of the 8 waves issue the patch DMA, 6 pieces per thread
     const int cp = cin / 8, nt = w44 ? 256 : c.threads;
     const int bands = sm_ceil_div(p.W, 32);
     int TW = sm_ceil_div(p.W, bands);
     if (p.ups && (TW & 1)) TW++;                                       // fused upsampling: even tile origins
-    const bool xhead = strstr(nm, " xhead") != nullptr;              // head weights + bias in LDS too (conv3x3_ws.hpp HX)
+    const bool xhead = (c.flags & CF_XHEAD) != 0;                    // head weights + bias in LDS too (conv3x3_ws.hpp HX)
     const size_t fixed = (size_t)9 * p.Cout * cin * 2 + (size_t)p.Cout * 4 + WS_DUMMY + (xhead ? (size_t)ws_hx_bytes(p.Cout) : 0);
     const int nic = w44 ? 6 : cin == 64 ? 12 : 6;                    // the kernels' NIC
     int best_th = 0; long best_tiles = 0; size_t best_lds = 0, best_patch = 0;
@@ -790,20 +810,17 @@ size_t ws_setup(ConvParams& p, const TileCfg& c) {
 
 // Dynamic LDS of the persistent pointwise kernel: ring ("... s<stages>") + the layer's bias vector
 size_t ps_lds_bytes(const ConvParams& p, const TileCfg& c) {
-    const char* sk = strstr(c.name, " s");
-    return (size_t)(sk ? atoi(sk + 2) : 3) * (c.BM + c.BN) * 128 + ((size_t)p.Cout * 4 + 15) / 16 * 16;
+    return (size_t)(c.p0 ? c.p0 : 3) * (c.BM + c.BN) * 128 + ((size_t)p.Cout * 4 + 15) / 16 * 16;
 }
 
 // Geometry of the stem form of the weight-stationary kernel (kind 6): the same search over the OUTPUT image; a patch is
 // ((TH-1)s + 2(taps-1) + 1) x ((TW-1)s + 8) 16-byte row-pair pixels.  Returns the dynamic LDS size in bytes, 0 if the config does not fit.
 size_t wst_setup(ConvParams& p, const TileCfg& c) {
-    const int taps = atoi(c.name + 4), s = p.sH, nic = 6;
-    const char* ld = strstr(c.name, " ld");                            // loader waves: c.threads counts them, the patch is sized for the MFMA waves' NIC * NT slots
-    const int nt = ld ? c.threads - atoi(ld + 3) * 64 : c.threads;
+    const int taps = c.p0, s = p.sH, nic = 6;
+    const int nt = c.threads - c.p2 * 64;                               // loader waves: c.threads counts them, the patch is sized for the MFMA waves' NIC * NT slots
     if (p.kH != taps || p.Cin != 64) return 0;
-    const char* pk = strstr(c.name, " p");
     const size_t fixed = (size_t)taps * p.Cout * 128 + (size_t)p.Cout * 4 + WS_DUMMY;
-    const size_t stride = pk ? (size_t)atoi(pk + 2) * 1024 : (size_t)ws_pstride((int)fixed);
+    const size_t stride = c.p1 ? (size_t)c.p1 * 1024 : (size_t)ws_pstride((int)fixed);
     const int bands = sm_ceil_div(p.Wo, 32), TW = sm_ceil_div(p.Wo, bands), PW = (TW - 1) * s + 8;
     int best_th = 0; long best_tiles = 0; size_t best_patch = 0;
     for (int th = 1; th * TW <= c.BM && th <= p.Ho; th++) {
@@ -827,7 +844,7 @@ size_t wst_setup(ConvParams& p, const TileCfg& c) {
 // 16-byte DMA slots.  Returns the dynamic LDS size in bytes, 0 if the config does not fit the layer.
 size_t p9_setup(ConvParams& p, const TileCfg& c) {
     if ((p.Cin % 64) != 0) return 0;
-    const int nsb = strstr(c.name, " s2") ? 2 : 3, nic = 11 - nsb, nt = c.threads, BM = c.BM;
+    const int nsb = c.p0 == 2 ? 2 : 3, nic = 11 - nsb, nt = c.threads, BM = c.BM;
     const size_t ring = (size_t)nsb * c.BN * 128;
     int best_tw = 0; long best_px = 0; size_t best_patch = 0;
     const int cand[2] = {p.W, sm_ceil_div(p.W, sm_ceil_div(p.W, 32))};
@@ -860,12 +877,12 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
         const bool ok = same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
                ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && p.Cout == c.BN && ws_setup(q, c) > 0;
         // fused max-pool: two fragments per wave that are the image rows 2k, 2k+1 of one 32-pixel column band
-        const bool is_head = strstr(c.name, " head") != nullptr, is_xhead = strstr(c.name, " xhead") != nullptr;
+        const bool is_head = (c.flags & CF_HEAD) != 0, is_xhead = (c.flags & CF_XHEAD) != 0;
         const bool want_x = p.y3 && (p.n3 > 32 || p.res3 || p.w3s);                                       // wide or residual heads: the expand-head instantiations
         if (ok && ((p.y3 != nullptr && !want_x) != is_head || want_x != is_xhead)) return false;   // head launches <-> head instantiations
         if (ok && p.y3 && !want_x && !(p.n3 > 0 && p.n3 <= 32 && (p.n3 & 7) == 0 && (p.y3_ld & 3) == 0 && ((((uintptr_t)p.y3) & 7) == 0) && ((((uintptr_t)p.w3) & 15) == 0) && p.act3 <= SM_ACT_PRELU && !p.y2)) return false;
-        if (ok && is_xhead && strstr(c.name, "w4+4") && (p.y || p.ups)) return false;            // the two-role kernel never stores the 3x3 output
-        if (ok && is_xhead && (strstr(c.name, " side") != nullptr) != (p.w3s != nullptr)) return false;
+        if (ok && is_xhead && (c.flags & CF_W44) && (p.y || p.ups)) return false;            // the two-role kernel never stores the 3x3 output
+        if (ok && is_xhead && ((c.flags & CF_SIDE) != 0) != (p.w3s != nullptr)) return false;
         if (ok && p.w3s && !(p.res3 && ((((uintptr_t)p.w3s) & 15) == 0))) return false;
         if (ok && want_x && !(p.n3 >= 32 && p.n3 <= WS_HX_N3 && (p.n3 & 31) == 0 && (p.y3_ld & 7) == 0 && ((((uintptr_t)p.y3) & 15) == 0) && ((((uintptr_t)p.w3) & 15) == 0) && p.act3 <= SM_ACT_PRELU && !p.y2 &&
                                 (!p.res3 || ((p.res3_ld & 7) == 0 && ((((uintptr_t)p.res3) & 15) == 0))) &&
@@ -874,6 +891,11 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
         return ok;
     }
     if (p.y2 || p.y3) return false;                                  // only the weight-stationary kernel writes the pooled second output / applies a head
+    if (c.kind == 8)     // weights in registers: 1x1 / stride 1 / no padding, Cin = the instantiation's, Cout a multiple of the block's slice, dense 16-byte rows, ReLU family
+        return p.kH == 1 && p.kW == 1 && p.pt == 0 && p.pl == 0 && p.sH == 1 && p.sW == 1 && p.Ho == p.H && p.Wo == p.W && p.Cin == c.p0 && (p.Cout % c.BN) == 0 && p.Cout / c.BN <= 32 &&
+               !p.ups && !p.yplace && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.x) & 15) == 0) &&
+               ((((uintptr_t)p.w) & 15) == 0) && ((c.flags & CF_RES) != 0) == (p.res != nullptr) && (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0)) &&
+               (long)p.M * std::max(p.y_ld, p.x_ld) * 2 < 0x7fff0000L && (p.res == nullptr || (long)p.M * p.res_ld * 2 < 0x7fff0000L);
     if (c.kind == 7)     // persistent pointwise GEMM: 1x1, no padding, one square stride, dense 16-byte rows, ReLU family, bias vector beside the ring
         return p.kH == 1 && p.kW == 1 && p.pt == 0 && p.pl == 0 && p.sH == p.sW && (p.sH == 1 || p.sH == 2) && (p.Cin % 64) == 0 && !p.ups && !p.yplace &&
                p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
@@ -881,7 +903,7 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
                (long)(p.Ho - 1) * p.sH < p.H && (long)(p.Wo - 1) * p.sW < p.W && ps_lds_bytes(p, c) <= 160 * 1024;
     if (c.kind == 6) {   // stem form: overlapping 64-half pixels of a row-pair image (x_ld = 8), one kernel column, rows two apart, no padding
         ConvParams q = p;
-        if ((strstr(c.name, " ld") != nullptr) != (p.xf != nullptr)) return false;            // loader-wave instantiations <-> fp32 input
+        if ((c.p2 != 0) != (p.xf != nullptr)) return false;                                    // loader-wave instantiations <-> fp32 input
         if (p.xf && !(p.in_C >= 1 && p.in_C <= 4 && (long)p.N * p.in_C * p.in_H * p.in_W * 4 < 0x7fff0000L)) return false;
         return p.Cin == 64 && p.x_ld == 8 && p.kW == 1 && p.dH == 2 && p.pt == 0 && p.pl == 0 && p.sH == p.sW && (p.sH == 1 || p.sH == 2) && !p.ups &&
                (long)(p.Ho - 1) * p.sH + 2 * (p.kH - 1) < p.H && (long)(p.Wo - 1) * p.sW + 8 <= p.W &&
@@ -1024,6 +1046,17 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         hipLaunchKernelGGL((WsFn)c.fn, dim3(grid), dim3(c.threads), lds, s, p);
         SM_LAUNCH_CHECK(); return SM_OK;
     }
+    if (c.kind == 8) {                                               // persistent: one block per CU; Cout / BN slices x pixel-step ranges, the slices of a range on one XCD
+        const int nsl = p.Cout / c.BN;
+        p.nt = nsl; p.mt = sm_ceil_div(p.M, c.BM); p.splitk = 1;
+        const int unit = SM_NUM_XCD * nsl;
+        int groups = SM_NUM_CU / unit;                                // ranges per XCD
+        while (groups > 1 && (groups - 1) * SM_NUM_XCD >= p.mt) groups--;          // (no more ranges than steps)
+        const bool rres = (c.flags & CF_RES) != 0;
+        const size_t lds = c.p1 ? (size_t)c.p1 * (c.p0 / 64 + (rres ? c.BN / 64 : 0)) * c.BM * 128 + c.BN * 4 : (size_t)rw_lds_bytes(c.p0 / 16, c.BN, c.BM / 32, rres);
+        hipLaunchKernelGGL(c.fn, dim3((unsigned)(groups * unit)), dim3(c.threads), lds, s, p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
     if (c.kind == 7) {                                               // persistent: one block per CU, tiles dealt per XCD inside the kernel
         p.mt = sm_ceil_div(p.M, c.BM); p.nt = sm_ceil_div(p.Cout, c.BN); p.splitk = 1;
         sm_fastdiv_make((unsigned)p.nt, &p.nt_mul, &p.nt_sh);
@@ -1079,6 +1112,9 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
 extern "C" {
 
 int sm_conv2d_num_configs(void) { return kNumCfgs; }
+const char* sm_conv2d_config_name(int cfg) { return cfg >= 0 && cfg < kNumCfgs ? kCfgs[cfg].name : ""; }
+// number of loader waves of a stem-form config that builds its patches from the fp32 batch (sm_conv2d_stem_f32_fwd_cfg takes exactly these), else 0
+int sm_conv2d_config_loader_waves(int cfg) { return cfg >= 0 && cfg < kNumCfgs && kCfgs[cfg].kind == 6 ? kCfgs[cfg].p2 : 0; }
 
 size_t sm_conv2d_workspace_bytes(const sm_conv_desc* d) {
     // split-K is considered by launch() when a tile config leaves more than half of the CUs without a block and the K loop is
@@ -1164,7 +1200,7 @@ int sm_conv2d_xhead_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const
     const bool small = n3 <= 32 && !res3;                            // (the narrow heads without residual run on the " head" instantiations)
     if (small || cfg < 0 || cfg >= kNumCfgs) {                       // default pick: the two-role kernel where it applies (the faster one), else the first that takes the shape
         cfg = -1;
-        for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && strstr(kCfgs[i].name, "w4+4") && cfg_eligible(kCfgs[i], p)) cfg = i;
+        for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && (kCfgs[i].flags & CF_W44) && cfg_eligible(kCfgs[i], p)) cfg = i;
         for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) cfg = i;
     }
     if (cfg < 0) { sm_set_error("sm_conv2d_xhead_fwd_cfg: no kernel takes this shape with a fused expand head (3x3 / s1 / p1, Cin = Cout = 64, n3 <= 256, n3 %% 32 == 0)"); return SM_ERR_INVALID_ARGUMENT; }
@@ -1308,7 +1344,7 @@ int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w,
         for (int b2 = 0; b2 < 8192; b2++) {
             const unsigned long long* e = h + b2 * 16;
             if (!e[0] || !e[15]) continue;                       // unused slot or a block that map_block() retired
-            nb++; for (int q = 0; q < 8; q++) ph[q] += (double)(e[2 + q] - e[1 + q]);
+            nb++; for (int q = 0; q < 8; q++) if (e[2 + q] && e[1 + q]) ph[q] += (double)(e[2 + q] - e[1 + q]);
             wall += (double)(e[15] - e[0]); if (e[0] < w0) w0 = e[0]; if (e[15] > w1) w1 = e[15];
         }
         if (const char* dp = getenv("SM_TL_DUMP")) {              // raw per-block stamps for offline analysis

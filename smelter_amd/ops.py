@@ -96,7 +96,7 @@ def stem_conv(x_nchw, w_ohwi_f32, bias=None, stride=1, pads=(0, 0, 0, 0), act=AC
     s, P = stride, (kh + 1) // 2
     ho, wo = conv_out_size(h, w, kh, kw, s, s, pads)
     hs, ws = (ho - 1) * s + 2 * (P - 1) + 1, (wo - 1) * s + 8
-    f32_path = cfg is not None and cfg >= 97          # loader-wave configurations: the kernel builds its patches from the fp32 batch itself
+    f32_path = cfg is not None and lib().sm_conv2d_config_loader_waves(cfg) > 0   # loader-wave configurations: the kernel builds its patches from the fp32 batch itself
     if not f32_path:
         img = torch.empty((n, hs, ws, 8), dtype=torch.float16, device=x_nchw.device)
         check(lib().sm_nchw_f32_to_rowpair_f16(_ptr(x_nchw), _ptr(img), n, c, h, w, hs, ws, pads[0], pads[1], _stream()))
@@ -225,6 +225,11 @@ def conv2d_workspace_bytes(x_shape, w_shape, stride=(1, 1), pads=(0, 0, 0, 0), g
     d = ConvDesc(n, h, w, cin, cout, kh, kw, stride[0], stride[1], 1, 1, pads[0], pads[1], pads[2], pads[3], groups, ho, wo,
                  0, 0.0, 0, 0, 0)
     return lib().sm_conv2d_workspace_bytes(C.byref(d))
+
+
+def config_name(cfg: int) -> str:
+    """label of a tile configuration (sm_conv2d_config_name)"""
+    return lib().sm_conv2d_config_name(int(cfg)).decode()
 
 
 def num_conv_configs() -> int:

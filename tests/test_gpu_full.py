@@ -69,14 +69,18 @@ def test_mobilenet_v2_bs256_and_unet_bs16_run_and_are_deterministic():
 def test_tight_parity_at_full_size(name):
     """The 1e-3 bar of BASELINE.json at the FULL BASELINE sizes (bs = 64 / 256 / 16, so the tile configs are the benchmarked ones):
     both sides read the same ONNX2MPS-flavoured fp16 file and the oracle rounds to fp16 exactly the tensors the executor
-    materialises, so only the fp32 accumulation order differs.  Checked on a 2- (1-) image sub-batch; `floor` = the oracle against
-    itself with fp64 accumulation = what a different summation order alone does to fp16-stored activations.  The assertion is
-    nerr <= 1e-3 + floor; both numbers go to gpurun_out/parity_full_size.json (DESIGN.md §5 quotes them)."""
+    materialises, so only the fp32 accumulation order differs.  Checked on a 2-image sub-batch (all three models).
+
+    Norms.  "1e-3 rel-tol" is claimed in rel-L2 = |got - ref|_2 / |ref|_2, asserted <= 1e-3 for all three models.  The max-norm
+    nerr = max|got - ref| / max|ref| has a storage floor: `floor` = the oracle against itself with fp64 accumulation = what a different
+    summation order alone does to fp16-stored activations (U-Net: 2e-3, one flipped fp16 rounding of a value near the output maximum);
+    it is asserted <= 1e-3 + floor.  Both numbers, their floors and the per-element error distribution go to
+    gpurun_out/parity_full_size.json (committed as profiles/r03_parity_full_size.json; DESIGN.md 5 quotes them)."""
     import json
     import os
     from smelter_amd import onnx2mps
     make, hw, bs, sub = {"resnet50": (zoo.resnet50, (224, 224), 64, 2), "mobilenet_v2": (zoo.mobilenet_v2, (224, 224), 256, 2),
-                         "unet": (zoo.unet, (512, 512), 16, 1)}[name]
+                         "unet": (zoo.unet, (512, 512), 16, 2)}[name]
     model = onnx2mps.optimize_model(make(), half=True)
     x = zoo.synthetic_images(bs, 3, hw)
     ex = ONNXGraph(model, Configuration()).hipGraph(0, bs)
@@ -87,24 +91,65 @@ def test_tight_parity_at_full_size(name):
     ref = og.run(x[:sub])
     O.set_acc64(True)
     try:
-        floor = nerr(og.run(x[:sub]), ref)
+        ref64 = og.run(x[:sub])
     finally:
         O.set_acc64(False)
-    e = nerr(got, ref)
-    rl2 = float(np.linalg.norm((got - ref).ravel()) / np.linalg.norm(ref.ravel()))
+    rl2f = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
+    floor, floor_rl2 = nerr(ref64, ref), rl2f(ref64, ref)
+    e, rl2 = nerr(got, ref), rl2f(got, ref)
+    err = np.abs(got - ref).ravel() / np.abs(ref).max()
+    dist = {"max": float(err.max()), "p99_99": float(np.quantile(err, 0.9999)), "p99": float(np.quantile(err, 0.99)), "median": float(np.median(err)),
+            "count_above_1e-3_of_max_ref": int((err > 1e-3).sum()), "elements": int(err.size)}
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     try:
         os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
         path = os.path.join(root, "gpurun_out", "parity_full_size.json")
         d = json.load(open(path)) if os.path.exists(path) else {}
-        d[name] = {"batch": bs, "checked_images": sub, "nerr_vs_fp16_storage_oracle": e, "floor_fp32_vs_fp64_accumulation": floor, "rel_l2": rl2}
+        d[name] = {"batch": bs, "checked_images": sub, "launches": ex.numLaunches, "nerr_vs_fp16_storage_oracle": e, "floor_fp32_vs_fp64_accumulation": floor, "rel_l2": rl2,
+                   "floor_rel_l2": floor_rl2, "error_over_max_ref": dist}
         json.dump(d, open(path, "w"), indent=1)
     except OSError:
         pass
+    assert rl2 <= 1e-3, (rl2, floor_rl2)
     assert e <= 1e-3 + floor, (e, floor)
-    assert rl2 <= 2e-3, rl2
     del ex
     torch.cuda.empty_cache()
+
+
+def test_weight_arena_broadcast_over_rccl_world_size_1():
+    """The multi-GPU load path with the REAL backend on one GPU: torch.distributed "nccl" (= RCCL on ROCm; loads librccl) at world size 1,
+    dist.broadcast of the packed 51 MB ResNet-50 arena, smelter_graph_compile(..., weight_arena, upload = 0) on the received bytes: output
+    bit-identical to the executor that packed and uploaded its own weights (what ranks 1..7 of BASELINE config 5 do)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from smelter_amd import dist as sd
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    model = zoo.resnet50()
+    x = torch.from_numpy(zoo.synthetic_images(8)).cuda()
+    ref_ex = ONNXGraph(model, Configuration(autotune=False)).hipGraph(0, 8)
+    ref_ex.encode(x)
+    ref = ref_ex.toFloatArray()
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1)
+    try:
+        assert dist.get_backend() == "nccl"
+        g = ONNXGraph(model, Configuration(autotune=False))
+        arena = torch.from_numpy(g.packWeights(8)).cuda()
+        want = sd.arena_checksum(arena)
+        dist.broadcast(arena, src=0)                       # RCCL collective on the real arena (a self-broadcast at world size 1)
+        dist.barrier()
+        torch.cuda.synchronize()
+        assert arena.numel() == g.weightBytes(8) and 51.0e6 < arena.numel() < 51.5e6
+        assert sd.arena_checksum(arena) == want
+        ex = g.hipGraph(0, 8, weight_arena=arena, upload_weights=False)
+        ex.encode(x)
+        assert np.array_equal(ex.toFloatArray(), ref)
+        maps = open("/proc/self/maps").read()
+        assert "librccl" in maps, "the nccl backend did not map librccl"
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("launcher", ["torchrun", "plain"])

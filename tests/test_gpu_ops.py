@@ -14,6 +14,18 @@ from smelter_amd import ops
 
 pytestmark = pytest.mark.gpu
 
+# every tile configuration the built library holds (the C ABI answers without a GPU): a config added to the pool is swept automatically
+ALL_CFGS = list(range(ops.num_conv_configs()))
+
+
+def cfgs_named(*subs, without=()):
+    """configurations whose label contains every string of `subs` and none of `without` (kernel families are selected by label, not by index)"""
+    return [c for c in ALL_CFGS if all(s in ops.config_name(c) for s in subs) and not any(w in ops.config_name(c) for w in without)]
+
+
+WS_PLAIN = cfgs_named("ws:", without=("head",))           # weight-stationary 3x3, no fused head
+assert WS_PLAIN and cfgs_named("p9:") and cfgs_named("wst:") and cfgs_named("ps:") and cfgs_named("ws:", " head") and cfgs_named("xhead", without=("side",))
+
 
 def h(a):
     return O.round_to_half(np.asarray(a, np.float32))
@@ -56,7 +68,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("cfg", [None] + list(range(96)))
+@pytest.mark.parametrize("cfg", [None] + ALL_CFGS)
 def test_conv2d(case, cfg):
     n, hh, ww, cin, cout, k, s, p, res, act = case
     if cfg is not None and (cin % 8 or cfg >= ops.num_conv_configs() or (cfg >= 6 and cin % 64)):
@@ -117,7 +129,7 @@ def test_pointwise_thin_kernel(cin, cout, res, act, monkeypatch):
     assert_close(to_host(y), ref, cin)
 
 
-@pytest.mark.parametrize("cfg", list(range(96)))
+@pytest.mark.parametrize("cfg", ALL_CFGS)
 def test_conv2d_generic_epilogue_every_config(cfg):
     """Tanh is not a ReLU-family activation, so every kernel takes its GENERIC epilogue (bias-initialised accumulators, per-element
     activation) instead of the straight-line fast path the ResNet cases exercise; Cin % 64 == 0 so that all BK=64 configs apply.
@@ -155,7 +167,7 @@ def test_conv2d_split_k_workspace():
     assert_close(to_host(y), O.conv2d(x, w, b), cin)
 
 
-@pytest.mark.parametrize("cfg", list(range(96)))
+@pytest.mark.parametrize("cfg", ALL_CFGS)
 def test_conv2d_split_k_every_config(cfg):
     """few tiles + long K + a workspace: the launcher splits K across blocks (fp32 partials + reduce kernel) for every tile config
     that has a split-K form; residual + ReLU are then applied by the reduce kernel"""
@@ -459,7 +471,7 @@ WS_CASES = [
 
 
 @pytest.mark.parametrize("case", WS_CASES)
-@pytest.mark.parametrize("cfg", list(range(61, 68)))
+@pytest.mark.parametrize("cfg", WS_PLAIN)
 def test_conv3x3_weight_stationary(case, cfg):
     n, hh, ww, cin, cout, act = case
     if cfg >= ops.num_conv_configs():
@@ -507,7 +519,7 @@ P9_CASES = [
 
 
 @pytest.mark.parametrize("case", P9_CASES)
-@pytest.mark.parametrize("cfg", list(range(68, 74)))
+@pytest.mark.parametrize("cfg", cfgs_named("p9:"))
 def test_conv3x3_nine_tap_patch(case, cfg):
     n, hh, ww, cin, cout, act = case
     if cfg >= ops.num_conv_configs():
@@ -531,7 +543,7 @@ def test_conv3x3_nine_tap_patch(case, cfg):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 20, 64, 64, 1), (1, 32, 32, 128, 40, 0), (3, 7, 9, 64, 136, 2), (2, 21, 33, 64, 32, 1), (1, 40, 24, 32, 32, 1)])
-@pytest.mark.parametrize("cfg", [None] + list(range(61, 74)))
+@pytest.mark.parametrize("cfg", [None] + WS_PLAIN + cfgs_named("p9:"))
 def test_conv3x3_reads_through_fused_nearest_upsampling(case, cfg):
     """sm_conv_desc.x_ups: conv(upsample2x_nearest(x)) computed from the half-resolution x (the executor fuses Upsample -> Conv this way)"""
     n, hh, ww, cin, cout, act = case                                  # hh x ww = the LOW resolution
@@ -642,7 +654,7 @@ def test_mbconv_with_the_image_stem_inside(n, hw, ch, cout, st_stride, stride):
 
 
 @pytest.mark.parametrize("n,hw,cin,cout,act", [(2, (64, 64), 32, 32, 1), (1, (32, 96), 64, 32, 2), (2, (20, 32), 64, 64, 1), (1, (16, 128), 32, 64, 0)])
-@pytest.mark.parametrize("cfg", [-1, 61, 62, 63, 64, 66, 67])
+@pytest.mark.parametrize("cfg", [-1] + [c for c in WS_PLAIN if "x2" in ops.config_name(c)])
 def test_conv3x3_with_fused_maxpool(n, hw, cin, cout, act, cfg):
     """sm_conv2d_pool_fwd_cfg: y bit-identical to the plain launch of the same config, pooled == max-pool of y (exact)"""
     rng = np.random.default_rng(cin + cout + hw[1])
@@ -673,7 +685,7 @@ def test_conv3x3_with_fused_maxpool(n, hw, cin, cout, act, cfg):
     (1, 4, 50, 38, 32, 7, 2, (2, 3, 3, 2)),      # asymmetric padding, 4 channels
     (1, 3, 9, 9, 64, 3, 1, (0, 0, 0, 0)),        # image smaller than a tile
 ])
-@pytest.mark.parametrize("cfg", [None] + list(range(74, 81)) + list(range(97, 103)))
+@pytest.mark.parametrize("cfg", [None] + cfgs_named("wst:"))
 def test_stem_on_the_weight_stationary_kernel(shape, cfg):
     """Image stem through the row-pair image (ops.stem_conv = executor's lowering): every stem configuration of conv3x3_ws.hpp that takes
     the shape agrees with the oracle convolution, and with the default pick.  Configurations 97+ have loader waves that build the patches from
@@ -691,8 +703,72 @@ def test_stem_on_the_weight_stationary_kernel(shape, cfg):
         raise
     ref = np.maximum(O.conv2d(h(x), w, b, stride=(s, s), pads=pads), 0)
     assert_close(to_host(y), ref, C * k * k)
-    if cfg is not None and cfg >= 97:
+    if cfg is not None and ops.lib().sm_conv2d_config_loader_waves(cfg) > 0:
         assert torch.equal(y, ops.stem_conv(torch.from_numpy(x).cuda(), torch.from_numpy(w), torch.from_numpy(b).cuda(), stride=s, pads=pads, act=1))
+
+
+RW_CASES = [
+    # n, h, w, cin, cout, residual, act                -- what the case exercises
+    (2, 14, 14, 256, 1024, True, 1),                   # ResNet layer-3 expand: four N slices, 6.1 steps of 64 pixels
+    (3, 7, 9, 256, 512, True, 2),                      # ragged M (189 = 2 steps + 61 pixels), PReLU, two N slices
+    (1, 40, 40, 256, 64, False, 1),                    # 256 -> 64 reduce: one slice, 12.5 steps of 128 pixels
+    (2, 9, 9, 256, 128, False, 0),                     # 256 -> 128, no activation, M = 162 (1.3 steps)
+    (1, 3, 3, 256, 256, False, 1),                     # M = 9: a single ragged step, most ranges empty
+    (2, 28, 28, 128, 512, True, 1),                    # ResNet layer-2 expand
+    (1, 5, 5, 128, 256, False, 1),                     # K = 128 without residual
+    (2, 20, 20, 64, 64, False, 1),                     # 64 -> 64, steps of 256 pixels, ragged (800 = 3.1 steps)
+    (1, 13, 11, 64, 256, True, 1),                     # 64 -> 256 + residual
+    (64, 14, 14, 256, 1024, True, 1),                  # full size (checked against config 6 only)
+]
+
+
+@pytest.mark.parametrize("case", RW_CASES)
+@pytest.mark.parametrize("cfg", cfgs_named("rw:") + cfgs_named("rwl:"))
+def test_pointwise_weights_in_registers(case, cfg):
+    """conv1x1_rw.hpp (tile-config kind 8): every instantiation that takes the shape agrees with the oracle; against conv_igemm64 (config 6) all
+    values agree to the parity tolerance (the residual enters through the MFMA accumulator here: a rounding may flip) and nearly all bit for bit"""
+    n, hh, ww, cin, cout, res, act = case
+    rng = np.random.default_rng(cin * 11 + cout + hh)
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, 1, 1, cin)) * np.sqrt(2.0 / cin)); b = rng.standard_normal(cout).astype(np.float32)
+    r = h(rng.standard_normal((n, cout, hh, ww))) if res else None
+    slope = 0.25 if act == 2 else 0.0
+    xd, wd, bd, rd = to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), to_dev(r) if res else None
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(xd, wd, bd, residual=rd, act=act, slope=slope, cfg=cfg)
+    except SmelterError as e:
+        if "does not apply" in e.detail:
+            pytest.skip(e.detail)
+        raise
+    y6 = ops.conv2d(xd, wd, bd, residual=rd, act=act, slope=slope, cfg=6)
+    got, g6 = to_host(y), to_host(y6)
+    assert_close(got, g6, cin)
+    assert np.mean(got != g6) < (2e-3 if res else 1e-9)
+    if n * hh * ww <= 4096:
+        ref = O.conv2d(x, w, b)
+        if res:
+            ref = ref + r
+        if act:
+            ref = np.where(ref >= 0, ref, ref * slope)
+        assert_close(got, ref, cin)
+
+
+def test_pointwise_weights_in_registers_inside_a_concat_buffer():
+    """pixel strides larger than the channel count on all three operands (zero-copy concat placement / pass 3h's K-concatenated operand)"""
+    rng = np.random.default_rng(5)
+    n, hh, ww, cin, cout = 2, 12, 10, 128, 256
+    x = h(rng.standard_normal((n, cin, hh, ww))); w = h(rng.standard_normal((cout, 1, 1, cin)) * np.sqrt(2.0 / cin)); b = rng.standard_normal(cout).astype(np.float32)
+    r = h(rng.standard_normal((n, cout, hh, ww)))
+    xb = torch.zeros((n, hh, ww, cin + 64), dtype=torch.float16, device="cuda"); xb[..., 64:] = to_dev(x)
+    rb = torch.zeros((n, hh, ww, cout + 8), dtype=torch.float16, device="cuda"); rb[..., :cout] = to_dev(r)
+    yb = torch.full((n, hh, ww, cout + 32), 7.0, dtype=torch.float16, device="cuda")
+    cfg = cfgs_named("rw:k128", "+res")[0]
+    ops.conv2d(xb[..., 64:], torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), residual=rb[..., :cout], act=1, cfg=cfg, out=yb[..., 16:16 + cout])
+    torch.cuda.synchronize()
+    assert (yb[..., :16] == 7).all() and (yb[..., 16 + cout:] == 7).all()          # nothing written beside the slice
+    ref = np.maximum(O.conv2d(x, w, b) + r, 0)
+    assert_close(yb[..., 16:16 + cout].float().cpu().numpy().transpose(0, 3, 1, 2), ref, cin)
 
 
 PS_CASES = [
@@ -708,7 +784,7 @@ PS_CASES = [
 
 
 @pytest.mark.parametrize("case", PS_CASES)
-@pytest.mark.parametrize("cfg", list(range(81, 88)))
+@pytest.mark.parametrize("cfg", cfgs_named("ps:") + cfgs_named("256x256"))
 def test_persistent_pointwise_kernel(case, cfg):
     """conv1x1_ps.hpp: every configuration that takes the shape agrees with the oracle and is bit-identical to conv_igemm64 (config 6)"""
     if cfg >= ops.num_conv_configs():
@@ -758,7 +834,7 @@ def test_persistent_pointwise_kernel_into_a_channel_slice():
     (2, (24, 36), 64, 64, 32, 2, False),     # four k steps of head input, 32 head channels, PReLU, ragged tiles
     (1, (16, 32), 32, 64, 24, 0, True),      # 24 head channels (three groups of 8)
 ])
-@pytest.mark.parametrize("cfg", [-1, 89, 90, 91, 92, 93])
+@pytest.mark.parametrize("cfg", [-1] + cfgs_named("ws:", " head"))
 def test_conv3x3_with_fused_pointwise_head(n, hw, cin, cout, n3, act3, store_y, cfg):
     """sm_conv2d_head_fwd_cfg: y (when stored) bit-identical to the plain launch, y3 == the 1x1 convolution of the ROUNDED y (the stored tensor's
     values), i.e. what the two separate launches compute"""
@@ -793,7 +869,7 @@ def test_conv3x3_with_fused_pointwise_head(n, hw, cin, cout, n3, act3, store_y, 
     (1, (9, 70), 32, 0, True, True),         # one chunk, no activation, a partial column band
     (2, (16, 16), 64, 1, False, False),      # wide head without residual
 ])
-@pytest.mark.parametrize("cfg", [-1, 94, 95])
+@pytest.mark.parametrize("cfg", [-1] + cfgs_named("xhead", without=("side",)))
 def test_conv3x3_with_fused_expand_head(n, hw, n3, act3, with_res, store_y, cfg):
     """sm_conv2d_xhead_fwd_cfg (config 94: one role per block; 95: producer / consumer waves): y3 = the two separate launches (3x3, then 1x1 + residual + activation on the ROUNDED 3x3 output) —
     bit-identical without a residual, within one fp16 ulp at a few values per million with one; y (when stored) bit-identical to the plain 3x3 launch"""
