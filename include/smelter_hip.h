@@ -106,6 +106,13 @@ int sm_conv2d_uses_tile_config(const sm_conv_desc* d);
 int sm_conv2d_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias,
                       const void* residual, void* y, void* workspace, size_t workspace_bytes, sm_stream_t stream);
 
+/* Two MPSCNNConvolutionNodes joined by an MPSNNAdditionNode (Converters.swift:253, :440) as ONE pointwise convolution over two sources concatenated along K:
+ * y = act([W_a | W_b] . [x ; x2] + bias).  `d` = the 1x1 / stride 1 / no padding convolution over x = [N, H, W, K1] with d->Cin = K1 + K2 (the row length of
+ * w_ohwi = [Cout][K1 + K2]); x2 = [N, x2_H, x2_W, K2] (pixel stride x2_ld, 0 = K2) is read at pixel (oy * x2_stride, ox * x2_stride) — a stride-2 projection
+ * shortcut reads the block input in place.  K1 % 64 == K2 % 64 == 0.  Only the persistent pointwise configurations take a second source. */
+int sm_conv2d_dual_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* x2, int32_t K2, int32_t x2_ld, int32_t x2_H, int32_t x2_W, int32_t x2_stride,
+                           const void* w_ohwi, const float* bias, void* y, sm_stream_t stream);
+
 /* MPSCNNConvolutionNode (3x3 / stride 1 / pad 1, Cin, Cout in {32, 64}) + the MPSCNNPoolingMaxNode (2x2 / stride 2, Converters.swift:662)
  * that consumes it, in ONE launch; both the full-resolution tensor `y` (the U-Net's skip connection) and the pooled one are written.
  * W % 32 == 0, H even.  cfg < 0 picks a configuration. */
@@ -142,19 +149,15 @@ int sm_conv2d_xhead_proj_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, 
  * the stem kernel's row-pair patches from the fp32 NCHW batch (`x_nchw`: [N, C, H_in, W_in]; zero outside the image = the padding (pt, pl)).
  * `d` is the stem-form descriptor sm_conv2d_fwd takes for the same layer (row-pair geometry: Cin = 64, kW = 1, dH = 2, x_ld = 8), `w` the weights
  * packed for it. */
+/* ... + the MPSCNNPoolingMaxNode (3x3 / stride 2, Converters.swift:662; window start by PyTorchPoolPadding.swift:60-75 = 0 here) that consumes the stem, in ONE
+ * launch (stem_pool.hpp): the stem's own output — the largest tensor of a ResNet — is neither written nor read.  y_pool = [N, pool_H, pool_W, Cout] fp16,
+ * pixel stride pool_ld (0 = Cout).  Taken: row-pair stem form with 2 | 4 taps, Cout = 64, pool_H = ceil((Ho - 2) / 2) or that + 1 (windows clamped at the edge). */
+int sm_conv2d_stem_f32_pool_supported(const sm_conv_desc* d, int32_t C, int32_t H_in, int32_t W_in, int32_t pool_H, int32_t pool_W);
+int sm_conv2d_stem_f32_pool_fwd(const sm_conv_desc* d, const float* x_nchw, int32_t C, int32_t H_in, int32_t W_in, int32_t pt, int32_t pl, const void* w_stem,
+                                const float* bias, void* y_pool, int32_t pool_H, int32_t pool_W, int32_t pool_ld, sm_stream_t stream);
 int sm_conv2d_stem_f32_supported(const sm_conv_desc* d, int32_t C, int32_t H_in, int32_t W_in);
 int sm_conv2d_stem_f32_fwd_cfg(const sm_conv_desc* d, int cfg, const float* x_nchw, int32_t C, int32_t H_in, int32_t W_in, int32_t pt, int32_t pl,
                                const void* w_packed, const float* bias, void* y, sm_stream_t stream);
-
-/* Two MPSCNNConvolutionNodes in a row, both 1x1 / stride 1 (Converters.swift:253), in ONE launch:
- *   y = act(x * w1 + bias1 + residual)   [d: Cin = 64 -> Cout = 256]      z = act2(y * w2 + bias2)   [256 -> N2 in {64, 128}]
- * Both tensors are stored (y is the next residual); y is rounded to fp16 once, exactly as the separate launches would store it.
- * The executor uses it for the expand -> reduce pairs of ResNet's 56x56 stage, where the second layer would otherwise spend its
- * whole life re-reading what the first has just written. */
-int sm_conv1x1_pair_supported(const sm_conv_desc* d, int32_t N2);
-int sm_conv1x1_pair_fwd(const sm_conv_desc* d, const void* x, const void* w1, const float* bias1, const void* residual, void* y,
-                        int32_t N2, const void* w2, const float* bias2, int32_t act2, float slope2, void* z, int32_t z_ld,
-                        sm_stream_t stream);
 
 /* Three MPSCNNConvolutionNodes in a row — [1x1 expand + act1] -> depthwise 3x3 (pad 1, stride 1|2) + act2 -> 1x1 project + act3
  * (+ the block input as residual) — in ONE launch; the two hidden tensors stay in LDS (the "inverted residual" block of

@@ -67,18 +67,19 @@ SYMBOLS = {
     "sm_conv2d_config_name": (C.c_char_p, [_i32]),
     "sm_conv2d_config_loader_waves": (_i32, [_i32]),
     "sm_conv2d_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sm_conv2d_dual_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sm_conv2d_pool_supported": (_i32, [C.POINTER(ConvDesc)]),
     "sm_conv2d_pool_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "sm_conv2d_head_supported": (_i32, [C.POINTER(ConvDesc), _i32]),
     "sm_conv2d_head_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _i32, _vp]),
     "sm_conv2d_stem_f32_supported": (_i32, [C.POINTER(ConvDesc), _i32, _i32, _i32]),
+    "sm_conv2d_stem_f32_pool_supported": (_i32, [C.POINTER(ConvDesc), _i32, _i32, _i32, _i32, _i32]),
+    "sm_conv2d_stem_f32_pool_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "sm_conv2d_stem_f32_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sm_conv2d_xhead_supported": (_i32, [C.POINTER(ConvDesc), _i32, _i32]),
     "sm_conv2d_xhead_proj_supported": (_i32, [C.POINTER(ConvDesc), _i32]),
     "sm_conv2d_xhead_proj_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sm_conv2d_xhead_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _i32, _vp, _i32, _vp]),
-    "sm_conv1x1_pair_supported": (_i32, [C.POINTER(ConvDesc), _i32]),
-    "sm_conv1x1_pair_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _f, _vp, _i32, _vp]),
     "sm_mbconv_supported": (_i32, [C.POINTER(MbConvDesc)]),
     "sm_mbconv_lds_bytes": (_sz, [C.POINTER(MbConvDesc)]),
     "sm_mbconv_fwd": (_i32, [C.POINTER(MbConvDesc)] + [_vp] * 9),

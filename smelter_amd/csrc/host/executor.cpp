@@ -369,42 +369,15 @@ int Executor::plan(ONNXGraph& g, int batch) {
         }
     }
 
-    // ---- 3b. pointwise pairs: a 1x1 expand (64 -> 256, + residual + ReLU) whose output feeds a 1x1 reduce (256 -> 64 | 128) runs together
-    // with it in one persistent launch (conv1x1_pair.hpp): the 256-channel tensor is written once and never read back by the reduce.
-    // The reduce moves up to the expand's position — legal, its only operand is produced there.
-    // OFF by default (SMELTER_POINTWISE_PAIRS=1 enables it): measured on ResNet-50 bs=64 the three pairs take 59 / 72 / 75 us against
-    // 74 / 73 / 82 us as separate launches — the tile-serial kernel (three barriers per tile) streams at 3.1-3.9 TB/s where the plain
-    // kernels reach 4.3-5.8, and the longer life of the moved-up output pushes the activation arena from 257 to 283 MB, past the
-    // 256 MiB Infinity Cache; the step time does not move.
-    const char* pairs_env = getenv("SMELTER_POINTWISE_PAIRS");
-    if (pairs_env && pairs_env[0] == '1' && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency) {
-        for (size_t t = 0; t < steps_.size(); t++) {
-            Step& c = steps_[t];
-            if (c.op.kind != OpKind::Conv || c.stem || c.op.grid_h || c.op.x_ups || c.op.output == output_value_) continue;
-            const Value& cin_v = values_[c.op.inputs[0]];
-            sm_conv_desc d{}; d.N = batch; d.H = d.Ho = cin_v.h; d.W = d.Wo = cin_v.w; d.Cin = c.op.cin; d.Cout = c.op.cout; d.kH = c.op.kh; d.kW = c.op.kw; d.sH = c.op.sh; d.sW = c.op.sw;
-            d.pt = c.op.pt; d.pl = c.op.pl; d.groups = c.op.groups; d.act = c.op.act;
-            if (values_[c.op.output].h != cin_v.h || values_[c.op.output].w != cin_v.w) continue;
-            for (size_t u = t + 1; u < steps_.size(); u++) {
-                Step& a = steps_[u];
-                if (a.op.kind != OpKind::Conv || a.op.inputs[0] != c.op.output || a.op.kh != 1 || a.op.kw != 1 || a.op.sh != 1 || a.op.sw != 1 || a.op.pt || a.op.pl || a.op.groups != 1 ||
-                    a.op.residual >= 0 || a.op.act > SM_ACT_PRELU || a.op.cin != c.op.cout || a.op.grid_h || a.op.x_ups || a.has_pair || !sm_conv1x1_pair_supported(&d, a.op.cout)) continue;
-                c.has_pair = true; c.pair = std::move(a.op); c.real_k += 0;
-                steps_.erase(steps_.begin() + u);
-                break;
-            }
-        }
-    }
-
     // ---- 3c. inverted-residual blocks (MobileNet-v2): 1x1 expand (+act) -> depthwise 3x3 / stride 1|2 / pad 1 (+act) -> 1x1 project
     // (+ the block input as residual) run as ONE launch (mbconv.hip) when the two hidden tensors have no other reader: they are 6x the block's
     // input and are otherwise written once and read once.  Domain = the all-in-LDS kernel's (Cin <= 32, Ch <= 192, Cout <= 64), where the fused
     // launch measured faster than the three separate ones; SMELTER_MBCONV=0 keeps the layers apart.
     {
         const char* mb_env = getenv("SMELTER_MBCONV");
-        auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; if (q.has_pair) for (int u : q.pair.inputs) if (u == v) n++; } return n; };
+        auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
         auto pointwise = [&](const Step& q) { const Op& o = q.op; return o.kind == OpKind::Conv && o.kh == 1 && o.kw == 1 && o.sh == 1 && o.sw == 1 && !o.pt && !o.pl && !o.pb && !o.pr && o.groups == 1 &&
-                                                     o.act <= SM_ACT_PRELU && !q.stem && !o.grid_h && !o.x_ups && !q.has_pair && q.pool_out < 0 && !q.has_mb; };
+                                                     o.act <= SM_ACT_PRELU && !q.stem && !o.grid_h && !o.x_ups && q.pool_out < 0 && !q.has_mb; };
         if (!(mb_env && mb_env[0] == '0') && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency)
             for (size_t t = 0; t < steps_.size(); t++) {
                 Step& e = steps_[t];
@@ -414,7 +387,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 if (!ud) continue;
                 const Op& dw = steps_[ud].op;
                 if (dw.kind != OpKind::Conv || dw.groups != dw.cin || dw.cin != dw.cout || dw.cin != e.op.cout || dw.kh != 3 || dw.kw != 3 || dw.dh != 1 || dw.dw != 1 || dw.sh != dw.sw ||
-                    (dw.sh != 1 && dw.sh != 2) || dw.pt != 1 || dw.pl != 1 || dw.residual >= 0 || dw.act > SM_ACT_PRELU || steps_[ud].has_pair || steps_[ud].pool_out >= 0 || readers(dw.output) != 1) continue;
+                    (dw.sh != 1 && dw.sh != 2) || dw.pt != 1 || dw.pl != 1 || dw.residual >= 0 || dw.act > SM_ACT_PRELU || steps_[ud].pool_out >= 0 || readers(dw.output) != 1) continue;
                 for (size_t u = ud + 1; u < steps_.size() && !up; u++) if (!steps_[u].op.inputs.empty() && steps_[u].op.inputs[0] == dw.output) up = u;
                 if (!up || !pointwise(steps_[up])) continue;
                 const Op& pj = steps_[up].op;
@@ -435,7 +408,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             for (size_t t = 0; t < steps_.size(); t++) {
                 Step& e = steps_[t];
                 const Op& dw = e.op;
-                if (e.has_mb || e.has_pair || e.pool_out >= 0 || e.stem || dw.kind != OpKind::Conv || dw.groups != dw.cin || dw.cin != dw.cout || dw.groups < 8 || dw.kh != 3 || dw.kw != 3 || dw.dh != 1 ||
+                if (e.has_mb || e.pool_out >= 0 || e.stem || dw.kind != OpKind::Conv || dw.groups != dw.cin || dw.cin != dw.cout || dw.groups < 8 || dw.kh != 3 || dw.kw != 3 || dw.dh != 1 ||
                     dw.dw != 1 || dw.sh != dw.sw || (dw.sh != 1 && dw.sh != 2) || dw.pt != 1 || dw.pl != 1 || dw.residual >= 0 || dw.act > SM_ACT_PRELU || dw.grid_h || dw.x_ups || readers(dw.output) != 1) continue;
                 size_t up = 0;
                 for (size_t u = t + 1; u < steps_.size() && !up; u++) if (!steps_[u].op.inputs.empty() && steps_[u].op.inputs[0] == dw.output) up = u;
@@ -456,7 +429,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
         for (size_t t = 0; t < steps_.size(); t++) {
             Step& c = steps_[t];
-            if (c.op.kind != OpKind::Conv || c.stem || c.op.grid_h || c.op.residual >= 0 || c.pool_out >= 0 || c.has_pair || c.has_mb || c.op.kh != 3 || readers(c.op.output) != 1 || !vecOk(c.op.inputs[0])) continue;
+            if (c.op.kind != OpKind::Conv || c.stem || c.op.grid_h || c.op.residual >= 0 || c.pool_out >= 0 || c.has_mb || c.op.kh != 3 || readers(c.op.output) != 1 || !vecOk(c.op.inputs[0])) continue;
             const Value& ov = values_[c.op.output];
             sm_conv_desc d{}; d.N = batch; d.H = d.Ho = ov.h; d.W = d.Wo = ov.w; d.Cin = c.op.cin; d.Cout = c.op.cout; d.kH = c.op.kh; d.kW = c.op.kw; d.sH = c.op.sh; d.sW = c.op.sw;
             d.dH = c.op.dh; d.dW = c.op.dw; d.pt = c.op.pt; d.pl = c.op.pl; d.pb = c.op.pb; d.pr = c.op.pr; d.groups = c.op.groups; d.act = c.op.act; d.x_ups = c.op.x_ups ? 1 : 0;
@@ -465,7 +438,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 if (h.op.inputs.empty() || h.op.inputs[0] != c.op.output) continue;
                 const Op& o = h.op;
                 if (o.kind != OpKind::Conv || o.kh != 1 || o.kw != 1 || o.sh != 1 || o.sw != 1 || o.pt || o.pl || o.pb || o.pr || o.groups != 1 || o.act > SM_ACT_PRELU || o.grid_h ||
-                    o.x_ups || h.has_pair || h.has_mb || h.pool_out >= 0 || o.cin != c.op.cout || !vecOk(o.output) || (o.residual >= 0 && !vecOk(o.residual))) break;
+                    o.x_ups || h.has_mb || h.pool_out >= 0 || o.cin != c.op.cout || !vecOk(o.output) || (o.residual >= 0 && !vecOk(o.residual))) break;
                 // narrow head without residual: the HEAD instantiations; a bottleneck's tail (1x1 expand to <= 256 channels + block input + ReLU): the
                 // expand head (conv3x3_ws.hpp HX), SMELTER_XHEAD=0 keeps the two launches
                 const bool xhead_on = !(getenv("SMELTER_XHEAD") && getenv("SMELTER_XHEAD")[0] == '0');      // (plan time, not the launch path)
@@ -476,7 +449,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                     // shortcut of a first block) moves in front of the 3x3 when its own operands allow it
                     auto producer = [&](int v) -> long {
                         for (size_t q = 0; q < steps_.size(); q++)
-                            if (steps_[q].op.output == v || steps_[q].pool_out == v || (steps_[q].has_pair && steps_[q].pair.output == v) || (steps_[q].has_mb && steps_[q].mb_proj.output == v) ||
+                            if (steps_[q].op.output == v || steps_[q].pool_out == v || (steps_[q].has_mb && steps_[q].mb_proj.output == v) ||
                                 (steps_[q].has_head && steps_[q].head.output == v)) return (long)q;
                         return -1L;
                     };
@@ -486,7 +459,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                     if (pr > (long)t) {
                         const Step& ps = steps_[pr];
                         // (one step must be the WHOLE producer: the phase steps of a ConvTranspose and the fallback copies of a Concat share an output)
-                        bool movable = !ps.has_pair && ps.pool_out < 0 && !ps.has_mb && !ps.has_head && ps.op.output == rootOf(o.residual) && !ps.op.grid_h && ps.op.kind != OpKind::Concat;
+                        bool movable = ps.pool_out < 0 && !ps.has_mb && !ps.has_head && ps.op.output == rootOf(o.residual) && !ps.op.grid_h && ps.op.kind != OpKind::Concat;
                         for (size_t q = 0; q < steps_.size(); q++) if ((long)q != pr && steps_[q].op.output == ps.op.output) movable = false;
                         for (int v : ps.op.inputs) { const long q = producer(rootOf(v)); if (q >= (long)t) movable = false; }
                         if (ps.op.residual >= 0 && producer(rootOf(ps.op.residual)) >= (long)t) movable = false;
@@ -512,7 +485,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
         auto producer = [&](int v) -> long {
             for (size_t q = 0; q < steps_.size(); q++)
-                if (steps_[q].op.output == v || steps_[q].pool_out == v || (steps_[q].has_pair && steps_[q].pair.output == v) || (steps_[q].has_mb && steps_[q].mb_proj.output == v) ||
+                if (steps_[q].op.output == v || steps_[q].pool_out == v || (steps_[q].has_mb && steps_[q].mb_proj.output == v) ||
                     (steps_[q].has_head && steps_[q].head.output == v)) return (long)q;
             return -1L;
         };
@@ -527,7 +500,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 if (sd.op.residual != c.head.output) continue;
                 const Op& o = sd.op;
                 if (o.kind != OpKind::Conv || o.kh != 1 || o.kw != 1 || o.sh != 1 || o.sw != 1 || o.pt || o.pl || o.pb || o.pr || o.groups != 1 || o.act > SM_ACT_PRELU || o.grid_h || o.x_ups ||
-                    sd.stem || sd.has_pair || sd.has_mb || sd.has_head || sd.pool_out >= 0 || o.cin != 64 || o.cout != c.head.cout || o.inputs.empty()) break;
+                    sd.stem || sd.has_mb || sd.has_head || sd.pool_out >= 0 || o.cin != 64 || o.cout != c.head.cout || o.inputs.empty()) break;
                 const Value& sv = values_[o.inputs[0]];
                 if (sv.h != ov.h || sv.w != ov.w || producer(rootOf(o.inputs[0])) >= (long)t || !vecOk(o.inputs[0]) || !vecOk(o.output) || !sm_conv2d_xhead_proj_supported(&d, o.cout)) break;
                 c.has_side = true; c.side = std::move(sd.op);
@@ -550,11 +523,11 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 if (q.op.residual == v) n++;
                 if (q.has_head && q.head.residual == v) n++;
                 if (q.has_side) for (int u : q.side.inputs) if (u == v) n++;
-                if (q.has_pair) for (int u : q.pair.inputs) if (u == v) n++;
+               
             }
             return n;
         };
-        auto plainConv = [&](const Step& q) { return q.op.kind == OpKind::Conv && !q.stem && !q.has_pair && !q.has_mb && !q.has_head && !q.has_side && q.pool_out < 0 && !q.op.grid_h && !q.op.x_ups && q.join < 0; };
+        auto plainConv = [&](const Step& q) { return q.op.kind == OpKind::Conv && !q.stem && !q.has_mb && !q.has_head && !q.has_side && q.pool_out < 0 && !q.op.grid_h && !q.op.x_ups && q.join < 0; };
         auto pointwise = [&](const Op& o) { return o.kh == 1 && o.kw == 1 && !o.pt && !o.pl && !o.pb && !o.pr && o.groups == 1 && o.dh == 1 && o.dw == 1 && o.sh == o.sw; };
         for (size_t u = 0; u < steps_.size(); u++) {
             if (!plainConv(steps_[u])) continue;
@@ -575,7 +548,25 @@ int Executor::plan(ONNXGraph& g, int batch) {
             if (hv.h != ov.h || hv.w != ov.w || (xv.h - 1) / so.sh + 1 != ov.h || (xv.w - 1) / so.sw + 1 != ov.w || hv.c != eo.cin || xv.c != so.cin) continue;
             const int K1 = eo.cin, K2 = so.cin, N = so.cout, oh = hv.h, ow = hv.w;        // (values_ grows below: no reference into it survives)
             const double x_full = (double)batch * xv.c * xv.h * xv.w;
-            // two new values: the concatenated operand, and the strided copy of the block input inside it
+            // Form 1 (default when both K parts are whole K tiles): the merged convolution reads its SECOND source in place — K tiles beyond K1 come from the block
+            // input at pixel stride s (conv1x1_ps.hpp): no concatenated buffer, no strided copy, no extra launch.  SMELTER_KCAT=copy keeps form 2 below.
+            const bool kcat_copy = getenv("SMELTER_KCAT") && !strcmp(getenv("SMELTER_KCAT"), "copy");     // (plan time)
+            if (!kcat_copy && (K1 % 64) == 0 && (K2 % 64) == 0 && vecOk(xs) && vecOk(h2) && vecOk(so.output)) {
+                Step& S = steps_[u]; Op& mo = S.op;
+                std::vector<float> w((size_t)N * (K1 + K2));
+                for (int n = 0; n < N; n++) {
+                    std::copy(eo.weight.begin() + (size_t)n * K1, eo.weight.begin() + (size_t)(n + 1) * K1, w.begin() + (size_t)n * (K1 + K2));
+                    std::copy(mo.weight.begin() + (size_t)n * K2, mo.weight.begin() + (size_t)(n + 1) * K2, w.begin() + (size_t)n * (K1 + K2) + K1);
+                }
+                if (!eo.bias.empty()) { if (mo.bias.empty()) mo.bias.assign(N, 0.f); for (int n = 0; n < N; n++) mo.bias[n] += eo.bias[n]; }
+                S.dual_src = xs; S.dual_stride = mo.sh;
+                mo.name = eo.name + "+" + mo.name; mo.weight.swap(w); mo.cin = K1 + K2; mo.inputs = {h2, xs}; mo.residual = -1; mo.sh = mo.sw = 1;
+                S.real_k = K1 + K2; S.kcat = true;
+                S.kcat_extra_elems = 2.0 * (double)S.M * N + x_full;       // E's output written and read back; S's whole input tensor (the merged step is charged h2 only)
+                steps_.erase(steps_.begin() + ei);                        // ei < u
+                continue;
+            }
+            // Form 2: two new values: the concatenated operand, and the strided copy of the block input inside it
             Value cv; cv.name = values_[eo.output].name + "/kcat"; cv.c = K1 + K2; cv.h = oh; cv.w = ow;
             Value gv; gv.name = values_[xs].name + "/strided"; gv.c = K2; gv.h = oh; gv.w = ow;
             const int cat = (int)values_.size(); values_.push_back(cv); const int gq = (int)values_.size(); values_.push_back(gv);
@@ -637,6 +628,30 @@ int Executor::plan(ONNXGraph& g, int batch) {
             stem_f32_ = sm_conv2d_stem_f32_supported(&d, iv.c, iv.h, iv.w) != 0;
         }
     if (stem_in_block_) stem_f32_ = true;                             // (no conversion launch, no row-pair image either)
+    // ---- 3i. image stem -> MaxPool 3x3 / stride 2 (ResNet's first two layers): the stem's output — the largest tensor of the network, written once and read
+    // once — never exists: the loader waves of the stem kernel pool the previous tile from an LDS hand-over buffer (stem_pool.hpp).  SMELTER_STEM_POOL=0
+    // keeps the two launches.
+    if (stem_ && !stem_in_block_ && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && !(getenv("SMELTER_STEM_POOL") && getenv("SMELTER_STEM_POOL")[0] == '0') &&
+        !(getenv("SMELTER_STEM_F32") && getenv("SMELTER_STEM_F32")[0] == '0')) {                     // (the fused kernel is a loader-wave stem: it reads the fp32 batch)
+        auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
+        for (size_t t = 0; t < steps_.size(); t++) {
+            Step& sc = steps_[t];
+            if (!sc.stem || sc.has_mb || sc.op.residual >= 0 || sc.op.act > SM_ACT_PRELU || readers(sc.op.output) != 1) continue;
+            for (size_t u = t + 1; u < steps_.size(); u++) {
+                const Op& m = steps_[u].op;
+                if (m.inputs.empty() || m.inputs[0] != sc.op.output) continue;
+                const Value& pv = values_[m.output]; const Value& iv = values_[input_value_];
+                const sm_conv_desc d = convDesc(sc);
+                if (m.kind != OpKind::MaxPool || m.kh != 3 || m.kw != 3 || m.sh != 2 || m.sw != 2 || m.y0 || m.x0 || m.act != SM_ACT_NONE || !vecOk(m.output) ||
+                    !sm_conv2d_stem_f32_pool_supported(&d, iv.c, iv.h, iv.w, pv.h, pv.w)) break;
+                sc.pool3_out = m.output;
+                steps_.erase(steps_.begin() + u);
+                stem_f32_ = true;
+                break;
+            }
+            break;
+        }
+    }
     if (stem_f32_) launches_ -= 1;
 
     // ---- 4. memory plan ------------------------------------------------------------------------------------
@@ -672,11 +687,11 @@ int Executor::plan(ONNXGraph& g, int batch) {
         const int until = steps_[t].join >= 0 ? steps_[t].join : t;   // a side step may still be reading its operands at the join
         for (int u : op.inputs) { touch(u, t); touch(u, until); }
         if (op.residual >= 0) { touch(op.residual, t); touch(op.residual, until); }
+        if (steps_[t].pool3_out >= 0) { touch(steps_[t].pool3_out, t); continue; }             // (the stem's own output exists in LDS only)
         if (steps_[t].has_mb) { touch(steps_[t].mb_proj.output, t); continue; }
         if (steps_[t].has_side) { touch(steps_[t].side.output, t); touch(steps_[t].side.inputs[0], t); continue; }                    // (neither the 3x3 nor the expand output exists)
         if (steps_[t].has_head) { touch(steps_[t].head.output, t); if (steps_[t].head.residual >= 0) touch(steps_[t].head.residual, t); continue; }             // (the 3x3 output exists in registers only)      // (the hidden tensors exist in LDS only; the residual is the step's own input)
         touch(op.output, t);
-        if (steps_[t].has_pair) touch(steps_[t].pair.output, t);
         if (steps_[t].pool_out >= 0) touch(steps_[t].pool_out, t);
     }
     touch(output_value_, ns);                               // result image must survive until read back
@@ -742,13 +757,6 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 flops_ += 2.0 * st.M * st.head.cout * (double)st.head.cin;
                 alg_bytes_ += 2.0 * ((double)st.M * st.head.cin + (double)st.M * st.head.cout * (st.head.residual >= 0 ? 2 : 1) + (double)st.head.cout * st.head.cin);      // (accounted as the layer the graph holds)
             }
-            if (st.has_pair) {
-                st.w2_off = off; off = alignUp(off + st.pair.weight.size() * 2);
-                st.has_bias2 = !st.pair.bias.empty();
-                if (st.has_bias2) { st.b2_off = off; off = alignUp(off + st.pair.bias.size() * 4); }
-                flops_ += 2.0 * st.M * st.pair.cout * (double)st.pair.cin;
-                alg_bytes_ += 2.0 * ((double)st.M * st.pair.cout + (double)st.pair.cout * st.pair.cin);     // (its input is not read from memory)
-            }
             const Value& ov = values_[op.output];
             const double K = (double)st.real_k;
             flops_ += 2.0 * st.M * op.cout * K;
@@ -774,14 +782,16 @@ int Executor::plan(ONNXGraph& g, int batch) {
                      st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem ? " stem" : op.grid_h ? " convT-phase" : op.x_ups ? " +ups2x" : "");
         else snprintf(buf, sizeof buf, "%s %s pixels=%d C=%d%s", kindName(op.kind), op.name.c_str(), st.M, values_[op.output].c, op.act ? " +act" : "");
         st.desc = buf;
+        if (st.pool3_out >= 0) { const Value& pv = values_[st.pool3_out]; st.desc += " >> MaxPool 3x3/2 (same launch)";
+                                 alg_bytes_ += 2.0 * ((double)st.M * pv.c + (double)batch * pv.h * pv.w * pv.c); }       // (the pooling layer of the graph: input read, output written)
         if (st.pool_out >= 0) { st.desc += " >> MaxPool 2x2/2 (same launch)"; alg_bytes_ += 2.0 * (double)(st.M / 4) * values_[st.pool_out].c; }
-        if (st.has_pair) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.pair.name.c_str(), st.pair.cout, st.pair.cin, st.pair.act ? " +act" : ""); st.desc += buf; }
         if (st.has_head) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.head.name.c_str(), st.head.cout, st.head.cin, st.head.residual >= 0 ? " +res" : "", st.head.act ? " +act" : ""); st.desc += buf; }
         if (st.has_side) { snprintf(buf, sizeof buf, " + Conv %s N=%d K=%d k=1x1 projection%s (same launch)", st.side.name.c_str(), st.side.cout, st.side.cin, st.side.act ? " +act" : ""); st.desc += buf; }
         if (st.has_mb && st.mb_noexp) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.act ? " +act" : ""); st.desc += buf; }
         if (st.has_mb && st.mb_stem) st.desc = "Conv " + st.stem_name + " k=3x3 stem (fp32 image, same launch) >> " + st.desc;
         else if (st.has_mb) { snprintf(buf, sizeof buf, " >> Conv %s k=3x3 s=%d g=%d%s >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.mb_dw.name.c_str(), st.mb_dw.sh, st.mb_dw.groups, st.mb_dw.act ? " +act" : "",
                                   st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.residual >= 0 ? " +res" : "", st.mb_proj.act ? " +act" : ""); st.desc += buf; }
+        if (st.dual_src >= 0) { snprintf(buf, sizeof buf, " [K = %d + %d: second source %s read in place, pixel stride %d]", op.cin - values_[st.dual_src].c, values_[st.dual_src].c, values_[st.dual_src].name.c_str(), st.dual_stride); st.desc += buf; }
         if (st.join >= 0) st.desc += " side-stream";
     }
     arena_bytes_ = std::max(off, (size_t)kAlign);
@@ -796,8 +806,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
             materialized_.push_back(values_[st.mb_dw.output].name); materialized_.push_back(values_[st.mb_proj.output].name); continue;
         }
         if (st.op.kind != OpKind::Concat && materialized_.back() != values_[st.op.output].name) materialized_.push_back(values_[st.op.output].name);
-        if (st.has_pair) materialized_.push_back(values_[st.pair.output].name);
         if (st.pool_out >= 0) materialized_.push_back(values_[st.pool_out].name);
+        if (st.pool3_out >= 0) materialized_.push_back(values_[st.pool3_out].name);      // (the stem's output is rounded to fp16 in LDS exactly as a stored tensor would be: it stays in the list above)
     }
     return SM_OK;
 }
@@ -836,10 +846,6 @@ int Executor::packWeights(std::vector<uint8_t>* host) const {
                     for (int i = 0; i < st.head.cout; i++) b2[i] = (st.head.bias.empty() ? 0.f : st.head.bias[i]) + ((st.has_side && !st.side.bias.empty()) ? st.side.bias[i] : 0.f);
                 }
                 if (st.has_side) sm_float_to_half(st.side.weight.data(), (uint16_t*)(host->data() + st.wd_off), st.side.weight.size());
-            }
-            if (st.has_pair) {
-                sm_float_to_half(st.pair.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.pair.weight.size());
-                if (st.has_bias2) memcpy(host->data() + st.b2_off, st.pair.bias.data(), st.pair.bias.size() * 4);
             }
         } else if (op.kind == OpKind::BatchNorm || op.kind == OpKind::GroupNorm) {
             memcpy(host->data() + st.s_off, op.scale.data(), op.scale.size() * 4);
@@ -889,7 +895,7 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     const Value& ov = e->values_[e->output_value_];
     e->out_f32_count_ = std::max(sm_float_array_count(batch, ov.c, ov.h, ov.w), (size_t)batch * ov.c * ov.h * ov.w);
     SM_HIP_CHECK(hipMalloc((void**)&e->out_f32_, e->out_f32_count_ * 4));
-    for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit(); st.pair.weight.clear(); st.pair.weight.shrink_to_fit();
+    for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit();
                                  st.head.weight.clear(); st.head.weight.shrink_to_fit(); st.side.weight.clear(); st.side.weight.shrink_to_fit(); st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
     if (e->cfg_.autotune) {   // with an external arena and upload == 0 the caller filled it before compiling
         hipStream_t s; SM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -930,6 +936,11 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
         if (st.stem && stem_f32_) {
             if (!cur_in_) { sm_set_error("stem step launched before any input was bound"); return SM_ERR_INCONSISTENT_STATE; }
             const Value& iv = values_[input_value_];
+            if (st.pool3_out >= 0) {
+                const Value& pv = values_[st.pool3_out];
+                return sm_conv2d_stem_f32_pool_fwd(&d, cur_in_, iv.c, iv.h, iv.w, stem_pt_, stem_pl_, arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
+                                                   valuePtr(st.pool3_out), pv.h, pv.w, valueLd(st.pool3_out), ss);
+            }
             return sm_conv2d_stem_f32_fwd_cfg(&d, st.conv_cfg, cur_in_, iv.c, iv.h, iv.w, stem_pt_, stem_pl_, arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, y, ss);
         }
         if (st.has_side)
@@ -944,13 +955,14 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
         if (st.has_head)
             return sm_conv2d_head_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, nullptr, arena_ + st.w2_off,
                                           st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr, st.head.cout, st.head.act, st.head.slope, valuePtr(st.head.output), valueLd(st.head.output), ss);
+        if (st.dual_src >= 0) {
+            const Value& xv = values_[st.dual_src];
+            return sm_conv2d_dual_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), valuePtr(st.dual_src), xv.c, valueLd(st.dual_src), xv.h, xv.w, st.dual_stride, arena_ + st.w_off,
+                                          st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, y, ss);
+        }
         if (st.pool_out >= 0)
             return sm_conv2d_pool_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, y,
                                           valuePtr(st.pool_out), valueLd(st.pool_out), ss);
-        if (st.has_pair)
-            return sm_conv1x1_pair_fwd(&d, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
-                                       op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, st.pair.cout, arena_ + st.w2_off, st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr,
-                                       st.pair.act, st.pair.slope, valuePtr(st.pair.output), valueLd(st.pair.output), ss);
         return sm_conv2d_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
                                  op.residual >= 0 ? valuePtr(op.residual) : nullptr, y, st.join >= 0 ? nullptr : ws_, st.join >= 0 ? 0 : ws_bytes_, ss);   // the split-K scratch belongs to the main branch
     }
@@ -1171,7 +1183,7 @@ int Executor::autotune(hipStream_t s) {
     }
     for (size_t i = 0; i < steps_.size() && !rc; i++) {
         Step& st = steps_[i];
-        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8) || st.has_pair || st.has_mb) continue;
+        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8) || st.has_mb || st.pool3_out >= 0) continue;
         if (st.op.kind != OpKind::ConvTranspose) { const sm_conv_desc cd = convDesc(st); if (!sm_conv2d_uses_tile_config(&cd)) continue; }   // dedicated kernel, nothing to tune
         // one config: `reps` timed launches after an untimed first one (code fetch); returns false if the config does not apply
         auto timeCfg = [&](int c, int reps, std::vector<float>& samples) -> bool {

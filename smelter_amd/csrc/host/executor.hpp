@@ -35,10 +35,9 @@ struct Step {                // one op after fusion, with everything resolved
     // step `join` runs on the side stream, concurrently with the steps in between
     int join = -1;           // >= 0: this step runs on the side stream and step `join` waits for it
     bool waits_side = false; // this step is the join of an earlier side step
-    // pointwise pair (executor.cpp pass 3b): `pair` is the 1x1 convolution that consumes this step's output, run in the same launch
-    // (sm_conv1x1_pair_fwd); both outputs are materialised
+    int pool3_out = -1;      // >= 0 (image stem only): value id of the 3x3 / stride-2 max-pool of the stem's output, the ONLY tensor the launch writes (sm_conv2d_stem_f32_pool_fwd)
     int pool_out = -1;       // >= 0: value id of the 2x2 / stride-2 max-pool of this conv's output, written by the same launch (sm_conv2d_pool_fwd_cfg)
-    bool has_pair = false; Op pair; size_t w2_off = 0, b2_off = 0; bool has_bias2 = false;
+    size_t w2_off = 0, b2_off = 0; bool has_bias2 = false;                // second weight block of a fused step (head / projection of an inverted-residual block)
     // inverted-residual block (executor.cpp pass 3c): this step is the 1x1 EXPAND; `mb_dw` (depthwise 3x3) and `mb_proj` (1x1 project, optional
     // residual = this step's input) run in the same launch (sm_mbconv_fwd) and the two hidden tensors are never materialised
     bool has_mb = false; Op mb_dw, mb_proj; size_t wd_off = 0, bd_off = 0; bool has_biasd = false;
@@ -56,6 +55,7 @@ struct Step {                // one op after fusion, with everything resolved
     // pass 3h: `kcat` = this 1x1 convolution is an expand layer and the projection shortcut that carried its Add, concatenated along K (its extra
     // algorithmic bytes = the expand output the graph writes and reads back); `gather` = the strided copy of the block input placed beside the expand
     // layer's input (a MaxPool 1x1 step the graph does not hold: not accounted)
+    int dual_src = -1, dual_stride = 1;   // >= 0: value id of the SECOND source of a K-concatenated pointwise convolution, read in place at this pixel stride (sm_conv2d_dual_fwd_cfg)
     bool kcat = false, gather = false; double kcat_extra_elems = 0;   // elements the two graph layers move beyond the merged layer's own operands
     bool mb_noexp = false;   // the block has no expand layer: this step IS the depthwise convolution (mb_dw is a copy of it), mb_proj follows
     std::string desc;

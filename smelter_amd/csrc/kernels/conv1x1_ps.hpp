@@ -66,16 +66,19 @@ __global__ __launch_bounds__((WGM * WGN + 4) * 64) void conv1x1_ps_kernel(ConvPa
         const int HoWo = p.Ho * p.Wo;
         const bool unit = p.sH == 1 && p.sW == 1;
         const half_t* arow[A_IT]; const half_t* brow[B_IT];
+        const half_t* arow2[A_IT];                                     // second source (p.x2): the rows K tiles >= p.kt_sw are read from
+        const bool dual = p.x2 != nullptr;
         auto rows_of = [&](int j) {
             int mtile, ntile; tile_of(j < nmine ? j : nmine - 1, mtile, ntile);
 #pragma unroll
             for (int i = 0; i < A_IT; i++) {
                 int m = mtile * BM + i * (NLT / 8) + (ltid >> 3); if (m >= p.M) m = p.M - 1;   // ragged rows only feed outputs that are never stored
                 int pix = m;
-                if (!unit) {
+                if (!unit || dual) {
                     const int n = (int)sm_fastdiv((unsigned)m, p.dhw_mul, p.dhw_sh), r = m - n * HoWo;
                     const int oy = (int)sm_fastdiv((unsigned)r, p.dw_mul, p.dw_sh), ox = r - oy * p.Wo;
-                    pix = (n * p.H + oy * p.sH) * p.W + ox * p.sW;
+                    if (!unit) pix = (n * p.H + oy * p.sH) * p.W + ox * p.sW;
+                    arow2[i] = dual ? p.x2 + (long)((n * p.x2_H + oy * p.x2_s) * p.x2_W + ox * p.x2_s) * p.x2_ld + csrc * 8 : nullptr;
                 }
                 arow[i] = p.x + (long)pix * p.x_ld + csrc * 8;
             }
@@ -90,8 +93,14 @@ __global__ __launch_bounds__((WGM * WGN + 4) * 64) void conv1x1_ps_kernel(ConvPa
         auto issue = [&]() {                                            // ring item `issued` -> slot issued % NSB
             unsigned char* sa = ps_smem + (issued % NSB) * STAGE_BYTES + lwave * 1024;
             const int koff = ld_kt * 64;
+            if (dual && ld_kt >= p.kt_sw) {                             // (wave-uniform)
+                const int koff2 = (ld_kt - p.kt_sw) * 64;
 #pragma unroll
-            for (int i = 0; i < A_IT; i++) SM_GLDS16(arow[i] + koff, sa + i * NLT * 16);
+                for (int i = 0; i < A_IT; i++) SM_GLDS16(arow2[i] + koff2, sa + i * NLT * 16);
+            } else {
+#pragma unroll
+                for (int i = 0; i < A_IT; i++) SM_GLDS16(arow[i] + koff, sa + i * NLT * 16);
+            }
 #pragma unroll
             for (int i = 0; i < B_IT; i++) SM_GLDS16(brow[i] + koff, sa + A_BYTES + i * NLT * 16);
             ++issued;

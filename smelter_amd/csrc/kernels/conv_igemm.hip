@@ -53,6 +53,10 @@ struct ConvParams {
     const half_t* w3s;               // conv3x3_wsx.hpp SIDE: weights [n3][64] of the head's second GEMM; res3 / res3_ld then name its 64-channel input tensor
     const half_t* res3; int res3_ld; int hx_dbg;   // hx_dbg: SM_HX_DEBUG ablation bits (1 = no stores, 2 = no residual loads, 4 = no head at all)
     unsigned p9_pw_mul, p9_pw_sh, p9_h2_mul, p9_h2_sh;
+    int pq_OH, pq_OW;                // stem_pool.hpp: size of the pooled output (y2)
+    // conv1x1_ps.hpp: SECOND SOURCE of a pointwise convolution whose reduction runs over two tensors, K = K1 + K2 (sm_conv2d_dual_fwd_cfg): K tiles
+    // [0, kt_sw) read x as usual, K tiles [kt_sw, K/64) read pixel (n, oy*x2_s, ox*x2_s) of x2 [N, x2_H, x2_W, K2] (pixel stride x2_ld)
+    const half_t* x2; int x2_ld, x2_H, x2_W, x2_s, kt_sw;
 };
 
 // Division of n < 2^31 by a launch-time constant d: q = (n * mul) >> sh with s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1
@@ -495,8 +499,8 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 #include "conv3x3_wsx.hpp"
 #include "conv3x3_p9.hpp"
 #include "conv1x1_ps.hpp"
-#include "conv1x1_pair.hpp"
 #include "conv1x1_rw.hpp"
+#include "stem_pool.hpp"
 
 // 3x3 depthwise through LDS (the MobileNet-v2 path): the register-strip kernel above re-reads every input pixel 4.5x through
 // L1/L2 and needs 227 VGPRs (1.2..2 TB/s of algorithmic bytes).  Here a block owns a tile of TH x TW output pixels x `cbv`
@@ -715,7 +719,9 @@ const TileCfg kCfgs[] = {
     {256, 64, 4, 256, conv3x3_ws_kernel<32, 64, 4, 2, 6, 0, 0, 0, true>, "ws:32->64 w4x2 head", CF_HEAD, 32},      // 91
     {256, 32, 4, 256, conv3x3_ws_kernel<32, 32, 4, 2, 6, 0, 0, 0, true>, "ws:32->32 w4x2 head", CF_HEAD, 32},      // 92
     {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2, 6, 0, 0, 0, true>, "ws:32->32 w8x2 head", CF_HEAD, 32},      // 93
+#ifdef SM_ABLATION   // the single-role expand head (conv3x3_ws.hpp HX): 16 of 55 us added to the 3x3; the two-role kernel below replaced it
     {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead", CF_XHEAD, 64},  // 94  expand head (bottleneck tail): + 1x1 to <= 256 channels + residual
+#endif
     {128, 64, 4, 512, conv3x3_wsx_kernel<6>, "ws:64->64 w4+4 xhead", CF_XHEAD | CF_W44, 64},                                 // 95  ... with the two layers on different waves (conv3x3_wsx.hpp)
     {128, 64, 4, 512, conv3x3_wsx_kernel<6, true>, "ws:64->64 w4+4 xhead side", CF_XHEAD | CF_W44 | CF_SIDE, 64},                      // 96  ... and a second GEMM (the projection shortcut) instead of the residual tensor
     // stem form with loader waves (conv3x3_ws.hpp NLW): the patches are built from the fp32 NCHW input inside the launch (sm_conv2d_stem_f32_fwd_cfg)
@@ -870,6 +876,7 @@ size_t p9_setup(ConvParams& p, const TileCfg& c) {
 // kind 2 = single LDS stage: only for K == 64 (one K tile)
 // kinds 1/2 (conv_igemm64.hpp): Cin % 64 == 0 and a tap mask of <= 32 bits
 bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
+    if (p.x2 && c.kind != 7) return false;                           // a second source: the persistent pointwise kernel only
     if (c.kind == 0) return p.y2 == nullptr && p.y3 == nullptr;
     const bool same3x3 = p.kH == 3 && p.kW == 3 && p.sH == 1 && p.sW == 1 && p.dH == 1 && p.dW == 1 && p.pt == 1 && p.pl == 1 && p.Ho == p.H && p.Wo == p.W;
     if (c.kind == 4) {   // weight-stationary: the template's Cin / Cout exactly, no residual, dense 16-byte rows on both sides, ReLU family
@@ -955,7 +962,7 @@ int fill_params(const sm_conv_desc* d, const void* x, const void* w, const float
     p->act = d->act; p->slope = d->act == SM_ACT_RELU ? 0.f : d->slope;
     p->M = d->N * d->Ho * d->Wo; p->K = d->kH * d->kW * (d->Cin / d->groups);
     p->splitk = 1; p->mt = p->nt = 0; p->ktiles_per_split = 0; p->ups = d->x_ups ? 1 : 0; p->y2 = nullptr; p->y2_ld = 0;
-    p->w3 = nullptr; p->b3 = nullptr; p->y3 = nullptr; p->n3 = 0; p->y3_ld = 0; p->act3 = 0; p->sl3 = 0.f; p->res3 = nullptr; p->res3_ld = 0; p->hx_dbg = 0; p->w3s = nullptr; p->xf = nullptr; p->in_C = p->in_H = p->in_W = p->in_pt = p->in_pl = 0;
+    p->w3 = nullptr; p->b3 = nullptr; p->y3 = nullptr; p->n3 = 0; p->y3_ld = 0; p->act3 = 0; p->sl3 = 0.f; p->res3 = nullptr; p->res3_ld = 0; p->hx_dbg = 0; p->w3s = nullptr; p->xf = nullptr; p->in_C = p->in_H = p->in_W = p->in_pt = p->in_pl = 0; p->pq_OH = p->pq_OW = 0; p->x2 = nullptr; p->x2_ld = p->x2_H = p->x2_W = p->x2_s = p->kt_sw = 0;
     SM_REQUIRE(!d->x_ups || ((d->H & 1) == 0 && (d->W & 1) == 0 && d->groups == 1), "sm_conv2d_fwd: x_ups needs even H and W");
     SM_REQUIRE((long)d->N * d->Ho * d->Wo < (1L << 31), "sm_conv2d_fwd: more than 2^31 output pixels");
     SM_REQUIRE((long)d->N * d->H * d->W < (1L << 31) - (1L << 24), "sm_conv2d_fwd: more than 2^31 input pixels");
@@ -1242,6 +1249,63 @@ int sm_conv2d_stem_f32_fwd_cfg(const sm_conv_desc* d, int cfg, const float* x_nc
     if (kCfgs[cfg].kind != 6) { sm_set_error("conv tile config %d (%s) does not apply to an fp32 NCHW input", cfg, kCfgs[cfg].name); return SM_ERR_INVALID_ARGUMENT; }
     return launch(d, p, cfg, nullptr, 0, sm_s(stream));
 }
+// Image stem + the 3x3 / stride-2 max-pool that consumes it, one launch (stem_pool.hpp): `d` is the stem-form descriptor as above, the convolution's own
+// output is never stored; y_pool = [N, pool_H, pool_W, Cout] fp16 with pixel stride pool_ld.  The pooling windows start at row / column 2 p of the
+// convolution output (PyTorchPoolPadding's rule gives offset 0 for these shapes) and are clamped at its edge.
+namespace {
+constexpr int SP_PSB = 24 * 1024;                                    // bytes between the two patch buffers of the instantiations below
+size_t stem_pool_setup(ConvParams& p, int pool_H, int pool_W) {
+    const int taps = p.kH, s = p.sH;
+    if ((taps != 4 && taps != 2) || p.Cout != 64 || p.Cin != 64 || (s != 1 && s != 2)) return 0;
+    int best_th = 0, best_tw = 0; long best_tiles = 0, best_px = 0;
+    for (int th = 3; th <= 31; th += 2)
+        for (int tw = 3; tw <= 63 && th * tw <= 256; tw += 2) {
+            const long slots = (long)((th - 1) * s + 2 * (taps - 1) + 1) * ((tw - 1) * s + 8);
+            if (slots > 6 * 256 || slots * 16 > SP_PSB) continue;
+            const int qh = (th - 1) / 2, qw = (tw - 1) / 2;
+            const long tiles = (long)sm_ceil_div(pool_H, qh) * sm_ceil_div(pool_W, qw), px = tiles * th * tw;
+            if (!best_th || tiles < best_tiles || (tiles == best_tiles && px < best_px)) { best_th = th; best_tw = tw; best_tiles = tiles; best_px = px; }
+        }
+    if (!best_th) return 0;
+    p.ws_TH = best_th; p.ws_TW = best_tw; p.ws_tiles_y = sm_ceil_div(pool_H, (best_th - 1) / 2); p.ws_tiles_x = sm_ceil_div(pool_W, (best_tw - 1) / 2);
+    const long nt_all = (long)p.N * p.ws_tiles_x * p.ws_tiles_y;
+    if (nt_all >= (1L << 31)) return 0;
+    p.ws_ntiles = (int)nt_all; p.pq_OH = pool_H; p.pq_OW = pool_W;
+    sm_fastdiv_make((unsigned)((best_tw - 1) * s + 8), &p.ws_pw_mul, &p.ws_pw_sh); sm_fastdiv_make((unsigned)best_tw, &p.ws_tw_mul, &p.ws_tw_sh);
+    sm_fastdiv_make((unsigned)(p.ws_tiles_x * p.ws_tiles_y), &p.ws_txy_mul, &p.ws_txy_sh); sm_fastdiv_make((unsigned)p.ws_tiles_y, &p.ws_ty_mul, &p.ws_ty_sh);
+    return (size_t)taps * 64 * 128 + 64 * 4 + 2 * (size_t)(256 * 64 * 2) + 2 * (size_t)SP_PSB;
+}
+bool stem_pool_ok(const sm_conv_desc* d, const ConvParams& p, int C, int H_in, int W_in, int pool_H, int pool_W) {
+    return d->groups == 1 && p.Cin == 64 && p.x_ld == 8 && p.kW == 1 && p.dH == 2 && p.pt == 0 && p.pl == 0 && p.sH == p.sW && (p.sH == 1 || p.sH == 2) && !p.ups && !p.yplace &&
+           p.act <= SM_ACT_PRELU && C >= 1 && C <= 4 && (long)p.N * C * H_in * W_in * 4 < 0x7fff0000L && ((((uintptr_t)p.w) & 15) == 0) &&
+           (long)(p.Ho - 1) * p.sH + 2 * (p.kH - 1) < p.H && (long)(p.Wo - 1) * p.sW + 8 <= p.W &&
+           pool_H >= 1 && pool_W >= 1 && 2 * (pool_H - 1) < p.Ho && 2 * (pool_W - 1) < p.Wo;
+}
+}  // namespace
+int sm_conv2d_stem_f32_pool_supported(const sm_conv_desc* d, int32_t C, int32_t H_in, int32_t W_in, int32_t pool_H, int32_t pool_W) {
+    if (!d) return 0;
+    static const int dummy[4] = {0, 0, 0, 0};
+    ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, (void*)dummy, &p)) return 0;
+    return stem_pool_ok(d, p, C, H_in, W_in, pool_H, pool_W) && stem_pool_setup(p, pool_H, pool_W) > 0;
+}
+int sm_conv2d_stem_f32_pool_fwd(const sm_conv_desc* d, const float* x_nchw, int32_t C, int32_t H_in, int32_t W_in, int32_t pt, int32_t pl, const void* w, const float* bias,
+                                void* y_pool, int32_t pool_H, int32_t pool_W, int32_t pool_ld, sm_stream_t stream) {
+    SM_REQUIRE(x_nchw && y_pool && H_in > 0 && W_in > 0 && pt >= 0 && pl >= 0, "sm_conv2d_stem_f32_pool_fwd: bad input description");
+    ConvParams p; int rc = fill_params(d, x_nchw, w, bias, nullptr, y_pool, &p); if (rc) return rc;
+    p.xf = x_nchw; p.in_C = C; p.in_H = H_in; p.in_W = W_in; p.in_pt = pt; p.in_pl = pl; p.y = nullptr;
+    p.y2 = (half_t*)y_pool; p.y2_ld = pool_ld ? pool_ld : p.Cout;
+    { static const int dbg = getenv("SM_SP_DEBUG") ? atoi(getenv("SM_SP_DEBUG")) : 0; p.hx_dbg = dbg; }   // ablation switch (1 = no pooling, 2 = no k loop, 4 = no patch building, 8 = no hand-over), read once
+    size_t lds = 0;
+    if (!stem_pool_ok(d, p, C, H_in, W_in, pool_H, pool_W) || (p.y2_ld & 7) || (((uintptr_t)y_pool) & 15) || (long)p.N * pool_H * pool_W * p.y2_ld * 2 >= 0x7fff0000L ||
+        !(lds = stem_pool_setup(p, pool_H, pool_W))) {
+        sm_set_error("sm_conv2d_stem_f32_pool_fwd: shape not taken (row-pair stem form with 2 | 4 taps, Cout = 64, pool 3x3 / 2 whose windows start at 2p)"); return SM_ERR_INVALID_ARGUMENT;
+    }
+    const int grid = std::min(p.ws_ntiles, SM_NUM_CU);
+    if (p.kH == 4 && C == 3) hipLaunchKernelGGL((conv_stem_pool_kernel<64, 4, SP_PSB, 3>), dim3(grid), dim3(512), lds, sm_s(stream), p);
+    else if (p.kH == 4) hipLaunchKernelGGL((conv_stem_pool_kernel<64, 4, SP_PSB, 0>), dim3(grid), dim3(512), lds, sm_s(stream), p);
+    else hipLaunchKernelGGL((conv_stem_pool_kernel<64, 2, SP_PSB, 0>), dim3(grid), dim3(512), lds, sm_s(stream), p);
+    SM_LAUNCH_CHECK(); return SM_OK;
+}
 int sm_conv2d_stem_f32_supported(const sm_conv_desc* d, int32_t C, int32_t H_in, int32_t W_in) {
     if (!d || d->groups != 1) return 0;
     alignas(16) static char dummy[16];
@@ -1254,41 +1318,35 @@ int sm_conv2d_xhead_supported(const sm_conv_desc* d, int32_t n3, int32_t has_res
     if (!d || d->groups != 1) return 0;
     alignas(16) static char dummy[16];
     ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
+    p.y = nullptr;                                                    // (the expand head's 3x3 output is never stored: what the executor launches)
     p.w3 = (const half_t*)dummy; p.y3 = (half_t*)dummy; p.n3 = n3; p.y3_ld = n3; p.res3 = has_res ? (const half_t*)dummy : nullptr; p.res3_ld = n3;
     for (int i = 0; i < kNumCfgs; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) return 1;
     return 0;
 }
 
+// Pointwise convolution over TWO sources concatenated along K (a ResNet stage's first block: the expand layer and the stride-2 projection shortcut whose
+// Add it feeds are one GEMM, y = act([W_E | W_S] . [h ; x_s] + b)): `d` describes the convolution over x = [N, H, W, K1] (1x1 / stride 1 / no padding,
+// d->Cin = K1 + K2 = the row length of w), x2 = [N, x2_H, x2_W, K2] is read at pixel (oy * x2_stride, ox * x2_stride); K1 % 64 == K2 % 64 == 0.
+int sm_conv2d_dual_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* x2, int32_t K2, int32_t x2_ld, int32_t x2_H, int32_t x2_W, int32_t x2_stride,
+                           const void* w, const float* bias, void* y, sm_stream_t stream) {
+    SM_REQUIRE(d && x2 && K2 > 0 && (K2 % 64) == 0 && d->Cin > K2 && ((d->Cin - K2) % 64) == 0 && x2_stride >= 1 && x2_H > 0 && x2_W > 0, "sm_conv2d_dual_fwd_cfg: bad second source");
+    SM_REQUIRE(d->kH == 1 && d->kW == 1 && d->sH == 1 && d->sW == 1 && d->pt == 0 && d->pl == 0 && d->groups == 1 && d->Ho == d->H && d->Wo == d->W && !d->x_ups,
+               "sm_conv2d_dual_fwd_cfg: 1x1 / stride 1 / no padding over the first source");
+    SM_REQUIRE((long)(d->Ho - 1) * x2_stride < x2_H && (long)(d->Wo - 1) * x2_stride < x2_W && (long)d->N * x2_H * x2_W < (1L << 31), "sm_conv2d_dual_fwd_cfg: the second source is too small for the output grid");
+    const int K1 = d->Cin - K2;
+    ConvParams p; int rc = fill_params(d, x, w, bias, nullptr, y, &p); if (rc) return rc;
+    if (!d->x_ld) p.x_ld = K1;                                          // (the first source's rows hold K1 channels, not d->Cin)
+    p.x2 = (const half_t*)x2; p.x2_ld = x2_ld ? x2_ld : K2; p.x2_H = x2_H; p.x2_W = x2_W; p.x2_s = x2_stride; p.kt_sw = K1 / 64;
+    SM_REQUIRE((p.x2_ld & 7) == 0 && ((((uintptr_t)x2) & 15) == 0), "sm_conv2d_dual_fwd_cfg: the second source needs 16-byte rows");
+    if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 7 && cfg_eligible(kCfgs[i], p)) cfg = i; }
+    if (cfg < 0) { sm_set_error("sm_conv2d_dual_fwd_cfg: no kernel takes this shape"); return SM_ERR_INVALID_ARGUMENT; }
+    return launch(d, p, cfg, nullptr, 0, sm_s(stream));
+}
 int sm_conv_transpose2d_fwd(const sm_conv_desc* d, const void* x, const void* w, const float* bias, void* y, sm_stream_t stream) {
     ConvParams p; int rc = fill_params(d, x, w, bias, nullptr, y, &p); if (rc) return rc;
     SM_REQUIRE(d->groups == 1, "sm_conv_transpose2d_fwd: groups != 1");
     SM_REQUIRE(!p.yplace, "sm_conv_transpose2d_fwd: output placement not supported");
     hipLaunchKernelGGL(convt_direct_kernel, dim3(sm_stream_grid((long)p.M * p.Cout, 256)), dim3(256), 0, sm_s(stream), p);
-    SM_LAUNCH_CHECK(); return SM_OK;
-}
-
-// Two chained pointwise convolutions in one launch (conv1x1_pair.hpp): d = the first one (1x1 / stride 1, Cin = 64, Cout = 256, optional
-// residual, ReLU-family activation); the second maps its 256 channels to N2 in {64, 128}.
-int sm_conv1x1_pair_supported(const sm_conv_desc* d, int32_t N2) {
-    return d && d->groups == 1 && d->kH == 1 && d->kW == 1 && d->sH == 1 && d->sW == 1 && d->pt == 0 && d->pl == 0 && d->Cin == 64 && d->Cout == 256 &&
-           (N2 == 64 || N2 == 128) && d->act <= SM_ACT_PRELU && !d->x_ups && !(d->y_sH | d->y_sW | d->y_oH | d->y_oW | d->y_H | d->y_W) && d->Ho == d->H && d->Wo == d->W;
-}
-int sm_conv1x1_pair_fwd(const sm_conv_desc* d, const void* x, const void* w1, const float* bias1, const void* residual, void* y, int32_t N2, const void* w2,
-                        const float* bias2, int32_t act2, float slope2, void* z, int32_t z_ld, sm_stream_t stream) {
-    SM_REQUIRE(sm_conv1x1_pair_supported(d, N2) && act2 <= SM_ACT_PRELU && w2 && z, "sm_conv1x1_pair_fwd: unsupported geometry (1x1 s1, 64 -> 256 -> 64|128, ReLU family)");
-    ConvParams p; int rc = fill_params(d, x, w1, bias1, residual, y, &p); if (rc) return rc;
-    z_ld = z_ld ? z_ld : N2;
-    SM_REQUIRE((p.x_ld & 7) == 0 && (p.y_ld & 7) == 0 && (z_ld & 7) == 0 && (!residual || (p.res_ld & 7) == 0) &&
-               ((((uintptr_t)x) | ((uintptr_t)w1) | ((uintptr_t)w2) | ((uintptr_t)y) | ((uintptr_t)z) | ((uintptr_t)residual)) & 15) == 0, "sm_conv1x1_pair_fwd: operands must be 16-byte aligned with pixel strides % 8 == 0");
-    const float s2 = act2 == SM_ACT_RELU ? 0.f : slope2;
-    const int tiles = sm_ceil_div(p.M, 64);
-    if (N2 == 64) {        // weights in registers: 4-wave blocks, 41 KB of LDS, two blocks per CU
-        const size_t lds = (size_t)64 * 64 * 2 + (size_t)64 * 256 * 2 + (256 + N2) * 4;
-        hipLaunchKernelGGL((conv1x1_pair_kernel<64, 256, 64, 64, 4, true>), dim3(std::min(tiles, 2 * SM_NUM_CU)), dim3(256), lds, sm_s(stream), p, (const half_t*)w2, bias2, (half_t*)z, z_ld, act2, s2);
-    } else {               // weights in LDS: 8-wave blocks, one per CU
-        const size_t lds = (size_t)256 * 64 * 2 + (size_t)N2 * 256 * 2 + (size_t)64 * 64 * 2 + (size_t)64 * 256 * 2 + (256 + N2) * 4;
-        hipLaunchKernelGGL((conv1x1_pair_kernel<64, 256, 128, 64, 8, false>), dim3(std::min(tiles, SM_NUM_CU)), dim3(512), lds, sm_s(stream), p, (const half_t*)w2, bias2, (half_t*)z, z_ld, act2, s2);
-    }
     SM_LAUNCH_CHECK(); return SM_OK;
 }
 

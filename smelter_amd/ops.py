@@ -85,6 +85,19 @@ def conv2d(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0)
     return out
 
 
+def conv2d_dual(x, x2, w_ohwi, bias=None, stride2=1, act=ACT_NONE, slope=0.0, cfg=-1, out=None):
+    """pointwise convolution over two sources concatenated along K (sm_conv2d_dual_fwd_cfg): y = act(w[:, :K1] . x + w[:, K1:] . x2[:, ::stride2, ::stride2] + bias)"""
+    n, h, w, k1, x_ld = _check_nhwc(x)
+    n2, h2, w2, k2, x2_ld = _check_nhwc(x2)
+    cout, kh, kw, kk = w_ohwi.shape
+    assert n2 == n and (kh, kw) == (1, 1) and kk == k1 + k2 and w_ohwi.dtype == torch.float16 and w_ohwi.is_contiguous()
+    if out is None:
+        out = torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device)
+    d = ConvDesc(n, h, w, k1 + k2, cout, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, h, w, act, slope, x_ld, _ld(out), 0)
+    check(lib().sm_conv2d_dual_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(x2), k2, x2_ld, h2, w2, stride2, _ptr(w_ohwi), _ptr(bias), _ptr(out), _stream()))
+    return out
+
+
 def stem_conv(x_nchw, w_ohwi_f32, bias=None, stride=1, pads=(0, 0, 0, 0), act=ACT_NONE, slope=0.0, cfg=None):
     """First-layer convolution of a C <= 4 fp32 NCHW image the way the executor runs it (executor.cpp "image stem"): row-pair image
     (sm_nchw_f32_to_rowpair_f16) + weights repacked to [Cout][ceil(kH/2)][8 pixels][2 rows][4 channels], launched as a Cin = 64, kW = 1,
@@ -113,6 +126,32 @@ def stem_conv(x_nchw, w_ohwi_f32, bias=None, stride=1, pads=(0, 0, 0, 0), act=AC
         check(lib().sm_conv2d_fwd(C.byref(d), _ptr(img), _ptr(wp), _ptr(bias), None, _ptr(out), _stream()))
     else:
         check(lib().sm_conv2d_fwd_cfg(C.byref(d), cfg, _ptr(img), _ptr(wp), _ptr(bias), None, _ptr(out), None, 0, _stream()))
+    return out
+
+
+def stem_conv_pool(x_nchw, w_ohwi_f32, bias=None, stride=2, pads=(3, 3, 3, 3), act=ACT_RELU, slope=0.0, pool_pad=1, out=None):
+    """Image stem + MaxPool 3x3 / stride 2 (padding pool_pad, the reference's window-start rule) in one launch (sm_conv2d_stem_f32_pool_fwd):
+    returns the pooled NHWC fp16 tensor; the stem's own output is never stored."""
+    assert x_nchw.is_cuda and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous()
+    n, c, h, w = x_nchw.shape
+    cout, kh, kw, c2 = w_ohwi_f32.shape
+    assert c == c2 and c <= 4 and kw <= 8
+    s, P = stride, (kh + 1) // 2
+    ho, wo = conv_out_size(h, w, kh, kw, s, s, pads)
+    hs, ws = (ho - 1) * s + 2 * (P - 1) + 1, (wo - 1) * s + 8
+    L = lib()
+    pw_, ph_ = C.c_int32(), C.c_int32()
+    L.sm_pool_padded_size(wo, ho, 3, 3, 2, 2, pool_pad, pool_pad, C.byref(pw_), C.byref(ph_))
+    assert L.sm_pool_window_start(ho, ph_.value, 3, 2) == 0 and L.sm_pool_window_start(wo, pw_.value, 3, 2) == 0, "fused pooling: windows start at 2p"
+    wp = torch.zeros((cout, P, 8, 2, 4), dtype=torch.float32)
+    wc = w_ohwi_f32.detach().cpu().float()
+    for r in range(kh):
+        wp[:, r // 2, :kw, r & 1, :c] = wc[:, r]
+    wp = wp.reshape(cout, P, 1, 64).to(torch.float16).to(x_nchw.device).contiguous()
+    if out is None:
+        out = torch.empty((n, ph_.value, pw_.value, cout), dtype=torch.float16, device=x_nchw.device)
+    d = ConvDesc(n, hs, ws, 64, cout, P, 1, s, s, 2, 1, 0, 0, 0, 0, 1, ho, wo, act, slope, 8, cout, 0)
+    check(L.sm_conv2d_stem_f32_pool_fwd(C.byref(d), _ptr(x_nchw), c, h, w, pads[0], pads[1], _ptr(wp), _ptr(bias), _ptr(out), ph_.value, pw_.value, _ld(out), _stream()))
     return out
 
 
@@ -163,18 +202,6 @@ def conv2d_xhead_proj(x, w_ohwi, bias, w3, b3sum, xs, ws, act=ACT_RELU, slope=0.
     check(lib().sm_conv2d_xhead_proj_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(w3), _ptr(b3sum), n3, act3, slope3,
                                              _ptr(xs), _check_nhwc(xs)[4], _ptr(ws), _ptr(y3), _ld(y3), _stream()))
     return y3
-
-
-def conv1x1_pair(x, w1, b1, residual, w2, b2, act1=ACT_RELU, act2=ACT_RELU, out_y=None, out_z=None):
-    """y = act1(conv1x1(x, w1) + b1 + residual), z = act2(conv1x1(y, w2) + b2) in one launch (sm_conv1x1_pair_fwd)"""
-    n, h, w, cin, x_ld = _check_nhwc(x)
-    n1, n2 = w1.shape[0], w2.shape[0]
-    y = torch.empty((n, h, w, n1), dtype=torch.float16, device=x.device) if out_y is None else out_y
-    z = torch.empty((n, h, w, n2), dtype=torch.float16, device=x.device) if out_z is None else out_z
-    res_ld = _check_nhwc(residual)[4] if residual is not None else 0
-    d = ConvDesc(n, h, w, cin, n1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, h, w, act1, 0.0, x_ld, _ld(y), res_ld)
-    check(lib().sm_conv1x1_pair_fwd(C.byref(d), _ptr(x), _ptr(w1), _ptr(b1), _ptr(residual), _ptr(y), n2, _ptr(w2), _ptr(b2), act2, 0.0, _ptr(z), _ld(z), _stream()))
-    return y, z
 
 
 def mbconv(x, w1, b1, wd, bd, w2, b2, stride=1, residual=False, acts=(ACT_RELU, ACT_RELU, ACT_NONE)):

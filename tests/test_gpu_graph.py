@@ -83,22 +83,9 @@ def test_fusion_counts_resnet50():
     ex, _ = run_hip(zoo.resnet50(hw=(64, 64)), zoo.synthetic_images(1, 3, (64, 64)))
     # 53 convs (BN folded, Add/Relu in epilogues) + MaxPool + GlobalAveragePool + FC = 56 ops, of which the three 1x1 expand convolutions of the
     # first stage run inside the 3x3 launch in front of them (pass 3d, expand head) and so does the first block's projection shortcut (pass 3e);
-    # + input conversion
-    assert ex.numOps == 52 and ex.numLaunches in (52, 53)         # (no input-conversion launch: the stem's loader waves read the fp32 batch, pass 3f)
+    # + input conversion; the max-pool runs inside the stem launch (pass 3i)
+    assert ex.numOps == 48 and ex.numLaunches in (48, 49)         # (no input-conversion launch: the stem's loader waves read the fp32 batch, pass 3f)
     assert abs(ex.flops - 2 * 4089184256 * (64 * 64) / (224 * 224)) / ex.flops < 0.2      # scaled MAC count, FC unscaled
-
-
-def test_pointwise_pairs_experiment_is_the_same_function(monkeypatch):
-    """SMELTER_POINTWISE_PAIRS=1: the three 1x1 expand -> 1x1 reduce pairs of ResNet's first stage run as one launch each
-    (conv1x1_pair.hpp); off by default because it does not pay, kept correct"""
-    model = zoo.resnet50(hw=(64, 64))
-    x = zoo.synthetic_images(3, 3, (64, 64))
-    monkeypatch.setenv("SMELTER_XHEAD", "0")                 # (the expand head would take the same 1x1 layers first)
-    ex0, a = run_hip(model, x)
-    monkeypatch.setenv("SMELTER_POINTWISE_PAIRS", "1")
-    ex1, b = run_hip(model, x)
-    assert ex1.numOps == ex0.numOps - 3 and sum("(same launch)" in ex1.opDesc(i) for i in range(ex1.numOps)) == 3
-    assert nerr(a, b) <= 1e-3
 
 
 def test_resnet50_runs_its_first_stage_bottleneck_tails_as_one_launch_each(monkeypatch):
@@ -108,12 +95,13 @@ def test_resnet50_runs_its_first_stage_bottleneck_tails_as_one_launch_each(monke
     model = zoo.resnet50(hw=(64, 64))
     x = zoo.synthetic_images(3, 3, (64, 64))
     ex, got = run_hip(model, x)
-    fused = [ex.opDesc(i) for i in range(ex.numOps) if "(same launch)" in ex.opDesc(i)]
+    fused = [ex.opDesc(i) for i in range(ex.numOps) if "(same launch)" in ex.opDesc(i) and "stem" not in ex.opDesc(i)]     # (the stem carries its max-pool: pass 3i)
     assert len(fused) == 3 and all("k=3x3" in d and "N=256 K=64 k=1x1" in d for d in fused) and sum("+res" in d.split(">>")[1] for d in fused) == 2
     assert sum("projection" in d for d in fused) == 1             # pass 3e: the first block's shortcut convolution is the head's second GEMM
     monkeypatch.setenv("SMELTER_XHEAD", "0")
     ex0, plain = run_hip(model, x)
-    assert ex0.numOps == ex.numOps + 4 and not any("(same launch)" in ex0.opDesc(i) for i in range(ex0.numOps))
+    # (+3: the three expand layers run on their own again; the first block's expand + shortcut pair is then ONE K-concatenated convolution, pass 3h)
+    assert ex0.numOps == ex.numOps + 3 and not any("(same launch)" in ex0.opDesc(i) and "stem" not in ex0.opDesc(i) for i in range(ex0.numOps))
     assert nerr(got, plain) <= 1e-3
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3
 
@@ -126,7 +114,7 @@ def test_resnet50_expand_head_with_the_shortcut_listed_elsewhere(order, monkeypa
     model = zoo.resnet50(hw=(64, 64), shortcut_order=order)
     x = zoo.synthetic_images(2, 3, (64, 64))
     ex, got = run_hip(model, x)
-    fused = [ex.opDesc(i) for i in range(ex.numOps) if "(same launch)" in ex.opDesc(i)]
+    fused = [ex.opDesc(i) for i in range(ex.numOps) if "(same launch)" in ex.opDesc(i) and " stem " not in ex.opDesc(i)]     # (the stem carries its max-pool: pass 3i)
     assert len(fused) == 3 and sum("+res" in d.split(">>")[1] for d in fused) == 3 and not any("projection" in d for d in fused)
     monkeypatch.setenv("SMELTER_XHEAD", "0")
     ex0, plain = run_hip(model, x)
@@ -411,27 +399,33 @@ def test_reshape_net_materialises_exactly_the_order_changing_reshapes():
     assert kinds.count("FC") == 1 and "Alias" not in kinds
 
 
-def test_resnet50_projection_shortcuts_are_concatenated_along_k(monkeypatch):
+@pytest.mark.parametrize("form", ["dual", "copy"])
+def test_resnet50_projection_shortcuts_are_concatenated_along_k(form, monkeypatch):
     """executor pass 3h: in the first block of stages 2-4 the 1x1 expand layer and the stride-2 shortcut convolution that carries its Add are ONE 1x1
-    convolution over [h ; x_strided] (a MaxPool 1x1 / stride 2 step copies the block input's pixels beside h); same function as the two layers"""
+    convolution over [h ; x_strided].  "dual" (default): the block input is the GEMM's second source, read in place at pixel stride 2 (sm_conv2d_dual_fwd_cfg);
+    "copy" (SMELTER_KCAT=copy): a MaxPool 1x1 / stride 2 step copies its pixels beside h.  Same function as the two layers of the graph."""
     model = zoo.resnet50(hw=(64, 64))
     x = zoo.synthetic_images(3, 3, (64, 64))
+    if form == "copy":
+        monkeypatch.setenv("SMELTER_KCAT", "copy")
     ex, got = run_hip(model, x)
     descs = [ex.opDesc(i) for i in range(ex.numOps)]
-    assert sum("/strided" in d and d.startswith("MaxPool") for d in descs) == 3
+    assert sum("/strided" in d and d.startswith("MaxPool") for d in descs) == (3 if form == "copy" else 0)
     merged = [d for d in descs if d.startswith("Conv") and "+conv" in d.split()[1]]
     assert len(merged) == 3 and [int(d.split(" K=")[1].split()[0]) for d in merged] == [384, 768, 1536] and all("+res" not in d for d in merged)
+    assert all(("second source" in d) == (form == "dual") for d in merged)
     monkeypatch.setenv("SMELTER_KCAT", "0")
     ex0, plain = run_hip(model, x)
-    assert ex0.numOps == ex.numOps and abs(ex0.algorithmicBytes - ex.algorithmicBytes) <= 1e-6 * ex.algorithmicBytes
+    assert ex0.numOps == ex.numOps + (0 if form == "copy" else 3) and abs(ex0.algorithmicBytes - ex.algorithmicBytes) <= 1e-6 * ex.algorithmicBytes
     assert nerr(got, plain) <= 1e-3
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3
 
 
 @pytest.mark.parametrize("env,make,shape,fewer_launches", [
     ("SMELTER_XHEAD_PROJ", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 1),        # pass 3e: the first block's shortcut as the head's second GEMM
-    ("SMELTER_STEM_F32", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 1),          # pass 3f: no input-conversion launch
+    ("SMELTER_STEM_F32", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 2),          # pass 3f: no input-conversion launch (and no pool fusion, which needs it)
     ("SMELTER_STEM_F32", lambda: zoo.unet(hw=(64, 48)), (2, 3, 64, 48), 1),
+    ("SMELTER_STEM_POOL", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 1),         # pass 3i: the 3x3 / 2 max-pool inside the stem launch (bit-identical: max is exact)
     ("SMELTER_MBCONV_STEM", lambda: zoo.mobilenet_v2(hw=(96, 96)), (2, 3, 96, 96), 1),   # pass 3g: the stem inside the first block (the stem launch goes;
 ])                                                                                          # the conversion launch is gone either way: loader-wave stem)
 def test_fusion_pass_switches_keep_the_function(env, make, shape, fewer_launches, monkeypatch):
@@ -445,4 +439,6 @@ def test_fusion_pass_switches_keep_the_function(env, make, shape, fewer_launches
     # (MobileNet-v2: the stem's fp32 summation order differs between the two forms and a flipped fp16 rounding travels through 52 layers — the
     #  bound of the block-fusion test above)
     assert nerr(got, plain) <= (2e-3 if env == "SMELTER_MBCONV_STEM" else 1e-3)
+    if env == "SMELTER_STEM_POOL":
+        assert np.array_equal(got, plain)
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3

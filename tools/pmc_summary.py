@@ -49,7 +49,7 @@ def main():
     print("%3s %-44s %10s %10s %8s %9s" % ("#", "kernel", "rd_MB", "wr_MB", "L2hit%", "mfma_busy"))
     for i, e in disp.items():
         name = e["name"]
-        key = next((k for k in ("conv_igemm", "conv3x3_strip", "conv3x3_ws", "conv3x3_p9", "conv1x1_ps", "conv1x1_pair", "mbconv", "pw_thin") if k in name), None)
+        key = next((k for k in ("conv_igemm", "conv3x3_strip", "conv3x3_ws", "conv3x3_p9", "conv1x1_ps", "conv1x1_rw", "conv_stem_pool", "mbconv", "pw_thin") if k in name), None)
         short = name[name.find(key):][:40] if key else name[:40]
         rd = e.get("FETCH_SIZE", 0) * 1024 * 2 / 1e6
         wr = e.get("WRITE_SIZE", 0) * 1024 / 1e6
