@@ -171,13 +171,18 @@ def main():
             # event gap (~3 us) and is reported next to it, not used for `achieved`.
             scale = region_ms / max(conv_ms + other_ms, 1e-9)             # event-gap inflation of the eager pass, shared pro rata
             conv_region_ms = max(region_ms - other_ms * scale, 1e-6)
-            traffic, traffic_src = None, None
+            traffic, traffic_src, pmc_step = None, None, None
             import glob
-            pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))   # HBM bytes/launch from rocprofv3 --pmc (tools/profile.sh)
-            if pmcs and a.model == "r50":
+            suffix = "" if a.model == "r50" else "_" + a.model
+            pmcs = sorted(p_ for p_ in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic%s.json" % suffix)))   # HBM bytes from rocprofv3 --pmc (tools/profile.sh <tag> <rev> <model>)
+            if pmcs:
                 pj = json.load(open(pmcs[-1]))
-                traffic = pj.get("hbm_bytes_per_launch")
+                pmc_step = pj.get("hbm_read_bytes_per_step", 0) + pj.get("hbm_write_bytes_per_step", 0)
+                traffic = pj.get("hbm_bytes_per_launch") if bound == "mfma" else round(pmc_step / max(ex.numLaunches, 1))
                 traffic_src = "carried over, NOT measured in this run: %s (rocprofv3 --pmc passes, binary %s)" % (os.path.relpath(pmcs[-1], ROOT), pj.get("head", "unrecorded"))
+            # two byte models: every layer of the graph charged its own operands vs what the launches must move after fusion
+            byte_models = {"graph_per_layer_bytes_per_step": round(ex.algorithmicBytes), "post_fusion_compulsory_bytes_per_step": round(ex.launchBytes),
+                           "pmc_hbm_bytes_per_step": pmc_step}
             if bound == "mfma":
                 achieved = flops_step / (conv_region_ms * 1e-3) / 1e12
                 out["roofline"] = {"bound": "mfma", "kernel": "MFMA implicit-GEMM conv/FC family (%d launches/step)" % conv_n,
@@ -185,14 +190,17 @@ def main():
                                    "traffic": traffic, "traffic_source": traffic_src,
                                    "flops_per_launch": round(flops_step / max(conv_n, 1)), "avg_launch_us": round(conv_region_ms / max(conv_n, 1) * 1e3, 2)}
             else:
-                achieved = ex.algorithmicBytes / (region_ms * 1e-3) / 1e9
+                # HBM-bound step: the bytes the launches MUST move (post-fusion compulsory bytes) per second against 8 TB/s.  The graph's per-layer bytes
+                # (hidden tensors of fused blocks included) are reported beside it, not used: 14 blocks never write those tensors.
+                achieved = ex.launchBytes / (region_ms * 1e-3) / 1e9
                 out["roofline"] = {"bound": "hbm", "kernel": "whole step (%d launches: depthwise + pointwise + pooling, all HBM-bound)" % ex.numLaunches,
                                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                                   "traffic": traffic, "traffic_source": traffic_src,
-                                   "bytes_per_launch": round(ex.algorithmicBytes / ex.numLaunches), "avg_launch_us": round(region_ms / ex.numLaunches * 1e3, 2)}
+                                   "traffic": traffic, "traffic_source": traffic_src, "byte_model": "post-fusion compulsory bytes (smelter_exec_launch_bytes)",
+                                   "bytes_per_launch": round(ex.launchBytes / ex.numLaunches), "avg_launch_us": round(region_ms / ex.numLaunches * 1e3, 2),
+                                   "graph_per_layer_GBps": round(ex.algorithmicBytes / (region_ms * 1e-3) / 1e9, 1)}
             out["roofline"].update({"region_ms_per_step_hip_events": round(region_ms, 4), "insitu_avg_launch_us": round(conv_ms / max(conv_n, 1) * 1e3, 2),
                                     "sum_conv_ms": round(conv_region_ms, 4), "sum_other_ms": round(region_ms - conv_region_ms, 4),
-                                    "algorithmic_bytes_per_step": round(ex.algorithmicBytes),
+                                    "algorithmic_bytes_per_step": round(ex.algorithmicBytes), "byte_models": byte_models,
                                     "hbm_frac_of_8TBps_whole_step": round(ex.algorithmicBytes / (ms_per_step * 1e-3) / 8e12, 4)})
             if os.environ.get("SMELTER_BENCH_VERBOSE"):
                 for ms, d in per:

@@ -376,7 +376,8 @@ size_t smelter_exec_weight_bytes(const smelter_exec* e);
 void* smelter_exec_weight_arena(const smelter_exec* e);
 size_t smelter_exec_activation_bytes(const smelter_exec* e);
 double smelter_exec_flops(const smelter_exec* e);           /* 2*MACs of conv+fc per encode */
-double smelter_exec_algorithmic_bytes(const smelter_exec* e); /* per-layer compulsory bytes per encode */
+double smelter_exec_algorithmic_bytes(const smelter_exec* e); /* per-layer compulsory bytes per encode: every layer of the GRAPH charged its own operands */
+double smelter_exec_launch_bytes(const smelter_exec* e);      /* post-fusion compulsory bytes per encode: what the launches must read + write (tensors fused away do not count) */
 /* per-op description for profiling: returns a static-lifetime string "idx kind name MxNxK cfg" */
 const char* smelter_exec_op_desc(const smelter_exec* e, int32_t idx);
 /* names of the tensors materialised in fp16 storage after fusion (graph input + every kernel output) */

@@ -152,6 +152,7 @@ SYMBOLS = {
     "smelter_exec_activation_bytes": (_sz, [_vp]),
     "smelter_exec_flops": (C.c_double, [_vp]),
     "smelter_exec_algorithmic_bytes": (C.c_double, [_vp]),
+    "smelter_exec_launch_bytes": (C.c_double, [_vp]),
     "smelter_exec_op_desc": (C.c_char_p, [_vp, _i32]),
     "smelter_exec_num_values": (_i32, [_vp]),
     "smelter_exec_value_name": (C.c_char_p, [_vp, _i32]),

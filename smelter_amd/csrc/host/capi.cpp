@@ -93,6 +93,7 @@ void* smelter_exec_weight_arena(const smelter_exec* e) { return e ? e->e->weight
 size_t smelter_exec_activation_bytes(const smelter_exec* e) { return e ? e->e->activationBytes() : 0; }
 double smelter_exec_flops(const smelter_exec* e) { return e ? e->e->flops() : 0; }
 double smelter_exec_algorithmic_bytes(const smelter_exec* e) { return e ? e->e->algorithmicBytes() : 0; }
+double smelter_exec_launch_bytes(const smelter_exec* e) { return e ? e->e->launchBytes() : 0; }
 const char* smelter_exec_op_desc(const smelter_exec* e, int32_t idx) { return e ? e->e->opDesc(idx) : ""; }
 int smelter_exec_num_values(const smelter_exec* e) { return e ? e->e->numMaterialized() : 0; }
 const char* smelter_exec_value_name(const smelter_exec* e, int32_t idx) { return e ? e->e->materializedName(idx) : ""; }

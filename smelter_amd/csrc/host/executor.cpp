@@ -795,6 +795,39 @@ int Executor::plan(ONNXGraph& g, int batch) {
         if (st.join >= 0) st.desc += " side-stream";
     }
     arena_bytes_ = std::max(off, (size_t)kAlign);
+    // ---- post-fusion compulsory bytes: per launch, every distinct tensor it reads + every tensor it writes + its weights, once each.  Tensors that exist in
+    // LDS / registers only (the hidden tensors of a fused block, a head's 3x3 output, the stem's output under the fused pool, E's output under pass 3h) do
+    // not appear.  This is the byte model a counter-measured HBM traffic (rocprofv3 FETCH_SIZE + WRITE_SIZE) is to be read against; `alg_bytes_` above
+    // charges every layer of the GRAPH its own operands and therefore exceeds it wherever layers were fused.
+    {
+        auto elems = [&](int v) { return (double)batch * values_[v].c * values_[v].h * values_[v].w; };
+        const Value& inv = values_[input_value_];
+        launch_bytes_ = stem_f32_ ? 0.0 : (4.0 + 2.0 * (stem_ ? 8.0 / inv.c : (double)input_ld_ / inv.c)) * elems(input_value_);     // conversion launch: fp32 in, fp16 image out
+        for (auto& st : steps_) {
+            const Op& op = st.op;
+            std::vector<int> rd, wr;
+            auto add = [](std::vector<int>& a, int v) { if (v >= 0 && std::find(a.begin(), a.end(), v) == a.end()) a.push_back(v); };
+            for (int u : op.inputs) add(rd, u);
+            add(rd, op.residual);
+            if (st.has_head) add(rd, st.head.residual);
+            if (st.has_side) for (int u : st.side.inputs) add(rd, u);
+            if (st.has_mb && st.mb_proj.residual >= 0) add(rd, st.mb_proj.residual);
+            if (st.has_side) add(wr, st.side.output);
+            else if (st.has_head) add(wr, st.head.output);
+            else if (st.has_mb) add(wr, st.mb_proj.output);
+            else if (st.pool3_out >= 0) add(wr, st.pool3_out);
+            else { add(wr, op.output); add(wr, st.pool_out); }
+            double b = 0;
+            for (int v : rd) b += (v == input_value_ && (stem_f32_ || st.mb_stem)) ? 4.0 * elems(v) : 2.0 * elems(v);      // (the fp32 batch is read directly)
+            for (int v : wr) b += 2.0 * ((op.kind == OpKind::Concat) ? elems(op.inputs[0]) : elems(v));
+            if (op.x_ups) b -= 0.0;                                                                                   // (the half-resolution tensor is op.inputs[0]: already its true size)
+            double wb = 2.0 * (double)op.weight.size() + 4.0 * (double)op.bias.size();
+            if (st.has_head) wb += 2.0 * (double)st.head.weight.size();
+            if (st.has_side) wb += 2.0 * (double)st.side.weight.size();
+            if (st.has_mb) wb += 2.0 * ((double)st.mb_dw.weight.size() + (double)st.mb_proj.weight.size()) + (st.mb_stem ? 2.0 * (double)st.stem_w.size() : 0.0);
+            launch_bytes_ += b + wb;
+        }
+    }
     value_names_.resize(nv); for (int v = 0; v < nv; v++) value_names_[v] = values_[v].name;
     materialized_.clear(); materialized_.push_back(values_[input_value_].name);
     for (auto& st : steps_) {

@@ -89,6 +89,7 @@ class Executor {
     size_t activationBytes() const { return act_bytes_; }
     double flops() const { return flops_; }
     double algorithmicBytes() const { return alg_bytes_; }
+    double launchBytes() const { return launch_bytes_; }       // post-fusion compulsory bytes: what the launches of one encode must read and write
     const char* opDesc(int idx) const { return idx >= 0 && idx < (int)steps_.size() ? steps_[idx].desc.c_str() : ""; }
     // names of the tensors that exist in fp16 storage after fusion (graph input + every step output)
     int numMaterialized() const { return (int)materialized_.size(); }
@@ -125,7 +126,7 @@ class Executor {
     char* ws_ = nullptr; size_t ws_bytes_ = 0;           // split-K scratch
     float* out_f32_ = nullptr; size_t out_f32_count_ = 0; // readback staging
     int launches_ = 0;
-    double flops_ = 0, alg_bytes_ = 0;
+    double flops_ = 0, alg_bytes_ = 0, launch_bytes_ = 0;
 
     // hipGraph replay
     hipGraph_t graph_ = nullptr; hipGraphExec_t graph_exec_ = nullptr; const float* captured_in_ = nullptr;

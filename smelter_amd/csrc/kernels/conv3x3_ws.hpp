@@ -158,29 +158,36 @@ __global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams 
             const int C = p.in_C, IH = p.in_H, IW = p.in_W;
             const unsigned plane = (unsigned)IH * (unsigned)IW;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xf, 0, (int)((unsigned)p.N * (unsigned)C * plane * 4u), 0x00020000);
-            int lpr[LNI], lpc[LNI];
+            int lpr[LNI], lpc[LNI], lrel[LNI];
 #pragma unroll
             for (int i = 0; i < LNI; i++) {
                 const int sl = i * NLT + ltid;
                 const int pr = (int)sm_fastdiv((unsigned)sl, p.ws_pw_mul, p.ws_pw_sh);
                 lpr[i] = sl < patch_slots ? pr : -0x40000000; lpc[i] = sl - pr * PW;   // beyond the patch: a row far outside the image (nothing read, nothing written)
+                lrel[i] = sl < patch_slots ? pr * IW + lpc[i] : 0;                       // dword offset from the tile's first input pixel (tile-invariant)
             }
             // the loads of a patch are issued a whole tile before they are converted and written (two register sets, alternating): what a loader
-            // wave waits for at the top of a tile was requested one tile ago, and the next request is already out before it writes
+            // wave waits for at the top of a tile was requested one tile ago, and the next request is already out before it writes.
+            // The VALU is scarce (a loader and an MFMA wave share a SIMD, ~4 clk per vector instruction): per load only the select of a dead offset is a
+            // vector instruction — the vector offset is the offset of the ROW that is read (the descriptor's range check sees it alone), the plane offset
+            // rides in the instruction's scalar offset operand.
             auto request = [&](float (&v)[LNI][2][4], int t) __attribute__((always_inline)) {
                 int n, y0, x0; tile_origin(t, n, y0, x0);
                 const int r0 = y0 * SS - p.in_pt, c0 = x0 * SS - p.in_pl;               // input pixel of patch pixel (0, 0), top row
-                const unsigned img = (unsigned)n * (unsigned)C * plane;
+                const int base = (int)((unsigned)n * (unsigned)C * plane) + r0 * IW + c0;
+                const bool tile_on = t < t_end;
 #pragma unroll
                 for (int i = 0; i < LNI; i++) {
                     const int r = r0 + lpr[i], c = c0 + lpc[i];
-                    const bool okc = (unsigned)c < (unsigned)IW && t < t_end;
+                    const bool okc = (unsigned)c < (unsigned)IW && tile_on;
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        const bool ok = okc && (unsigned)(r + h) < (unsigned)IH;
-                        const unsigned off = (img + (unsigned)(r + h) * (unsigned)IW + (unsigned)c) * 4u;
+                        const unsigned voff = (okc && (unsigned)(r + h) < (unsigned)IH) ? (unsigned)(base + lrel[i] + h * IW) << 2 : DEAD;
 #pragma unroll
-                        for (int ch = 0; ch < 4; ch++) v[i][h][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)((ch < C && ok) ? off + (unsigned)ch * plane * 4u : DEAD), 0, 0));
+                        for (int ch = 0; ch < 4; ch++) {
+                            if (ch < C) v[i][h][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)((unsigned)ch * plane * 4u), 0));   // (wave-uniform branch)
+                            else v[i][h][ch] = 0.f;
+                        }
                     }
                 }
             };
@@ -425,8 +432,9 @@ __global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams 
     // is full: issued as one burst the 11 pieces cost ~2 k clk of dead issue time per tile), fragments requested PF k steps ahead of
     // the MFMAs that consume them (the compiler's own schedule waited lgkmcnt(0) before every MFMA pair: <= 50 % MFMA duty)
     constexpr int PF = (TM + TN) * 4 <= 15 ? 4 : 3;                    // k steps of fragment prefetch (lgkmcnt field: PF * (TM + TN) <= 15)
-    auto do_tile = [&](auto bufc, int t) {
+    auto do_tile = [&](auto bufc, auto relu0c, int t) {
         constexpr int BUF = decltype(bufc)::value;
+        constexpr bool RELU0 = decltype(relu0c)::value;               // slope 0: ReLU as a packed fp16 max AFTER the rounding (max commutes with it): 1 instead of 6 VALU per pair
         int n, y0, x0; tile_origin(t, n, y0, x0);
         // the NEXT patch (the last tile of the range re-fetches itself: no branch anywhere in the k loop — behind a join hipcc waits
         // lgkmcnt(0) for fragment reads it has just issued).  A wave without slots in piece i sends it to the dummy sink.
@@ -441,13 +449,7 @@ __global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams 
             const bool in = (unsigned)(iy0 + pr) < (unsigned)p.H && (unsigned)(ix0 + pc) < (unsigned)p.W;
             ws_glds16(in ? xb + rel[i] : zero, (unsigned)__builtin_amdgcn_readfirstlane((int)(mine ? dst_a + i * NT * 16 : dummy_a)));
         };
-        floatx16 acc[TN][TM];
-#pragma unroll
-        for (int a = 0; a < TN; a++)
-#pragma unroll
-            for (int b = 0; b < TM; b++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+        floatx16 acc[TN][TM];                                         // (never zeroed: the first k step accumulates onto a literal 0, an inline constant of the MFMA)
         // Fragment reads are asm statements with HAND-COUNTED waits: whatever sits between two compiler-visible LDS reads (a DMA builtin,
         // an asm statement) makes hipcc wait lgkmcnt(0) before the next MFMA, i.e. for reads it has only just issued.  DS operations
         // return in order, so before the MFMAs of k step s exactly the fetches of steps s+1 .. s+PF may still be in flight.
@@ -485,8 +487,9 @@ __global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams 
             for (int a = 0; a < TN; a++)
 #pragma unroll
                 for (int b = 0; b < TM; b++) {
-                    if constexpr (!(ABL & 2)) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S2 % (PF + 1)][a], fx[S2 % (PF + 1)][b], acc[a][b], 0, 0, 0);
-                    else asm volatile("" ::"v"(fw[S2 % (PF + 1)][a]), "v"(fx[S2 % (PF + 1)][b]));
+                    if constexpr ((ABL & 2) != 0) { asm volatile("" ::"v"(fw[S2 % (PF + 1)][a]), "v"(fx[S2 % (PF + 1)][b])); if constexpr (S2 == 0) { for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f; } }
+                    else if constexpr (S2 == 0) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S2 % (PF + 1)][a], fx[S2 % (PF + 1)][b], (floatx16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    else acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S2 % (PF + 1)][a], fx[S2 % (PF + 1)][b], acc[a][b], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -504,8 +507,9 @@ __global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams 
 #pragma unroll
                     for (int h2 = 0; h2 < 2; h2++) {
                         float v0 = acc[a][b][4 * q + 2 * h2] + bq[q][2 * h2], v1 = acc[a][b][4 * q + 2 * h2 + 1] + bq[q][2 * h2 + 1];
-                        v0 = v0 < 0.f ? v0 * sl : v0; v1 = v1 < 0.f ? v1 * sl : v1;
-                        const half2_t hv = {(half_t)v0, (half_t)v1};
+                        if constexpr (!RELU0) { v0 = v0 < 0.f ? v0 * sl : v0; v1 = v1 < 0.f ? v1 * sl : v1; }
+                        half2_t hv = {(half_t)v0, (half_t)v1};
+                        if constexpr (RELU0) hv = __builtin_elementwise_max(hv, half2_t{0, 0});
                         d[q][h2] = __builtin_bit_cast(unsigned, hv);
                     }
                 // (q, q+1): low half-wave keeps couts 8q..8q+3 and receives 8q+4..8q+7 from its partner lane; the high half-wave ends
@@ -522,17 +526,20 @@ __global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams 
     };
 
     if (t_begin < t_end) issue_patch(0, t_begin);
+    auto run = [&](auto relu0c) __attribute__((always_inline)) {
 #pragma unroll 1
-    for (int t = t_begin; t < t_end; t += 2) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of patch t (issued during tile t-1), my stores of tile t-2, [first tile: the weights]
-        __builtin_amdgcn_s_barrier();                                 // everybody's share landed; everybody is done reading the other buffer
-        __builtin_amdgcn_sched_barrier(0);
-        do_tile(std::integral_constant<int, 0>(), t);
-        if (t + 1 >= t_end) break;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        do_tile(std::integral_constant<int, 1>(), t + 1);
-    }
+        for (int t = t_begin; t < t_end; t += 2) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of patch t (issued during tile t-1), my stores of tile t-2, [first tile: the weights]
+            __builtin_amdgcn_s_barrier();                                 // everybody's share landed; everybody is done reading the other buffer
+            __builtin_amdgcn_sched_barrier(0);
+            do_tile(std::integral_constant<int, 0>(), relu0c, t);
+            if (t + 1 >= t_end) break;
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            do_tile(std::integral_constant<int, 1>(), relu0c, t + 1);
+        }
+    };
+    if (p.act != SM_ACT_NONE && p.slope == 0.f) run(std::true_type()); else run(std::false_type());
     if (pending) store_prev();
 }

@@ -118,8 +118,9 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
             }
         constexpr int PF = 4, RD = 1 + TN;
         static_assert(PF * RD <= 15, "lgkmcnt field");
-        auto do_tile = [&](auto bufc, int t) {
+        auto do_tile = [&](auto bufc, auto relu0c, int t) {
             constexpr int BUF = decltype(bufc)::value;
+            constexpr bool PRELU0 = decltype(relu0c)::value;           // the 3x3's own activation is a plain ReLU: packed fp16 max after the rounding
             int nn, ny0, nx0; tile_origin(t + 1 < t_end ? t + 1 : t, nn, ny0, nx0);
             const int iy0 = ny0 - 1, ix0 = nx0 - 1;
             const half_t* xb = p.x + (((long)nn * p.H + iy0) * p.W + ix0) * p.x_ld;
@@ -130,11 +131,7 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
                 const bool in = (unsigned)(iy0 + pr) < (unsigned)p.H && (unsigned)(ix0 + pc) < (unsigned)p.W;
                 ws_glds16(in ? xb + rel[i] : zero, (unsigned)__builtin_amdgcn_readfirstlane((int)(mine ? dst_a + i * NTP * 16 : dummy_a)));
             };
-            floatx16 acc[TN];
-#pragma unroll
-            for (int a = 0; a < TN; a++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[a][r] = 0.f;
+            floatx16 acc[TN];                                          // (the first k step accumulates onto a literal 0)
             half8_t fx[PF + 1], fw[PF + 1][TN];
             auto fetch = [&](auto sc) {
                 constexpr int S2 = decltype(sc)::value, TAP = S2 / KS, KSI = S2 % KS, SLOT = S2 % (PF + 1);
@@ -152,7 +149,10 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
                 asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(AHEAD) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int a = 0; a < TN; a++) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S2 % (PF + 1)][a], fx[S2 % (PF + 1)], acc[a], 0, 0, 0);
+                for (int a = 0; a < TN; a++) {
+                    if constexpr (S2 == 0) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S2 % (PF + 1)][a], fx[S2 % (PF + 1)], (floatx16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    else acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[S2 % (PF + 1)][a], fx[S2 % (PF + 1)], acc[a], 0, 0, 0);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
             // epilogue: bias, activation, one rounding, lane swaps -> k step 2a + j of the head's B operand -> hand-over buffer BUF
@@ -167,8 +167,9 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
 #pragma unroll
                     for (int h2 = 0; h2 < 2; h2++) {
                         float v0 = acc[a][4 * q + 2 * h2] + bq[q][2 * h2], v1 = acc[a][4 * q + 2 * h2 + 1] + bq[q][2 * h2 + 1];
-                        v0 = v0 < 0.f ? v0 * sl : v0; v1 = v1 < 0.f ? v1 * sl : v1;
-                        const half2_t hv = {(half_t)v0, (half_t)v1};
+                        if constexpr (!PRELU0) { v0 = v0 < 0.f ? v0 * sl : v0; v1 = v1 < 0.f ? v1 * sl : v1; }
+                        half2_t hv = {(half_t)v0, (half_t)v1};
+                        if constexpr (PRELU0) hv = __builtin_elementwise_max(hv, half2_t{0, 0});
                         d[q][h2] = __builtin_bit_cast(unsigned, hv);
                     }
 #pragma unroll
@@ -180,18 +181,21 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
             }
         };
         issue_patch(0, t_begin);
+        auto prun = [&](auto relu0c) __attribute__((always_inline)) {
 #pragma unroll 1
-        for (int t = t_begin; t < t_end; t += 2) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of patch t; my hand-over writes of tile t-1; [first tile: the weights]
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            do_tile(std::integral_constant<int, 0>(), t);
-            if (t + 1 >= t_end) break;
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            do_tile(std::integral_constant<int, 1>(), t + 1);
-        }
+            for (int t = t_begin; t < t_end; t += 2) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // my share of patch t; my hand-over writes of tile t-1; [first tile: the weights]
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                do_tile(std::integral_constant<int, 0>(), relu0c, t);
+                if (t + 1 >= t_end) break;
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                do_tile(std::integral_constant<int, 1>(), relu0c, t + 1);
+            }
+        };
+        if (p.act != SM_ACT_NONE && p.slope == 0.f) prun(std::true_type()); else prun(std::false_type());
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // the last tile's hand-over
         __builtin_amdgcn_s_barrier();
     } else {

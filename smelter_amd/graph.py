@@ -186,6 +186,7 @@ class Executor:
     activationBytes = property(lambda s: N.lib().smelter_exec_activation_bytes(s._h))
     flops = property(lambda s: N.lib().smelter_exec_flops(s._h))
     algorithmicBytes = property(lambda s: N.lib().smelter_exec_algorithmic_bytes(s._h))
+    launchBytes = property(lambda s: N.lib().smelter_exec_launch_bytes(s._h))
 
     @property
     def valueNames(self):
