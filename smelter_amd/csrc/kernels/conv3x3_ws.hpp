@@ -171,7 +171,9 @@ __global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams 
             // The VALU is scarce (a loader and an MFMA wave share a SIMD, ~4 clk per vector instruction): per load only the select of a dead offset is a
             // vector instruction — the vector offset is the offset of the ROW that is read (the descriptor's range check sees it alone), the plane offset
             // rides in the instruction's scalar offset operand.
-            auto request = [&](float (&v)[LNI][2][4], int t) __attribute__((always_inline)) {
+            // ccv = the number of planes as a compile-time constant (3: RGB, the loads of the fourth plane vanish), or 0 = runtime (dead offset by select)
+            auto request = [&](float (&v)[LNI][2][4], int t, auto ccv) __attribute__((always_inline)) {
+                constexpr int CC = decltype(ccv)::value;
                 int n, y0, x0; tile_origin(t, n, y0, x0);
                 const int r0 = y0 * SS - p.in_pt, c0 = x0 * SS - p.in_pl;               // input pixel of patch pixel (0, 0), top row
                 const int base = (int)((unsigned)n * (unsigned)C * plane) + r0 * IW + c0;
@@ -185,8 +187,10 @@ __global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams 
                         const unsigned voff = (okc && (unsigned)(r + h) < (unsigned)IH) ? (unsigned)(base + lrel[i] + h * IW) << 2 : DEAD;
 #pragma unroll
                         for (int ch = 0; ch < 4; ch++) {
-                            if (ch < C) v[i][h][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)((unsigned)ch * plane * 4u), 0));   // (wave-uniform branch)
-                            else v[i][h][ch] = 0.f;
+                            if constexpr (CC > 0) {
+                                if (ch < CC) v[i][h][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)((unsigned)ch * plane * 4u), 0));   // (folds: the loop is unrolled)
+                                else v[i][h][ch] = 0.f;
+                            } else v[i][h][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(ch < C ? voff : DEAD), (int)((unsigned)ch * plane * 4u), 0));
                         }
                     }
                 }
@@ -198,21 +202,24 @@ __global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams 
                     if (lpr[i] >= 0) *(half8_t*)(patch0 + buf * WS_PSTRIDE + (i * NLT + ltid) * 16) = o;
                 }
             };
-            float va[LNI][2][4], vb[LNI][2][4];
-            request(va, t_begin); deposit(va, 0);
-            request(va, t_begin + 1);                                 // (beyond the range: dead offsets, nothing is read)
+            auto lrun = [&](auto ccv) __attribute__((always_inline)) {
+                float va[LNI][2][4], vb[LNI][2][4];
+                request(va, t_begin, ccv); deposit(va, 0);
+                request(va, t_begin + 1, ccv);                        // (beyond the range: dead offsets, nothing is read)
 #pragma unroll 1
-            for (int t = t_begin; t < t_end; t += 2) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my share of patch t is in LDS
-                __builtin_amdgcn_s_barrier();                         // ... everybody's; the MFMA waves are done with the other buffer
-                request(vb, t + 2);
-                if (t + 1 < t_end) deposit(va, 1);
-                if (t + 1 >= t_end) break;
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                request(va, t + 3);
-                if (t + 2 < t_end) deposit(vb, 0);
-            }
+                for (int t = t_begin; t < t_end; t += 2) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my share of patch t is in LDS
+                    __builtin_amdgcn_s_barrier();                         // ... everybody's; the MFMA waves are done with the other buffer
+                    request(vb, t + 2, ccv);
+                    if (t + 1 < t_end) deposit(va, 1);
+                    if (t + 1 >= t_end) break;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    request(va, t + 3, ccv);
+                    if (t + 2 < t_end) deposit(vb, 0);
+                }
+            };
+            if (C == 3) lrun(std::integral_constant<int, 3>()); else lrun(std::integral_constant<int, 0>());
             return;
         }
     }
