@@ -255,10 +255,15 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
     constexpr int SLAB_BYTES = ROWS * 128, XT = NSLAB * SLAB_BYTES, STAGE = (NSLAB + RSLAB) * SLAB_BYTES;
     constexpr int LOADS = (NSLAB + RSLAB) * ROWS * 8 / NLT;          // DMA instructions per loader thread and stage
     static_assert(KS % 4 == 0 && ((NSLAB + RSLAB) * ROWS * 8) % NLT == 0 && NST >= 2 && NST <= 4 && (NST - 1) * LOADS <= 63, "geometry / vmcnt range");
-    static_assert(NSLAB * BN * 128 <= NST * STAGE, "the weight slice passes through the ring");
+    // LDS: the weight slice passes through [0, WB) on its way into the consumers' registers.  E ring slots lie BEHIND that area, so their stages are in flight
+    // while the slice lands and is lifted (the first stage used to start its ~4 k clk round trip only after that); the other NST - E slots reuse the slice's area.
+    constexpr int WB = NSLAB * BN * 128, E_FIT = (160 * 1024 - WB) / STAGE, E = E_FIT < NST - 1 ? E_FIT : NST - 1;
+    constexpr int LDS_TOTAL = (WB > (NST - E) * STAGE ? WB : (NST - E) * STAGE) + E * STAGE;
+    static_assert(LDS_TOTAL <= 160 * 1024 && (NST - E) * STAGE <= 160 * 1024, "LDS");
     static_assert((NSLAB - 1) * SLAB_BYTES + (RSLAB ? RSLAB - 1 : 0) * SLAB_BYTES + XT < 65536, "ds_read offset field");
+    static_assert(E * LOADS <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) unsigned char rw_smem[];
-    float* const bl = (float*)(rw_smem + NST * STAGE);
+    auto slot_base = [](int s) { return s < E ? WB + s * STAGE : (s - E) * STAGE; };     // byte offset of ring slot s
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -287,13 +292,10 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
                 SM_GLDS16(p.w + ((long)slice * BN + row) * K + slab * 64 + ((dchunk ^ ((row >> 1) & 7)) << 3), rw_smem + (i * NLT + lwave * 64) * 16);
             }
         }
-        sm_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                                 // P1: the slice is in LDS
-        __builtin_amdgcn_s_barrier();                                 // P2: every consumer holds its fragments: the ring may be overwritten
         int issued = 0;
         auto issue = [&]() __attribute__((always_inline)) {          // stage `issued` -> slot issued % NST
             const long m0 = (long)(t_begin + issued) * ROWS;
-            unsigned char* sa = rw_smem + (issued % NST) * STAGE + lwave * 1024;
+            unsigned char* sa = rw_smem + slot_base(issued % NST) + lwave * 1024;
 #pragma unroll
             for (int i = 0; i < LOADS; i++) {
                 const int g = i * 32 + drow;                          // row-slab index inside the stage: x slabs first, then the residual's
@@ -306,8 +308,14 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
             }
             ++issued;
         };
+        // early stages (slots behind the slice's area) ride behind the weight loads; the slice is complete when only they are left in flight
 #pragma unroll
-        for (int s = 0; s < NST - 1; s++) if (issued < n_st) issue();
+        for (int s = 0; s < E; s++) if (issued < n_st) issue();
+        if (issued == E) sm_wait_vmcnt<E * LOADS>(); else sm_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                                 // P1: the slice is in LDS
+        __builtin_amdgcn_s_barrier();                                 // P2: every consumer holds its fragments: the slice's area may be overwritten
+#pragma unroll
+        for (int s = E; s < NST - 1; s++) if (issued < n_st) issue();
 #pragma unroll 1
         for (int i = 0; i < n_st; i++) {
             const int newer = issued - i - 1;                         // stages behind stage i that may stay in flight
@@ -324,7 +332,9 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
 
     // ===================================================== consumer waves ======================================================
     const int n0 = slice * BN + wave * 32;                            // this wave's 32 output channels
-    for (int i = tid; i < BN; i += NCONS * 64) bl[i] = p.bias ? p.bias[slice * BN + i] : 0.f;
+    floatx4 bq[4];                                                    // this lane's 16 bias values (channels n0 + 8q + 4hi ..): straight from global, once
+#pragma unroll
+    for (int q = 0; q < 4; q++) bq[q] = p.bias ? *(const floatx4*)(p.bias + n0 + 8 * q + 4 * hi) : floatx4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_s_barrier();                                     // P1
     half8_t wr[KS];
 #pragma unroll
@@ -352,9 +362,6 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
         for (int i = 0; i < 8; i++) onehot[q][i] = (half_t)((RES && l31 == 16 * q + 8 * hi + i) ? 1.f : 0.f);
     const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;
     const bool relu0 = p.act != SM_ACT_NONE && p.slope == 0.f;
-    floatx4 bq[4];                                                    // this lane's 16 bias values (channels n0 + 8q + 4hi ..)
-#pragma unroll
-    for (int q = 0; q < 4; q++) bq[q] = *(const floatx4*)(bl + wave * 32 + 8 * q + 4 * hi);
 
     constexpr int PF = 4;
     int slot = 0;
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
 #ifdef SM_TIMELINE
         if (i < 10) SM_TL(2 + i);
 #endif
-        const unsigned sb = (unsigned)(slot * STAGE);
+        const unsigned sb = (unsigned)slot_base(slot);
         const long mb = (long)(t_begin + i) * ROWS;
         sm_static_for<0, FS>([&](auto jc) {
             constexpr int J = decltype(jc)::value;

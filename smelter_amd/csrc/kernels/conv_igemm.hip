@@ -901,7 +901,7 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
     if (c.kind == 8)     // weights in registers: 1x1 / stride 1 / no padding, Cin = the instantiation's, Cout a multiple of the block's slice, dense 16-byte rows, ReLU family
         return p.kH == 1 && p.kW == 1 && p.pt == 0 && p.pl == 0 && p.sH == 1 && p.sW == 1 && p.Ho == p.H && p.Wo == p.W && p.Cin == c.p0 && (p.Cout % c.BN) == 0 && p.Cout / c.BN <= 32 &&
                !p.ups && !p.yplace && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.x) & 15) == 0) &&
-               ((((uintptr_t)p.w) & 15) == 0) && ((c.flags & CF_RES) != 0) == (p.res != nullptr) && (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0)) &&
+               ((((uintptr_t)p.w) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && ((c.flags & CF_RES) != 0) == (p.res != nullptr) && (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0)) &&
                (long)p.M * std::max(p.y_ld, p.x_ld) * 2 < 0x7fff0000L && (p.res == nullptr || (long)p.M * p.res_ld * 2 < 0x7fff0000L);
     if (c.kind == 7)     // persistent pointwise GEMM: 1x1, no padding, one square stride, dense 16-byte rows, ReLU family, bias vector beside the ring
         return p.kH == 1 && p.kW == 1 && p.pt == 0 && p.pl == 0 && p.sH == p.sW && (p.sH == 1 || p.sH == 2) && (p.Cin % 64) == 0 && !p.ups && !p.yplace &&
@@ -1060,7 +1060,12 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         int groups = SM_NUM_CU / unit;                                // ranges per XCD
         while (groups > 1 && (groups - 1) * SM_NUM_XCD >= p.mt) groups--;          // (no more ranges than steps)
         const bool rres = (c.flags & CF_RES) != 0;
-        const size_t lds = c.p1 ? (size_t)c.p1 * (c.p0 / 64 + (rres ? c.BN / 64 : 0)) * c.BM * 128 + c.BN * 4 : (size_t)rw_lds_bytes(c.p0 / 16, c.BN, c.BM / 32, rres);
+        size_t lds = (size_t)rw_lds_bytes(c.p0 / 16, c.BN, c.BM / 32, rres);
+        if (c.p1) {   // ring form (conv1x1_rwl_kernel): E slots behind the weight slice's area, the others inside it
+            const size_t wb = (size_t)(c.p0 / 64) * c.BN * 128, stage = (size_t)(c.p0 / 64 + (rres ? c.BN / 64 : 0)) * c.BM * 128;
+            const size_t e = std::min<size_t>((160 * 1024 - wb) / stage, (size_t)c.p1 - 1);
+            lds = std::max(wb, (c.p1 - e) * stage) + e * stage;
+        }
         hipLaunchKernelGGL(c.fn, dim3((unsigned)(groups * unit)), dim3(c.threads), lds, s, p);
         SM_LAUNCH_CHECK(); return SM_OK;
     }

@@ -613,6 +613,10 @@ def test_mbconv_fused_block_equals_the_three_layers(n, hw, cin, ch, cout, stride
     (1, (45, 51), 32, 16, 2, 1),      # odd image, ragged tiles
     (2, (40, 24), 32, 24, 1, 2),      # stride-1 stem, stride-2 depthwise
     (1, (30, 38), 16, 64, 2, 1),      # 16 stem channels, 64 outputs (two cout blocks)
+    (2, (40, 24), 32, 24, 1, 1),      # stride-1 stem, 24 outputs
+    (3, (224, 224), 32, 16, 2, 1),    # the real size
+    (1, (33, 70), 32, 32, 2, 1),      # 32 outputs, ragged tiles
+    (1, (20, 20), 32, 8, 2, 1),       # 8 outputs
 ])
 def test_mbconv_with_the_image_stem_inside(n, hw, ch, cout, st_stride, stride):
     """sm_mbconv_stem_fwd: stem (3x3 on the fp32 NCHW batch, padding 1, ReLU) -> depthwise 3x3 -> project in one launch, against the oracle's three
