@@ -408,7 +408,9 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
                     s0[k2] += t0; s1[k2] += t1;
                 }
             }
-            auto emit = [&](const bool has_res) {
+            // relu0: plain ReLU as a packed fp16 max AFTER the rounding (max commutes with it): 4 v_pk_max_f16 per item instead of 24 compare / multiply / select
+            auto emit = [&](const bool has_res, auto relu0c) {
+                constexpr bool RELU0 = decltype(relu0c)::value;
 #pragma unroll
                 for (int k2 = 0; k2 < IPT; k2++) {
                     const int m = m0 + rowi[k2], co = co0 + chi[k2] * 8;
@@ -418,13 +420,21 @@ __global__ __launch_bounds__((WGM * WGN * KS + NLW) * 64) void conv_igemm64_kern
 #pragma unroll
                         for (int j = 0; j < 8; j++) v[j] += (float)rr[j]; }
                     half8_t o;
+                    if constexpr (RELU0) {
 #pragma unroll
-                    for (int j = 0; j < 8; j++) o[j] = (half_t)(v[j] < 0.f ? v[j] * sl : v[j]);
+                        for (int j = 0; j < 8; j++) o[j] = (half_t)v[j];
+                        o = __builtin_elementwise_max(o, half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; j++) o[j] = (half_t)(v[j] < 0.f ? v[j] * sl : v[j]);
+                    }
                     const bool live = (ITEMS % NT == 0 || tid + k2 * NT < ITEMS) && m < p.M && co < p.Cout;
                     if (live) *(half8_t*)(p.y + (long)m * p.y_ld + co) = o;
                 }
             };
-            if (p.res) emit(true); else emit(false);
+            const bool relu0 = p.act != SM_ACT_NONE && p.slope == 0.f;
+            if (p.res) { if (relu0) emit(true, std::true_type()); else emit(true, std::false_type()); }
+            else { if (relu0) emit(false, std::true_type()); else emit(false, std::false_type()); }
             if (pw + 1 < EP_PASSES) __syncthreads();
             continue;
         }
