@@ -249,15 +249,21 @@ __global__ __launch_bounds__(512) void conv1x1_rw_kernel(ConvParams p) {
 //   * one s_barrier per stage for both roles (stage t landed; the slot of stage t-1 is free): conv_igemm64's ring protocol;
 //   * a stage is FS fragments of 32 pixels (FS = 1 at K = 256: 16 KB of activations + 16 KB of residual), so pixel ranges are dealt in 32-pixel units
 //     (392 of them over 64 ranges per slice at 14x14: 6 or 7 per block instead of 3 or 4 steps of 64).
-template <int KS, int FS, int NST, bool RES>
+//
+// WP > 1: the weight slice passes the LDS in WP parts (K = 384: 192 KB for 256 rows; each part = NSLAB / WP slabs, lifted between its own pair of barriers).
+// DUAL (sm_conv2d_dual_fwd_cfg): K slabs >= p.kt_sw of a stage come from the SECOND source p.x2, pixel (n, oy * x2_s, ox * x2_s) of
+// [N, x2_H, x2_W, K2] — the projection shortcut of a bottleneck's first block as the tail of the expand layer's reduction.  Only the loaders know.
+template <int KS, int FS, int NST, bool RES, int WP = 1, bool DUAL = false>
 __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
     constexpr int NCONS = 8, NLT = 256, NSLAB = KS / 4, ROWS = FS * 32, BN = 256, K = KS * 16, RSLAB = RES ? BN / 64 : 0;
+    constexpr int WSLAB = NSLAB / WP, KSP = KS / WP;                  // slabs / k steps of one weight part
+    static_assert(NSLAB % WP == 0 && (!DUAL || FS == 1), "weight parts are whole slabs; the second source is addressed per 32-pixel stage");
     constexpr int SLAB_BYTES = ROWS * 128, XT = NSLAB * SLAB_BYTES, STAGE = (NSLAB + RSLAB) * SLAB_BYTES;
     constexpr int LOADS = (NSLAB + RSLAB) * ROWS * 8 / NLT;          // DMA instructions per loader thread and stage
     static_assert(KS % 4 == 0 && ((NSLAB + RSLAB) * ROWS * 8) % NLT == 0 && NST >= 2 && NST <= 4 && (NST - 1) * LOADS <= 63, "geometry / vmcnt range");
     // LDS: the weight slice passes through [0, WB) on its way into the consumers' registers.  E ring slots lie BEHIND that area, so their stages are in flight
     // while the slice lands and is lifted (the first stage used to start its ~4 k clk round trip only after that); the other NST - E slots reuse the slice's area.
-    constexpr int WB = NSLAB * BN * 128, E_FIT = (160 * 1024 - WB) / STAGE, E = E_FIT < NST - 1 ? E_FIT : NST - 1;
+    constexpr int WB = WSLAB * BN * 128, E_FIT = (160 * 1024 - WB) / STAGE, E = E_FIT < NST - 1 ? E_FIT : NST - 1;
     constexpr int LDS_TOTAL = (WB > (NST - E) * STAGE ? WB : (NST - E) * STAGE) + E * STAGE;
     static_assert(LDS_TOTAL <= 160 * 1024 && (NST - E) * STAGE <= 160 * 1024, "LDS");
     static_assert((NSLAB - 1) * SLAB_BYTES + (RSLAB ? RSLAB - 1 : 0) * SLAB_BYTES + XT < 65536, "ds_read offset field");
@@ -283,19 +289,27 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
         // =================================================== loader waves =====================================================
         const int ltid = tid - NCONS * 64, lwave = wave - NCONS;
         const int drow = ltid >> 3, dchunk = ltid & 7;               // a DMA instruction of the four waves covers 32 rows x 8 chunks of one slab
-        // ---- weight slice -> ring area (slab layout with BN rows) ----
-        {
-            constexpr int NPW = NSLAB * BN * 8 / NLT;
+        // ---- weight slice (part wp) -> ring area (slab layout with BN rows) ----
+        auto weights = [&](auto wpc) __attribute__((always_inline)) {
+            constexpr int WPI = decltype(wpc)::value, NPW = WSLAB * BN * 8 / NLT;
 #pragma unroll
             for (int i = 0; i < NPW; i++) {
                 const int g = i * 32 + drow, slab = g / BN, row = g % BN;      // (i: compile time, BN a power of two)
-                SM_GLDS16(p.w + ((long)slice * BN + row) * K + slab * 64 + ((dchunk ^ ((row >> 1) & 7)) << 3), rw_smem + (i * NLT + lwave * 64) * 16);
+                SM_GLDS16(p.w + ((long)slice * BN + row) * K + (WPI * WSLAB + slab) * 64 + ((dchunk ^ ((row >> 1) & 7)) << 3), rw_smem + (i * NLT + lwave * 64) * 16);
             }
-        }
+        };
+        weights(std::integral_constant<int, 0>());
         int issued = 0;
         auto issue = [&]() __attribute__((always_inline)) {          // stage `issued` -> slot issued % NST
             const long m0 = (long)(t_begin + issued) * ROWS;
             unsigned char* sa = rw_smem + slot_base(issued % NST) + lwave * 1024;
+            const half_t* row2 = nullptr;                             // DUAL: this thread's pixel of the second source (FS = 1: one row per thread and stage)
+            if constexpr (DUAL) {
+                long m = m0 + drow; if (m >= p.M) m = p.M - 1;
+                const int n = (int)sm_fastdiv((unsigned)m, p.dhw_mul, p.dhw_sh), r = (int)m - n * (p.Ho * p.Wo);
+                const int oy = (int)sm_fastdiv((unsigned)r, p.dw_mul, p.dw_sh), ox = r - oy * p.Wo;
+                row2 = p.x2 + (long)((n * p.x2_H + oy * p.x2_s) * p.x2_W + ox * p.x2_s) * p.x2_ld;
+            }
 #pragma unroll
             for (int i = 0; i < LOADS; i++) {
                 const int g = i * 32 + drow;                          // row-slab index inside the stage: x slabs first, then the residual's
@@ -304,6 +318,7 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
                 const int sw = (dchunk ^ ((row >> 1) & 7)) << 3;
                 const half_t* src = slab < NSLAB ? p.x + (m0 + row) * p.x_ld + slab * 64 + sw
                                                  : p.res + (m0 + row) * p.res_ld + slice * BN + (slab - NSLAB) * 64 + sw;
+                if constexpr (DUAL) { if (slab >= p.kt_sw) src = row2 + (slab - p.kt_sw) * 64 + sw; }      // (slab = i: compile time; kt_sw uniform)
                 SM_GLDS16(in ? src : zero, sa + i * NLT * 16);
             }
             ++issued;
@@ -312,8 +327,14 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
 #pragma unroll
         for (int s = 0; s < E; s++) if (issued < n_st) issue();
         if (issued == E) sm_wait_vmcnt<E * LOADS>(); else sm_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();                                 // P1: the slice is in LDS
+        __builtin_amdgcn_s_barrier();                                 // P1: the slice (its first part) is in LDS
         __builtin_amdgcn_s_barrier();                                 // P2: every consumer holds its fragments: the slice's area may be overwritten
+        sm_static_for<1, WP>([&](auto wpc) {                          // the other parts, one round trip each (the early stages are long in by then)
+            weights(wpc);
+            sm_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
+        });
 #pragma unroll
         for (int s = E; s < NST - 1; s++) if (issued < n_st) issue();
 #pragma unroll 1
@@ -335,15 +356,18 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
     floatx4 bq[4];                                                    // this lane's 16 bias values (channels n0 + 8q + 4hi ..): straight from global, once
 #pragma unroll
     for (int q = 0; q < 4; q++) bq[q] = p.bias ? *(const floatx4*)(p.bias + n0 + 8 * q + 4 * hi) : floatx4{0.f, 0.f, 0.f, 0.f};
-    __builtin_amdgcn_s_barrier();                                     // P1
     half8_t wr[KS];
+    sm_static_for<0, WP>([&](auto wpc) {
+        constexpr int WPI = decltype(wpc)::value;
+        __builtin_amdgcn_s_barrier();                                 // P1 (of part WPI)
 #pragma unroll
-    for (int ks = 0; ks < KS; ks++) {
-        const int row = wave * 32 + l31;
-        wr[ks] = *(const half8_t*)(rw_smem + (ks >> 2) * (BN * 128) + row * 128 + (((2 * (ks & 3) + hi) ^ ((row >> 1) & 7)) << 4));
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                     // P2
+        for (int ks = 0; ks < KSP; ks++) {
+            const int row = wave * 32 + l31;
+            wr[WPI * KSP + ks] = *(const half8_t*)(rw_smem + (ks >> 2) * (BN * 128) + row * 128 + (((2 * (ks & 3) + hi) ^ ((row >> 1) & 7)) << 4));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                 // P2
+    });
     SM_TL(1);
     // fragment addresses inside a stage: fragment j = rows 32 j + l31; activations: k step ks -> slab ks / 4 (instruction offset), chunk 2 (ks % 4) + hi;
     // residual: channels 32 wave + 16 q + 8 hi -> slab wave / 2, chunk 4 (wave & 1) + 2 q + hi

@@ -605,8 +605,9 @@ __global__ __launch_bounds__(256) void dwconv3x3_lds_kernel(ConvParams p, int cb
 //   kind 4: p0 = Cin of the instantiation; CF_HEAD / CF_XHEAD / CF_W44 (two-role kernel: 4 of the 8 waves issue the patch DMA) / CF_SIDE
 //   kind 6: p0 = taps (kH' of the row-pair form), p1 = KB between the two patch buffers (0 = as large as the weights allow), p2 = loader waves
 //   kinds 5, 7: p0 = ring stages
-//   kind 8: BM = pixels per step (32 FS), BN = channels per block, p0 = Cin of the instantiation; CF_RES = the instantiation that stages a residual tile
-enum { CF_HEAD = 1, CF_XHEAD = 2, CF_W44 = 4, CF_SIDE = 8, CF_RES = 16 };
+//   kind 8: BM = pixels per step (32 FS), BN = channels per block, p0 = Cin of the instantiation; CF_RES = the instantiation that stages a residual tile;
+//           ring form: p1 = stages, p2 = parts the weight slice passes the LDS in (0 = 1); CF_DUAL = takes (only) launches with a second source
+enum { CF_HEAD = 1, CF_XHEAD = 2, CF_W44 = 4, CF_SIDE = 8, CF_RES = 16, CF_DUAL = 32 };
 struct TileCfg { int BM, BN, kind, threads; void (*fn)(ConvParams); const char* name; int flags = 0, p0 = 0, p1 = 0, p2 = 0; };
 const TileCfg kCfgs[] = {
     {128, 128, 0, 256, conv_igemm_kernel<128, 128, 2, 2>, "128x128"},
@@ -745,6 +746,8 @@ const TileCfg kCfgs[] = {
     {64, 256, 8, 768, conv1x1_rwl_kernel<8, 2, 3, true>, "rwl:k128 n256 s64x3 +res", CF_RES, 128, 3},     // 112
     {32, 256, 8, 768, conv1x1_rwl_kernel<8, 1, 4, true>, "rwl:k128 n256 s32x4 +res", CF_RES, 128, 4},     // 113
     {64, 256, 8, 768, conv1x1_rwl_kernel<16, 2, 4, false>, "rwl:k256 n256 s64x4", 0, 256, 4},             // 114
+    // ... over two sources (sm_conv2d_dual_fwd_cfg: K = K1 + K2 = 384, ResNet-50 stage 2's first block): the slice passes the LDS in two parts
+    {32, 256, 8, 768, conv1x1_rwl_kernel<24, 1, 4, false, 2, true>, "rwl:k384 n256 s32x4 dual", CF_DUAL, 384, 4, 2},   // 115
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
@@ -876,7 +879,8 @@ size_t p9_setup(ConvParams& p, const TileCfg& c) {
 // kind 2 = single LDS stage: only for K == 64 (one K tile)
 // kinds 1/2 (conv_igemm64.hpp): Cin % 64 == 0 and a tap mask of <= 32 bits
 bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
-    if (p.x2 && c.kind != 7) return false;                           // a second source: the persistent pointwise kernel only
+    if (p.x2 && c.kind != 7 && !(c.kind == 8 && (c.flags & CF_DUAL))) return false;     // a second source: the persistent pointwise kernel and the dual ring instantiations only
+    if (!p.x2 && (c.flags & CF_DUAL)) return false;
     if (c.kind == 0) return p.y2 == nullptr && p.y3 == nullptr;
     const bool same3x3 = p.kH == 3 && p.kW == 3 && p.sH == 1 && p.sW == 1 && p.dH == 1 && p.dW == 1 && p.pt == 1 && p.pl == 1 && p.Ho == p.H && p.Wo == p.W;
     if (c.kind == 4) {   // weight-stationary: the template's Cin / Cout exactly, no residual, dense 16-byte rows on both sides, ReLU family
@@ -902,7 +906,8 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
         return p.kH == 1 && p.kW == 1 && p.pt == 0 && p.pl == 0 && p.sH == 1 && p.sW == 1 && p.Ho == p.H && p.Wo == p.W && p.Cin == c.p0 && (p.Cout % c.BN) == 0 && p.Cout / c.BN <= 32 &&
                !p.ups && !p.yplace && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.x) & 15) == 0) &&
                ((((uintptr_t)p.w) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && ((c.flags & CF_RES) != 0) == (p.res != nullptr) && (p.res == nullptr || ((p.res_ld & 7) == 0 && (((uintptr_t)p.res) & 15) == 0)) &&
-               (long)p.M * std::max(p.y_ld, p.x_ld) * 2 < 0x7fff0000L && (p.res == nullptr || (long)p.M * p.res_ld * 2 < 0x7fff0000L);
+               (long)p.M * std::max(p.y_ld, p.x_ld) * 2 < 0x7fff0000L && (p.res == nullptr || (long)p.M * p.res_ld * 2 < 0x7fff0000L) &&
+               (!p.x2 || (p.kt_sw > 0 && p.kt_sw < c.p0 / 64));
     if (c.kind == 7)     // persistent pointwise GEMM: 1x1, no padding, one square stride, dense 16-byte rows, ReLU family, bias vector beside the ring
         return p.kH == 1 && p.kW == 1 && p.pt == 0 && p.pl == 0 && p.sH == p.sW && (p.sH == 1 || p.sH == 2) && (p.Cin % 64) == 0 && !p.ups && !p.yplace &&
                p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
@@ -1062,7 +1067,7 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         const bool rres = (c.flags & CF_RES) != 0;
         size_t lds = (size_t)rw_lds_bytes(c.p0 / 16, c.BN, c.BM / 32, rres);
         if (c.p1) {   // ring form (conv1x1_rwl_kernel): E slots behind the weight slice's area, the others inside it
-            const size_t wb = (size_t)(c.p0 / 64) * c.BN * 128, stage = (size_t)(c.p0 / 64 + (rres ? c.BN / 64 : 0)) * c.BM * 128;
+            const size_t wb = (size_t)(c.p0 / 64) / (c.p2 ? c.p2 : 1) * c.BN * 128, stage = (size_t)(c.p0 / 64 + (rres ? c.BN / 64 : 0)) * c.BM * 128;
             const size_t e = std::min<size_t>((160 * 1024 - wb) / stage, (size_t)c.p1 - 1);
             lds = std::max(wb, (c.p1 - e) * stage) + e * stage;
         }

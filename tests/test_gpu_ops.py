@@ -726,8 +726,11 @@ def test_stem_with_fused_maxpool3x3(shape):
     (3, 7, 9, 256, 512, 1024, 2, 2),                   # stage 3 class, ragged M (189), PReLU
     (2, 5, 5, 64, 64, 200, 1, 0),                      # stride 1 second source, ragged N, no activation
     (1, 7, 7, 512, 1024, 2048, 2, 1),                  # stage 4 class: 24 K tiles
+    (3, 9, 7, 128, 256, 256, 2, 1),                    # K = 384 (the weights-in-registers ring form), ragged M (189), one N slice
+    (2, 6, 6, 64, 320, 512, 1, 2),                     # K = 384 split 64 + 320, stride 1 second source, PReLU
+    (16, 28, 28, 128, 256, 512, 2, 1),                 # the real stage-2 shape at bs 16: 392 stages of 32 pixels
 ])
-@pytest.mark.parametrize("cfg", [-1] + cfgs_named("ps:"))
+@pytest.mark.parametrize("cfg", [-1] + cfgs_named("ps:") + cfgs_named("rwl:", "dual"))
 def test_pointwise_over_two_sources(case, cfg):
     """sm_conv2d_dual_fwd_cfg (conv1x1_ps.hpp, second source): equals the convolution over the channel-concatenated, subsampled operand (oracle), and is
     bit-identical to that convolution run by the same configuration on a materialised concatenation"""
@@ -749,7 +752,10 @@ def test_pointwise_over_two_sources(case, cfg):
             pytest.skip(e.detail)
         raise
     assert_close(to_host(y), ref, k1 + k2)
-    if cfg >= 0:
+    if cfg >= 0 and "dual" in ops.config_name(cfg):   # (takes launches with a second source only: compared with the persistent tiled kernel instead)
+        y0 = ops.conv2d_dual(to_dev(x), to_dev(x2), wd, bd, stride2=s2, act=act, slope=slope, cfg=cfgs_named("ps:")[0])
+        assert (y == y0).float().mean().item() > 0.995
+    elif cfg >= 0:
         assert torch.equal(y, ops.conv2d(to_dev(cat), wd, bd, act=act, slope=slope, cfg=cfg))
 
 
