@@ -162,7 +162,10 @@ int sm_conv2d_stem_f32_fwd_cfg(const sm_conv_desc* d, int cfg, const float* x_nc
 /* Three MPSCNNConvolutionNodes in a row — [1x1 expand + act1] -> depthwise 3x3 (pad 1, stride 1|2) + act2 -> 1x1 project + act3
  * (+ the block input as residual) — in ONE launch; the two hidden tensors stay in LDS (the "inverted residual" block of
  * MobileNet-v2).  expand = 0: no 1x1 in front (Ch == Cin).  Weights: w1 [Ch][Cin], wd [Ch][3][3] (the depthwise data source's
- * OHWI image), w2 [Cout][Ch], fp16; biases fp32 or NULL.  Cin <= 32, Ch <= 192, Cout <= 64, all % 8 == 0; ReLU-family activations.
+ * OHWI image), w2 [Cout][Ch], fp16; biases fp32 or NULL.  All channel counts % 8 == 0; ReLU-family activations.  Four kernels behind it
+ * (sm_mbconv_kernel_kind: 1 = all-in-LDS, Cin <= 32, Ch <= 192, Cout <= 64; 2 = chunked; 3 = one wave per tile, Cin <= 46 or weights from
+ * global memory up to Cin 110 / Cout 96; 4 = one IMAGE per block for H * W <= 224 at stride 1: Cin % 16 == 0, Cin <= 96 / Cout <= 96 above
+ * 64 pixels, Cin <= 160 / Cout <= 384 up to 64 pixels, Ch >= 128, everything within 160 KB of LDS — MobileNet-v2's 14 x 14 and 7 x 7 blocks); sm_mbconv_supported = any of them.
  * Same roundings as the separate launches: the hidden tensors are rounded to fp16 once each. */
 typedef struct sm_mbconv_desc {
     int32_t N, H, W, Ho, Wo, stride;
@@ -171,6 +174,7 @@ typedef struct sm_mbconv_desc {
     int32_t x_ld, y_ld;           /* pixel strides in elements, 0 = dense */
 } sm_mbconv_desc;
 int sm_mbconv_supported(const sm_mbconv_desc* d);
+int sm_mbconv_kernel_kind(const sm_mbconv_desc* d);   /* 0 = none, else the kernel sm_mbconv_fwd launches for this geometry */
 size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d);
 int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const float* b1, const void* wd, const float* bd,
                   const void* w2, const float* b2, void* y, sm_stream_t stream);

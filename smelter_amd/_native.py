@@ -81,6 +81,7 @@ SYMBOLS = {
     "sm_conv2d_xhead_proj_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sm_conv2d_xhead_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _i32, _vp, _i32, _vp]),
     "sm_mbconv_supported": (_i32, [C.POINTER(MbConvDesc)]),
+    "sm_mbconv_kernel_kind": (_i32, [C.POINTER(MbConvDesc)]),
     "sm_mbconv_lds_bytes": (_sz, [C.POINTER(MbConvDesc)]),
     "sm_mbconv_fwd": (_i32, [C.POINTER(MbConvDesc)] + [_vp] * 9),
     "sm_mbconv_stem_supported": (_i32, [C.POINTER(MbConvDesc)] + [_i32] * 5),

@@ -399,7 +399,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 const char* dom_env = getenv("SMELTER_MBCONV_DOMAIN");
                 int max_cin = 96, max_ch = 576, max_cout = 160;
                 if (dom_env) sscanf(dom_env, "%d,%d,%d", &max_cin, &max_ch, &max_cout);
-                if (d.Cin > max_cin || d.Ch > max_ch || d.Cout > max_cout || !vecOk(e.op.inputs[0]) || !vecOk(pj.output) || !sm_mbconv_supported(&d)) continue;
+                // (the image-per-block kernel, kind 4, brings its own domain: the 14 x 14 and 7 x 7 blocks up to Ch = 960)
+                if (((d.Cin > max_cin || d.Ch > max_ch || d.Cout > max_cout) && (dom_env || sm_mbconv_kernel_kind(&d) != 4)) || !vecOk(e.op.inputs[0]) || !vecOk(pj.output) || !sm_mbconv_supported(&d)) continue;
                 e.has_mb = true; e.mb_dw = steps_[ud].op; e.mb_proj = steps_[up].op;
                 steps_.erase(steps_.begin() + up); steps_.erase(steps_.begin() + ud);
             }

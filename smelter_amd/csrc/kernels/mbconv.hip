@@ -19,7 +19,7 @@
 #include "common.hpp"
 
 #ifdef SM_TIMELINE   // diagnostic build: clock64() spent per phase by thread 0 of block 0, summed over its tiles (sm_mbconv_debug_timeline)
-__device__ unsigned long long g_mb_tl[8];
+__device__ unsigned long long g_mb_tl[8];   // (v4: slot 7 = the wait for the weight DMA at the top of phase B)
 #define MB_TL(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long now = clock64(); g_mb_tl[i] += now - mb_t0; mb_t0 = now; } } while (0)
 #else
 #define MB_TL(i)
@@ -732,6 +732,300 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     }
 }
 
+// ---- v4: one IMAGE per block, every hidden chunk shared by the block's waves --------------------------------------------------------------
+// MobileNet-v2's 14 x 14 and 7 x 7 blocks (Ch = 384 / 576 / 960) in v3 are one wave per 4 x 8 tile walking 12..30 chunks in a single dependent chain
+// (expand MFMAs -> LDS -> depthwise -> LDS -> project MFMAs, W1 / W2 fragments from global memory per chunk): 49..71 us per block at 14 x 14 although
+// no resource is busy, and nothing at 7 x 7; the 6 x 10 patch of a 4 x 8 tile also computes the expand layer 1.9 times.  Here the tile is the WHOLE
+// image (zero padding is then the layer's own, nothing is recomputed) and the eight waves of a block cut every phase of a chunk between them:
+//   A  expand: the wave that owns pixel fragment pf (32 pixels, its X fragments stay in registers for the whole image) multiplies them with the
+//      chunk's W1 rows (CF fragments of 32 hidden channels, A operand from LDS; bias = one more k step against a {hi(b), lo(b)} fragment) and writes
+//      act1(.) rounded to fp16 into the block's hidden image [(H+2) x (W+2)][chunk channels] (border = the depthwise layer's zero padding, written once);
+//   B  depthwise 3x3: the 512 lanes are (column, channel vector of 8, row part) tasks over the hidden image, a task walks its rows with a three-row
+//      window in registers (3 LDS reads + 72 fp32 FMAs per output), act2, one rounding -> [pixel][chunk channels], the B operand of
+//   C  project: wave (pf, g) accumulates its cout fragments (a = g mod NG) over the chunk's k steps, W2's chunk columns from LDS.
+//   The chunk weights arrive by LDS-DMA in MFMA-fragment order (1 KB per fragment = one wave instruction, lane-linear: conflict-free reads, no registers),
+//   two buffers each: phase B of chunk g requests W1 of chunk g+2 and W2 of chunk g+1 and first waits for the group requested one chunk earlier —
+//   a whole chunk of flight time, nothing else in the loop touches global memory.  Two barriers per chunk (A | B | C + next A); the accumulators of C
+//   live across chunks, epilogue (+ b2, + X, act3, 16-byte stores) per image.
+// T = pixel fragments of an image (7: H*W <= 224, waves 0..6 own one each; 2: H*W <= 64, waves = (pf, g) with four cout groups g),
+// CF = hidden fragments per chunk, KSX = k steps of X (Cin / 16, runtime p.Cin may be smaller: zero steps are skipped).  Stride 1 only.
+__device__ __attribute__((aligned(64))) unsigned int g_mb_zero[16];       // zero-initialised at module load: source of the fragments beyond Ch / Cout / Cin
+#define MB_GLDS16(gptr, ldsptr) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
+
+template <int T, int CF, int KSX>
+__global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
+    constexpr int NT = 512, TP = T > 4 ? 8 : (T > 2 ? 4 : 2), NG = 8 / TP, NFW = 3, CK = CF * 32, HSB = CK * 2 + 16, NCV = CF * 4, RPTM = 4;
+    constexpr int F1 = CF * KSX, W1B = F1 * 1024, NI1 = (F1 + 7) / 8, NI2 = (NFW * NG * 2 * CF + 7) / 8, ACF = (CF + NG - 1) / NG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
+    const int H = p.H, W = p.W, P = H * W, PW = W + 2, HP = (H + 2) * PW;
+    const int ChP = p.ChP, NC = ChP / CK, nfc = (p.Cout + 31) >> 5, CoP = nfc * 32, ksx = p.Cin >> 4, F2 = nfc * 2 * CF, W2B = F2 * 1024;
+    unsigned char* const w1b = mb_smem;                                   // [2][CF][KSX] fragments of 1 KB
+    unsigned char* const w2b = w1b + 2 * W1B;                             // [2][nfc][2 CF] fragments
+    unsigned char* const hid = w2b + 2 * W2B;                             // [(H+2)(W+2)][HSB]
+    unsigned char* const dwo = hid + HP * HSB;                            // [T*32][HSB]
+    half_t* const wdl = (half_t*)(dwo + T * 32 * HSB);                    // [9][ChP]
+    float* const bdl = (float*)(wdl + 9 * ChP);                           // [ChP]
+    float* const b1l = bdl + ChP;                                         // [ChP]
+    float* const b2l = b1l + ChP;                                         // [CoP]
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const half8_t hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    const half_t* const zero = (const half_t*)g_mb_zero;
+
+    // weights of chunk c (index into the hidden channels) -> buffer b; every wave issues its share (fragment f = wave + 8 i)
+    auto dma_w1 = [&](int c, int b) {
+#pragma unroll
+        for (int i = 0; i < NI1; i++) {
+            const int f = wave + 8 * i;
+            if (f < F1) {
+                const int cf = f / KSX, ks = f - cf * KSX, ch = c * CK + cf * 32 + l31;
+                MB_GLDS16((ch < p.Ch && ks < ksx) ? p.w1 + (long)ch * p.Cin + ks * 16 + hi * 8 : zero, w1b + b * W1B + f * 1024);
+            }
+        }
+    };
+    auto dma_w2 = [&](int c, int b) {
+#pragma unroll
+        for (int i = 0; i < NI2; i++) {
+            const int f = wave + 8 * i;
+            if (f < F2) {
+                const int a = f / (2 * CF), ks = f - a * (2 * CF), co = a * 32 + l31, k = c * CK + ks * 16 + hi * 8;
+                MB_GLDS16((co < p.Cout && k < p.Ch) ? p.w2 + (long)co * p.Ch + k : zero, w2b + b * W2B + f * 1024);
+            }
+        }
+    };
+#ifdef SM_TIMELINE   // per-phase cycles of wave 0 in scalar registers (a stamp that touches memory would itself be waited for by the kernel's vmcnt(0))
+    unsigned long long tl4[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mb_t0 = __builtin_amdgcn_s_memtime();
+#define MB4_TL(i) do { const unsigned long long now = __builtin_amdgcn_s_memtime(); tl4[i] += now - mb_t0; mb_t0 = now; } while (0)
+#else
+#define MB4_TL(i)
+#endif
+    dma_w1(0, 0); dma_w2(0, 0); dma_w1(NC > 1 ? 1 : 0, 1);
+    const int pf = wave % TP, grp = wave / TP;
+    const bool act_pf = pf < T;
+    const int q = pf * 32 + l31;                                          // my pixel of the image (phases A and C, epilogue)
+    const bool valid = act_pf && q < P;
+    half8_t fx[KSX];                                                      // X fragments of my pixel fragment: loaded a whole image ahead (here: under the prologue)
+    auto load_x = [&](int n) {
+        const half_t* const xim = p.x + (long)n * P * p.x_ld;
+#pragma unroll
+        for (int ks = 0; ks < KSX; ks++) fx[ks] = (valid && ks < ksx && n < p.N) ? *(const half8_t*)(xim + (long)q * p.x_ld + ks * 16 + hi * 8) : hz;
+    };
+    load_x(blockIdx.x);
+    {   // depthwise weights [Ch][9] -> [9][ChP]: the loads of a batch are independent (one round trip per batch, not per element)
+        constexpr int WB = 8;
+        for (int i0 = tid; i0 < 9 * ChP; i0 += NT * WB) {
+            half_t v[WB];
+#pragma unroll
+            for (int j = 0; j < WB; j++) { const int i = i0 + j * NT, t = i / ChP, c = i - t * ChP; v[j] = (i < 9 * ChP && c < p.Ch) ? p.wd[(long)c * 9 + t] : (half_t)0.f; }
+#pragma unroll
+            for (int j = 0; j < WB; j++) { const int i = i0 + j * NT; if (i < 9 * ChP) wdl[i] = v[j]; }
+        }
+    }
+    for (int i = tid; i < ChP; i += NT) { bdl[i] = (p.bd && i < p.Ch) ? p.bd[i] : 0.f; b1l[i] = (p.b1 && i < p.Ch) ? p.b1[i] : 0.f; }
+    for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
+    for (int i = tid; i < HP * HSB / 16; i += NT) *(half8_t*)(hid + i * 16) = hz;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    MB4_TL(0);
+
+    // ---- lane constants ----
+    const int qy = q / W, qx = q - qy * W;
+    const unsigned hid_q = (unsigned)(((qy + 1) * PW + qx + 1) * HSB);
+    // depthwise tasks = (column, channel vector, row part): RP row parts, the first H % RP of them one row longer.  A wave takes tasks of ONE row part
+    // when the parts split evenly over the waves (RP | 8: lanes = (column, cv) pairs, NCV * W / (8 / RP) per wave), and waves w, w + 4 — SIMD partners —
+    // take parts from opposite ends of the list, so that every SIMD sees the same number of rows; otherwise tasks are dealt lane-linearly.
+    int RP = NT / (NCV * W); if (RP > H) RP = H;
+    int cv, tx, rp; bool task_on;
+    if ((8 % RP) == 0 && ((NCV * W) % (8 / RP)) == 0 && NCV * W / (8 / RP) <= 64) {
+        const int wpp = 8 / RP, per = NCV * W / wpp;                      // waves per part, tasks per wave
+        const int part = wave < 4 ? wave / wpp : RP - 1 - (wave - 4) / wpp, sub = wave % wpp;
+        const int id = sub * per + lane;
+        rp = part; cv = id % NCV; tx = id / NCV; task_on = lane < per;
+        if (tx >= W) tx = W - 1;
+    } else {
+        const int trest = tid / NCV;
+        cv = tid % NCV; tx = trest % W; rp = trest / W; task_on = rp < RP;
+    }
+    const int rlong = H % RP, rbase = H / RP;
+    const int ty0 = rp * rbase + (rp < rlong ? rp : rlong), ty1 = task_on ? ty0 + rbase + (rp < rlong ? 1 : 0) : 0;
+    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;
+
+    int g = 0;                                                            // chunks done since the launch (buffer parity), cw = g % NC (the chunk's channels)
+#pragma unroll 1
+    for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
+        half8_t fone = hz; if (valid && !hi) { fone[0] = (half_t)1.f; fone[1] = (half_t)1.f; }
+        floatx16 acc2[NFW];
+#pragma unroll
+        for (int a = 0; a < NFW; a++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc2[a][i] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < NC; c++, g++) {
+            const int gb = g & 1;
+            // ---- phase A ----------------------------------------------------------------------------------------------------------------
+            if (act_pf) {
+                half8_t fw[ACF][KSX];                                     // all fragments first: one LDS round trip, then the row blocks' MFMA chains interleaved
+                float bv[ACF];
+#pragma unroll
+                for (int i = 0; i < ACF; i++) {
+                    const int cf = grp + NG * i < CF ? grp + NG * i : CF - 1;
+#pragma unroll
+                    for (int ks = 0; ks < KSX; ks++) fw[i][ks] = *(const half8_t*)(w1b + gb * W1B + (cf * KSX + ks) * 1024 + lane * 16);
+                    bv[i] = b1l[c * CK + cf * 32 + l31];
+                }
+                floatx16 acc[ACF];
+#pragma unroll
+                for (int i = 0; i < ACF; i++) {
+                    half8_t fb = hz;
+                    if (!hi) { const half_t bh = (half_t)bv[i]; fb[0] = bh; fb[1] = (half_t)(bv[i] - (float)bh); }
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fone, (floatx16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                }
+#pragma unroll
+                for (int ks = 0; ks < KSX; ks++)
+#pragma unroll
+                    for (int i = 0; i < ACF; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i][ks], fx[ks], acc[i], 0, 0, 0);      // (k steps beyond Cin: zero fragments on both sides)
+#pragma unroll
+                for (int i = 0; i < ACF; i++) {
+                    const int cf = grp + NG * i;
+                    if (cf < CF) {
+#pragma unroll
+                        for (int qq = 0; qq < 4; qq++) {
+                            half4_t o;
+                            if (relu1) {
+#pragma unroll
+                                for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[i][4 * qq + r2];
+                                o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                            } else {
+#pragma unroll
+                                for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[i][4 * qq + r2], p.sl1);
+                            }
+                            if (valid) *(half4_t*)(hid + hid_q + (cf * 32 + 8 * qq + 4 * hi) * 2) = o;
+                        }
+                    }
+                }
+            }
+            MB4_TL(1);
+            mb_lds_barrier();                                             // the hidden image of chunk c is complete; C(c-1) is over everywhere
+            MB4_TL(2);
+            // ---- phase B ----------------------------------------------------------------------------------------------------------------
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my share of W1(g+1), W2(g), requested one chunk ago (first chunk of an image: + X, residual loads)
+            MB4_TL(7);
+            {
+                const int c2 = (c + 2) % NC, c1 = c + 1 < NC ? c + 1 : 0;
+                dma_w1(c2, gb); dma_w2(c1, gb ^ 1);                       // W1(g) was read in A(g), W2(g-1) in C(g-1): both buffers are free
+            }
+            if (ty0 < ty1) {
+                const int chl = c * CK + cv * 8;
+                u32x4 wreg[9];
+#pragma unroll
+                for (int tp = 0; tp < 9; tp++) wreg[tp] = *(const u32x4*)(wdl + tp * ChP + chl);
+                const floatx4 bd0 = *(const floatx4*)(bdl + chl), bd1 = *(const floatx4*)(bdl + chl + 4);
+                const unsigned char* const hcol = hid + tx * HSB + cv * 16;  // padded column tx (= image column tx - 1) of my channel vector
+                u32x4 win[3][3];
+#pragma unroll
+                for (int k = 0; k < 2; k++)
+#pragma unroll
+                    for (int kw = 0; kw < 3; kw++) win[k][kw] = *(const u32x4*)(hcol + ((ty0 + k) * PW + kw) * HSB);
+#pragma unroll
+                for (int i = 0; i < RPTM; i++) {
+                    const int y = ty0 + i;
+                    if (y < ty1) {
+#pragma unroll
+                        for (int kw = 0; kw < 3; kw++) win[(i + 2) % 3][kw] = *(const u32x4*)(hcol + ((y + 2) * PW + kw) * HSB);
+                        float a[8];
+#pragma unroll
+                        for (int j = 0; j < 4; j++) { a[j] = bd0[j]; a[4 + j] = bd1[j]; }
+#pragma unroll
+                        for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                            for (int kw = 0; kw < 3; kw++) {
+                                const u32x4 xu = win[(i + kh) % 3][kw];
+                                const u32x4 wu = wreg[kh * 3 + kw];
+#pragma unroll
+                                for (int d2 = 0; d2 < 4; d2++) {
+                                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2]) : "v"(xu[d2]), "v"(wu[d2]));
+                                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2 + 1]) : "v"(xu[d2]), "v"(wu[d2]));
+                                }
+                            }
+                        half8_t ov;
+                        if (relu2) {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) ov[j] = (half_t)a[j];
+                            ov = __builtin_elementwise_max(ov, hz);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+                        }
+                        *(half8_t*)(dwo + (y * W + tx) * HSB + cv * 16) = ov;
+                    }
+                }
+            }
+            MB4_TL(3);
+            mb_lds_barrier();                                             // depthwise output complete; everybody's share of W1(g+1) and W2(g) has landed
+            MB4_TL(4);
+            // ---- phase C ----------------------------------------------------------------------------------------------------------------
+            if (act_pf) {
+                half8_t fy[2 * CF];
+#pragma unroll
+                for (int ks = 0; ks < 2 * CF; ks++) fy[ks] = *(const half8_t*)(dwo + q * HSB + (2 * ks + hi) * 16);
+#pragma unroll
+                for (int i = 0; i < NFW; i++) {
+                    const int a = grp + NG * i;
+                    if (a < nfc) {
+                        half8_t fw2[2 * CF];
+#pragma unroll
+                        for (int ks = 0; ks < 2 * CF; ks++) fw2[ks] = *(const half8_t*)(w2b + gb * W2B + (a * 2 * CF + ks) * 1024 + lane * 16);
+#pragma unroll
+                        for (int ks = 0; ks < 2 * CF; ks++) acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw2[ks], fy[ks], acc2[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        MB4_TL(5);                                                         // (phase C of a chunk is charged to the next chunk's A, the last one's here)
+        // ---- epilogue: + b2 (+ X), act3, 16-byte stores; lane = output pixel q -----------------------------------------------------------------
+        const long opix = (long)n * P + q;
+#pragma unroll
+        for (int i = 0; i < NFW; i++) {
+            const int a = grp + NG * i;
+            if (a < nfc) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    float o[8];
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; r2++) {
+                        unsigned ua = __builtin_bit_cast(unsigned, acc2[i][4 * (2 * j) + r2] + b2l[a * 32 + 8 * (2 * j) + 4 * hi + r2]);
+                        unsigned ub = __builtin_bit_cast(unsigned, acc2[i][4 * (2 * j + 1) + r2] + b2l[a * 32 + 8 * (2 * j + 1) + 4 * hi + r2]);
+                        sm_permlane32_swap(ua, ub);
+                        o[r2] = __builtin_bit_cast(float, ua); o[4 + r2] = __builtin_bit_cast(float, ub);
+                    }
+                    const int co = a * 32 + 16 * j + 8 * hi;
+                    if (valid && co < p.Cout) {
+                        if (p.res) {                                      // Cin == Cout, stride 1: the block input at the same pixel = my X fragment of k step 2 a + j (same lane layout)
+                            half8_t rv = hz;
+#pragma unroll
+                            for (int aa = 0; aa < NFW * NG; aa++)
+#pragma unroll
+                                for (int jj = 0; jj < 2; jj++) if (2 * aa + jj < KSX && aa == a && jj == j) rv = fx[2 * aa + jj];
+#pragma unroll
+                            for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2];
+                        }
+                        half8_t ov;
+#pragma unroll
+                        for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                        *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
+                    }
+                }
+            }
+        }
+        load_x(n + (int)gridDim.x);                                       // (a block that walks several images: in flight under the next image's first barriers)
+        MB4_TL(6);
+    }
+#ifdef SM_TIMELINE
+    if (threadIdx.x == 0 && blockIdx.x == 0) for (int i = 0; i < 8; i++) g_mb_tl[i] += tl4[i];
+#endif
+}
+
 }  // namespace
 
 extern "C" {
@@ -796,12 +1090,28 @@ static bool mb_v3_ok(const sm_mbconv_desc* d) {
     if (mb_v3_wg(d)) return d->Cin <= 110 && d->Cout <= 96 && mb_v3_lds(d) <= 160 * 1024;      // (five accumulator sets, Cout = 160, spill)
     return (d->expand ? d->Cin <= 46 : !d->residual) && d->Cout <= 64 && mb_v3_lds(d) <= 160 * 1024;
 }
-static int mb_pick(const sm_mbconv_desc* d) {                         // 3, 1 or 2; SMELTER_MBCONV_KERNEL=1|2|3 forces one where it applies
+// v4 (image per block): the expand form at stride 1 on small images (H*W <= 224) with wide hidden tensors; T = 7 | 2 pixel fragments, chunks of 64 channels
+static int mb_v4_T(const sm_mbconv_desc* d) { return (long)d->H * d->W <= 64 ? 2 : 7; }
+static int mb_v4_ksx(const sm_mbconv_desc* d) { const int k = d->Cin / 16; return mb_v4_T(d) == 7 ? (k <= 4 ? 4 : 6) : (k <= 6 ? 6 : 10); }
+static size_t mb_v4_lds(const sm_mbconv_desc* d) {
+    const int CF = 2, CK = CF * 32, HSB = CK * 2 + 16, ChP = (d->Ch + CK - 1) / CK * CK, nfc = (d->Cout + 31) / 32;
+    return (size_t)2 * CF * mb_v4_ksx(d) * 1024 + (size_t)2 * nfc * 2 * CF * 1024 + (size_t)((d->H + 2) * (d->W + 2) + mb_v4_T(d) * 32) * HSB + (size_t)9 * ChP * 2 + (size_t)(2 * ChP + nfc * 32) * 4;
+}
+static bool mb_v4_ok(const sm_mbconv_desc* d) {
+    if (!mb_common_ok(d) || !d->expand || d->stride != 1 || (long)d->H * d->W > 224 || d->W > 64 || (d->Cin & 15) || d->Ch < 128) return false;
+    const int T = mb_v4_T(d);
+    { int rp = 512 / (8 * d->W); if (rp > d->H) rp = d->H; if ((d->H + rp - 1) / rp > 4) return false; }      // (a depthwise task walks <= 4 rows)
+    if (d->Cin / 16 > (T == 7 ? 6 : 10) || d->Cout > (T == 7 ? 96 : 384)) return false;
+    return mb_v4_lds(d) <= 160 * 1024;
+}
+static int mb_pick(const sm_mbconv_desc* d) {                         // 4, 3, 1 or 2; SMELTER_MBCONV_KERNEL=1|2|3|4 forces one where it applies
     const char* fe = getenv("SMELTER_MBCONV_KERNEL"); const int force = fe ? atoi(fe) : 0;          // (read per call: the tests switch it)
-    const bool ok1 = d && mb_v1_ok(d), ok2 = d && mb_v2_ok(d), ok3 = d && mb_v3_ok(d);
+    const bool ok1 = d && mb_v1_ok(d), ok2 = d && mb_v2_ok(d), ok3 = d && mb_v3_ok(d), ok4 = d && mb_v4_ok(d);
     if (force == 1 && ok1) return 1;
     if (force == 2 && ok2) return 2;
     if (force == 3 && ok3) return 3;
+    if (force == 4 && ok4) return 4;
+    if (ok4 && !force) return 4;
     // measured on MobileNet-v2 bs = 256 (tools/mbconv_bench.py): the wave pipelines win everywhere (112^2 -> 56^2: 125 vs 307 us, 56^2: 143 vs 245,
     // 56^2 -> 28^2: 92 vs 122, 28^2: 60 vs 93) except on the 28^2 -> 14^2 block (58 vs 53: one or two ragged tiles per wave)
     if (ok3 && !(ok1 && d->stride == 2 && (long)d->Ho * d->Wo <= 196)) return 3;
@@ -813,10 +1123,11 @@ static int mb_pick(const sm_mbconv_desc* d) {                         // 3, 1 or
 size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d) {
     if (!d) return 0;
     const int k = mb_pick(d);
-    return k == 3 ? mb_v3_lds(d) : k == 1 ? mb_v1_lds(d) : mb_v2_lds(d);
+    return k == 4 ? mb_v4_lds(d) : k == 3 ? mb_v3_lds(d) : k == 1 ? mb_v1_lds(d) : mb_v2_lds(d);
 }
 
 int sm_mbconv_supported(const sm_mbconv_desc* d) { return mb_pick(d) ? 1 : 0; }
+int sm_mbconv_kernel_kind(const sm_mbconv_desc* d) { return mb_pick(d); }
 
 int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const float* b1, const void* wd, const float* bd, const void* w2, const float* b2, void* y,
                   sm_stream_t stream) {
@@ -840,6 +1151,14 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
     fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh); fastdiv_make((unsigned)PW, &p.pw_mul, &p.pw_sh);
     const size_t lds = sm_mbconv_lds_bytes(d);
     const int kernel = mb_pick(d);
+    if (kernel == 4) {                                               // image per block: persistent over the batch, one 8-wave block per CU
+        SM_REQUIRE(((((uintptr_t)w1) | ((uintptr_t)w2)) & 15) == 0, "sm_mbconv_fwd: weights must be 16-byte aligned");
+        p.ChP = (d->Ch + 63) / 64 * 64;
+        const int T = mb_v4_T(d), ksx = mb_v4_ksx(d);
+        void (*fn)(MbParams) = T == 7 ? (ksx == 4 ? mbconv4_kernel<7, 2, 4> : mbconv4_kernel<7, 2, 6>) : (ksx == 6 ? mbconv4_kernel<2, 2, 6> : mbconv4_kernel<2, 2, 10>);
+        hipLaunchKernelGGL(fn, dim3((unsigned)std::min<long>(d->N, SM_NUM_CU)), dim3(512), lds, sm_s(stream), p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
     if (kernel == 3) {                                               // wave pipelines: 4-wave blocks, tiles dealt to waves
         const int th3 = d->stride == 1 ? 4 : 2;
         const long nt3 = (long)d->N * sm_ceil_div(d->Ho, th3) * sm_ceil_div(d->Wo, 8);

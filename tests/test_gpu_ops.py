@@ -577,19 +577,31 @@ def test_conv3x3_reads_through_fused_nearest_upsampling(case, cfg):
     (1, (14, 14), 64, 384, 64, 1, True, True),     # 14x14 blocks: W1 / W2 read as fragments from global memory (five k steps, two cout blocks)
     (2, (14, 14), 96, 576, 96, 1, True, True),     # seven k steps, three cout blocks, 18 chunks
     (1, (15, 13), 64, 384, 96, 2, False, True),    # the same path at stride 2, odd sizes
+    (3, (14, 14), 64, 384, 96, 1, False, True),    # image per block (kernel 4): no residual, three cout fragments, more images than one block walks alone
+    (2, (7, 7), 160, 960, 160, 1, True, True),     # 7x7 blocks: two pixel fragments, cout fragments dealt to four wave groups, 15 chunks
+    (2, (7, 7), 160, 960, 320, 1, False, True),    # ten cout fragments
+    (2, (6, 9), 96, 200, 72, 1, False, True),      # ragged everything: 54 pixels, Ch not a multiple of the chunk, Cout not of 32
+    (1, (13, 15), 48, 136, 48, 1, True, True),     # 195 pixels (6.1 fragments), Cin = 48 on the four-k-step instantiation
 ])
-@pytest.mark.parametrize("kernel", [None, 1, 2, 3])
+@pytest.mark.parametrize("kernel", [None, 1, 2, 3, 4])
 def test_mbconv_fused_block_equals_the_three_layers(n, hw, cin, ch, cout, stride, res, expand, kernel, monkeypatch):
     """sm_mbconv_fwd against the oracle's three convolutions with the hidden tensors rounded to fp16 where the separate launches store them;
     kernel = the launcher's own choice, or one of the three implementations forced (mbconv.hip: all-in-LDS blocks, chunked blocks, wave pipelines)"""
+    from smelter_amd._native import MbConvDesc
+    import ctypes
+    so = lambda v: (v + 2 - 3) // stride + 1
+    dsc = MbConvDesc(n, hw[0], hw[1], so(hw[0]), so(hw[1]), stride, cin, ch, cout, 1 if expand else 0, 1 if res else 0, 1, 0.0, 1, 0.0, 0, 0.0, cin, cout)
     if kernel is not None:
         monkeypatch.setenv("SMELTER_MBCONV_KERNEL", str(kernel))
         v1 = cin <= 32 and ch <= 192 and cout <= 64
         v2 = (not expand or cin <= 64) and cout <= (64 if stride == 1 else 128) and (not res or expand)
         v3 = (cin <= 46 and cout <= 64 and ch <= 192) if expand else True
         v3 = v3 or (expand and ch >= 384 and cin <= 110 and cout <= 96)
-        if not (v1, v2, v3)[kernel - 1]:
+        v4 = ops.lib().sm_mbconv_kernel_kind(ctypes.byref(dsc)) == 4       # (the image-per-block kernel's domain includes an LDS budget: asked, not restated)
+        if not (v1, v2, v3, v4)[kernel - 1]:
             pytest.skip("outside this kernel's domain (the launcher falls back to another one)")
+    elif not ops.lib().sm_mbconv_supported(ctypes.byref(dsc)):
+        pytest.skip("no fused kernel takes this geometry (the executor keeps the three launches)")
     rng = np.random.default_rng(cin * 7 + ch + stride)
     x = h(rng.standard_normal((n, cin, hw[0], hw[1])))
     w1 = h(rng.standard_normal((ch, 1, 1, cin)) * np.sqrt(2.0 / cin)) if expand else None

@@ -14,7 +14,7 @@ def timed(fn, reps=5):
     ts.sort(); return ts[len(ts) // 2]
 n = 256
 for hw, cin, ch, cout, s, res in ((112, 16, 96, 24, 2, False), (56, 24, 144, 24, 1, True), (56, 24, 144, 32, 2, False), (28, 32, 192, 32, 1, True), (28, 32, 192, 64, 2, False), (112, 32, 32, 16, 1, False),
-                                    (14, 64, 384, 64, 1, True), (14, 64, 384, 96, 1, False), (14, 96, 576, 96, 1, True), (14, 96, 576, 160, 2, False), (7, 160, 960, 160, 1, True))[int(os.environ.get("MB_FROM", "0")):]:
+                                    (14, 64, 384, 64, 1, True), (14, 64, 384, 96, 1, False), (14, 96, 576, 96, 1, True), (14, 96, 576, 160, 2, False), (7, 160, 960, 160, 1, True), (7, 160, 960, 320, 1, False))[int(os.environ.get("MB_FROM", "0")):]:
     from smelter_amd._native import MbConvDesc
     import ctypes
     if not ops.lib().sm_mbconv_supported(ctypes.byref(MbConvDesc(n, hw, hw, (hw + 2 - 3) // s + 1, (hw + 2 - 3) // s + 1, s, cin, ch, cout, 1 if ch != cin else 0, 1 if res else 0, 1, 0.0, 1, 0.0, 0, 0.0, cin, cout))):
