@@ -34,6 +34,7 @@ struct MbParams {
     int act1, act2, act3; float sl1, sl2, sl3;
     int ChP, hstride;                // Ch rounded up to 32; LDS bytes per hidden pixel = ChP*2 + 16 (an odd number of 16-byte slots: conflict-free b128 columns)
     int tiles_x, tiles_y, ntiles;
+    int tile_o;                      // v4: side of the square output tile (14 at stride 1, 7 at stride 2; <= the image)
     unsigned tx_mul, tx_sh, txy_mul, txy_sh, pw_mul, pw_sh;
     // v3 IMC (the block behind an image stem): the "expand" layer is the stem's 3x3 convolution of the fp32 NCHW image `xf` (3 planes of in_H x in_W,
     // stride st_s, padding st_p): K = 27 taps (kh, kw, c) + the two bias columns, gathered per patch pixel; H x W above = the stem's OUTPUT image
@@ -732,38 +733,40 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     }
 }
 
-// ---- v4: one IMAGE per block, every hidden chunk shared by the block's waves --------------------------------------------------------------
-// MobileNet-v2's 14 x 14 and 7 x 7 blocks (Ch = 384 / 576 / 960) in v3 are one wave per 4 x 8 tile walking 12..30 chunks in a single dependent chain
-// (expand MFMAs -> LDS -> depthwise -> LDS -> project MFMAs, W1 / W2 fragments from global memory per chunk): 49..71 us per block at 14 x 14 although
-// no resource is busy, and nothing at 7 x 7; the 6 x 10 patch of a 4 x 8 tile also computes the expand layer 1.9 times.  Here the tile is the WHOLE
-// image (zero padding is then the layer's own, nothing is recomputed) and the eight waves of a block cut every phase of a chunk between them:
-//   A  expand: the wave that owns pixel fragment pf (32 pixels, its X fragments stay in registers for the whole image) multiplies them with the
-//      chunk's W1 rows (CF fragments of 32 hidden channels, A operand from LDS; bias = one more k step against a {hi(b), lo(b)} fragment) and writes
-//      act1(.) rounded to fp16 into the block's hidden image [(H+2) x (W+2)][chunk channels] (border = the depthwise layer's zero padding, written once);
-//   B  depthwise 3x3: the 512 lanes are (column, channel vector of 8, row part) tasks over the hidden image, a task walks its rows with a three-row
-//      window in registers (3 LDS reads + 72 fp32 FMAs per output), act2, one rounding -> [pixel][chunk channels], the B operand of
-//   C  project: wave (pf, g) accumulates its cout fragments (a = g mod NG) over the chunk's k steps, W2's chunk columns from LDS.
-//   The chunk weights arrive by LDS-DMA in MFMA-fragment order (1 KB per fragment = one wave instruction, lane-linear: conflict-free reads, no registers),
-//   two buffers each: phase B of chunk g requests W1 of chunk g+2 and W2 of chunk g+1 and first waits for the group requested one chunk earlier —
-//   a whole chunk of flight time, nothing else in the loop touches global memory.  Two barriers per chunk (A | B | C + next A); the accumulators of C
-//   live across chunks, epilogue (+ b2, + X, act3, 16-byte stores) per image.
-// T = pixel fragments of an image (7: H*W <= 224, waves 0..6 own one each; 2: H*W <= 64, waves = (pf, g) with four cout groups g),
-// CF = hidden fragments per chunk, KSX = k steps of X (Cin / 16, runtime p.Cin may be smaller: zero steps are skipped).  Stride 1 only.
+// ---- v4: one TILE per block, every hidden chunk shared by the block's eight waves ------------------------------------------------------------------
+// v3 is one wave per 4 x 8 tile walking its chunks in a single dependent chain (expand MFMAs -> LDS -> depthwise -> LDS -> project MFMAs): nothing in
+// a CU is busy, the 6 x 10 patch of a 4 x 8 tile computes the expand layer 1.9 times, and from Ch = 384 on the weights come from global memory per
+// chunk.  Here a block owns a tile of TO x TO output pixels (14 x 14 at stride 1, 7 x 7 at stride 2: a patch of 16 x 16 / 15 x 15 hidden pixels = the
+// eight waves' eight 32-pixel fragments; a 14 x 14 or 7 x 7 image is one tile) and the waves cut every phase of a 64-channel chunk between them:
+//   A  expand: wave w multiplies the X fragments of patch fragment w (registers, loaded once per tile straight from global memory; pixels outside the
+//      image are zero fragments AND have a zero in the bias column, so their hidden value is act1(0) = 0: the depthwise layer's padding) with the
+//      chunk's W1 rows (two A fragments per k step from LDS; bias = one more k step against a {hi(b), lo(b)} fragment) and writes act1(.) rounded to
+//      fp16 into the block's hidden patch [PW x PW][64 channels];
+//   B  depthwise 3x3: the 512 lanes are (column, channel vector of 8, row part) tasks over the tile; at stride 1 a task walks its rows with a
+//      three-row window in registers (3 LDS reads + 72 fp32 FMAs per output), act2, one rounding -> [output pixel][64 channels], the B operand of
+//   C  project: wave (pf, g) accumulates its cout fragments (a = g mod NG) for output fragment pf over the chunk's four k steps, W2's chunk columns
+//      from LDS; the accumulators live across the chunks, epilogue (+ b2, + X, act3, 16-byte stores) per tile.
+//   The chunk weights arrive by LDS-DMA in MFMA-fragment order (1 KB per fragment = one wave instruction, lane-linear: conflict-free reads, no
+//   registers), two buffers each: phase B of chunk g requests W1 of chunk g+2 and W2 of chunk g+1 and first waits for the group requested one chunk
+//   earlier — a whole chunk of flight time; the next tile's X fragments and the residual rows are requested under the last chunk.
+//   Two barriers per chunk (A | B | C + next A).
+// S = stride, TCF = output fragments of a tile that phase C deals to the waves (7: 14 x 14 tiles, one per wave; 2: <= 64 output pixels, waves =
+// (fragment, cout group of four)), KSX = k steps of X (ceil(Cin / 16)), NFW = cout fragments per wave.
 __device__ __attribute__((aligned(64))) unsigned int g_mb_zero[16];       // zero-initialised at module load: source of the fragments beyond Ch / Cout / Cin
 #define MB_GLDS16(gptr, ldsptr) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
-template <int T, int CF, int KSX>
+template <int S, int TCF, int KSX, int NFW>
 __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
-    constexpr int NT = 512, TP = T > 4 ? 8 : (T > 2 ? 4 : 2), NG = 8 / TP, NFW = 3, CK = CF * 32, HSB = CK * 2 + 16, NCV = CF * 4, RPTM = 4;
-    constexpr int F1 = CF * KSX, W1B = F1 * 1024, NI1 = (F1 + 7) / 8, NI2 = (NFW * NG * 2 * CF + 7) / 8, ACF = (CF + NG - 1) / NG;
+    constexpr int NT = 512, CF = 2, TP = TCF > 4 ? 8 : (TCF > 2 ? 4 : 2), NG = 8 / TP, CK = CF * 32, HSB = CK * 2 + 16, NCV = CF * 4, RPTM = 4, HPA = 256;
+    constexpr int F1 = CF * KSX, W1B = F1 * 1024, NI1 = (F1 + 7) / 8, NI2 = (NFW * NG * 2 * CF + 7) / 8;
     extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
-    const int H = p.H, W = p.W, P = H * W, PW = W + 2, HP = (H + 2) * PW;
-    const int ChP = p.ChP, NC = ChP / CK, nfc = (p.Cout + 31) >> 5, CoP = nfc * 32, ksx = p.Cin >> 4, F2 = nfc * 2 * CF, W2B = F2 * 1024;
+    const int TO = p.tile_o, PW = (TO - 1) * S + 3, HP = PW * PW, TOO = TO * TO;
+    const int ChP = p.ChP, NC = ChP / CK, nfc = (p.Cout + 31) >> 5, CoP = nfc * 32, F2 = nfc * 2 * CF, W2B = F2 * 1024;
     unsigned char* const w1b = mb_smem;                                   // [2][CF][KSX] fragments of 1 KB
     unsigned char* const w2b = w1b + 2 * W1B;                             // [2][nfc][2 CF] fragments
-    unsigned char* const hid = w2b + 2 * W2B;                             // [(H+2)(W+2)][HSB]
-    unsigned char* const dwo = hid + HP * HSB;                            // [T*32][HSB]
-    half_t* const wdl = (half_t*)(dwo + T * 32 * HSB);                    // [9][ChP]
+    unsigned char* const hid = w2b + 2 * W2B;                             // [256 patch pixels][HSB]
+    unsigned char* const dwo = hid + HPA * HSB;                           // [TCF*32 output pixels][HSB]
+    half_t* const wdl = (half_t*)(dwo + TCF * 32 * HSB);                  // [9][ChP]
     float* const bdl = (float*)(wdl + 9 * ChP);                           // [ChP]
     float* const b1l = bdl + ChP;                                         // [ChP]
     float* const b2l = b1l + ChP;                                         // [CoP]
@@ -779,8 +782,8 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
         for (int i = 0; i < NI1; i++) {
             const int f = wave + 8 * i;
             if (f < F1) {
-                const int cf = f / KSX, ks = f - cf * KSX, ch = c * CK + cf * 32 + l31;
-                MB_GLDS16((ch < p.Ch && ks < ksx) ? p.w1 + (long)ch * p.Cin + ks * 16 + hi * 8 : zero, w1b + b * W1B + f * 1024);
+                const int cf = f / KSX, ks = f - cf * KSX, ch = c * CK + cf * 32 + l31, k = ks * 16 + hi * 8;
+                MB_GLDS16((ch < p.Ch && k < p.Cin) ? p.w1 + (long)ch * p.Cin + k : zero, w1b + b * W1B + f * 1024);
             }
         }
     };
@@ -801,15 +804,25 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
 #define MB4_TL(i)
 #endif
     dma_w1(0, 0); dma_w2(0, 0); dma_w1(NC > 1 ? 1 : 0, 1);
+    // ---- lane constants: my patch pixel (phase A), my output pixel (phase C, epilogue) ----
+    const int pp = wave * 32 + l31, ppy = pp / PW, ppx = pp - ppy * PW;   // (pp >= HP: rows beyond the patch, written and never read)
     const int pf = wave % TP, grp = wave / TP;
-    const bool act_pf = pf < T;
-    const int q = pf * 32 + l31;                                          // my pixel of the image (phases A and C, epilogue)
-    const bool valid = act_pf && q < P;
-    half8_t fx[KSX];                                                      // X fragments of my pixel fragment: loaded a whole image ahead (here: under the prologue)
-    auto load_x = [&](int n) {
-        const half_t* const xim = p.x + (long)n * P * p.x_ld;
+    const bool act_pf = pf < TCF;
+    const int q = pf * 32 + l31, qy = q / TO, qx = q - qy * TO;
+    auto tile_origin = [&](int t, int& n, int& oy0, int& ox0) {
+        n = (int)fastdiv((unsigned)t, p.txy_mul, p.txy_sh);
+        const int r = t - n * (p.tiles_x * p.tiles_y), by = (int)fastdiv((unsigned)r, p.tx_mul, p.tx_sh);
+        oy0 = by * TO; ox0 = (r - by * p.tiles_x) * TO;
+    };
+    constexpr bool PREF = KSX <= 4;                                       // the next tile's X fragments are requested under the last chunk (a second register set: short K only)
+    half8_t fx[KSX]; bool inimg;                                          // X fragments of my patch fragment + "my patch pixel is inside the image"
+    auto load_x = [&](int t) {
+        int n, oy0, ox0; tile_origin(t < p.ntiles ? t : 0, n, oy0, ox0);
+        const int iy = oy0 * S - 1 + ppy, ix = ox0 * S - 1 + ppx;
+        inimg = t < p.ntiles && pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const half_t* const src = p.x + (((long)n * p.H + iy) * p.W + ix) * p.x_ld;
 #pragma unroll
-        for (int ks = 0; ks < KSX; ks++) fx[ks] = (valid && ks < ksx && n < p.N) ? *(const half8_t*)(xim + (long)q * p.x_ld + ks * 16 + hi * 8) : hz;
+        for (int ks = 0; ks < KSX; ks++) { const int k = ks * 16 + hi * 8; fx[ks] = (inimg && k < p.Cin) ? *(const half8_t*)(src + k) : hz; }
     };
     load_x(blockIdx.x);
     {   // depthwise weights [Ch][9] -> [9][ChP]: the loads of a batch are independent (one round trip per batch, not per element)
@@ -824,37 +837,44 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
     }
     for (int i = tid; i < ChP; i += NT) { bdl[i] = (p.bd && i < p.Ch) ? p.bd[i] : 0.f; b1l[i] = (p.b1 && i < p.Ch) ? p.b1[i] : 0.f; }
     for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
-    for (int i = tid; i < HP * HSB / 16; i += NT) *(half8_t*)(hid + i * 16) = hz;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     MB4_TL(0);
 
-    // ---- lane constants ----
-    const int qy = q / W, qx = q - qy * W;
-    const unsigned hid_q = (unsigned)(((qy + 1) * PW + qx + 1) * HSB);
-    // depthwise tasks = (column, channel vector, row part): RP row parts, the first H % RP of them one row longer.  A wave takes tasks of ONE row part
-    // when the parts split evenly over the waves (RP | 8: lanes = (column, cv) pairs, NCV * W / (8 / RP) per wave), and waves w, w + 4 — SIMD partners —
-    // take parts from opposite ends of the list, so that every SIMD sees the same number of rows; otherwise tasks are dealt lane-linearly.
-    int RP = NT / (NCV * W); if (RP > H) RP = H;
+    // depthwise tasks = (column, channel vector, row part) over the TO x TO tile: RP row parts, the first TO % RP of them one row longer.  A wave takes
+    // tasks of ONE row part when the parts split evenly over the waves (RP | 8), and waves w, w + 4 — SIMD partners — take parts from opposite ends of
+    // the list, so that every SIMD sees the same number of rows; otherwise tasks are dealt lane-linearly.
+    int RP = NT / (NCV * TO); if (RP > TO) RP = TO;
     int cv, tx, rp; bool task_on;
-    if ((8 % RP) == 0 && ((NCV * W) % (8 / RP)) == 0 && NCV * W / (8 / RP) <= 64) {
-        const int wpp = 8 / RP, per = NCV * W / wpp;                      // waves per part, tasks per wave
+    if ((8 % RP) == 0 && ((NCV * TO) % (8 / RP)) == 0 && NCV * TO / (8 / RP) <= 64) {
+        const int wpp = 8 / RP, per = NCV * TO / wpp;                     // waves per part, tasks per wave
         const int part = wave < 4 ? wave / wpp : RP - 1 - (wave - 4) / wpp, sub = wave % wpp;
         const int id = sub * per + lane;
         rp = part; cv = id % NCV; tx = id / NCV; task_on = lane < per;
-        if (tx >= W) tx = W - 1;
+        if (tx >= TO) tx = TO - 1;
     } else {
         const int trest = tid / NCV;
-        cv = tid % NCV; tx = trest % W; rp = trest / W; task_on = rp < RP;
+        cv = tid % NCV; tx = trest % TO; rp = trest / TO; task_on = rp < RP;
     }
-    const int rlong = H % RP, rbase = H / RP;
+    const int rlong = TO % RP, rbase = TO / RP;
     const int ty0 = rp * rbase + (rp < rlong ? rp : rlong), ty1 = task_on ? ty0 + rbase + (rp < rlong ? 1 : 0) : 0;
     const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;
 
-    int g = 0;                                                            // chunks done since the launch (buffer parity), cw = g % NC (the chunk's channels)
+    int g = 0;                                                            // chunks done since the launch (buffer parity); the chunk's channels = g % NC
 #pragma unroll 1
-    for (int n = blockIdx.x; n < p.N; n += gridDim.x) {
-        half8_t fone = hz; if (valid && !hi) { fone[0] = (half_t)1.f; fone[1] = (half_t)1.f; }
+    for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x) {
+        int n, oy0, ox0; tile_origin(t, n, oy0, ox0);
+        const int oy = oy0 + qy, ox = ox0 + qx;
+        const bool valid = act_pf && q < TOO && oy < p.Ho && ox < p.Wo;   // my output pixel exists
+        const long opix = ((long)n * p.Ho + oy) * p.Wo + ox;
+        if (!PREF && t != (int)blockIdx.x) load_x(t);
+        half8_t fone = hz; if (inimg && !hi) { fone[0] = (half_t)1.f; fone[1] = (half_t)1.f; }
+        half8_t fxc[PREF ? KSX : 1];                                      // PREF: this tile's fragments (fx is refilled with the next tile's under the last chunk)
+        if constexpr (PREF) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ks++) fxc[ks] = fx[ks];
+        }
+        half8_t rres[NFW][2];                                             // residual rows of my output pixel (requested under the last chunk)
         floatx16 acc2[NFW];
 #pragma unroll
         for (int a = 0; a < NFW; a++)
@@ -864,56 +884,63 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
         for (int c = 0; c < NC; c++, g++) {
             const int gb = g & 1;
             // ---- phase A ----------------------------------------------------------------------------------------------------------------
-            if (act_pf) {
-                half8_t fw[ACF][KSX];                                     // all fragments first: one LDS round trip, then the row blocks' MFMA chains interleaved
-                float bv[ACF];
+            {
+                half8_t fw[CF][KSX];                                      // all fragments first: one LDS round trip, then the two row blocks' MFMA chains interleaved
+                float bv[CF];
 #pragma unroll
-                for (int i = 0; i < ACF; i++) {
-                    const int cf = grp + NG * i < CF ? grp + NG * i : CF - 1;
+                for (int cf = 0; cf < CF; cf++) {
 #pragma unroll
-                    for (int ks = 0; ks < KSX; ks++) fw[i][ks] = *(const half8_t*)(w1b + gb * W1B + (cf * KSX + ks) * 1024 + lane * 16);
-                    bv[i] = b1l[c * CK + cf * 32 + l31];
+                    for (int ks = 0; ks < KSX; ks++) fw[cf][ks] = *(const half8_t*)(w1b + gb * W1B + (cf * KSX + ks) * 1024 + lane * 16);
+                    bv[cf] = b1l[c * CK + cf * 32 + l31];
                 }
-                floatx16 acc[ACF];
+                floatx16 acc[CF];
 #pragma unroll
-                for (int i = 0; i < ACF; i++) {
+                for (int cf = 0; cf < CF; cf++) {
                     half8_t fb = hz;
-                    if (!hi) { const half_t bh = (half_t)bv[i]; fb[0] = bh; fb[1] = (half_t)(bv[i] - (float)bh); }
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fone, (floatx16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    if (!hi) { const half_t bh = (half_t)bv[cf]; fb[0] = bh; fb[1] = (half_t)(bv[cf] - (float)bh); }
+                    acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fone, (floatx16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                 }
 #pragma unroll
                 for (int ks = 0; ks < KSX; ks++)
 #pragma unroll
-                    for (int i = 0; i < ACF; i++) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[i][ks], fx[ks], acc[i], 0, 0, 0);      // (k steps beyond Cin: zero fragments on both sides)
+                    for (int cf = 0; cf < CF; cf++) acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[cf][ks], PREF ? fxc[PREF ? ks : 0] : fx[ks], acc[cf], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < ACF; i++) {
-                    const int cf = grp + NG * i;
-                    if (cf < CF) {
+                for (int cf = 0; cf < CF; cf++)
 #pragma unroll
-                        for (int qq = 0; qq < 4; qq++) {
-                            half4_t o;
-                            if (relu1) {
+                    for (int qq = 0; qq < 4; qq++) {
+                        half4_t o;
+                        if (relu1) {
 #pragma unroll
-                                for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[i][4 * qq + r2];
-                                o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
-                            } else {
+                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[cf][4 * qq + r2];
+                            o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                        } else {
 #pragma unroll
-                                for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[i][4 * qq + r2], p.sl1);
-                            }
-                            if (valid) *(half4_t*)(hid + hid_q + (cf * 32 + 8 * qq + 4 * hi) * 2) = o;
+                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[cf][4 * qq + r2], p.sl1);
                         }
+                        *(half4_t*)(hid + pp * HSB + (cf * 32 + 8 * qq + 4 * hi) * 2) = o;
                     }
-                }
             }
             MB4_TL(1);
-            mb_lds_barrier();                                             // the hidden image of chunk c is complete; C(c-1) is over everywhere
+            mb_lds_barrier();                                             // the hidden patch of chunk c is complete; C(c-1) is over everywhere
             MB4_TL(2);
             // ---- phase B ----------------------------------------------------------------------------------------------------------------
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my share of W1(g+1), W2(g), requested one chunk ago (first chunk of an image: + X, residual loads)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // my share of W1(g+1), W2(g), requested one chunk ago
             MB4_TL(7);
             {
                 const int c2 = (c + 2) % NC, c1 = c + 1 < NC ? c + 1 : 0;
                 dma_w1(c2, gb); dma_w2(c1, gb ^ 1);                       // W1(g) was read in A(g), W2(g-1) in C(g-1): both buffers are free
+            }
+            if (c == NC - 1) {                                            // under the last chunk: the next tile's X fragments, this tile's residual rows
+                if constexpr (PREF) load_x(t + (int)gridDim.x);
+                if (p.res) {
+#pragma unroll
+                    for (int i = 0; i < NFW; i++)
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const int co = (grp + NG * i) * 32 + 16 * j + 8 * hi;
+                            rres[i][j] = (valid && co < p.Cout) ? *(const half8_t*)(p.x + opix * p.x_ld + co) : hz;      // stride 1, Cin == Cout: the block input at the same pixel
+                        }
+                }
             }
             if (ty0 < ty1) {
                 const int chl = c * CK + cv * 8;
@@ -921,43 +948,70 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
 #pragma unroll
                 for (int tp = 0; tp < 9; tp++) wreg[tp] = *(const u32x4*)(wdl + tp * ChP + chl);
                 const floatx4 bd0 = *(const floatx4*)(bdl + chl), bd1 = *(const floatx4*)(bdl + chl + 4);
-                const unsigned char* const hcol = hid + tx * HSB + cv * 16;  // padded column tx (= image column tx - 1) of my channel vector
-                u32x4 win[3][3];
+                const unsigned char* const hcol = hid + tx * S * HSB + cv * 16;   // patch column of tap kw = 0 for my output column, my channel vector
+                auto finish = [&](float* a, int y) __attribute__((always_inline)) {
+                    half8_t ov;
+                    if (relu2) {
 #pragma unroll
-                for (int k = 0; k < 2; k++)
+                        for (int j = 0; j < 8; j++) ov[j] = (half_t)a[j];
+                        ov = __builtin_elementwise_max(ov, hz);
+                    } else {
 #pragma unroll
-                    for (int kw = 0; kw < 3; kw++) win[k][kw] = *(const u32x4*)(hcol + ((ty0 + k) * PW + kw) * HSB);
+                        for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+                    }
+                    *(half8_t*)(dwo + (y * TO + tx) * HSB + cv * 16) = ov;
+                };
+                if constexpr (S == 1) {
+                    u32x4 win[3][3];
 #pragma unroll
-                for (int i = 0; i < RPTM; i++) {
-                    const int y = ty0 + i;
-                    if (y < ty1) {
+                    for (int k = 0; k < 2; k++)
 #pragma unroll
-                        for (int kw = 0; kw < 3; kw++) win[(i + 2) % 3][kw] = *(const u32x4*)(hcol + ((y + 2) * PW + kw) * HSB);
+                        for (int kw = 0; kw < 3; kw++) win[k][kw] = *(const u32x4*)(hcol + ((ty0 + k) * PW + kw) * HSB);
+#pragma unroll
+                    for (int i = 0; i < RPTM; i++) {
+                        const int y = ty0 + i;
+                        if (y < ty1) {
+#pragma unroll
+                            for (int kw = 0; kw < 3; kw++) win[(i + 2) % 3][kw] = *(const u32x4*)(hcol + ((y + 2) * PW + kw) * HSB);
+                            float a[8];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) { a[j] = bd0[j]; a[4 + j] = bd1[j]; }
+#pragma unroll
+                            for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                                for (int kw = 0; kw < 3; kw++) {
+                                    const u32x4 xu = win[(i + kh) % 3][kw];
+                                    const u32x4 wu = wreg[kh * 3 + kw];
+#pragma unroll
+                                    for (int d2 = 0; d2 < 4; d2++) {
+                                        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2]) : "v"(xu[d2]), "v"(wu[d2]));
+                                        asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2 + 1]) : "v"(xu[d2]), "v"(wu[d2]));
+                                    }
+                                }
+                            finish(a, y);
+                        }
+                    }
+                } else {
+#pragma unroll 1
+                    for (int y = ty0; y < ty1; y++) {
+                        u32x4 xv[9];
+#pragma unroll
+                        for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                            for (int kw = 0; kw < 3; kw++) xv[kh * 3 + kw] = *(const u32x4*)(hcol + ((y * S + kh) * PW + kw) * HSB);
                         float a[8];
 #pragma unroll
                         for (int j = 0; j < 4; j++) { a[j] = bd0[j]; a[4 + j] = bd1[j]; }
 #pragma unroll
-                        for (int kh = 0; kh < 3; kh++)
+                        for (int tp = 0; tp < 9; tp++) {
+                            const u32x4 xu = xv[tp], wu = wreg[tp];
 #pragma unroll
-                            for (int kw = 0; kw < 3; kw++) {
-                                const u32x4 xu = win[(i + kh) % 3][kw];
-                                const u32x4 wu = wreg[kh * 3 + kw];
-#pragma unroll
-                                for (int d2 = 0; d2 < 4; d2++) {
-                                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2]) : "v"(xu[d2]), "v"(wu[d2]));
-                                    asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2 + 1]) : "v"(xu[d2]), "v"(wu[d2]));
-                                }
+                            for (int d2 = 0; d2 < 4; d2++) {
+                                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2]) : "v"(xu[d2]), "v"(wu[d2]));
+                                asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2 + 1]) : "v"(xu[d2]), "v"(wu[d2]));
                             }
-                        half8_t ov;
-                        if (relu2) {
-#pragma unroll
-                            for (int j = 0; j < 8; j++) ov[j] = (half_t)a[j];
-                            ov = __builtin_elementwise_max(ov, hz);
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
                         }
-                        *(half8_t*)(dwo + (y * W + tx) * HSB + cv * 16) = ov;
+                        finish(a, y);
                     }
                 }
             }
@@ -984,7 +1038,6 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
         }
         MB4_TL(5);                                                         // (phase C of a chunk is charged to the next chunk's A, the last one's here)
         // ---- epilogue: + b2 (+ X), act3, 16-byte stores; lane = output pixel q -----------------------------------------------------------------
-        const long opix = (long)n * P + q;
 #pragma unroll
         for (int i = 0; i < NFW; i++) {
             const int a = grp + NG * i;
@@ -1001,14 +1054,9 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
                     }
                     const int co = a * 32 + 16 * j + 8 * hi;
                     if (valid && co < p.Cout) {
-                        if (p.res) {                                      // Cin == Cout, stride 1: the block input at the same pixel = my X fragment of k step 2 a + j (same lane layout)
-                            half8_t rv = hz;
+                        if (p.res) {
 #pragma unroll
-                            for (int aa = 0; aa < NFW * NG; aa++)
-#pragma unroll
-                                for (int jj = 0; jj < 2; jj++) if (2 * aa + jj < KSX && aa == a && jj == j) rv = fx[2 * aa + jj];
-#pragma unroll
-                            for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2];
+                            for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rres[i][j][r2];
                         }
                         half8_t ov;
 #pragma unroll
@@ -1018,7 +1066,6 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
                 }
             }
         }
-        load_x(n + (int)gridDim.x);                                       // (a block that walks several images: in flight under the next image's first barriers)
         MB4_TL(6);
     }
 #ifdef SM_TIMELINE
@@ -1090,18 +1137,19 @@ static bool mb_v3_ok(const sm_mbconv_desc* d) {
     if (mb_v3_wg(d)) return d->Cin <= 110 && d->Cout <= 96 && mb_v3_lds(d) <= 160 * 1024;      // (five accumulator sets, Cout = 160, spill)
     return (d->expand ? d->Cin <= 46 : !d->residual) && d->Cout <= 64 && mb_v3_lds(d) <= 160 * 1024;
 }
-// v4 (image per block): the expand form at stride 1 on small images (H*W <= 224) with wide hidden tensors; T = 7 | 2 pixel fragments, chunks of 64 channels
-static int mb_v4_T(const sm_mbconv_desc* d) { return (long)d->H * d->W <= 64 ? 2 : 7; }
-static int mb_v4_ksx(const sm_mbconv_desc* d) { const int k = d->Cin / 16; return mb_v4_T(d) == 7 ? (k <= 4 ? 4 : 6) : (k <= 6 ? 6 : 10); }
+// v4 (tile per block, the waves share every chunk): the expand form at stride 1 | 2 on any image; tiles of 14 x 14 (stride 1) / 7 x 7 (stride 2) output
+// pixels, chunks of 64 channels; phase C deals 7 output fragments to 7 waves (cout <= 96) or, for tiles of <= 64 pixels, 2 fragments x 4 cout groups
+static int mb_v4_tile(const sm_mbconv_desc* d) { const int m = d->stride == 1 ? 14 : 7, o = d->Ho > d->Wo ? d->Ho : d->Wo; return o < m ? o : m; }
+static int mb_v4_tcf(const sm_mbconv_desc* d) { const int t = mb_v4_tile(d); return t * t <= 64 ? 2 : 7; }
+static int mb_v4_ksx(const sm_mbconv_desc* d) { const int k = (d->Cin + 15) / 16; return k <= 2 ? 2 : k <= 4 ? 4 : k <= 6 ? 6 : 10; }
+static int mb_v4_nfw(const sm_mbconv_desc* d) { const int nfc = (d->Cout + 31) / 32, ng = mb_v4_tcf(d) == 7 ? 1 : 4; return (nfc + ng - 1) / ng; }
 static size_t mb_v4_lds(const sm_mbconv_desc* d) {
     const int CF = 2, CK = CF * 32, HSB = CK * 2 + 16, ChP = (d->Ch + CK - 1) / CK * CK, nfc = (d->Cout + 31) / 32;
-    return (size_t)2 * CF * mb_v4_ksx(d) * 1024 + (size_t)2 * nfc * 2 * CF * 1024 + (size_t)((d->H + 2) * (d->W + 2) + mb_v4_T(d) * 32) * HSB + (size_t)9 * ChP * 2 + (size_t)(2 * ChP + nfc * 32) * 4;
+    return (size_t)2 * CF * mb_v4_ksx(d) * 1024 + (size_t)2 * nfc * 2 * CF * 1024 + (size_t)(256 + mb_v4_tcf(d) * 32) * HSB + (size_t)9 * ChP * 2 + (size_t)(2 * ChP + nfc * 32) * 4;
 }
 static bool mb_v4_ok(const sm_mbconv_desc* d) {
-    if (!mb_common_ok(d) || !d->expand || d->stride != 1 || (long)d->H * d->W > 224 || d->W > 64 || (d->Cin & 15) || d->Ch < 128) return false;
-    const int T = mb_v4_T(d);
-    { int rp = 512 / (8 * d->W); if (rp > d->H) rp = d->H; if ((d->H + rp - 1) / rp > 4) return false; }      // (a depthwise task walks <= 4 rows)
-    if (d->Cin / 16 > (T == 7 ? 6 : 10) || d->Cout > (T == 7 ? 96 : 384)) return false;
+    if (!mb_common_ok(d) || !d->expand || d->Cin > 160 || d->Ch < 64) return false;
+    if (mb_v4_nfw(d) > 3) return false;                               // (three accumulator sets per wave: cout <= 96 on 14 x 14 tiles, <= 384 on small ones)
     return mb_v4_lds(d) <= 160 * 1024;
 }
 static int mb_pick(const sm_mbconv_desc* d) {                         // 4, 3, 1 or 2; SMELTER_MBCONV_KERNEL=1|2|3|4 forces one where it applies
@@ -1111,7 +1159,12 @@ static int mb_pick(const sm_mbconv_desc* d) {                         // 4, 3, 1
     if (force == 2 && ok2) return 2;
     if (force == 3 && ok3) return 3;
     if (force == 4 && ok4) return 4;
-    if (ok4 && !force) return 4;
+    // v4 measured against v3 / the three launches per MobileNet-v2 block (bs 256, cold, tools/mbconv_bench.py): 28^2 45.6 vs 61.5 us, 28^2 -> 14^2 33.7 vs 53, 14^2 30 vs 52 /
+    // 36 vs 54 / 51 vs 80, 14^2 -> 7^2 (Ch 576 -> 160) 35 vs 70 as three launches; it LOSES on the large images (56^2: 166 vs 141, 112^2 -> 56^2: 293 vs 122 — sixteen
+    // and more tiles per CU, each a chain of barrier-separated phases, against v3's sixteen independent waves) and on the 7^2 blocks (82 vs 61 as three launches:
+    // eleven k steps, 15 chunks, spills), which stay where they were
+    // => v4 for images of at most four tiles (56^2 -> 28^2 has sixteen 7 x 7 tiles: 107 vs 90 us)
+    if (ok4 && !force && sm_ceil_div(d->Ho, mb_v4_tile(d)) * sm_ceil_div(d->Wo, mb_v4_tile(d)) <= 4 && !(d->stride == 1 && mb_v4_tcf(d) == 2)) return 4;
     // measured on MobileNet-v2 bs = 256 (tools/mbconv_bench.py): the wave pipelines win everywhere (112^2 -> 56^2: 125 vs 307 us, 56^2: 143 vs 245,
     // 56^2 -> 28^2: 92 vs 122, 28^2: 60 vs 93) except on the 28^2 -> 14^2 block (58 vs 53: one or two ragged tiles per wave)
     if (ok3 && !(ok1 && d->stride == 2 && (long)d->Ho * d->Wo <= 196)) return 3;
@@ -1151,12 +1204,24 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
     fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh); fastdiv_make((unsigned)PW, &p.pw_mul, &p.pw_sh);
     const size_t lds = sm_mbconv_lds_bytes(d);
     const int kernel = mb_pick(d);
-    if (kernel == 4) {                                               // image per block: persistent over the batch, one 8-wave block per CU
+    if (kernel == 4) {                                               // tile per block: persistent over the tiles, one 8-wave block per CU
         SM_REQUIRE(((((uintptr_t)w1) | ((uintptr_t)w2)) & 15) == 0, "sm_mbconv_fwd: weights must be 16-byte aligned");
         p.ChP = (d->Ch + 63) / 64 * 64;
-        const int T = mb_v4_T(d), ksx = mb_v4_ksx(d);
-        void (*fn)(MbParams) = T == 7 ? (ksx == 4 ? mbconv4_kernel<7, 2, 4> : mbconv4_kernel<7, 2, 6>) : (ksx == 6 ? mbconv4_kernel<2, 2, 6> : mbconv4_kernel<2, 2, 10>);
-        hipLaunchKernelGGL(fn, dim3((unsigned)std::min<long>(d->N, SM_NUM_CU)), dim3(512), lds, sm_s(stream), p);
+        const int to = mb_v4_tile(d), tcf = mb_v4_tcf(d), ksx = mb_v4_ksx(d), nfw = mb_v4_nfw(d);
+        p.tile_o = to; p.tiles_x = sm_ceil_div(d->Wo, to); p.tiles_y = sm_ceil_div(d->Ho, to);
+        const long nt4 = (long)d->N * p.tiles_x * p.tiles_y;
+        SM_REQUIRE(nt4 < (1L << 31), "sm_mbconv_fwd: too many tiles");
+        p.ntiles = (int)nt4;
+        fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
+        void (*fn)(MbParams) = nullptr;
+#define MB4_PICK(S_, T_) (ksx == 2 ? (nfw == 1 ? mbconv4_kernel<S_, T_, 2, 1> : nfw == 2 ? mbconv4_kernel<S_, T_, 2, 2> : mbconv4_kernel<S_, T_, 2, 3>) \
+                        : ksx == 4 ? (nfw <= 2 ? mbconv4_kernel<S_, T_, 4, 2> : mbconv4_kernel<S_, T_, 4, 3>) \
+                        : ksx == 6 ? (nfw <= 2 ? mbconv4_kernel<S_, T_, 6, 2> : mbconv4_kernel<S_, T_, 6, 3>) \
+                                   : (nfw <= 2 ? mbconv4_kernel<S_, T_, 10, 2> : mbconv4_kernel<S_, T_, 10, 3>))
+        if (d->stride == 1) fn = tcf == 7 ? MB4_PICK(1, 7) : MB4_PICK(1, 2);
+        else fn = MB4_PICK(2, 2);
+#undef MB4_PICK
+        hipLaunchKernelGGL(fn, dim3((unsigned)std::min<long>(nt4, SM_NUM_CU)), dim3(512), lds, sm_s(stream), p);
         SM_LAUNCH_CHECK(); return SM_OK;
     }
     if (kernel == 3) {                                               // wave pipelines: 4-wave blocks, tiles dealt to waves
