@@ -253,9 +253,11 @@ __global__ __launch_bounds__(512) void conv1x1_rw_kernel(ConvParams p) {
 // WP > 1: the weight slice passes the LDS in WP parts (K = 384: 192 KB for 256 rows; each part = NSLAB / WP slabs, lifted between its own pair of barriers).
 // DUAL (sm_conv2d_dual_fwd_cfg): K slabs >= p.kt_sw of a stage come from the SECOND source p.x2, pixel (n, oy * x2_s, ox * x2_s) of
 // [N, x2_H, x2_W, K2] — the projection shortcut of a bottleneck's first block as the tail of the expand layer's reduction.  Only the loaders know.
-template <int KS, int FS, int NST, bool RES, int WP = 1, bool DUAL = false>
-__global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
-    constexpr int NCONS = 8, NLT = 256, NSLAB = KS / 4, ROWS = FS * 32, BN = 256, K = KS * 16, RSLAB = RES ? BN / 64 : 0;
+// NCONS = consumer waves (x 32 output channels = the block's slice): 8, or 4 for K = 512 — 128 W registers per consumer fit the 256-register budget of an
+// 8-wave block (4 + 4), not the 168 of twelve waves: ResNet-50's 512 -> 128 reduce layers at 28 x 28 (N = 128 is one slice).
+template <int KS, int FS, int NST, bool RES, int WP = 1, bool DUAL = false, int NCONS = 8>
+__global__ __launch_bounds__((NCONS + 4) * 64) void conv1x1_rwl_kernel(ConvParams p) {
+    constexpr int NLT = 256, NSLAB = KS / 4, ROWS = FS * 32, BN = NCONS * 32, K = KS * 16, RSLAB = RES ? BN / 64 : 0;
     constexpr int WSLAB = NSLAB / WP, KSP = KS / WP;                  // slabs / k steps of one weight part
     static_assert(NSLAB % WP == 0 && (!DUAL || FS == 1), "weight parts are whole slabs; the second source is addressed per 32-pixel stage");
     constexpr int SLAB_BYTES = ROWS * 128, XT = NSLAB * SLAB_BYTES, STAGE = (NSLAB + RSLAB) * SLAB_BYTES;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(768) void conv1x1_rwl_kernel(ConvParams p) {
     constexpr int WB = WSLAB * BN * 128, E_FIT = (160 * 1024 - WB) / STAGE, E = E_FIT < NST - 1 ? E_FIT : NST - 1;
     constexpr int LDS_TOTAL = (WB > (NST - E) * STAGE ? WB : (NST - E) * STAGE) + E * STAGE;
     static_assert(LDS_TOTAL <= 160 * 1024 && (NST - E) * STAGE <= 160 * 1024, "LDS");
-    static_assert((NSLAB - 1) * SLAB_BYTES + (RSLAB ? RSLAB - 1 : 0) * SLAB_BYTES + XT < 65536, "ds_read offset field");
+    static_assert((NSLAB - 1) * SLAB_BYTES + (FS - 1) * 4096 < 65536, "ds_read offset field (slab + fragment; the slot and the residual's slab are in the address register)");
     static_assert(E * LOADS <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) unsigned char rw_smem[];
     auto slot_base = [](int s) { return s < E ? WB + s * STAGE : (s - E) * STAGE; };     // byte offset of ring slot s

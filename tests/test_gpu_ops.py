@@ -783,6 +783,11 @@ RW_CASES = [
     (2, 20, 20, 64, 64, False, 1),                     # 64 -> 64, steps of 256 pixels, ragged (800 = 3.1 steps)
     (1, 13, 11, 64, 256, True, 1),                     # 64 -> 256 + residual
     (64, 14, 14, 256, 1024, True, 1),                  # full size (checked against config 6 only)
+    (2, 28, 28, 512, 128, False, 1),                   # ResNet layer-2 reduce on the four-consumer ring form (K = 512: 128 W registers per consumer)
+    (3, 7, 9, 512, 256, False, 2),                     # two slices of 128, ragged M (189), PReLU
+    (1, 3, 3, 512, 128, False, 0),                     # a single ragged stage
+    (4, 7, 7, 512, 2048, True, 1),                     # ResNet layer-4 expand + block input: sixteen slices of 128
+    (2, 5, 9, 512, 384, True, 2),                      # three slices, ragged M (90), PReLU
 ]
 
 
