@@ -389,7 +389,7 @@ __global__ __launch_bounds__((NCONS + 4) * 64) void conv1x1_rwl_kernel(ConvParam
     const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;
     const bool relu0 = p.act != SM_ACT_NONE && p.slope == 0.f;
 
-    constexpr int PF = 4;
+    constexpr int PF = KS >= 48 ? 2 : 4;                             // (K = 768: 192 W registers leave room for two k steps of prefetch)
     int slot = 0;
 #pragma unroll 1
     for (int i = 0; i < n_st; i++) {
