@@ -788,6 +788,7 @@ RW_CASES = [
     (1, 3, 3, 512, 128, False, 0),                     # a single ragged stage
     (4, 7, 7, 512, 2048, True, 1),                     # ResNet layer-4 expand + block input: sixteen slices of 128
     (2, 5, 9, 512, 384, True, 2),                      # three slices, ragged M (90), PReLU
+    (5, 7, 7, 320, 1280, False, 1),                    # MobileNet-v2's last pointwise layer: five slabs of K, ten slices
 ]
 
 
