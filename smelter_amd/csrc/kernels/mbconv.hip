@@ -755,7 +755,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 __device__ __attribute__((aligned(64))) unsigned int g_mb_zero[16];       // zero-initialised at module load: source of the fragments beyond Ch / Cout / Cin
 #define MB_GLDS16(gptr, ldsptr) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
-template <int S, int TCF, int KSX, int NFW>
+// AS: the patch has at most four fragments (a 7 x 7 image: 81 pixels): waves (fragment, row block) — every wave multiplies ONE of the chunk's two row blocks.
+template <int S, int TCF, int KSX, int NFW, bool AS = false>
 __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
     constexpr int NT = 512, CF = 2, TP = TCF > 4 ? 8 : (TCF > 2 ? 4 : 2), NG = 8 / TP, CK = CF * 32, HSB = CK * 2 + 16, NCV = CF * 4, RPTM = 4, HPA = 256;
     constexpr int F1 = CF * KSX, W1B = F1 * 1024, NI1 = (F1 + 7) / 8, NI2 = (NFW * NG * 2 * CF + 7) / 8;
@@ -805,7 +806,9 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
 #endif
     dma_w1(0, 0); dma_w2(0, 0); dma_w1(NC > 1 ? 1 : 0, 1);
     // ---- lane constants: my patch pixel (phase A), my output pixel (phase C, epilogue) ----
-    const int pp = wave * 32 + l31, ppy = pp / PW, ppx = pp - ppy * PW;   // (pp >= HP: rows beyond the patch, written and never read)
+    constexpr int CFA = AS ? 1 : 2;                                       // row blocks of a chunk per wave in phase A
+    const int pp = (AS ? (wave & 3) : wave) * 32 + l31, ppy = pp / PW, ppx = pp - ppy * PW;   // (pp >= HP: rows beyond the patch, written and never read)
+    const int cfa0 = AS ? (wave >> 2) : 0;                                // my first row block
     const int pf = wave % TP, grp = wave / TP;
     const bool act_pf = pf < TCF;
     const int q = pf * 32 + l31, qy = q / TO, qx = q - qy * TO;
@@ -885,17 +888,17 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
             const int gb = g & 1;
             // ---- phase A ----------------------------------------------------------------------------------------------------------------
             {
-                half8_t fw[CF][KSX];                                      // all fragments first: one LDS round trip, then the two row blocks' MFMA chains interleaved
-                float bv[CF];
+                half8_t fw[CFA][KSX];                                      // all fragments first: one LDS round trip, then the two row blocks' MFMA chains interleaved
+                float bv[CFA];
 #pragma unroll
-                for (int cf = 0; cf < CF; cf++) {
+                for (int cf = 0; cf < CFA; cf++) {
 #pragma unroll
-                    for (int ks = 0; ks < KSX; ks++) fw[cf][ks] = *(const half8_t*)(w1b + gb * W1B + (cf * KSX + ks) * 1024 + lane * 16);
-                    bv[cf] = b1l[c * CK + cf * 32 + l31];
+                    for (int ks = 0; ks < KSX; ks++) fw[cf][ks] = *(const half8_t*)(w1b + gb * W1B + ((cfa0 + cf) * KSX + ks) * 1024 + lane * 16);
+                    bv[cf] = b1l[c * CK + (cfa0 + cf) * 32 + l31];
                 }
-                floatx16 acc[CF];
+                floatx16 acc[CFA];
 #pragma unroll
-                for (int cf = 0; cf < CF; cf++) {
+                for (int cf = 0; cf < CFA; cf++) {
                     half8_t fb = hz;
                     if (!hi) { const half_t bh = (half_t)bv[cf]; fb[0] = bh; fb[1] = (half_t)(bv[cf] - (float)bh); }
                     acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fb, fone, (floatx16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -903,9 +906,9 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
 #pragma unroll
                 for (int ks = 0; ks < KSX; ks++)
 #pragma unroll
-                    for (int cf = 0; cf < CF; cf++) acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[cf][ks], PREF ? fxc[PREF ? ks : 0] : fx[ks], acc[cf], 0, 0, 0);
+                    for (int cf = 0; cf < CFA; cf++) acc[cf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[cf][ks], PREF ? fxc[PREF ? ks : 0] : fx[ks], acc[cf], 0, 0, 0);
 #pragma unroll
-                for (int cf = 0; cf < CF; cf++)
+                for (int cf = 0; cf < CFA; cf++)
 #pragma unroll
                     for (int qq = 0; qq < 4; qq++) {
                         half4_t o;
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[cf][4 * qq + r2], p.sl1);
                         }
-                        *(half4_t*)(hid + pp * HSB + (cf * 32 + 8 * qq + 4 * hi) * 2) = o;
+                        *(half4_t*)(hid + pp * HSB + ((cfa0 + cf) * 32 + 8 * qq + 4 * hi) * 2) = o;
                     }
             }
             MB4_TL(1);
@@ -1164,7 +1167,8 @@ static int mb_pick(const sm_mbconv_desc* d) {                         // 4, 3, 1
     // and more tiles per CU, each a chain of barrier-separated phases, against v3's sixteen independent waves) and on the 7^2 blocks (82 vs 61 as three launches:
     // eleven k steps, 15 chunks, spills), which stay where they were
     // => v4 for images of at most four tiles (56^2 -> 28^2 has sixteen 7 x 7 tiles: 107 vs 90 us)
-    if (ok4 && !force && sm_ceil_div(d->Ho, mb_v4_tile(d)) * sm_ceil_div(d->Wo, mb_v4_tile(d)) <= 4 && !(d->stride == 1 && mb_v4_tcf(d) == 2)) return 4;
+    // (7^2 blocks: with the row blocks of a chunk dealt to different waves — AS — 50 vs 63 us as three launches, cold)
+    if (ok4 && !force && sm_ceil_div(d->Ho, mb_v4_tile(d)) * sm_ceil_div(d->Wo, mb_v4_tile(d)) <= 4) return 4;
     // measured on MobileNet-v2 bs = 256 (tools/mbconv_bench.py): the wave pipelines win everywhere (112^2 -> 56^2: 125 vs 307 us, 56^2: 143 vs 245,
     // 56^2 -> 28^2: 92 vs 122, 28^2: 60 vs 93) except on the 28^2 -> 14^2 block (58 vs 53: one or two ragged tiles per wave)
     if (ok3 && !(ok1 && d->stride == 2 && (long)d->Ho * d->Wo <= 196)) return 3;
@@ -1218,7 +1222,10 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
                         : ksx == 4 ? (nfw <= 2 ? mbconv4_kernel<S_, T_, 4, 2> : mbconv4_kernel<S_, T_, 4, 3>) \
                         : ksx == 6 ? (nfw <= 2 ? mbconv4_kernel<S_, T_, 6, 2> : mbconv4_kernel<S_, T_, 6, 3>) \
                                    : (nfw <= 2 ? mbconv4_kernel<S_, T_, 10, 2> : mbconv4_kernel<S_, T_, 10, 3>))
-        if (d->stride == 1) fn = tcf == 7 ? MB4_PICK(1, 7) : MB4_PICK(1, 2);
+        const int pw = (to - 1) * d->stride + 3;
+        if (d->stride == 1 && tcf == 2 && pw * pw <= 128 && ksx >= 6) fn = ksx == 6 ? (nfw <= 2 ? mbconv4_kernel<1, 2, 6, 2, true> : mbconv4_kernel<1, 2, 6, 3, true>)
+                                                                                   : (nfw <= 2 ? mbconv4_kernel<1, 2, 10, 2, true> : mbconv4_kernel<1, 2, 10, 3, true>);
+        else if (d->stride == 1) fn = tcf == 7 ? MB4_PICK(1, 7) : MB4_PICK(1, 2);
         else fn = MB4_PICK(2, 2);
 #undef MB4_PICK
         hipLaunchKernelGGL(fn, dim3((unsigned)std::min<long>(nt4, SM_NUM_CU)), dim3(512), lds, sm_s(stream), p);
