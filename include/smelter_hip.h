@@ -179,16 +179,6 @@ size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d);
 int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const float* b1, const void* wd, const float* bd,
                   const void* w2, const float* b2, void* y, sm_stream_t stream);
 
-/* A whole ResNet bottleneck block — 1x1 reduce C -> Cm (+act1) -> 3x3 / stride 1 / pad 1 Cm -> Cm (+act2) -> 1x1 expand Cm -> C + the block input
- * (+act3): three MPSCNNConvolutionNodes (Converters.swift:253), the MPSNNAdditionNode (:440) and the ReLU nodes (:351) — in ONE launch; the two
- * intermediate tensors stay in LDS, rounded to fp16 once each exactly as the separate launches store them (csrc/kernels/bottleneck.hip).
- * C = 4 Cm, Cm = 64 | 128; x, y [N,H,W,C] fp16 (pixel strides x_ld / y_ld in elements, 0 = dense); w1 [Cm][C], w2 [Cm][3][3][Cm] (OHWI),
- * w3 [C][Cm] fp16; biases fp32 or NULL; ReLU-family activations. */
-int sm_bottleneck_supported(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm);
-int sm_bottleneck_fwd(int32_t N, int32_t H, int32_t W, int32_t C, int32_t Cm, const void* x, int32_t x_ld, const void* w1, const float* b1, int32_t act1, float slope1,
-                      const void* w2, const float* b2, int32_t act2, float slope2, const void* w3, const float* b3, int32_t act3, float slope3, void* y, int32_t y_ld,
-                      sm_stream_t stream);
-
 /* The same block directly behind an image stem, the stem included (MobileNet-v2's first three layers): 3x3 convolution of the fp32 NCHW batch
  * (`C` = 3 planes of in_H x in_W, stride st_stride, padding st_pad, activation d->act1) -> depthwise 3x3 -> 1x1 project, ONE launch; neither the
  * input conversion nor the stem's output tensor exists.  d->H x d->W = the stem's output image, d->Ch = its channels (<= 32), d->Cin ignored;

@@ -84,8 +84,6 @@ SYMBOLS = {
     "sm_mbconv_kernel_kind": (_i32, [C.POINTER(MbConvDesc)]),
     "sm_mbconv_lds_bytes": (_sz, [C.POINTER(MbConvDesc)]),
     "sm_mbconv_fwd": (_i32, [C.POINTER(MbConvDesc)] + [_vp] * 9),
-    "sm_bottleneck_supported": (_i32, [_i32] * 5),
-    "sm_bottleneck_fwd": (_i32, [_i32] * 5 + [_vp, _i32, _vp, _vp, _i32, _f, _vp, _vp, _i32, _f, _vp, _vp, _i32, _f, _vp, _i32, _vp]),
     "sm_mbconv_stem_supported": (_i32, [C.POINTER(MbConvDesc)] + [_i32] * 5),
     "sm_mbconv_stem_fwd": (_i32, [C.POINTER(MbConvDesc), _vp] + [_i32] * 5 + [_vp] * 8),
     "sm_conv_transpose2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),

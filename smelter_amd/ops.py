@@ -216,19 +216,6 @@ def mbconv(x, w1, b1, wd, bd, w2, b2, stride=1, residual=False, acts=(ACT_RELU, 
     return y
 
 
-def bottleneck(x, w1, b1, w2, b2, w3, b3, acts=(ACT_RELU, ACT_RELU, ACT_RELU), slopes=(0.0, 0.0, 0.0), out=None):
-    """a whole ResNet bottleneck block in one launch (sm_bottleneck_fwd): 1x1 w1 [Cm,1,1,C] -> 3x3 w2 [Cm,3,3,Cm] -> 1x1 w3 [C,1,1,Cm] + x; C = 4 Cm, Cm = 64 | 128"""
-    n, h, w, c, x_ld = _check_nhwc(x)
-    cm = w1.shape[0]
-    assert w1.dtype == w2.dtype == w3.dtype == torch.float16 and w1.is_contiguous() and w2.is_contiguous() and w3.is_contiguous()
-    assert tuple(w1.shape) == (cm, 1, 1, c) and tuple(w2.shape) == (cm, 3, 3, cm) and tuple(w3.shape) == (c, 1, 1, cm)
-    if out is None:
-        out = torch.empty((n, h, w, c), dtype=torch.float16, device=x.device)
-    check(lib().sm_bottleneck_fwd(n, h, w, c, cm, _ptr(x), x_ld, _ptr(w1), _ptr(b1), acts[0], slopes[0], _ptr(w2), _ptr(b2), acts[1], slopes[1], _ptr(w3), _ptr(b3), acts[2], slopes[2],
-                                  _ptr(out), _ld(out), _stream()))
-    return out
-
-
 def conv_transpose2d(x, w_ohwi_flipped, bias=None, stride=(1, 1), pads=(0, 0, 0, 0), dilation=(1, 1), out_pad=(0, 0), act=ACT_NONE, slope=0.0):
     """sm_conv_transpose2d_fwd: direct kernel over the flipped OHWI weights the reference's ConvDataSource produces"""
     n, h, w, cin, x_ld = _check_nhwc(x)

@@ -1010,37 +1010,3 @@ def test_conv3x3_with_fused_expand_head_and_projection(n, hw, n3, act3):
     assert float((y3.float() - z.float()).abs().max()) <= 2e-2 * float(z.float().abs().max())
 
 
-
-@pytest.mark.parametrize("n,hw,cm,acts", [
-    (2, (28, 28), 128, (1, 1, 1)),      # ResNet-50 stage 2: four 14 x 14 tiles per image
-    (1, (56, 56), 64, (1, 1, 1)),       # stage 1: sixteen tiles, two hidden fragments
-    (3, (17, 19), 64, (1, 1, 1)),       # ragged tiles on both axes, more tiles than one block walks alone when the grid is small
-    (2, (14, 14), 128, (2, 0, 2)),      # one tile per image; PReLU / no activation / PReLU
-    (1, (9, 30), 128, (1, 1, 0)),       # an image narrower than a tile, no final activation
-])
-def test_bottleneck_block_in_one_launch(n, hw, cm, acts):
-    """sm_bottleneck_fwd (bottleneck.hip) against the oracle's three convolutions + Add with the two hidden tensors rounded to fp16 where the separate
-    launches store them, and against the three launches of this library"""
-    c = 4 * cm
-    rng = np.random.default_rng(cm + hw[0])
-    x = h(rng.standard_normal((n, c, hw[0], hw[1])))
-    w1 = h(rng.standard_normal((cm, 1, 1, c)) * np.sqrt(2.0 / c)); b1 = rng.standard_normal(cm).astype(np.float32) * 0.1
-    w2 = h(rng.standard_normal((cm, 3, 3, cm)) * np.sqrt(2.0 / (9 * cm))); b2 = rng.standard_normal(cm).astype(np.float32) * 0.1
-    w3 = h(rng.standard_normal((c, 1, 1, cm)) * np.sqrt(1.0 / cm)); b3 = rng.standard_normal(c).astype(np.float32) * 0.1
-    slopes = tuple(0.25 if a == 2 else 0.0 for a in acts)
-    f = lambda v, a, s: v if a == 0 else np.where(v >= 0, v, v * s)
-    h1 = h(f(O.conv2d(x, w1, b1), acts[0], slopes[0]))
-    h2 = h(f(O.conv2d(h1, w2, b2, pads=(1, 1, 1, 1)), acts[1], slopes[1]))
-    ref = h(f(O.conv2d(h2, w3, b3) + x, acts[2], slopes[2]))
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    xd = to_dev(x)
-    y = ops.bottleneck(xd, dev(w1).half(), dev(b1), dev(w2).half(), dev(b2), dev(w3).half(), dev(b3), acts=acts, slopes=slopes)
-    got = to_host(y)
-    assert (np.abs(got - ref) <= np.abs(ref) * 2.0 ** -9 + np.abs(ref).max() * 2.0 ** -10).all(), np.abs(got - ref).max()
-    assert np.mean(got != ref) < 0.2
-    # the three launches
-    t1 = ops.conv2d(xd, dev(w1).half(), dev(b1), act=acts[0], slope=slopes[0])
-    t2 = ops.conv2d(t1, dev(w2).half(), dev(b2), pads=(1, 1, 1, 1), act=acts[1], slope=slopes[1])
-    t3 = ops.conv2d(t2, dev(w3).half(), dev(b3), residual=xd, act=acts[2], slope=slopes[2])
-    g3 = to_host(t3)
-    assert (np.abs(got - g3) <= np.abs(g3) * 2.0 ** -9 + np.abs(g3).max() * 2.0 ** -10).all()
