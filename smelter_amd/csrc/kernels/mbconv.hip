@@ -483,17 +483,42 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     unsigned char* const hid = wave_base + wave * ((MFA * 32 + OPX) * HS);// hidden chunk [MFA*32][HS] | depthwise output chunk [OPX][HS]
     unsigned char* const dwo = hid + MFA * 32 * HS;
 
-    if constexpr (KS1 > 0 && !WG) for (int i = tid; i < ChP * KP1; i += NT) {
-        const int n = i / KP1, k = i - n * KP1;
-        half_t v = (half_t)0.f;
-        if (n < p.Ch) {
-            if (k < p.Cin) v = p.w1[(long)n * p.Cin + k];
-            else if (k < p.Cin + 2 && p.b1) { const float b = p.b1[n]; const half_t bh = (half_t)b; v = k == p.Cin ? bh : (half_t)(b - (float)bh); }
+    // (the loads of a batch are independent of each other: one memory round trip per batch of eight elements, not per element — the plain loops
+    //  were 5 + 2 + 6 dependent round trips in front of the first tile of a 144-channel block)
+    constexpr int PB = 8;
+    if constexpr (KS1 > 0 && !WG) for (int i0 = tid; i0 < ChP * KP1; i0 += NT * PB) {
+        half_t v[PB]; float bb[PB];
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+            const int i = i0 + j * NT, n = i / KP1, k = i - n * KP1;
+            const bool on = i < ChP * KP1 && n < p.Ch;
+            v[j] = (on && k < p.Cin) ? p.w1[(long)n * p.Cin + k] : (half_t)0.f;
+            bb[j] = (on && k >= p.Cin && k < p.Cin + 2 && p.b1) ? p.b1[n] : 0.f;
         }
-        w1l[i] = v;
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+            const int i = i0 + j * NT, n = i / KP1, k = i - n * KP1;
+            if (i < ChP * KP1) {
+                half_t o = v[j];
+                if (n < p.Ch && k >= p.Cin && k < p.Cin + 2) { const half_t bh = (half_t)bb[j]; o = k == p.Cin ? bh : (half_t)(bb[j] - (float)bh); }
+                w1l[i] = o;
+            }
+        }
     }
-    for (int i = tid; i < 9 * ChP; i += NT) { const int t = i / ChP, c = i - t * ChP; wdl[i] = c < p.Ch ? p.wd[(long)c * 9 + t] : (half_t)0.f; }
-    if constexpr (!WG) for (int i = tid; i < CoP * (hs2 / 2); i += NT) { const int n = i / (hs2 / 2), k = i - n * (hs2 / 2); ((half_t*)w2l)[i] = (n < p.Cout && k < p.Ch) ? p.w2[(long)n * p.Ch + k] : (half_t)0.f; }
+    for (int i0 = tid; i0 < 9 * ChP; i0 += NT * PB) {
+        half_t v[PB];
+#pragma unroll
+        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT, t = i / ChP, c = i - t * ChP; v[j] = (i < 9 * ChP && c < p.Ch) ? p.wd[(long)c * 9 + t] : (half_t)0.f; }
+#pragma unroll
+        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT; if (i < 9 * ChP) wdl[i] = v[j]; }
+    }
+    if constexpr (!WG) for (int i0 = tid; i0 < CoP * (hs2 / 2); i0 += NT * PB) {
+        half_t v[PB];
+#pragma unroll
+        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT, n = i / (hs2 / 2), k = i - n * (hs2 / 2); v[j] = (i < CoP * (hs2 / 2) && n < p.Cout && k < p.Ch) ? p.w2[(long)n * p.Ch + k] : (half_t)0.f; }
+#pragma unroll
+        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT; if (i < CoP * (hs2 / 2)) ((half_t*)w2l)[i] = v[j]; }
+    }
     for (int i = tid; i < ChP; i += NT) bdl[i] = (p.bd && i < p.Ch) ? p.bd[i] : 0.f;
     for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
     __syncthreads();                                                     // the only barrier of the kernel
