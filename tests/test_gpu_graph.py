@@ -442,3 +442,18 @@ def test_fusion_pass_switches_keep_the_function(env, make, shape, fewer_launches
     if env == "SMELTER_STEM_POOL":
         assert np.array_equal(got, plain)
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3
+
+
+def test_inverted_residual_blocks_on_either_block_kernel(monkeypatch):
+    """MobileNet-v2 at 224 x 224: the 28 x 28 / 14 x 14 / 7 x 7 blocks run on the tile-per-block kernel (mbconv.hip v4, `sm_mbconv_kernel_kind` = 4) by
+    default; with the wave-per-tile kernel forced (SMELTER_MBCONV_KERNEL=3) the 7 x 7 blocks and the 14 -> 7 block fall back to three launches each.
+    Same function either way, both inside the oracle's bar."""
+    model = zoo.mobilenet_v2(hw=(224, 224))
+    x = zoo.synthetic_images(2, 3, (224, 224))
+    ex, got = run_hip(model, x)
+    monkeypatch.setenv("SMELTER_MBCONV_KERNEL", "3")
+    ex3, got3 = run_hip(model, x)
+    assert ex3.numLaunches > ex.numLaunches
+    assert nerr(got, got3) <= 2e-3
+    ref = O.Graph(model).run(x)
+    assert nerr(got, ref) <= 5e-3 and nerr(got3, ref) <= 5e-3
