@@ -753,6 +753,9 @@ const TileCfg kCfgs[] = {
     {32, 128, 8, 512, conv1x1_rwl_kernel<32, 1, 3, true, 1, false, 4>, "rwl:k512 n128 s32x3 +res", CF_RES, 512, 3},        // 117 (512 -> 2048 + block input + ReLU at 7 x 7)
     {32, 128, 8, 512, conv1x1_rwl_kernel<48, 1, 3, false, 2, true, 4>, "rwl:k768 n128 s32x3 dual", CF_DUAL, 768, 3, 2},    // 118 (stage 3's first block: K = 256 + 512)
     {32, 128, 8, 512, conv1x1_rwl_kernel<20, 1, 4, false, 1, false, 4>, "rwl:k320 n128 s32x4", 0, 320, 4},                 // 119 (MobileNet-v2's last pointwise layer 320 -> 1280)
+    // ... K = 256 with narrow outputs (256 -> 128 | 64 at 56 x 56: one slice of 4 | 2 consumer waves)
+    {64, 128, 8, 512, conv1x1_rwl_kernel<16, 2, 4, false, 1, false, 4>, "rwl:k256 n128 s64x4", 0, 256, 4},                 // 120
+    {64, 64, 8, 384, conv1x1_rwl_kernel<16, 2, 4, false, 1, false, 2>, "rwl:k256 n64 s64x4", 0, 256, 4},                   // 121
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
