@@ -17,12 +17,14 @@ $(FLAGSTAMP): FORCE
 	@mkdir -p build; echo '$(HIPCC) $(HIPFLAGS)' | cmp -s - $@ || echo '$(HIPCC) $(HIPFLAGS)' > $@
 FORCE:
 
-$(OBJDIR)/%.o: $(CSRC)/%.hip $(wildcard $(CSRC)/kernels/*.hpp) include/smelter_hip.h $(FLAGSTAMP)
+# header dependencies come from the compiler (-MMD): touching one kernel header rebuilds only the translation units that include it
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(FLAGSTAMP)
 	@mkdir -p $(dir $@)
-	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(OBJDIR)/%.o: $(CSRC)/%.cpp $(wildcard $(CSRC)/host/*.hpp) $(wildcard $(CSRC)/kernels/*.hpp) include/smelter_hip.h $(FLAGSTAMP)
+	$(HIPCC) $(HIPFLAGS) -MMD -MP -c $< -o $@
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(FLAGSTAMP)
 	@mkdir -p $(dir $@)
-	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+	$(HIPCC) $(HIPFLAGS) -MMD -MP -x hip -c $< -o $@
+-include $(OBJS:.o=.d)
 $(LIB): $(OBJS)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
 

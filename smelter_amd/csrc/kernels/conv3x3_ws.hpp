@@ -26,21 +26,6 @@ template <int CP> __device__ __forceinline__ int ws_swz(int idx) {   // XOR key 
 }
 
 constexpr int ws_pstride(int fixed_bytes) { const int half = ((160 * 1024 - fixed_bytes) / 2) & ~1023; return half < 60 * 1024 ? half : 60 * 1024; }
-// LDS-DMA as an asm statement (cdna_hip_programming.md §5.7): behind a `global_load_lds` BUILTIN hipcc's waitcnt pass treats the LGKM
-// counter as out of order and waits lgkmcnt(0) — for fragment reads it has only just issued — before the next MFMA (one exposed LDS
-// latency per DMA piece, ~30 % of the k loop).  The asm form is invisible to that pass; its completion is waited for explicitly
-// (s_waitcnt vmcnt(0) + s_barrier at the top of every tile).  M0 is saved and restored inside the statement.
-__device__ __forceinline__ void ws_glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ unsigned ws_lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
-
-template <int I, int N, class F> __device__ __forceinline__ void sm_static_for(F&& f) {       // f(integral_constant<int, I>) ... f(<N-1>)
-    if constexpr (I < N) { f(std::integral_constant<int, I>()); sm_static_for<I + 1, N>(f); }
-}
-
 constexpr int WS_DUMMY = 1024;                                        // LDS sink of the DMA instructions a wave has no patch slots for
 
 // NIC = LDS-DMA instructions per thread per patch (the launcher picks a tile geometry that needs no more)

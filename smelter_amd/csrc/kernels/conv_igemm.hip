@@ -25,48 +25,10 @@
 #include <string.h>
 
 #include "common.hpp"
+#include "conv_shared.hpp"
 
 namespace {
 
-struct ConvParams {
-    const half_t* x; const half_t* w; const float* bias; const half_t* res; half_t* y;
-    float* ws;                       // split-K partials (fp32) or nullptr
-    int N, H, W, Cin, Cout, kH, kW, sH, sW, dH, dW, pt, pl, Ho, Wo;
-    int x_ld, y_ld, res_ld, act; float slope;
-    int M, K, mt, nt, splitk, ktiles_per_split;
-    int order, mt_per_xcd, cpx;      // block -> tile map (map_block)
-    unsigned dhw_mul, dhw_sh, dw_mul, dw_sh;   // sm_fastdiv constants for / (Ho*Wo) and / Wo
-    unsigned pm_mul, pm_sh, mt_mul, mt_sh, nt_mul, nt_sh;   // ... for / (nt*splitk), / mt, / nt (map_block)
-    unsigned rowpat;                 // sum over kh < kH of 1 << (kh*kW): tap-mask pattern (conv_igemm64.hpp)
-    int yplace, ysH, ysW, yoH, yoW, yH, yW;   // output placement (sm_conv_desc.y_sH ...): strided/offset output pixels
-    // weight-stationary 3x3 kernel (conv3x3_ws.hpp): tile geometry chosen by ws_setup()
-    int ws_TH, ws_TW, ws_tiles_x, ws_tiles_y, ws_ntiles, ws_patch_bytes;
-    unsigned ws_pw_mul, ws_pw_sh, ws_tw_mul, ws_tw_sh, ws_txy_mul, ws_txy_sh, ws_ty_mul, ws_ty_sh;
-    // nine-tap patch kernel (conv3x3_p9.hpp): geometry chosen by p9_setup(); ups = the input is read through a fused nearest 2x upsampling
-    int p9_TW, p9_tiles_per_band, p9_patch_bytes, p9_patch_px, ups;
-    half_t* y2; int y2_ld;           // conv3x3_ws only: second output = 2x2 / stride-2 max-pool of y (nullptr = none)
-    // conv3x3_ws only: a 1x1 convolution applied to the output tile while it is still in registers ("head": w3 [n3][Cout] fp16, b3 fp32,
-    // y3 = act3(w3 . y + b3), n3 <= 32); y itself is stored only if p.y != nullptr
-    const half_t* w3; const float* b3; half_t* y3; int n3, y3_ld, act3; float sl3;
-    // ... the EXPAND head (" xhead" instantiations): n3 = 32 .. 256 (multiple of 32), w3 / b3 in LDS, optional residual added to the head's output
-    const float* xf; int in_C, in_H, in_W, in_pt, in_pl;   // stem form with loader waves (conv3x3_ws.hpp NLW): the fp32 NCHW input the patches are built from
-    const half_t* w3s;               // conv3x3_wsx.hpp SIDE: weights [n3][64] of the head's second GEMM; res3 / res3_ld then name its 64-channel input tensor
-    const half_t* res3; int res3_ld; int hx_dbg;   // hx_dbg: SM_HX_DEBUG ablation bits (1 = no stores, 2 = no residual loads, 4 = no head at all)
-    unsigned p9_pw_mul, p9_pw_sh, p9_h2_mul, p9_h2_sh;
-    int pq_OH, pq_OW;                // stem_pool.hpp: size of the pooled output (y2)
-    // conv1x1_ps.hpp: SECOND SOURCE of a pointwise convolution whose reduction runs over two tensors, K = K1 + K2 (sm_conv2d_dual_fwd_cfg): K tiles
-    // [0, kt_sw) read x as usual, K tiles [kt_sw, K/64) read pixel (n, oy*x2_s, ox*x2_s) of x2 [N, x2_H, x2_W, K2] (pixel stride x2_ld)
-    const half_t* x2; int x2_ld, x2_H, x2_W, x2_s, kt_sw;
-};
-
-// Division of n < 2^31 by a launch-time constant d: q = (n * mul) >> sh with s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1
-// (< 2^32), sh = 31 + s.  Exact: mul*d - 2^(31+s) = e in (0, d], so n*mul / 2^(31+s) = n/d + n*e / (d * 2^(31+s)) and the
-// excess is < 2^-s <= 1/d, too small to carry the fraction of n/d (<= (d-1)/d) over the next integer.
-inline void sm_fastdiv_make(unsigned d, unsigned* mul, unsigned* sh) {
-    unsigned s = 0; while ((1ull << s) < d) s++;
-    *mul = (unsigned)(((1ull << (31 + s)) / d) + 1); *sh = 31 + s;
-}
-__device__ __forceinline__ unsigned sm_fastdiv(unsigned n, unsigned mul, unsigned sh) { return (unsigned)(((unsigned long long)n * mul) >> sh); }
 // pixel index of output row m (= (n, oy, ox) of the Ho x Wo grid) inside the destination image
 __device__ __forceinline__ long sm_out_pixel(const ConvParams& p, int m) {
     if (!p.yplace) return m;
@@ -605,6 +567,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_lds_kernel(ConvParams p, int cb
 //   kind 4: p0 = Cin of the instantiation; CF_HEAD / CF_XHEAD / CF_W44 (two-role kernel: 4 of the 8 waves issue the patch DMA) / CF_SIDE
 //   kind 6: p0 = taps (kH' of the row-pair form), p1 = KB between the two patch buffers (0 = as large as the weights allow), p2 = loader waves
 //   kinds 5, 7: p0 = ring stages
+//   kind 9: flags = patch buffers (1 | 2), p0 = KG, p1 = NG, p2 = NF
 //   kind 8: BM = pixels per step (32 FS), BN = channels per block, p0 = Cin of the instantiation; CF_RES = the instantiation that stages a residual tile;
 //           ring form: p1 = stages, p2 = parts the weight slice passes the LDS in (0 = 1); CF_DUAL = takes (only) launches with a second source
 enum { CF_HEAD = 1, CF_XHEAD = 2, CF_W44 = 4, CF_SIDE = 8, CF_RES = 16, CF_DUAL = 32 };
@@ -720,10 +683,7 @@ const TileCfg kCfgs[] = {
     {256, 64, 4, 256, conv3x3_ws_kernel<32, 64, 4, 2, 6, 0, 0, 0, true>, "ws:32->64 w4x2 head", CF_HEAD, 32},      // 91
     {256, 32, 4, 256, conv3x3_ws_kernel<32, 32, 4, 2, 6, 0, 0, 0, true>, "ws:32->32 w4x2 head", CF_HEAD, 32},      // 92
     {512, 32, 4, 512, conv3x3_ws_kernel<32, 32, 8, 2, 6, 0, 0, 0, true>, "ws:32->32 w8x2 head", CF_HEAD, 32},      // 93
-#ifdef SM_ABLATION   // the single-role expand head (conv3x3_ws.hpp HX): 16 of 55 us added to the 3x3; the two-role kernel below replaced it
-    {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead", CF_XHEAD, 64},  // 94  expand head (bottleneck tail): + 1x1 to <= 256 channels + residual
-#endif
-    {128, 64, 4, 512, conv3x3_wsx_kernel<6>, "ws:64->64 w4+4 xhead", CF_XHEAD | CF_W44, 64},                                 // 95  ... with the two layers on different waves (conv3x3_wsx.hpp)
+    {128, 64, 4, 512, conv3x3_wsx_kernel<6>, "ws:64->64 w4+4 xhead", CF_XHEAD | CF_W44, 64},                                 // 94  expand head (bottleneck tail: + 1x1 to <= 256 channels + residual) with the two layers on different waves (conv3x3_wsx.hpp)
     {128, 64, 4, 512, conv3x3_wsx_kernel<6, true>, "ws:64->64 w4+4 xhead side", CF_XHEAD | CF_W44 | CF_SIDE, 64},                      // 96  ... and a second GEMM (the projection shortcut) instead of the residual tensor
     // stem form with loader waves (conv3x3_ws.hpp NLW): the patches are built from the fp32 NCHW input inside the launch (sm_conv2d_stem_f32_fwd_cfg)
     {256, 64, 6, 512, conv3x3_ws_kernel<64, 64, 4, 2, 6, 0, 4, 0, false, false, 4>, "wst:4->64 w4x2 ld4", 0, 4, 0, 4},            // 97  (ResNet-50 7x7/2)
@@ -756,6 +716,20 @@ const TileCfg kCfgs[] = {
     // ... K = 256 with narrow outputs (256 -> 128 | 64 at 56 x 56: one slice of 4 | 2 consumer waves)
     {64, 128, 8, 512, conv1x1_rwl_kernel<16, 2, 4, false, 1, false, 4>, "rwl:k256 n128 s64x4", 0, 256, 4},                 // 120
     {64, 64, 8, 384, conv1x1_rwl_kernel<16, 2, 4, false, 1, false, 2>, "rwl:k256 n64 s64x4", 0, 256, 4},                   // 121
+    // kind 9 (conv3x3_kq.hpp): 3x3 / stride 1 / pad 1 on few small images with many channels: 196-pixel tiles (one 14x14 image | 7 rows of 28 | four 7x7
+    // images) x BN couts, the K reduction split over the block's four waves (p0 = KG channel slices x p1 = NG cout groups, p2 = NF 16-cout fragments per wave),
+    // weights straight from global memory into registers
+    {208, 64, 9, 256, nullptr, "kq:k4n1 196x64", 1, 4, 1, 4},
+    {208, 128, 9, 256, nullptr, "kq:k2n2 196x128", 1, 2, 2, 4},
+    {208, 32, 9, 256, nullptr, "kq:k4n1 196x32", 1, 4, 1, 2},
+    {208, 64, 9, 256, nullptr, "kq:k2n2 196x64", 1, 2, 2, 2},
+    // ... flags = 2: two patch buffers, the next super-block's patch is copied while this one is multiplied (layers with Cin > 64 KG)
+    {208, 64, 9, 256, nullptr, "kq:k2n2 196x64 b2", 2, 2, 2, 2},
+    {208, 128, 9, 256, nullptr, "kq:k1n4 196x128 b2", 2, 1, 4, 2},
+    // ---- build-conditional entries stay BEHIND the product pool so that product indices do not depend on the build ----
+#ifdef SM_ABLATION   // the single-role expand head (conv3x3_ws.hpp HX): 16 of 55 us added to the 3x3; the two-role kernel replaced it
+    {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead", CF_XHEAD, 64},
+#endif
 #ifdef SM_ABLATION   // two K tiles per ring stage (KT = 2, BK = 128 per barrier; every wave multiplies both): 24 vs 21.5 us on 14x14 1024->256,
                      // equal to the K-group configs on the 7x7 layers — halving the barriers buys nothing, not in the product pool
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 0, 0, 1, 2>, "k64kt2:128x128(64x32)"},
@@ -884,6 +858,28 @@ size_t p9_setup(ConvParams& p, const TileCfg& c) {
     return WS_DUMMY + 2 * best_patch + ring;
 }
 
+// Geometry of the wave-split 3x3 kernel (conv3x3_kq.hpp) for tile config `c` (p0 = KG, p1 = NG, p2 = NF): whole images per tile when an image has
+// <= 208 pixels, else a band of TH full rows.  Returns the dynamic LDS size in bytes, 0 if the config does not fit the layer.
+size_t kq_setup(ConvParams& p, const TileCfg& c) {
+    const int KG = c.p0, NG = c.p1, NF = c.p2, NB = c.flags;
+    if (p.W < 7 || p.W > 208 || (p.Cin % (KG * 64)) != 0) return 0;
+    const int HW = p.H * p.W, RS = (p.W + 1 + 7) / 8 * 8;             // slots per patch row: W pixels + >= 1 zero column, a whole number of 8-slot DMA instructions
+    int vrows;
+    if (HW <= 208) { p.kq_TH = 0; p.kq_TI = 208 / HW; p.kq_bands = 1; p.kq_mt = sm_ceil_div(p.N, p.kq_TI); vrows = p.kq_TI * (p.H + 1) - 1; }
+    else { p.kq_TH = 208 / p.W; p.kq_TI = 1; p.kq_bands = sm_ceil_div(p.H, p.kq_TH); if ((long)p.N * p.kq_bands >= (1L << 30)) return 0; p.kq_mt = p.N * p.kq_bands; vrows = p.kq_TH; }
+    // rows 0 .. vrows + 1 (two halo rows); when the row has no spare zero column (RS == W + 1) the bottom-right tap of the last pixel is slot 0 of one more row
+    p.kq_RS = RS; p.kq_NI = (vrows + 2) * (RS / 8) + (RS == p.W + 1 ? 1 : 0); p.kq_slice_bytes = (p.kq_NI + 1) / 2 * 2048; p.kq_nsb = p.Cin / (KG * 64);
+    if ((long)p.N * HW * p.x_ld * 2 >= 0x7fff0000L || (long)p.N * HW * p.y_ld * 2 >= 0x7fff0000L) return 0;   // (32-bit buffer offsets on both sides)
+    p.nt = sm_ceil_div(p.Cout, NG * NF * 16); p.kq_mpx = sm_ceil_div(p.kq_mt, SM_NUM_XCD);
+    if ((long)p.kq_mpx * SM_NUM_XCD * p.nt >= (1L << 31)) return 0;
+    sm_fastdiv_make((unsigned)RS, &p.kq_rs_mul, &p.kq_rs_sh); sm_fastdiv_make((unsigned)(p.H + 1), &p.kq_h1_mul, &p.kq_h1_sh);
+    sm_fastdiv_make((unsigned)p.kq_bands, &p.kq_bands_mul, &p.kq_bands_sh); sm_fastdiv_make((unsigned)p.nt, &p.nt_mul, &p.nt_sh);
+    if (NB == 2 && (p.kq_nsb < 2 || sm_ceil_div(p.kq_NI, NG) > 17)) return 0;   // two buffers: something to prefetch, one patch instruction per unit and wave
+    const size_t patch = (size_t)KG * p.kq_slice_bytes * NB + (NB == 2 ? 1024 : 0), red = (size_t)4 * (NF == 4 ? 112 : 208) * (NF * 16 + 4) * 4;
+    const size_t lds = std::max(patch, red) + 2048;                  // (+ 2 KB: the kernel aligns its slices to 2 KB)
+    return lds <= 160 * 1024 ? lds : 0;
+}
+
 // kind 2 = single LDS stage: only for K == 64 (one K tile)
 // kinds 1/2 (conv_igemm64.hpp): Cin % 64 == 0 and a tap mask of <= 32 bits
 bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
@@ -929,6 +925,12 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
                (long)(p.Ho - 1) * p.sH + 2 * (p.kH - 1) < p.H && (long)(p.Wo - 1) * p.sW + 8 <= p.W &&
                !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
                ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && p.Cout == c.BN && wst_setup(q, c) > 0;
+    }
+    if (c.kind == 9) {   // wave-split 3x3: no residual, no upsampled input, dense 16-byte rows, ReLU family, 32-bit weight offsets
+        ConvParams q = p;
+        return same3x3 && !p.ups && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 &&
+               ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) &&
+               (long)p.Cout * p.K * 2 < 0x7fff0000L && kq_setup(q, c) > 0;
     }
     if (c.kind == 5) {   // nine-tap patch kernel: no residual, dense 16-byte rows, ReLU family
         ConvParams q = p;
@@ -1088,6 +1090,11 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         const long tiles = (long)p.mt * p.nt;
         // (a whole number of blocks per XCD: XCD x owns tiles [xT/8, (x+1)T/8), at most ceil(T/8) of them)
         hipLaunchKernelGGL(c.fn, dim3((unsigned)std::min<long>((tiles + SM_NUM_XCD - 1) / SM_NUM_XCD * SM_NUM_XCD, SM_NUM_CU)), dim3(c.threads), ps_lds_bytes(p, c), s, p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
+    if (c.kind == 9) {
+        const size_t lds = kq_setup(p, c);
+        kq_launch(kq_variant(c.p0, c.p1, c.p2, c.flags), p, (unsigned)(p.kq_mpx * SM_NUM_XCD * p.nt), lds, s);
         SM_LAUNCH_CHECK(); return SM_OK;
     }
     if (c.kind == 5) {

@@ -51,7 +51,6 @@ __device__ unsigned long long g_tl[8192 * 16];
 #define SM_TL_END()
 #endif
 
-template <int N> __device__ __forceinline__ void sm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 constexpr int sm_pow2_floor(int v) { int r = 1; while (r * 2 <= v) r *= 2; return r; }
 

@@ -1,0 +1,36 @@
+// conv_kq.hip — translation unit of the wave-split 3x3 convolution (conv3x3_kq.hpp, tile-config kind 9 of conv_igemm.hip's launcher).
+#include "conv_shared.hpp"
+
+namespace {
+#include "conv3x3_kq.hpp"
+typedef void (*KqFn)(KqParams);
+struct KqVariant { int KG, NG, NF, NB; KqFn fn; };
+const KqVariant kVariants[] = {
+    {4, 1, 4, 1, conv3x3_kq_kernel<4, 1, 4, 1>},
+    {2, 2, 4, 1, conv3x3_kq_kernel<2, 2, 4, 1>},
+    {4, 1, 2, 1, conv3x3_kq_kernel<4, 1, 2, 1>},
+    {2, 2, 2, 1, conv3x3_kq_kernel<2, 2, 2, 1>},
+    {2, 2, 2, 2, conv3x3_kq_kernel<2, 2, 2, 2>},
+    {1, 4, 2, 2, conv3x3_kq_kernel<1, 4, 2, 2>},
+};
+}  // namespace
+
+int kq_variant(int KG, int NG, int NF, int NB) {
+    for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); i++)
+        if (kVariants[i].KG == KG && kVariants[i].NG == NG && kVariants[i].NF == NF && kVariants[i].NB == NB) return i;
+    return -1;
+}
+#ifdef SM_KQ_TL
+extern "C" int sm_kq_timeline_read(unsigned long long* dst, int blocks) {   // diagnostic build: the stamps of the last launch (blocks x 4 waves x 16)
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_kq_tl), (size_t)blocks * 4 * 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
+#endif
+void kq_launch(int variant, const ConvParams& p, unsigned grid, size_t lds, hipStream_t s) {
+    KqParams q;
+    q.x = p.x; q.w = p.w; q.bias = p.bias; q.y = p.y;
+    q.N = p.N; q.H = p.H; q.W = p.W; q.Cin = p.Cin; q.Cout = p.Cout; q.K = p.K; q.x_ld = p.x_ld; q.y_ld = p.y_ld; q.act = p.act; q.slope = p.slope;
+    q.nt = p.nt; q.RS = p.kq_RS; q.NI = p.kq_NI; q.slice_bytes = p.kq_slice_bytes; q.TH = p.kq_TH; q.TI = p.kq_TI; q.mt = p.kq_mt; q.bands = p.kq_bands; q.mpx = p.kq_mpx; q.nsb = p.kq_nsb;
+    q.nt_mul = p.nt_mul; q.nt_sh = p.nt_sh; q.dhw_mul = p.dhw_mul; q.dhw_sh = p.dhw_sh; q.dw_mul = p.dw_mul; q.dw_sh = p.dw_sh;
+    q.h1_mul = p.kq_h1_mul; q.h1_sh = p.kq_h1_sh; q.bands_mul = p.kq_bands_mul; q.bands_sh = p.kq_bands_sh;
+    hipLaunchKernelGGL(kVariants[variant].fn, dim3(grid), dim3(256), lds, s, q);
+}

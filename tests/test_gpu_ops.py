@@ -24,7 +24,7 @@ def cfgs_named(*subs, without=()):
 
 
 WS_PLAIN = cfgs_named("ws:", without=("head",))           # weight-stationary 3x3, no fused head
-assert WS_PLAIN and cfgs_named("p9:") and cfgs_named("wst:") and cfgs_named("ps:") and cfgs_named("ws:", " head") and cfgs_named("xhead", without=("side",))
+assert WS_PLAIN and cfgs_named("p9:") and cfgs_named("kq:") and cfgs_named("wst:") and cfgs_named("ps:") and cfgs_named("ws:", " head") and cfgs_named("xhead", without=("side",))
 
 
 def h(a):
@@ -540,6 +540,53 @@ def test_conv3x3_nine_tap_patch(case, cfg):
             pytest.skip(e.detail)
         raise
     assert_close(to_host(y), ref, cin * 9)
+
+
+KQ_CASES = [
+    # n, h, w, cin, cout, act   -- conv3x3_kq.hpp: 196-pixel tiles, K split over the four waves, weights straight into registers
+    (3, 14, 14, 256, 256, 1),    # ResNet-50 stage 3: one image per tile, four cout tiles of 64 (or two of 128)
+    (2, 28, 28, 128, 128, 1),    # stage 2: bands of 7 rows, real halo rows above and below the inner bands
+    (9, 7, 7, 512, 64, 2),       # stage 4: four images per tile (shared zero rows between them), a ragged last tile of one image, two super-blocks, PRelu
+    (2, 13, 11, 256, 72, 0),     # 143-pixel images (three idle fragments), Cout % 16 != 0: clamped weight rows, partial cout tile, no activation
+    (1, 30, 9, 256, 64, 1),      # bands of 23 rows, ragged last band (7 rows)
+    (5, 8, 7, 512, 40, 1),       # three 56-pixel images per tile, last tile holds two; narrowest width the slot scheme takes
+    (1, 17, 40, 128, 136, 1),    # bands of 5 rows of a wide image, ragged last band of 2
+]
+
+
+@pytest.mark.parametrize("case", KQ_CASES)
+@pytest.mark.parametrize("cfg", cfgs_named("kq:"))
+def test_conv3x3_wave_split(case, cfg):
+    n, hh, ww, cin, cout, act = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * np.sqrt(2.0 / (cin * 9)))
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1))
+    slope = 0.25 if act == 2 else 0.0
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), act=act, slope=slope, cfg=cfg)
+    except SmelterError as e:
+        if "does not apply" in e.detail:                      # Cin is not a multiple of the config's super-block
+            pytest.skip(e.detail)
+        raise
+    assert_close(to_host(y), ref, cin * 9)
+
+
+def test_conv3x3_wave_split_between_concat_slices():
+    """pixel strides larger than the channel count on both sides, and nothing written outside the output slice"""
+    rng = np.random.default_rng(6)
+    x = h(rng.standard_normal((2, 256, 14, 14))); w = h(rng.standard_normal((64, 3, 3, 256)) * 0.03); b = rng.standard_normal(64).astype(np.float32)
+    xin = torch.zeros((2, 14, 14, 320), dtype=torch.float16, device="cuda"); xin[..., 32:288] = to_dev(x)
+    for cfg in cfgs_named("kq:"):
+        out = torch.full((2, 14, 14, 96), 7.0, dtype=torch.float16, device="cuda")
+        ops.conv2d(xin[..., 32:288], torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), act=1, cfg=cfg, out=out[..., 16:80])
+        ref = np.maximum(O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1)), 0)
+        assert_close(to_host(out[..., 16:80]), ref, 256 * 9)
+        assert float(out[..., :16].min()) == 7.0 and float(out[..., 80:].max()) == 7.0
 
 
 @pytest.mark.parametrize("case", [(2, 16, 20, 64, 64, 1), (1, 32, 32, 128, 40, 0), (3, 7, 9, 64, 136, 2), (2, 21, 33, 64, 32, 1), (1, 40, 24, 32, 32, 1)])

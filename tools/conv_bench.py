@@ -23,11 +23,13 @@ r = torch.randn((n, ho, wo, cout), device="cuda").half() if a.res else None
 flops = 2.0 * n * ho * wo * cout * cin * k * k
 byts = 2.0 * (x.numel() + y.numel() * (2 if a.res else 1) + wt.numel())
 ws = torch.empty(256 << 20, dtype=torch.uint8, device="cuda") if a.ws else None
-cfgs = range(ops.num_conv_configs()) if a.cfg == "all" else [int(c) for c in a.cfg.split(",")]
+def pick(tok):      # an index, or a substring of the configuration's label ("kq:", "p9:128x128")
+    return [int(tok)] if tok.isdigit() else [c for c in range(ops.num_conv_configs()) if tok in ops.config_name(c)]
+cfgs = range(ops.num_conv_configs()) if a.cfg == "all" else [c for tok in a.cfg.split(",") for c in pick(tok)]
 for cfg in cfgs:
     try:
         ms = ops.conv2d_time(x, wt, b, residual=r, stride=(s, s), pads=(p, p, p, p), act=1, cfg=cfg, iters=a.iters, out=y, workspace=ws)
     except Exception as e:
         continue
     us = ms * 1e3
-    print("cfg %2d  %8.1f us  %7.1f TFLOP/s  %6.2f TB/s (compulsory)" % (cfg, us, flops / us / 1e6, byts / us / 1e6))
+    print("cfg %3d  %8.1f us  %7.1f TFLOP/s  %6.2f TB/s (compulsory)  %s" % (cfg, us, flops / us / 1e6, byts / us / 1e6, ops.config_name(cfg)))
