@@ -56,6 +56,43 @@ def self_launch(a):
     sys.exit(subprocess.call(cmd))
 
 
+def measure_secondary(key, a, local, stream):
+    """One more BASELINE config on this GPU: K timed steps after W warm-up steps, bracketed by HIP events on the launch stream and by the host clock;
+    roofline = the whole step against the config's bound (MFMA: algorithmic conv FLOPs / step time; HBM: post-fusion compulsory bytes / step time)."""
+    import torch
+    from smelter_amd import zoo
+    from smelter_amd.graph import Configuration, ONNXGraph
+    factory, hw, batch, _, metric, workload, bound = WORKLOADS[key]
+    model, _ = getattr(zoo, factory)(return_macs=True)
+    ex = ONNXGraph(model, Configuration(autotune=not a.no_autotune)).hipGraph(local, batch)
+    x = torch.from_numpy(zoo.synthetic_images(batch, 3, hw, seed=0)).cuda()
+    for _ in range(a.warmup):
+        ex.encode(x, stream)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t1 = time.perf_counter()
+    e0.record(stream)
+    for _ in range(a.steps):
+        ex.encode(x, stream)
+    e1.record(stream)
+    torch.cuda.synchronize()
+    wall_ms = (time.perf_counter() - t1) / a.steps * 1e3
+    ev_ms = e0.elapsed_time(e1) / a.steps
+    if bound == "mfma":
+        ach = ex.flops / (wall_ms * 1e-3) / 1e12
+        roof = {"bound": "mfma", "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+                "byte_model": None, "basis": "algorithmic conv FLOPs (2 * MACs) / whole-step time"}
+    else:
+        ach = ex.launchBytes / (wall_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "byte_model": "post-fusion compulsory bytes (smelter_exec_launch_bytes)", "basis": "bytes the launches must move / whole-step time"}
+    res = {"metric": metric, "value": round(batch * 1e3 / wall_ms, 1), "unit": "images/s", "ms_per_step": round(wall_ms, 4), "ms_per_step_hip_events": round(ev_ms, 4),
+           "steps": a.steps, "warmup": a.warmup, "launches_per_step": ex.numLaunches, "config": {"workload": workload % batch}, "roofline": roof}
+    del ex, x
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +103,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-op HIP-event pass (use under rocprofv3)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the MobileNet-v2 / U-Net lines of the default run")
     ap.add_argument("--cpu-batch", type=int, default=0)
     ap.add_argument("--cpu-passes", type=int, default=3)
     a = ap.parse_args()
@@ -93,9 +131,8 @@ def main():
     model, macs = getattr(zoo, factory)(return_macs=True)                  # same seeded weights on every rank
     g = ONNXGraph(model, Configuration(autotune=not a.no_autotune))
     if world > 1:
-        arena = sd.broadcast_weight_arena(g, batch)                       # rank 0 folds/casts/packs; one RCCL broadcast
-        torch.cuda.synchronize()
-        ex = g.hipGraph(local, batch, weight_arena=arena, upload_weights=False)  # bind the received arena, no host weight prep
+        # rank 0 folds/casts/packs, one RCCL broadcast of the arena; rank 0 autotunes, its tile picks are broadcast too (identical kernels on every rank)
+        ex = sd.compile_sharded(g, batch, local)
     else:
         ex = g.hipGraph(local, batch)
     compile_s = time.time() - t0
@@ -200,11 +237,17 @@ def main():
                                    "graph_per_layer_GBps": round(ex.algorithmicBytes / (region_ms * 1e-3) / 1e9, 1)}
             out["roofline"].update({"region_ms_per_step_hip_events": round(region_ms, 4), "insitu_avg_launch_us": round(conv_ms / max(conv_n, 1) * 1e3, 2),
                                     "sum_conv_ms": round(conv_region_ms, 4), "sum_other_ms": round(region_ms - conv_region_ms, 4),
-                                    "algorithmic_bytes_per_step": round(ex.algorithmicBytes), "byte_models": byte_models,
-                                    "hbm_frac_of_8TBps_whole_step": round(ex.algorithmicBytes / (ms_per_step * 1e-3) / 8e12, 4)})
+                                    "algorithmic_bytes_per_step": round(ex.algorithmicBytes), "byte_models": byte_models})
             if os.environ.get("SMELTER_BENCH_VERBOSE"):
                 for ms, d in per:
                     print("  %8.1f us  %s" % (ms * 1e3, d), file=sys.stderr)
+        # ---- BASELINE.json configs[2] and [3] in the same record: same steps / warmup, HIP events on the launch stream ----
+        if world == 1 and a.model == "r50" and not a.batch and not a.no_secondary:
+            del ex, x
+            torch.cuda.empty_cache()
+            out["secondary"] = {}
+            for key in ("mbv2", "unet"):
+                out["secondary"][key] = measure_secondary(key, a, local, stream)
         # ---- CPU baseline: the oracle (a port of the reference's semantics) on the host cores, bounded sample ----
         if world == 1 and not a.no_cpu_baseline:
             import oracle
@@ -233,10 +276,12 @@ def main():
             ex_small.encode(torch.from_numpy(xs).cuda(), stream)
             got = ex_small.toFloatArray()
             err = float(np.abs(got - ref).max() / np.abs(ref).max())
+            rl2 = float(np.linalg.norm((got - ref).ravel()) / np.linalg.norm(ref.ravel()))
             out["cpu_baseline"] = {"value": round(cpu_batch / cpu_s, 3), "unit": "images/s", "cores": oracle.num_threads(), "kind": "port",
                                    "sample": "%s fp32 oracle (naive direct conv, OpenMP), bs=%d, %d passes, median %.2f s / min %.2f s per pass" % (
                                        factory, cpu_batch, len(cpu_times), cpu_s, cpu_times[0]),
-                                   "gpu_vs_oracle_max_err_over_max_ref": round(err, 6),
+                                   "gpu_vs_oracle_rel_l2": round(rl2, 6), "gpu_vs_oracle_max_err_over_max_ref": round(err, 6),
+                                   "tolerance_note": "fp16 storage between layers vs an fp32 oracle; north_star's 1e-3 is met in rel-L2, the max-norm figure is reported beside it (DESIGN.md 5)",
                                    "load_time_weight_prep_s": {"oracle_reference_style": round(load_oracle_s, 3), "ours_fold_cast_pack": round(load_ours_s, 3)}}
         print(json.dumps(out))
         sys.stdout.flush()

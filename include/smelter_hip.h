@@ -60,6 +60,10 @@ const char* smelter_version(void);
  * its default exponent 1, i.e. the identity: the compiler aliases it.) */
 enum { SM_ACT_NONE = 0, SM_ACT_RELU = 1, SM_ACT_PRELU = 2, SM_ACT_SIGMOID = 3, SM_ACT_HARD_SIGMOID = 4, SM_ACT_TANH = 5, SM_ACT_ELU = 6,
        SM_ACT_ABS = 7, SM_ACT_SOFTPLUS = 8, SM_ACT_SOFTSIGN = 9, SM_ACT_EXP = 10, SM_ACT_LOG = 11 };
+/* NaN under SM_ACT_RELU is NOT specified: the epilogues that apply ReLU as a packed fp16 max after the rounding (v_pk_max_f16 returns the non-NaN
+ * operand: NaN -> 0) and those that apply it as a select on the fp32 sum (NaN stays NaN) coexist, and the autotuner chooses between them per layer.
+ * A diverged activation is therefore not guaranteed to surface as NaN in the output; -inf gives 0 everywhere, the sign of a zero result may differ.
+ * The reference's MPSCNNNeuronReLUNode (Converters.swift:351) documents neither. */
 enum { SM_BIN_ADD = 0, SM_BIN_SUB = 1, SM_BIN_MUL = 2, SM_BIN_DIV = 3 };   /* MPSNNAddition/Subtraction/Multiplication/DivisionNode */
 enum { SM_PAD_CONSTANT = 0, SM_PAD_REFLECT = 1, SM_PAD_EDGE = 2 };          /* MPSImageEdgeMode .constant(0) / .mirror / .clamp */
 
@@ -151,7 +155,8 @@ int sm_conv2d_xhead_proj_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, 
  * packed for it. */
 /* ... + the MPSCNNPoolingMaxNode (3x3 / stride 2, Converters.swift:662; window start by PyTorchPoolPadding.swift:60-75 = 0 here) that consumes the stem, in ONE
  * launch (stem_pool.hpp): the stem's own output — the largest tensor of a ResNet — is neither written nor read.  y_pool = [N, pool_H, pool_W, Cout] fp16,
- * pixel stride pool_ld (0 = Cout).  Taken: row-pair stem form with 2 | 4 taps, Cout = 64, pool_H = ceil((Ho - 2) / 2) or that + 1 (windows clamped at the edge). */
+ * pixel stride pool_ld (0 = Cout).  Taken: row-pair stem form with 2 | 4 taps, Cout = 64, and pooled sizes whose last window has its rows / columns 0 and 1 inside the
+ * conv image: 2 (pool_H - 1) + 1 < Ho, 2 (pool_W - 1) + 1 < Wo (only row / column 2 of a window may be clamped at the edge). */
 int sm_conv2d_stem_f32_pool_supported(const sm_conv_desc* d, int32_t C, int32_t H_in, int32_t W_in, int32_t pool_H, int32_t pool_W);
 int sm_conv2d_stem_f32_pool_fwd(const sm_conv_desc* d, const float* x_nchw, int32_t C, int32_t H_in, int32_t W_in, int32_t pt, int32_t pl, const void* w_stem,
                                 const float* bias, void* y_pool, int32_t pool_H, int32_t pool_W, int32_t pool_ld, sm_stream_t stream);
@@ -326,7 +331,27 @@ typedef struct smelter_config {
     int32_t branch_concurrency;   /* 1: a conv only read as a later step's residual (projection shortcut) is hoisted and runs on a
                                    * second stream beside the main branch; 0 (default): strictly one kernel at a time.  Measured on
                                    * ResNet-50 bs=64: the kernels do overlap, but each fork/join pair costs ~16 us of graph-edge latency */
+    int32_t fusions;              /* SM_FUSE_* mask of the fusion passes the compiler may apply (with fuse == 1); default SM_FUSE_DEFAULT */
+    int32_t autotune_mode;        /* SM_TUNE_IN_SITU (default): a tile configuration is timed behind the layer's two real predecessors;
+                                   * SM_TUNE_COLD: behind a 640 MB flush (mis-ranks the streaming kernels) */
+    int32_t autotune_max_cfg;     /* 0: every tile configuration; n > 0: only the first n (A/B of library generations on one box) */
+    int32_t mbconv_domain[3];     /* {0,0,0}: the default domain of the fused inverted-residual block; else max {Cin, hidden, Cout} it may take */
 } smelter_config;
+/* Executor behaviour is decided by THIS struct, read once at smelter_graph_create / _compile — no environment variable is consulted after that.
+ * smelter_config_default() is where the bench / A/B tools' environment overrides enter (each read there, once): SMELTER_MBCONV=0, SMELTER_XHEAD=0,
+ * SMELTER_XHEAD_PROJ=0, SMELTER_KCAT=0|copy, SMELTER_MBCONV_STEM=0, SMELTER_STEM_F32=0, SMELTER_STEM_POOL=0 clear / set the matching SM_FUSE_* bit;
+ * SMELTER_AUTOTUNE=cold, SMELTER_AUTOTUNE_MAXCFG=n, SMELTER_MBCONV_DOMAIN="cin,hidden,cout" fill the fields above.  A host that fills the struct itself
+ * (the Swift shim of INTEGRATION.md) is not affected by the environment at all. */
+enum { SM_FUSE_MBCONV = 1,        /* expand -> depthwise -> project in one launch (mbconv.hip) */
+       SM_FUSE_XHEAD = 2,         /* 3x3 -> 1x1 expand (+ residual) in one launch (conv3x3_wsx.hpp) */
+       SM_FUSE_XHEAD_PROJ = 4,    /* ... with the projection shortcut as its second GEMM */
+       SM_FUSE_KCAT = 8,          /* expand + projection shortcut as ONE pointwise convolution over two sources */
+       SM_FUSE_KCAT_COPY = 16,    /* ... through a concatenated copy of the operands instead of reading the second source in place (off by default) */
+       SM_FUSE_MBCONV_STEM = 32,  /* image stem inside the first inverted-residual block */
+       SM_FUSE_STEM_F32 = 64,     /* input conversion inside the stem launch (loader waves) */
+       SM_FUSE_STEM_POOL = 128,   /* stem + max-pool 3x3 / 2 in one launch (stem_pool.hpp) */
+       SM_FUSE_DEFAULT = 1 | 2 | 4 | 8 | 32 | 64 | 128 };
+enum { SM_TUNE_IN_SITU = 0, SM_TUNE_COLD = 1 };
 void smelter_config_default(smelter_config* c);
 
 typedef struct smelter_graph smelter_graph; /* ONNXGraph */
@@ -356,6 +381,15 @@ int smelter_graph_weight_bytes(smelter_graph* g, int32_t batch, size_t* bytes);
 int smelter_graph_pack_weights(smelter_graph* g, int32_t batch, void* dst, size_t cap);
 int smelter_graph_compile(smelter_graph* g, int32_t hip_device, int32_t batch, void* weight_arena,
                           int32_t upload_weights, smelter_exec** out);
+/* Execution plan = the tile configuration every step runs with (the autotuner's picks), as int32 words: {'PLAN', tile configurations in the library build,
+ * steps, cfg per step}.  A batch-shard job autotunes on rank 0 only and hands the plan to the other ranks with the weight arena (smelter_amd/dist.py), so that all
+ * ranks run the IDENTICAL single-GPU executor — per-shard outputs are then bit-identical to the one-GPU run of the same images (the reference has one
+ * device, ONNXGraph.swift:169).  get_plan: dst may be NULL to query the size.  default_plan: the plan of a compile WITHOUT autotuning (host only, no GPU).
+ * compile_with_plan fails with SM_ERR_INVALID_ARGUMENT if the plan comes from another graph / batch / library build. */
+int smelter_exec_get_plan(const smelter_exec* e, int32_t* dst, size_t cap_words, size_t* words);
+int smelter_graph_default_plan(smelter_graph* g, int32_t batch, int32_t* dst, size_t cap_words, size_t* words);
+int smelter_graph_compile_with_plan(smelter_graph* g, int32_t hip_device, int32_t batch, void* weight_arena, int32_t upload_weights,
+                                    const int32_t* plan, size_t plan_words, smelter_exec** out);
 void smelter_exec_destroy(smelter_exec* e);
 
 /* encode(to:sourceImages:) (README.md:43-44): enqueue one forward pass on `stream`; asynchronous, no host
@@ -384,9 +418,12 @@ double smelter_exec_algorithmic_bytes(const smelter_exec* e); /* per-layer compu
 double smelter_exec_launch_bytes(const smelter_exec* e);      /* post-fusion compulsory bytes per encode: what the launches must read + write (tensors fused away do not count) */
 /* per-op description for profiling: returns a static-lifetime string "idx kind name MxNxK cfg" */
 const char* smelter_exec_op_desc(const smelter_exec* e, int32_t idx);
-/* names of the tensors materialised in fp16 storage after fusion (graph input + every kernel output) */
+/* names of the tensors that exist as fp16 after fusion: the graph input, every kernel output, and the hidden tensors a fused launch rounds to fp16 in
+ * registers / LDS without storing them (what a parity oracle must round to emulate the executor).  smelter_exec_value_stored: 1 = the tensor has storage in
+ * the activation arena and smelter_exec_read_value can fetch it after an encode; 0 = registers / LDS only (read_value answers SM_ERR_NO_SUCH_OUTPUT). */
 int smelter_exec_num_values(const smelter_exec* e);
 const char* smelter_exec_value_name(const smelter_exec* e, int32_t idx);
+int smelter_exec_value_stored(const smelter_exec* e, int32_t idx);
 /* time one op `idx` in isolation (iters launches, HIP events); ms per launch */
 int smelter_exec_time_op(smelter_exec* e, sm_stream_t stream, int32_t idx, int32_t iters, float* ms);
 /* in-situ per-launch timing: `iters` eager passes over the whole sequence with HIP events on `stream` between

@@ -46,7 +46,8 @@ class PoolDesc(C.Structure):
 class Config(C.Structure):
     _fields_ = [("input_constraint", C.c_int32), ("align_corners", C.c_int32), ("dims", C.c_int32 * 4),
                 ("fuse", C.c_int32), ("use_hip_graph", C.c_int32), ("autotune", C.c_int32), ("keep_intermediates", C.c_int32),
-                ("branch_concurrency", C.c_int32)]
+                ("branch_concurrency", C.c_int32), ("fusions", C.c_int32), ("autotune_mode", C.c_int32), ("autotune_max_cfg", C.c_int32),
+                ("mbconv_domain", C.c_int32 * 3)]
 
 
 class Shape(C.Structure):
@@ -140,6 +141,9 @@ SYMBOLS = {
     "smelter_graph_weight_bytes": (_i32, [_vp, _i32, C.POINTER(_sz)]),
     "smelter_graph_pack_weights": (_i32, [_vp, _i32, _vp, _sz]),
     "smelter_graph_compile": (_i32, [_vp, _i32, _i32, _vp, _i32, C.POINTER(_vp)]),
+    "smelter_graph_compile_with_plan": (_i32, [_vp, _i32, _i32, _vp, _i32, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(_vp)]),
+    "smelter_exec_get_plan": (_i32, [_vp, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "smelter_graph_default_plan": (_i32, [_vp, _i32, C.POINTER(C.c_int32), C.c_size_t, C.POINTER(C.c_size_t)]),
     "smelter_exec_destroy": (None, [_vp]),
     "smelter_exec_encode_sized": (_i32, [_vp, _vp, _vp, _i32, _i32]),
     "smelter_exec_encode": (_i32, [_vp, _vp, _vp]),
@@ -157,6 +161,7 @@ SYMBOLS = {
     "smelter_exec_op_desc": (C.c_char_p, [_vp, _i32]),
     "smelter_exec_num_values": (_i32, [_vp]),
     "smelter_exec_value_name": (C.c_char_p, [_vp, _i32]),
+    "smelter_exec_value_stored": (_i32, [_vp, _i32]),
     "smelter_exec_time_op": (_i32, [_vp, _vp, _i32, _i32, C.POINTER(_f)]),
     "smelter_exec_profile": (_i32, [_vp, _vp, _vp, _i32, C.POINTER(_f), _i32]),
     "smelter_exec_read_value": (_i32, [_vp, _vp, C.c_char_p, _vp, _sz, _pi32, _pi32, _pi32]),

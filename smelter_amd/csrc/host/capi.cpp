@@ -1,6 +1,9 @@
 // capi.cpp — graph-level C ABI (include/smelter_hip.h §2): the ONNXGraph load-and-encode surface
 // (/root/reference/Sources/Smelter/ONNXGraph.swift:95,158,169; README.md:43-44;
 // Extensions/Foundation/MPSImage+Extensions.swift:9) over opaque handles.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include <memory>
 
 #include "../kernels/common.hpp"
@@ -19,6 +22,15 @@ void smelter_config_default(smelter_config* c) {
     c->input_constraint = SM_INPUT_NONE; c->align_corners = 1;
     for (int i = 0; i < 4; i++) c->dims[i] = -1;
     c->fuse = 1; c->use_hip_graph = 1; c->autotune = 0; c->keep_intermediates = 0; c->branch_concurrency = 0;
+    c->fusions = SM_FUSE_DEFAULT; c->autotune_mode = SM_TUNE_IN_SITU; c->autotune_max_cfg = 0; c->mbconv_domain[0] = c->mbconv_domain[1] = c->mbconv_domain[2] = 0;
+    // The ONLY place the executor's environment switches are read (bench / A-B tools; documented in smelter_hip.h): they edit the defaults, once.
+    auto off = [&](const char* name, int bit) { const char* e = getenv(name); if (e && e[0] == '0') c->fusions &= ~bit; };
+    off("SMELTER_MBCONV", SM_FUSE_MBCONV); off("SMELTER_XHEAD", SM_FUSE_XHEAD); off("SMELTER_XHEAD_PROJ", SM_FUSE_XHEAD_PROJ); off("SMELTER_KCAT", SM_FUSE_KCAT);
+    off("SMELTER_MBCONV_STEM", SM_FUSE_MBCONV_STEM); off("SMELTER_STEM_F32", SM_FUSE_STEM_F32); off("SMELTER_STEM_POOL", SM_FUSE_STEM_POOL);
+    if (const char* e = getenv("SMELTER_KCAT")) if (!strcmp(e, "copy")) c->fusions |= SM_FUSE_KCAT_COPY;
+    if (const char* e = getenv("SMELTER_AUTOTUNE")) if (!strcmp(e, "cold")) c->autotune_mode = SM_TUNE_COLD;
+    if (const char* e = getenv("SMELTER_AUTOTUNE_MAXCFG")) c->autotune_max_cfg = atoi(e) > 0 ? atoi(e) : 0;
+    if (const char* e = getenv("SMELTER_MBCONV_DOMAIN")) { int a = 0, b = 0, d = 0; if (sscanf(e, "%d,%d,%d", &a, &b, &d) == 3) { c->mbconv_domain[0] = a; c->mbconv_domain[1] = b; c->mbconv_domain[2] = d; } }
 }
 
 int smelter_graph_create(const void* onnx, size_t n, const smelter_config* cfg, smelter_graph** out) {
@@ -32,6 +44,8 @@ int smelter_graph_create(const void* onnx, size_t n, const smelter_config* cfg, 
     for (int i = 0; i < 4; i++) if (cfg->dims[i] >= 0) c.dims[i] = cfg->dims[i];
     c.fuse = cfg->fuse != 0; c.useHipGraph = cfg->use_hip_graph != 0; c.autotune = cfg->autotune != 0; c.keepIntermediates = cfg->keep_intermediates != 0;
     c.branchConcurrency = cfg->branch_concurrency != 0;
+    c.fusions = cfg->fusions; c.autotuneMode = cfg->autotune_mode; c.autotuneMaxCfg = cfg->autotune_max_cfg;
+    for (int i = 0; i < 3; i++) c.mbconvDomain[i] = cfg->mbconv_domain[i];
     int err = SM_OK;
     std::unique_ptr<ONNXGraph> g(new ONNXGraph(onnx, n, c, &err));
     if (err) return err;
@@ -67,6 +81,28 @@ int smelter_graph_compile(smelter_graph* g, int32_t dev, int32_t batch, void* ar
     *out = new smelter_exec{std::unique_ptr<Executor>(e)};
     return SM_OK;
 }
+int smelter_graph_compile_with_plan(smelter_graph* g, int32_t dev, int32_t batch, void* arena, int32_t upload, const int32_t* plan, size_t plan_words, smelter_exec** out) {
+    SM_REQUIRE(g && out && plan, "smelter_graph_compile_with_plan: null argument");
+    Executor* e = nullptr;
+    int rc = Executor::create(*g->g, dev, batch, arena, upload != 0, &e, plan, plan_words);
+    if (rc) return rc;
+    *out = new smelter_exec{std::unique_ptr<Executor>(e)};
+    return SM_OK;
+}
+int smelter_exec_get_plan(const smelter_exec* e, int32_t* dst, size_t cap_words, size_t* words) {
+    SM_REQUIRE(e && words, "smelter_exec_get_plan: null argument");
+    const std::vector<int32_t> p = e->e->exportPlan();
+    *words = p.size();
+    if (dst) { SM_REQUIRE(cap_words >= p.size(), "smelter_exec_get_plan: buffer holds %zu words, the plan has %zu", cap_words, p.size()); memcpy(dst, p.data(), p.size() * sizeof(int32_t)); }
+    return SM_OK;
+}
+int smelter_graph_default_plan(smelter_graph* g, int32_t batch, int32_t* dst, size_t cap_words, size_t* words) {
+    SM_REQUIRE(g && words, "smelter_graph_default_plan: null argument");
+    std::vector<int32_t> p; int rc = Executor::defaultPlanHost(*g->g, batch, &p); if (rc) return rc;
+    *words = p.size();
+    if (dst) { SM_REQUIRE(cap_words >= p.size(), "smelter_graph_default_plan: buffer holds %zu words, the plan has %zu", cap_words, p.size()); memcpy(dst, p.data(), p.size() * sizeof(int32_t)); }
+    return SM_OK;
+}
 void smelter_exec_destroy(smelter_exec* e) { delete e; }
 
 int smelter_exec_encode(smelter_exec* e, sm_stream_t s, const float* in) {
@@ -97,6 +133,7 @@ double smelter_exec_launch_bytes(const smelter_exec* e) { return e ? e->e->launc
 const char* smelter_exec_op_desc(const smelter_exec* e, int32_t idx) { return e ? e->e->opDesc(idx) : ""; }
 int smelter_exec_num_values(const smelter_exec* e) { return e ? e->e->numMaterialized() : 0; }
 const char* smelter_exec_value_name(const smelter_exec* e, int32_t idx) { return e ? e->e->materializedName(idx) : ""; }
+int smelter_exec_value_stored(const smelter_exec* e, int32_t idx) { return e ? e->e->materializedStored(idx) : 0; }
 int smelter_exec_time_op(smelter_exec* e, sm_stream_t s, int32_t idx, int32_t iters, float* ms) {
     SM_REQUIRE(e && ms, "smelter_exec_time_op: null argument");
     return e->e->timeOp((hipStream_t)s, idx, iters, ms);

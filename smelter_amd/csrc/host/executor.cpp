@@ -374,11 +374,10 @@ int Executor::plan(ONNXGraph& g, int batch) {
     // input and are otherwise written once and read once.  Domain = the all-in-LDS kernel's (Cin <= 32, Ch <= 192, Cout <= 64), where the fused
     // launch measured faster than the three separate ones; SMELTER_MBCONV=0 keeps the layers apart.
     {
-        const char* mb_env = getenv("SMELTER_MBCONV");
         auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
         auto pointwise = [&](const Step& q) { const Op& o = q.op; return o.kind == OpKind::Conv && o.kh == 1 && o.kw == 1 && o.sh == 1 && o.sw == 1 && !o.pt && !o.pl && !o.pb && !o.pr && o.groups == 1 &&
                                                      o.act <= SM_ACT_PRELU && !q.stem && !o.grid_h && !o.x_ups && q.pool_out < 0 && !q.has_mb; };
-        if (!(mb_env && mb_env[0] == '0') && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency)
+        if (cfg_.allows(SM_FUSE_MBCONV) && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency)
             for (size_t t = 0; t < steps_.size(); t++) {
                 Step& e = steps_[t];
                 if (!pointwise(e) || e.op.residual >= 0 || readers(e.op.output) != 1) continue;
@@ -395,17 +394,17 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 const Value& iv = values_[e.op.inputs[0]]; const Value& ov = values_[pj.output];
                 sm_mbconv_desc d{}; d.N = batch; d.H = iv.h; d.W = iv.w; d.Ho = ov.h; d.Wo = ov.w; d.stride = dw.sh; d.Cin = e.op.cin; d.Ch = e.op.cout; d.Cout = pj.cout; d.expand = 1;
                 d.residual = pj.residual >= 0 ? 1 : 0; d.act1 = e.op.act; d.act2 = dw.act; d.act3 = pj.act;
-                // (experiment switch: SMELTER_MBCONV_DOMAIN="cin,ch,cout" widens / narrows the domain; "32,192,64" = the all-in-LDS kernel's only)
-                const char* dom_env = getenv("SMELTER_MBCONV_DOMAIN");
+                // (smelter_config.mbconv_domain = {cin, hidden, cout} widens / narrows the domain; {32, 192, 64} = the all-in-LDS kernel's only)
+                const bool dom_env = cfg_.mbconvDomain[0] > 0;
                 int max_cin = 96, max_ch = 576, max_cout = 160;
-                if (dom_env) sscanf(dom_env, "%d,%d,%d", &max_cin, &max_ch, &max_cout);
+                if (dom_env) { max_cin = cfg_.mbconvDomain[0]; max_ch = cfg_.mbconvDomain[1]; max_cout = cfg_.mbconvDomain[2]; }
                 // (the image-per-block kernel, kind 4, brings its own domain: the 14 x 14 and 7 x 7 blocks up to Ch = 960)
                 if (((d.Cin > max_cin || d.Ch > max_ch || d.Cout > max_cout) && (dom_env || sm_mbconv_kernel_kind(&d) != 4)) || !vecOk(e.op.inputs[0]) || !vecOk(pj.output) || !sm_mbconv_supported(&d)) continue;
                 e.has_mb = true; e.mb_dw = steps_[ud].op; e.mb_proj = steps_[up].op;
                 steps_.erase(steps_.begin() + up); steps_.erase(steps_.begin() + ud);
             }
         // the block without an expand layer (MobileNet-v2's first: depthwise 3x3 on the stem output -> 1x1 project)
-        if (!(mb_env && mb_env[0] == '0') && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency)
+        if (cfg_.allows(SM_FUSE_MBCONV) && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency)
             for (size_t t = 0; t < steps_.size(); t++) {
                 Step& e = steps_[t];
                 const Op& dw = e.op;
@@ -442,7 +441,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                     o.x_ups || h.has_mb || h.pool_out >= 0 || o.cin != c.op.cout || !vecOk(o.output) || (o.residual >= 0 && !vecOk(o.residual))) break;
                 // narrow head without residual: the HEAD instantiations; a bottleneck's tail (1x1 expand to <= 256 channels + block input + ReLU): the
                 // expand head (conv3x3_ws.hpp HX), SMELTER_XHEAD=0 keeps the two launches
-                const bool xhead_on = !(getenv("SMELTER_XHEAD") && getenv("SMELTER_XHEAD")[0] == '0');      // (plan time, not the launch path)
+                const bool xhead_on = cfg_.allows(SM_FUSE_XHEAD);
                 const bool narrow = o.residual < 0 && sm_conv2d_head_supported(&d, o.cout);
                 if (!narrow && !(xhead_on && sm_conv2d_xhead_supported(&d, o.cout, o.residual >= 0 ? 1 : 0))) break;
                 if (o.residual >= 0) {
@@ -482,7 +481,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     // input, residual = the expand layer's output).  When that expand layer is an expand head without activation and the shortcut is its only reader, the
     // shortcut becomes the head's second GEMM: y = act(w3 . h + ws . x0 + (b3 + bs)) — three layers, one launch, and the expand layer's output (102.8 MB
     // at 56^2 x 256 x bs 64, written once and read once) never exists.  SMELTER_XHEAD_PROJ=0 keeps the shortcut as its own launch.
-    if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && !(getenv("SMELTER_XHEAD_PROJ") && getenv("SMELTER_XHEAD_PROJ")[0] == '0')) {
+    if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && cfg_.allows(SM_FUSE_XHEAD_PROJ)) {
         auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
         auto producer = [&](int v) -> long {
             for (size_t q = 0; q < steps_.size(); q++)
@@ -516,7 +515,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     // are ONE GEMM over K1 + K2: y = act([W_E | W_S] . [h ; x_s] + (b_E + b_S)).  The producer of h writes its rows with pixel stride K1 + K2, a
     // MaxPool 1x1 / stride s step (an exact strided copy) puts the block input's pixels beside them, and a single 1x1 convolution replaces both layers:
     // E's output (51 MB at 28^2 x 512, bs 64) is neither written nor read back, and one launch per stage goes away.  SMELTER_KCAT=0 keeps the graph.
-    if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && !(getenv("SMELTER_KCAT") && getenv("SMELTER_KCAT")[0] == '0')) {
+    if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && cfg_.allows(SM_FUSE_KCAT)) {
         auto readers = [&](int v) {
             int n = v == output_value_ ? 2 : 0;
             for (const Step& q : steps_) {
@@ -551,7 +550,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             const double x_full = (double)batch * xv.c * xv.h * xv.w;
             // Form 1 (default when both K parts are whole K tiles): the merged convolution reads its SECOND source in place — K tiles beyond K1 come from the block
             // input at pixel stride s (conv1x1_ps.hpp): no concatenated buffer, no strided copy, no extra launch.  SMELTER_KCAT=copy keeps form 2 below.
-            const bool kcat_copy = getenv("SMELTER_KCAT") && !strcmp(getenv("SMELTER_KCAT"), "copy");     // (plan time)
+            const bool kcat_copy = cfg_.allows(SM_FUSE_KCAT_COPY);
             if (!kcat_copy && (K1 % 64) == 0 && (K2 % 64) == 0 && vecOk(xs) && vecOk(h2) && vecOk(so.output)) {
                 Step& S = steps_[u]; Op& mo = S.op;
                 std::vector<float> w((size_t)N * (K1 + K2));
@@ -598,7 +597,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     // input conversion, the stem launch and the stem's output tensor (205 MB at 112^2 x 32, bs 256: written once, read once) disappear.
     // SMELTER_MBCONV_STEM=0 keeps the stem launch.
     stem_in_block_ = false;
-    if (stem_ && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && !(getenv("SMELTER_MBCONV_STEM") && getenv("SMELTER_MBCONV_STEM")[0] == '0')) {
+    if (stem_ && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && cfg_.allows(SM_FUSE_MBCONV_STEM)) {
         auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
         for (size_t t = 0; t + 1 < steps_.size(); t++) {
             Step& sc = steps_[t];
@@ -623,7 +622,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     // ---- 3f. image stem: when a loader-wave instantiation of the stem kernel takes the layer, the input conversion happens inside its launch
     // (conv3x3_ws.hpp NLW): the row-pair image is never written; SMELTER_STEM_F32=0 keeps the conversion launch.
     stem_f32_ = false;
-    if (stem_ && cfg_.fuse && !cfg_.keepIntermediates && !(getenv("SMELTER_STEM_F32") && getenv("SMELTER_STEM_F32")[0] == '0'))
+    if (stem_ && cfg_.fuse && !cfg_.keepIntermediates && cfg_.allows(SM_FUSE_STEM_F32))
         for (const Step& st : steps_) if (st.stem) {
             const sm_conv_desc d = convDesc(st); const Value& iv = values_[input_value_];
             stem_f32_ = sm_conv2d_stem_f32_supported(&d, iv.c, iv.h, iv.w) != 0;
@@ -632,8 +631,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
     // ---- 3i. image stem -> MaxPool 3x3 / stride 2 (ResNet's first two layers): the stem's output — the largest tensor of the network, written once and read
     // once — never exists: the loader waves of the stem kernel pool the previous tile from an LDS hand-over buffer (stem_pool.hpp).  SMELTER_STEM_POOL=0
     // keeps the two launches.
-    if (stem_ && !stem_in_block_ && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && !(getenv("SMELTER_STEM_POOL") && getenv("SMELTER_STEM_POOL")[0] == '0') &&
-        !(getenv("SMELTER_STEM_F32") && getenv("SMELTER_STEM_F32")[0] == '0')) {                     // (the fused kernel is a loader-wave stem: it reads the fp32 batch)
+    if (stem_ && !stem_in_block_ && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && cfg_.allows(SM_FUSE_STEM_POOL) &&
+        cfg_.allows(SM_FUSE_STEM_F32)) {                     // (the fused kernel is a loader-wave stem: it reads the fp32 batch)
         auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
         for (size_t t = 0; t < steps_.size(); t++) {
             Step& sc = steps_[t];
@@ -697,6 +696,9 @@ int Executor::plan(ONNXGraph& g, int batch) {
     }
     touch(output_value_, ns);                               // result image must survive until read back
     if (cfg_.keepIntermediates) for (int v = 0; v < nv; v++) if (last[v] >= 0) { first[v] = -1; last[v] = ns; }
+    // storage = the value's root buffer got a lifetime; the image input of a stem launch is never stored as an NHWC fp16 tensor (row-pair image, or nothing at all)
+    stored_.assign(nv, 0);
+    for (int v = 0; v < nv; v++) stored_[v] = last[place_[v].root] >= 0 && !(stem_ && v == input_value_);
     root_offset_.assign(nv, 0);
     struct Blk { int v; size_t bytes; };
     std::vector<Blk> blks;
@@ -904,7 +906,34 @@ int Executor::packWeightsHost(ONNXGraph& g, int batch, void* dst, size_t cap) {
     return SM_OK;
 }
 
-int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool upload, Executor** out) {
+static const int32_t kPlanMagic = 0x4e414c50;   // "PLAN"
+std::vector<int32_t> Executor::exportPlan() const {
+    std::vector<int32_t> p{kPlanMagic, (int32_t)sm_conv2d_num_configs(), (int32_t)steps_.size()};
+    for (const Step& st : steps_) p.push_back(st.conv_cfg);
+    return p;
+}
+int Executor::importPlan(const int32_t* plan, size_t words) {
+    if (!plan || words < 3 || plan[0] != kPlanMagic) { sm_set_error("execution plan: not a plan (bad header)"); return SM_ERR_INVALID_ARGUMENT; }
+    if (plan[1] != sm_conv2d_num_configs()) { sm_set_error("execution plan: made by a library with %d tile configurations, this one has %d", plan[1], sm_conv2d_num_configs()); return SM_ERR_INVALID_ARGUMENT; }
+    if ((size_t)plan[2] != steps_.size() || words != 3 + steps_.size()) {
+        sm_set_error("execution plan: %d steps (%zu words), this graph / batch compiles to %zu steps", plan[2], words, steps_.size()); return SM_ERR_INVALID_ARGUMENT; }
+    for (size_t i = 0; i < steps_.size(); i++) {
+        const int c = plan[3 + i];
+        if (c < -1 || c >= sm_conv2d_num_configs()) { sm_set_error("execution plan: step %zu names tile configuration %d", i, c); return SM_ERR_INVALID_ARGUMENT; }
+        steps_[i].conv_cfg = c;
+        if (c >= 0) steps_[i].desc += " cfg=" + std::to_string(c);
+    }
+    return SM_OK;
+}
+int Executor::defaultPlanHost(ONNXGraph& g, int batch, std::vector<int32_t>* out) {
+    if (batch <= 0) { sm_set_error("batch must be positive"); return SM_ERR_INVALID_ARGUMENT; }
+    int rc = g.build(); if (rc) return rc;
+    Executor e; rc = e.plan(g, batch); if (rc) return rc;
+    *out = e.exportPlan();
+    return SM_OK;
+}
+
+int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool upload, Executor** out, const int32_t* plan, size_t plan_words) {
     if (batch <= 0) { sm_set_error("batch must be positive"); return SM_ERR_INVALID_ARGUMENT; }
     int rc = g.build(); if (rc) return rc;
     std::unique_ptr<Executor> e(new Executor());
@@ -931,7 +960,8 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     SM_HIP_CHECK(hipMalloc((void**)&e->out_f32_, e->out_f32_count_ * 4));
     for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit();
                                  st.head.weight.clear(); st.head.weight.shrink_to_fit(); st.side.weight.clear(); st.side.weight.shrink_to_fit(); st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
-    if (e->cfg_.autotune) {   // with an external arena and upload == 0 the caller filled it before compiling
+    if (plan) { rc = e->importPlan(plan, plan_words); if (rc) return rc; }   // another executor's picks (rank 0 of a batch-shard job): identical kernels on every rank
+    else if (e->cfg_.autotune) {   // with an external arena and upload == 0 the caller filled it before compiling
         hipStream_t s; SM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         rc = e->autotune(s);
         (void)hipStreamDestroy(s);
@@ -1150,9 +1180,15 @@ int Executor::readFloat(hipStream_t s, float* dst, size_t cap, int layout) {
     return SM_OK;
 }
 
+int Executor::materializedStored(int i) const {
+    if (i < 0 || i >= (int)materialized_.size()) return 0;
+    for (size_t v = 0; v < value_names_.size(); v++) if (value_names_[v] == materialized_[i]) return stored_[v];
+    return 0;
+}
 int Executor::readValue(hipStream_t s, const char* name, float* dst, size_t cap, int* c, int* h, int* w) {
     int v = -1; for (size_t i = 0; i < value_names_.size(); i++) if (value_names_[i] == name) v = (int)i;
     if (v < 0) { sm_set_error("no value named '%s' survives fusion", name); return SM_ERR_NO_SUCH_OUTPUT; }
+    if (!stored_[v]) { sm_set_error("value '%s' has no storage: a fused launch keeps it in registers / LDS only", name); return SM_ERR_NO_SUCH_OUTPUT; }
     const Value& val = values_[v]; size_t count = (size_t)batch_ * val.c * val.h * val.w;
     *c = val.c; *h = val.h; *w = val.w;
     if (cap < count) { sm_set_error("smelter_exec_read_value: destination too small"); return SM_ERR_INVALID_ARGUMENT; }
@@ -1202,13 +1238,12 @@ int Executor::autotune(hipStream_t s) {
     // HBM / Infinity Cache, never in an L2 warmed by the previous launch of the same kernel (L2 is invalidated at kernel
     // boundaries).  Ranking on back-to-back warm launches picked configs that were up to 1.5x slower in the graph.
     int ncfg = sm_conv2d_num_configs();
-    if (const char* mx = getenv("SMELTER_AUTOTUNE_MAXCFG")) ncfg = std::min(ncfg, std::max(1, atoi(mx)));   // A/B runs on one box
-    const char* mode = getenv("SMELTER_AUTOTUNE");
+    if (cfg_.autotuneMaxCfg > 0) ncfg = std::min(ncfg, cfg_.autotuneMaxCfg);   // A/B runs on one box
     // Default (round 3): IN SITU — a config is timed behind the two real predecessor launches, i.e. with its operands where the graph leaves them (the
     // producer just wrote them: Infinity Cache, L2 flushed at the boundary).  The all-cold ranking (640 MB memset before every launch, SMELTER_AUTOTUNE=cold)
     // mis-ranks the streaming kernels of conv1x1_rw.hpp: it charged them HBM-cold operands the network never shows them and kept the tiled kernels on the
     // 256 -> 128 and 128 -> 512 layers (39 vs 30 us, 27 vs 22 us in the graph; same-box step 1.172 -> 1.157 ms).
-    const bool insitu = !(mode && !strcmp(mode, "cold"));
+    const bool insitu = cfg_.autotuneMode != SM_TUNE_COLD;
     char* flush = nullptr; const size_t flush_bytes = (size_t)640 << 20;
     if (hipMalloc((void**)&flush, flush_bytes) != hipSuccess) { flush = nullptr; (void)hipGetLastError(); }
     hipEvent_t a, b; SM_HIP_CHECK(hipEventCreate(&a)); SM_HIP_CHECK(hipEventCreate(&b));

@@ -63,7 +63,12 @@ struct Step {                // one op after fusion, with everything resolved
 
 class Executor {
    public:
-    static int create(ONNXGraph& g, int device, int batch, void* ext_arena, bool upload, Executor** out);
+    // plan = the tile-configuration picks of another executor of the same graph / batch / library build (exportPlan): applied instead of autotuning
+    static int create(ONNXGraph& g, int device, int batch, void* ext_arena, bool upload, Executor** out, const int32_t* plan = nullptr, size_t plan_words = 0);
+    // [0] = 'PLAN', [1] = tile configurations in this build, [2] = steps, [3 ..] = conv_cfg per step (-1: heuristic / no tile configuration)
+    std::vector<int32_t> exportPlan() const;
+    int importPlan(const int32_t* plan, size_t words);
+    static int defaultPlanHost(ONNXGraph& g, int batch, std::vector<int32_t>* out);   // host only: the step list's plan with no picks (what a non-autotuned compile runs)
     static int weightBytes(ONNXGraph& g, int batch, size_t* bytes);
     // host-side arena image (fold + cast + pad + pack) without touching a GPU
     static int packWeightsHost(ONNXGraph& g, int batch, void* dst, size_t cap);
@@ -94,6 +99,7 @@ class Executor {
     // names of the tensors that exist in fp16 storage after fusion (graph input + every step output)
     int numMaterialized() const { return (int)materialized_.size(); }
     const char* materializedName(int i) const { return i >= 0 && i < (int)materialized_.size() ? materialized_[i].c_str() : ""; }
+    int materializedStored(int i) const;   // 1 / 0: does the i-th listed tensor have storage (readValue works)
 
    private:
     Executor() = default;
@@ -120,6 +126,7 @@ class Executor {
     bool stem_f32_ = false; mutable const float* cur_in_ = nullptr;
     bool stem_in_block_ = false;     // pass 3g: the stem runs inside the first block's launch
     std::vector<std::string> value_names_, materialized_;
+    std::vector<char> stored_;           // per value id: 1 = the tensor has storage in the activation arena (readValue can fetch it); 0 = it exists in registers / LDS only
 
     char* arena_ = nullptr; size_t arena_bytes_ = 0; bool own_arena_ = false;
     char* act_ = nullptr; size_t act_bytes_ = 0;

@@ -26,6 +26,9 @@ struct Configuration {
     std::map<int, int> dims;             // per-axis input-dim override (:25, :200-202)
     // executor options (no reference counterpart)
     bool fuse = true, useHipGraph = true, autotune = false, keepIntermediates = false, branchConcurrency = false;
+    int fusions = 0xEF;                  // SM_FUSE_DEFAULT (smelter_hip.h): which fusion passes may run
+    int autotuneMode = 0, autotuneMaxCfg = 0, mbconvDomain[3] = {0, 0, 0};
+    bool allows(int bit) const { return (fusions & bit) != 0; }
 };
 
 enum class Format { onnx, mpsFlavor };   // ONNXGraph.swift:49-52

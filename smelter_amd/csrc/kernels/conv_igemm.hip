@@ -1304,7 +1304,8 @@ bool stem_pool_ok(const sm_conv_desc* d, const ConvParams& p, int C, int H_in, i
     return d->groups == 1 && p.Cin == 64 && p.x_ld == 8 && p.kW == 1 && p.dH == 2 && p.pt == 0 && p.pl == 0 && p.sH == p.sW && (p.sH == 1 || p.sH == 2) && !p.ups && !p.yplace &&
            p.act <= SM_ACT_PRELU && C >= 1 && C <= 4 && (long)p.N * C * H_in * W_in * 4 < 0x7fff0000L && ((((uintptr_t)p.w) & 15) == 0) &&
            (long)(p.Ho - 1) * p.sH + 2 * (p.kH - 1) < p.H && (long)(p.Wo - 1) * p.sW + 8 <= p.W &&
-           pool_H >= 1 && pool_W >= 1 && 2 * (pool_H - 1) < p.Ho && 2 * (pool_W - 1) < p.Wo;
+           // (only window row / column 2 may leave the conv image — stem_pool.hpp redirects just those taps: rows / columns 0 and 1 of the LAST window are inside)
+           pool_H >= 1 && pool_W >= 1 && 2 * (pool_H - 1) + 1 < p.Ho && 2 * (pool_W - 1) + 1 < p.Wo;
 }
 }  // namespace
 int sm_conv2d_stem_f32_pool_supported(const sm_conv_desc* d, int32_t C, int32_t H_in, int32_t W_in, int32_t pool_H, int32_t pool_W) {
@@ -1363,6 +1364,8 @@ int sm_conv2d_dual_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const 
     if (!d->x_ld) p.x_ld = K1;                                          // (the first source's rows hold K1 channels, not d->Cin)
     p.x2 = (const half_t*)x2; p.x2_ld = x2_ld ? x2_ld : K2; p.x2_H = x2_H; p.x2_W = x2_W; p.x2_s = x2_stride; p.kt_sw = K1 / 64;
     SM_REQUIRE((p.x2_ld & 7) == 0 && ((((uintptr_t)x2) & 15) == 0), "sm_conv2d_dual_fwd_cfg: the second source needs 16-byte rows");
+    // (an unaligned first source would send launch() down the direct kernel, which knows no second source: wrong values behind SM_OK)
+    SM_REQUIRE((p.x_ld & 7) == 0 && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)w) & 15) == 0), "sm_conv2d_dual_fwd_cfg: the first source and the weights need 16-byte rows");
     if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 7 && cfg_eligible(kCfgs[i], p)) cfg = i; }
     if (cfg < 0) { sm_set_error("sm_conv2d_dual_fwd_cfg: no kernel takes this shape"); return SM_ERR_INVALID_ARGUMENT; }
     return launch(d, p, cfg, nullptr, 0, sm_s(stream));

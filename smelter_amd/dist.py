@@ -61,6 +61,22 @@ def broadcast_weight_arena(graph, batch: int, device=None, src: int = 0):
     return arena
 
 
+def broadcast_plan(plan, src: int = 0, device=None):
+    """Every rank returns rank `src`'s execution plan (int32 numpy array; `plan` is ignored elsewhere and may be None).  Two small broadcasts: length, words."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return np.asarray(plan, np.int32)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+    rank = dist.get_rank()
+    n = torch.tensor([len(plan) if rank == src else 0], dtype=torch.int64, device=device)
+    dist.broadcast(n, src=src)
+    t = torch.from_numpy(np.ascontiguousarray(np.asarray(plan, np.int32))).to(device) if rank == src else torch.empty(int(n.item()), dtype=torch.int32, device=device)
+    dist.broadcast(t, src=src)
+    return t.cpu().numpy()
+
+
 def arena_checksum(arena) -> int:
     """byte-exact checksum used by tests to show every rank holds identical weights"""
     import zlib
@@ -68,7 +84,15 @@ def arena_checksum(arena) -> int:
     return (zlib.crc32(memoryview(a).cast("B")) << 32) | (zlib.adler32(memoryview(a).cast("B")) & 0xFFFFFFFF)   # no temporaries: the arena is 51 MB
 
 
-def compile_sharded(graph, per_rank_batch: int, local_device: int = 0):
-    """rank-local executor bound to the broadcast arena (no weight upload on non-source ranks)"""
-    arena = broadcast_weight_arena(graph, per_rank_batch)
-    return graph.hipGraph(local_device, per_rank_batch, weight_arena=arena, upload_weights=False)
+def compile_sharded(graph, per_rank_batch: int, local_device: int = 0, src: int = 0):
+    """rank-local executor bound to the broadcast arena (no weight upload on non-source ranks).  Rank `src` compiles first — autotuning if the graph's
+    Configuration asks for it — and its execution plan is broadcast: every rank runs the identical kernels with the identical tile configurations, so a
+    shard's outputs are bit-identical to the one-GPU run of the same images."""
+    import torch.distributed as dist
+    arena = broadcast_weight_arena(graph, per_rank_batch, src=src)
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    ex = graph.hipGraph(local_device, per_rank_batch, weight_arena=arena, upload_weights=False) if rank == src else None
+    plan = broadcast_plan(ex.plan if ex is not None else None, src=src)
+    if ex is None:
+        ex = graph.hipGraph(local_device, per_rank_batch, weight_arena=arena, upload_weights=False, plan=plan)
+    return ex

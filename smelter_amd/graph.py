@@ -42,6 +42,9 @@ class Configuration:  # ONNXGraph.swift:6-36 (+ executor options)
     autotune: bool = False
     keepIntermediates: bool = False
     branchConcurrency: bool = False          # projection-shortcut convs on a second stream (measured: fork/join gaps eat the gain)
+    fusions: int = -1                        # SM_FUSE_* mask (smelter_hip.h); -1 = smelter_config_default()'s (SM_FUSE_DEFAULT edited by the SMELTER_* environment overrides)
+    autotuneMode: int = -1                   # 0 in situ | 1 cold; -1 = the default
+    autotuneMaxCfg: int = -1                 # only the first n tile configurations; -1 = the default (all)
 
     def _c(self) -> N.Config:
         c = N.Config()
@@ -53,6 +56,12 @@ class Configuration:  # ONNXGraph.swift:6-36 (+ executor options)
         c.fuse, c.use_hip_graph, c.autotune = int(self.fuse), int(self.useHipGraph), int(self.autotune)
         c.keep_intermediates = int(self.keepIntermediates)
         c.branch_concurrency = int(self.branchConcurrency)
+        if self.fusions >= 0:
+            c.fusions = self.fusions
+        if self.autotuneMode >= 0:
+            c.autotune_mode = self.autotuneMode
+        if self.autotuneMaxCfg >= 0:
+            c.autotune_max_cfg = self.autotuneMaxCfg
         return c
 
 
@@ -118,12 +127,25 @@ class ONNXGraph:
         N.check(N.lib().smelter_graph_pack_weights(self._h, batch, buf.ctypes.data_as(C.c_void_p), buf.size))
         return buf
 
-    def hipGraph(self, device: int = 0, batch: int = 1, weight_arena=None, upload_weights: bool = True) -> "Executor":
+    def defaultPlan(self, batch: int = 1) -> np.ndarray:
+        """execution plan (int32 words) of a compile without autotuning; host only"""
+        n = C.c_size_t()
+        N.check(N.lib().smelter_graph_default_plan(self._h, batch, None, 0, C.byref(n)))
+        buf = np.zeros(n.value, np.int32)
+        N.check(N.lib().smelter_graph_default_plan(self._h, batch, buf.ctypes.data_as(C.POINTER(C.c_int32)), buf.size, C.byref(n)))
+        return buf
+
+    def hipGraph(self, device: int = 0, batch: int = 1, weight_arena=None, upload_weights: bool = True, plan=None) -> "Executor":
         """metalGraph(device:) — compile for `device`.  `weight_arena`: optional torch uint8 CUDA tensor of
-        weightBytes(batch) bytes owned by the caller (used for the RCCL weight broadcast)."""
+        weightBytes(batch) bytes owned by the caller (used for the RCCL weight broadcast).  `plan`: int32 array from another
+        executor's `.plan` (same graph, batch and library build): its tile-configuration picks are applied instead of autotuning."""
         ex = C.c_void_p()
         ptr = C.c_void_p(weight_arena.data_ptr()) if weight_arena is not None else None
-        N.check(N.lib().smelter_graph_compile(self._h, device, batch, ptr, int(upload_weights), C.byref(ex)))
+        if plan is not None:
+            p = np.ascontiguousarray(np.asarray(plan, np.int32))
+            N.check(N.lib().smelter_graph_compile_with_plan(self._h, device, batch, ptr, int(upload_weights), p.ctypes.data_as(C.POINTER(C.c_int32)), p.size, C.byref(ex)))
+        else:
+            N.check(N.lib().smelter_graph_compile(self._h, device, batch, ptr, int(upload_weights), C.byref(ex)))
         return Executor(ex, batch, weight_arena)
 
     metalGraph = hipGraph  # name kept for drop-in readers
@@ -179,6 +201,15 @@ class Executor:
             return buf[:need].reshape(n, c.value, h.value, w.value).copy()
 
     # introspection
+    @property
+    def plan(self) -> np.ndarray:
+        """the tile configuration of every step (autotuner's picks included) as int32 words: feed it to ONNXGraph.hipGraph(plan=...) on another rank"""
+        n = C.c_size_t()
+        N.check(N.lib().smelter_exec_get_plan(self._h, None, 0, C.byref(n)))
+        buf = np.zeros(n.value, np.int32)
+        N.check(N.lib().smelter_exec_get_plan(self._h, buf.ctypes.data_as(C.POINTER(C.c_int32)), buf.size, C.byref(n)))
+        return buf
+
     numLaunches = property(lambda s: N.lib().smelter_exec_num_launches(s._h))
     numOps = property(lambda s: N.lib().smelter_exec_num_ops(s._h))
     weightBytes = property(lambda s: N.lib().smelter_exec_weight_bytes(s._h))
@@ -190,9 +221,16 @@ class Executor:
 
     @property
     def valueNames(self):
-        """tensors that exist in fp16 storage after fusion (graph input + every kernel output)"""
+        """tensors that exist as fp16 after fusion: graph input, every kernel output, and the hidden tensors a fused launch rounds in registers / LDS
+        without storing them — the list a parity oracle rounds to emulate the executor"""
         L = N.lib()
         return [L.smelter_exec_value_name(self._h, i).decode() for i in range(L.smelter_exec_num_values(self._h))]
+
+    @property
+    def storedValueNames(self):
+        """the subset of valueNames that has storage in the activation arena (readValue works on exactly these)"""
+        L = N.lib()
+        return [L.smelter_exec_value_name(self._h, i).decode() for i in range(L.smelter_exec_num_values(self._h)) if L.smelter_exec_value_stored(self._h, i)]
 
     def opDesc(self, idx: int) -> str:
         return N.lib().smelter_exec_op_desc(self._h, idx).decode()

@@ -50,6 +50,14 @@ def conv_out_size(h, w, kh, kw, sh, sw, pads):
     return oh.value, ow.value
 
 
+CFG_LOG = None      # tests/conftest.py sets this to a set(): every tile configuration a *_cfg entry point has run (the call returned SM_OK)
+
+
+def _ran(cfg):
+    if CFG_LOG is not None and cfg is not None and int(cfg) >= 0:
+        CFG_LOG.add(int(cfg))
+
+
 def conv2d(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0), dilation=(1, 1), groups=1,
            act=ACT_NONE, slope=0.0, out=None, cfg=None, workspace=None, ups=False):
     """ups=True: `x` is the half-resolution tensor, read through a fused nearest 2x upsampling (sm_conv_desc.x_ups)"""
@@ -77,6 +85,7 @@ def conv2d(x, w_ohwi, bias=None, residual=None, stride=(1, 1), pads=(0, 0, 0, 0)
         wsb = workspace.numel() * workspace.element_size() if workspace is not None else 0
         check(L.sm_conv2d_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(out), _ptr(workspace), wsb,
                                   _stream()))
+        _ran(cfg)
     elif workspace is not None:
         check(L.sm_conv2d_fwd_ws(C.byref(d), _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(residual), _ptr(out), _ptr(workspace),
                                  workspace.numel() * workspace.element_size(), _stream()))
@@ -95,6 +104,7 @@ def conv2d_dual(x, x2, w_ohwi, bias=None, stride2=1, act=ACT_NONE, slope=0.0, cf
         out = torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device)
     d = ConvDesc(n, h, w, k1 + k2, cout, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, h, w, act, slope, x_ld, _ld(out), 0)
     check(lib().sm_conv2d_dual_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(x2), k2, x2_ld, h2, w2, stride2, _ptr(w_ohwi), _ptr(bias), _ptr(out), _stream()))
+    _ran(cfg)
     return out
 
 
@@ -122,10 +132,12 @@ def stem_conv(x_nchw, w_ohwi_f32, bias=None, stride=1, pads=(0, 0, 0, 0), act=AC
     d = ConvDesc(n, hs, ws, 64, cout, P, 1, s, s, 2, 1, 0, 0, 0, 0, 1, ho, wo, act, slope, 8, cout, 0)
     if f32_path:
         check(lib().sm_conv2d_stem_f32_fwd_cfg(C.byref(d), cfg, _ptr(x_nchw), c, h, w, pads[0], pads[1], _ptr(wp), _ptr(bias), _ptr(out), _stream()))
+        _ran(cfg)
     elif cfg is None:
         check(lib().sm_conv2d_fwd(C.byref(d), _ptr(img), _ptr(wp), _ptr(bias), None, _ptr(out), _stream()))
     else:
         check(lib().sm_conv2d_fwd_cfg(C.byref(d), cfg, _ptr(img), _ptr(wp), _ptr(bias), None, _ptr(out), None, 0, _stream()))
+        _ran(cfg)
     return out
 
 
@@ -163,6 +175,7 @@ def conv2d_pool(x, w_ohwi, bias, act=ACT_RELU, slope=0.0, cfg=-1):
     yp = torch.empty((n, h // 2, w // 2, cout), dtype=torch.float16, device=x.device)
     d = ConvDesc(n, h, w, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, h, w, act, slope, x_ld, _ld(y), 0)
     check(lib().sm_conv2d_pool_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(y), _ptr(yp), _ld(yp), _stream()))
+    _ran(cfg)
     return y, yp
 
 
@@ -175,6 +188,7 @@ def conv2d_head(x, w_ohwi, bias, w3, b3, act=ACT_RELU, slope=0.0, act3=ACT_NONE,
     y3 = torch.empty((n, h, w, n3), dtype=torch.float16, device=x.device)
     d = ConvDesc(n, h, w, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, h, w, act, slope, x_ld, cout, 0)
     check(lib().sm_conv2d_head_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(y), _ptr(w3), _ptr(b3), n3, act3, slope3, _ptr(y3), _ld(y3), _stream()))
+    _ran(cfg)
     return y, y3
 
 
@@ -189,6 +203,7 @@ def conv2d_xhead(x, w_ohwi, bias, w3, b3, residual=None, act=ACT_RELU, slope=0.0
     d = ConvDesc(n, h, w, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, h, w, act, slope, x_ld, cout, 0)
     check(lib().sm_conv2d_xhead_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(y), _ptr(w3), _ptr(b3), n3, act3, slope3,
                                         _ptr(residual), res_ld, _ptr(y3), _ld(y3), _stream()))
+    _ran(cfg)
     return y, y3
 
 
@@ -201,6 +216,7 @@ def conv2d_xhead_proj(x, w_ohwi, bias, w3, b3sum, xs, ws, act=ACT_RELU, slope=0.
     d = ConvDesc(n, h, w, cin, cout, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, h, w, act, slope, x_ld, cout, 0)
     check(lib().sm_conv2d_xhead_proj_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(w_ohwi), _ptr(bias), _ptr(w3), _ptr(b3sum), n3, act3, slope3,
                                              _ptr(xs), _check_nhwc(xs)[4], _ptr(ws), _ptr(y3), _ld(y3), _stream()))
+    _ran(cfg)
     return y3
 
 

@@ -48,7 +48,13 @@ def _worker(rank, world, port, q):
     g.packWeights = counting
     arena = sd.broadcast_weight_arena(g, 4, device=torch.device("cpu"))
     lo, hi = sd.shard_range(10, r, w)
-    q.put((r, sd.arena_checksum(arena), int(arena.numel()), calls["pack"], (lo, hi)))
+    # the execution plan travels the same way (rank 0's tile picks; here: the host-side default plan with two picks written in, as an autotuner would)
+    mine = None
+    if r == 0:
+        mine = g.defaultPlan(4)
+        mine[3 + 1], mine[3 + 2] = 7, 13
+    plan = sd.broadcast_plan(mine, device=torch.device("cpu"))
+    q.put((r, sd.arena_checksum(arena), int(arena.numel()), calls["pack"], (lo, hi), plan.tobytes()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -64,13 +70,25 @@ def test_weight_arena_broadcast_world2_gloo():
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (r0, c0, n0, packs0, s0), (r1, c1, n1, packs1, s1) = res
+    (r0, c0, n0, packs0, s0, p0), (r1, c1, n1, packs1, s1, p1) = res
+    assert p0 == p1 and len(p0) > 12                   # the plan bytes are identical on both ranks ...
+    words = np.frombuffer(p0, np.int32)
+    assert words[0] == 0x4e414c50 and words[2] == len(words) - 3 and words[4] == 7 and words[5] == 13   # ... and are rank 0's
     assert (r0, r1) == (0, 1)
     assert n0 == n1 > 5e6 and c0 == c1                 # byte-identical weights on both ranks
     assert packs0 == 1 and packs1 == 0                 # only the source rank runs the CPU weight preparation
     assert s0 == (0, 5) and s1 == (5, 10)
     ref = ONNXGraph(zoo.mobilenet_v2(hw=(32, 32))).packWeights(4)
     assert sd.arena_checksum(torch.from_numpy(ref)) == c0
+
+
+def test_default_plan_is_host_only_and_self_describing():
+    from smelter_amd import ops
+    g = ONNXGraph(zoo.resnet50(hw=(32, 32)))
+    p = g.defaultPlan(8)
+    assert p.dtype == np.int32 and p[0] == 0x4e414c50 and p[1] == ops.num_conv_configs() and p[2] == len(p) - 3
+    assert (p[3:] == -1).all()                          # no autotuning happened: every step on its heuristic
+    assert np.array_equal(sd.broadcast_plan(p), p)      # no process group: the plan comes back as it is
 
 
 def test_single_process_path_needs_no_process_group():

@@ -55,14 +55,18 @@ def test_tight_parity_on_mps_flavor_fp16_file(name):
     assert got.shape == ref.shape
     # fp16 storage has a noise floor: a different fp32 accumulation order flips roundings, and the flips propagate.
     # The floor is measured, not guessed: the oracle against itself with fp64 instead of fp32 accumulation.
+    rl2f = lambda a, b: float(np.linalg.norm((a - b).ravel()) / np.linalg.norm(b.ravel()))
     O.set_acc64(True)
     try:
-        floor = nerr(ref_g.run(x), ref)
+        ref64 = ref_g.run(x)
     finally:
         O.set_acc64(False)
+    floor, floor_rl2 = nerr(ref64, ref), rl2f(ref64, ref)
     assert nerr(got, ref) <= 1e-3 + floor, (nerr(got, ref), floor)
-    rl2 = float(np.linalg.norm((got - ref).ravel()) / np.linalg.norm(ref.ravel()))
-    assert rl2 <= 2e-3, rl2
+    # north_star's 1e-3 in the norm it is met in (rel-L2), with the same allowance as at full size (tests/test_gpu_full.py): 5 % above the storage floor
+    # when the floor itself is at 1e-3 (VERDICT r3 item 4 v: was a flat 2e-3)
+    rl2 = rl2f(got, ref)
+    assert rl2 <= max(1e-3, 1.05 * floor_rl2), (rl2, floor_rl2)
 
 
 @pytest.mark.parametrize("name", list(MODELS))
@@ -231,6 +235,35 @@ def test_batch_shard_outputs_equal_the_unsharded_run():
     assert np.array_equal(again, parts[0])
 
 
+def test_execution_plan_makes_autotuned_shards_bit_identical():
+    """VERDICT r3 item 7 / SURVEY.md 8e "rank r runs the identical single-GPU exec": with autotuning ON, two compiles of the same graph may pick different
+    tile configurations (different fp32 accumulation splits).  Rank 0's plan — exported, carried as int32 words, applied on another executor instead of
+    autotuning — makes the second executor run the identical kernels: same picks, bit-identical outputs on the same images."""
+    from smelter_amd._native import SmelterError
+    model = zoo.resnet50(hw=(64, 64))
+    x = torch.from_numpy(zoo.synthetic_images(2, 3, (64, 64))).cuda()
+    g0 = ONNXGraph(model, Configuration(autotune=True))
+    ex0 = g0.hipGraph(0, 2)                                            # "rank 0": autotunes
+    plan = ex0.plan
+    assert plan[0] == 0x4e414c50 and plan[2] == len(plan) - 3 and (plan[3:] >= 0).sum() >= 20, "an autotuned ResNet-50 names a tile configuration for its conv steps"
+    g1 = ONNXGraph(model, Configuration(autotune=True))               # "rank 1": same Configuration, but the plan wins — no autotune sweep
+    arena = torch.from_numpy(g1.packWeights(2)).cuda()
+    ex1 = g1.hipGraph(0, 2, weight_arena=arena, upload_weights=False, plan=plan.copy())
+    assert np.array_equal(ex1.plan, plan)
+    assert [ex1.opDesc(i) for i in range(ex1.numOps)] == [ex0.opDesc(i) for i in range(ex0.numOps)]
+    ex0.encode(x); ex1.encode(x)
+    assert np.array_equal(ex0.toFloatArray(), ex1.toFloatArray())
+    # a plan of another batch / graph / build is refused, not mis-applied
+    bad = plan.copy(); bad[2] += 1
+    with pytest.raises(SmelterError):
+        g1.hipGraph(0, 2, plan=bad)
+    with pytest.raises(SmelterError):
+        ONNXGraph(zoo.toy()).hipGraph(0, 2, plan=plan)
+    worse = plan.copy(); worse[1] += 1
+    with pytest.raises(SmelterError):
+        g1.hipGraph(0, 2, plan=worse)
+
+
 def test_external_weight_arena_without_upload():
     model = zoo.resnet50(hw=(64, 64))
     x = zoo.synthetic_images(2, 3, (64, 64))
@@ -248,6 +281,90 @@ def test_readback_layouts():
     ex, nchw = run_hip(model, x)
     packed = ex.toFloatArray(layout="mps")
     assert np.array_equal(packed, O.pack_float_array(nchw))     # MPSImage+Extensions.swift:26-59
+
+
+def test_value_list_is_consistent_with_what_is_stored():
+    """The tight parity tests hand ex.valueNames to the oracle as its rounding list ("the oracle is told what to round by the product").
+    What the list claims is checked against what the executor DOES, tensor by tensor, on the fused default path of three graph families:
+      * a listed tensor marked stored is readable with the oracle tensor's size (the graph output also with its numbers);
+      * a listed tensor marked not stored (hidden tensor of a fused launch) is refused by readValue — it must not hand out arena bytes (ADVICE r3);
+      * every other value of the ONNX graph is refused as well: nothing has storage that the list does not name;
+      * the graph's input and output are listed, nothing is listed twice."""
+    import ctypes as C
+    from smelter_amd import onnx_reader
+    from smelter_amd._native import SmelterError
+    for model, hw, n in ((zoo.resnet50(hw=(64, 64)), (64, 64), 2), (zoo.mobilenet_v2(hw=(64, 64)), (64, 64), 2), (zoo.unet(hw=(64, 64)), (64, 64), 1)):
+        model = onnx2mps.optimize_model(model, half=True)
+        x = zoo.synthetic_images(n, 3, hw)
+        ex, _ = run_hip(model, x)
+        names, stored = ex.valueNames, set(ex.storedValueNames)
+        assert len(set(names)) == len(names) and stored <= set(names)
+        g = onnx_reader.parse_model(model)
+        all_values = {o for nd in g.node for o in nd.output} | {i.name for i in g.input}
+        inits = {t.name for t in g.initializer}
+        assert set(names) <= all_values - inits
+        assert [o.name for o in g.output][0] in stored
+        og = O.Graph(model)
+        og.set_round_list(names)
+        og.run(x)
+        def oracle_tensor(name):
+            p, c, h, w = og.value(name)
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), (n * c * h * w,)).reshape(n, c, h, w)
+        aliases = 0
+        for name in sorted(all_values - inits):
+            if name in stored:
+                # (buffers are recycled along the liveness plan: after a whole pass only the last tensors still hold their own numbers — the values of
+                # every stored tensor are compared with keepIntermediates in test_intermediate_values_match_layer_by_layer; here: it exists, with its shape)
+                got, ref = ex.readValue(name), oracle_tensor(name)
+                assert got.size == ref.size, name
+                if name == g.output[0].name:
+                    assert nerr(got.reshape(ref.shape), ref) <= 3e-3, name
+            elif name in names:                                   # listed, not stored: a fused launch's hidden tensor
+                with pytest.raises(SmelterError):
+                    ex.readValue(name)
+            else:
+                # not listed: either nothing to read, or an ALIAS of a stored tensor (Flatten / Reshape / Dropout views share their source's buffer):
+                # then it must hold that tensor's numbers, i.e. match the oracle's value of the same name
+                try:
+                    got = ex.readValue(name)
+                except SmelterError:
+                    continue
+                assert got.size == oracle_tensor(name).size, ("unlisted value is readable and is not a view of a stored tensor", name)
+                aliases += 1
+        views = sum(nd.op_type in ("Concat", "Flatten", "Reshape", "Dropout") for nd in g.node)   # zero-copy Concat outputs and view ops own no rounding of their own
+        assert aliases <= views, "readable values the list does not name: %d, the graph has %d view / concat nodes" % (aliases, views)
+        assert len(stored) >= ex.numOps - 2, "every launch stores (at least) its last tensor"
+
+
+def test_fusions_fall_back_at_a_concat_offset_that_is_not_a_whole_channel_vector():
+    """zero-copy Concat places a member at a channel offset; the fused kernels (conv + pool, expand head, inverted-residual block, wave-split
+    3x3, weights-in-registers 1x1) move 8-channel vectors and need offsets that are multiples of 8.  With a FIRST member of 3 (and 12) channels the second
+    member starts at channel 3 (12): every consumer must take a kernel that can read / write there, or the concat must be copied — never a fault, never wrong
+    numbers.  The graphs: Concat(a[c0], b[64]) -> Conv3x3 (-> MaxPool) and Concat -> 1x1 expand -> depthwise -> 1x1 project."""
+    for c0 in (3, 12):
+        net = zoo._Net("catoff", 7)
+        g = net.g
+        x = "input"
+        a, _ = net.conv(x, (24, 24), 3, c0, 3, bias=True)
+        a = net.relu(a)
+        b, _ = net.conv(x, (24, 24), 3, 64, 3, bias=True)
+        b = net.relu(b)
+        cat = g.add_node("Concat", [a, b], axis=1)
+        y1, _ = net.conv(cat, (24, 24), c0 + 64, 64, 3, bias=True)
+        y1 = net.relu(y1)
+        y1, _ = net.maxpool(y1, (24, 24), 2, 2, 0)
+        e, _ = net.conv(b, (24, 24), 64, 192, 1, bias=True)          # an inverted-residual block on the SECOND member (it lives at channel offset c0)
+        e = net.relu(e)
+        d, _ = net.conv(e, (24, 24), 192, 192, 3, group=192, bias=True)
+        d = net.relu(d)
+        pj, _ = net.conv(d, (24, 24), 192, 64, 1, bias=True)
+        pj, _ = net.maxpool(pj, (24, 24), 2, 2, 0)
+        out = g.add_node("Add", [y1, pj])
+        model = zoo._finish(net, out, [1, 3, 24, 24], [1, 64, 12, 12])
+        xs = zoo.synthetic_images(2, 3, (24, 24))
+        ex, got = run_hip(model, xs)
+        ref = O.Graph(model).run(xs)
+        assert nerr(got, ref) <= 5e-3, (c0, nerr(got, ref))
 
 
 def test_intermediate_values_match_layer_by_layer():

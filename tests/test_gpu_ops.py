@@ -23,6 +23,16 @@ def cfgs_named(*subs, without=()):
     return [c for c in ALL_CFGS if all(s in ops.config_name(c) for s in subs) and not any(w in ops.config_name(c) for w in without)]
 
 
+def cfg_named(label):
+    """the configuration with exactly this label"""
+    hit = [c for c in ALL_CFGS if ops.config_name(c) == label]
+    assert len(hit) == 1, "tile configuration %r: %d matches" % (label, len(hit))
+    return hit[0]
+
+
+# every *_cfg call that returns SM_OK records its configuration here (ops._ran); the last test of this file reads it
+ops.CFG_LOG = CFGS_RUN = set()
+REF_K64 = cfg_named("k64:128x128")                         # conv_igemm64 two-stage 128x128: the reference tiling the specialised kernels are compared with
 WS_PLAIN = cfgs_named("ws:", without=("head",))           # weight-stationary 3x3, no fused head
 assert WS_PLAIN and cfgs_named("p9:") and cfgs_named("kq:") and cfgs_named("wst:") and cfgs_named("ps:") and cfgs_named("ws:", " head") and cfgs_named("xhead", without=("side",))
 
@@ -45,6 +55,23 @@ def assert_close(got, ref, k=1):
     tol = np.abs(ref16) * 2.0 ** -10 + np.abs(ref).max() * 2.0 ** -11 * max(1.0, np.sqrt(k)) * 1e-2 + 1e-7
     bad = np.abs(got - ref16) > tol
     assert not bad.any(), "max err %g at %d elements" % (np.abs(got - ref16).max(), bad.sum())
+
+
+def assert_pointwise_close_on_sampled_pixels(got, x, w, b, r, act, slope, stride=1, samples=4096, seed=0):
+    """A 1x1 convolution is per pixel: for tensors too large for the CPU oracle, `samples` random output pixels are gathered into a 1 x P image and THAT goes
+    through O.conv2d (same oracle code, same tolerance) — the full-size shapes meet the oracle at kernel level, not only another GPU kernel (VERDICT r3 item 4 i)."""
+    n, cout, ho, wo = got.shape
+    rng = np.random.default_rng(seed)
+    P = min(samples, n * ho * wo)
+    flat = rng.choice(n * ho * wo, size=P, replace=False)
+    ni, rem = np.divmod(flat, ho * wo); oy, ox = np.divmod(rem, wo)
+    xs = np.ascontiguousarray(x[ni, :, oy * stride, ox * stride].T[None, :, None, :])          # [1, cin, 1, P]
+    ref = O.conv2d(xs, w, b)[0, :, 0, :]                                                           # [cout, P]
+    if r is not None:
+        ref = ref + r[ni, :, oy, ox].T
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    assert_close(got[ni, :, oy, ox].T, ref, x.shape[1])
 
 
 CONV_CASES = [
@@ -352,9 +379,10 @@ def test_conv_transpose2d_direct(case):
     assert_close(to_host(got), ref, k=cin * k * k)
 
 
-@pytest.mark.parametrize("cfg", [None, 3, 9, 15, 32])
-def test_conv2d_output_placement(cfg):
+@pytest.mark.parametrize("label", [None, "64x64", "k64:64x64", "k64w8:128x128(64x32)", "k64w8s3i:128x128(64x32)"])   # generic / BK=64 / 8-wave / interleaved-issue kernels
+def test_conv2d_output_placement(label):
     """sm_conv_desc.y_sH...: the conv's Ho x Wo grid lands on a strided, offset pixel lattice of a larger image"""
+    cfg = None if label is None else cfg_named(label)
     import ctypes as C
     from smelter_amd import _native as N
     rng = np.random.default_rng(32)
@@ -500,7 +528,7 @@ def test_conv3x3_weight_stationary_writes_into_a_concat_slice():
     x = h(rng.standard_normal((2, 64, 24, 40))); w = h(rng.standard_normal((32, 3, 3, 64)) * 0.06); b = rng.standard_normal(32).astype(np.float32)
     xin = torch.zeros((2, 24, 40, 96), dtype=torch.float16, device="cuda"); xin[..., 16:80] = to_dev(x)
     out = torch.full((2, 24, 40, 64), 7.0, dtype=torch.float16, device="cuda")
-    ops.conv2d(xin[..., 16:80], torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), act=1, cfg=62, out=out[..., 32:])
+    ops.conv2d(xin[..., 16:80], torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), act=1, cfg=cfg_named("ws:64->32 w4x2"), out=out[..., 32:])
     ref = np.maximum(O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1)), 0)
     assert_close(to_host(out[..., 32:]), ref, 64 * 9)
     assert float(out[..., :32].min()) == 7.0 and float(out[..., :32].max()) == 7.0
@@ -611,7 +639,7 @@ def test_conv3x3_reads_through_fused_nearest_upsampling(case, cfg):
         raise
     assert_close(to_host(y), ref, cin * 9)
     with pytest.raises(SmelterError):                                 # every other kernel family refuses an upsampled input
-        ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), cfg=7, ups=True)
+        ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), cfg=cfg_named("k64:128x64"), ups=True)
 
 
 @pytest.mark.parametrize("n,hw,cin,ch,cout,stride,res,expand", [
@@ -829,7 +857,7 @@ RW_CASES = [
     (1, 5, 5, 128, 256, False, 1),                     # K = 128 without residual
     (2, 20, 20, 64, 64, False, 1),                     # 64 -> 64, steps of 256 pixels, ragged (800 = 3.1 steps)
     (1, 13, 11, 64, 256, True, 1),                     # 64 -> 256 + residual
-    (64, 14, 14, 256, 1024, True, 1),                  # full size (checked against config 6 only)
+    (64, 14, 14, 256, 1024, True, 1),                  # full size: against the reference tiling everywhere, against the oracle on 4096 sampled pixels
     (2, 28, 28, 512, 128, False, 1),                   # ResNet layer-2 reduce on the four-consumer ring form (K = 512: 128 W registers per consumer)
     (3, 7, 9, 512, 256, False, 2),                     # two slices of 128, ragged M (189), PReLU
     (1, 3, 3, 512, 128, False, 0),                     # a single ragged stage
@@ -842,7 +870,7 @@ RW_CASES = [
 @pytest.mark.parametrize("case", RW_CASES)
 @pytest.mark.parametrize("cfg", cfgs_named("rw:") + cfgs_named("rwl:"))
 def test_pointwise_weights_in_registers(case, cfg):
-    """conv1x1_rw.hpp (tile-config kind 8): every instantiation that takes the shape agrees with the oracle; against conv_igemm64 (config 6) all
+    """conv1x1_rw.hpp (tile-config kind 8): every instantiation that takes the shape agrees with the oracle; against conv_igemm64 (REF_K64) all
     values agree to the parity tolerance (the residual enters through the MFMA accumulator here: a rounding may flip) and nearly all bit for bit"""
     n, hh, ww, cin, cout, res, act = case
     rng = np.random.default_rng(cin * 11 + cout + hh)
@@ -858,7 +886,7 @@ def test_pointwise_weights_in_registers(case, cfg):
         if "does not apply" in e.detail:
             pytest.skip(e.detail)
         raise
-    y6 = ops.conv2d(xd, wd, bd, residual=rd, act=act, slope=slope, cfg=6)
+    y6 = ops.conv2d(xd, wd, bd, residual=rd, act=act, slope=slope, cfg=REF_K64)
     got, g6 = to_host(y), to_host(y6)
     assert_close(got, g6, cin)
     assert np.mean(got != g6) < (2e-3 if res else 1e-9)
@@ -869,6 +897,8 @@ def test_pointwise_weights_in_registers(case, cfg):
         if act:
             ref = np.where(ref >= 0, ref, ref * slope)
         assert_close(got, ref, cin)
+    else:
+        assert_pointwise_close_on_sampled_pixels(got, x, w, b, r, act, slope)
 
 
 def test_pointwise_weights_in_registers_inside_a_concat_buffer():
@@ -903,7 +933,7 @@ PS_CASES = [
 @pytest.mark.parametrize("case", PS_CASES)
 @pytest.mark.parametrize("cfg", cfgs_named("ps:") + cfgs_named("256x256"))
 def test_persistent_pointwise_kernel(case, cfg):
-    """conv1x1_ps.hpp: every configuration that takes the shape agrees with the oracle and is bit-identical to conv_igemm64 (config 6)"""
+    """conv1x1_ps.hpp: every configuration that takes the shape agrees with the oracle and is bit-identical to conv_igemm64 (REF_K64)"""
     if cfg >= ops.num_conv_configs():
         pytest.skip("no such config")
     n, hh, ww, cin, cout, s, res, act = case
@@ -921,7 +951,7 @@ def test_persistent_pointwise_kernel(case, cfg):
         if "does not apply" in e.detail:
             pytest.skip(e.detail)
         raise
-    y6 = ops.conv2d(xd, wd, bd, residual=rd, stride=(s, s), act=act, slope=slope, cfg=6)
+    y6 = ops.conv2d(xd, wd, bd, residual=rd, stride=(s, s), act=act, slope=slope, cfg=REF_K64)
     assert torch.equal(y, y6)
     if n * ho * wo <= 4096:
         ref = O.conv2d(x, w, b, stride=(s, s))
@@ -930,6 +960,8 @@ def test_persistent_pointwise_kernel(case, cfg):
         if act:
             ref = np.where(ref >= 0, ref, ref * slope)
         assert_close(to_host(y), ref, cin)
+    else:
+        assert_pointwise_close_on_sampled_pixels(to_host(y), x, w, b, r, act, slope, stride=s)
 
 
 def test_persistent_pointwise_kernel_into_a_channel_slice():
@@ -939,7 +971,7 @@ def test_persistent_pointwise_kernel_into_a_channel_slice():
     x = h(rng.standard_normal((n, cin, hh, ww))); w = h(rng.standard_normal((cout, 1, 1, cin)) * 0.1); b = rng.standard_normal(cout).astype(np.float32)
     big = torch.full((n, hh, ww, 160), 7.0, dtype=torch.float16, device="cuda")
     out = big[..., 32:96]
-    ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), act=1, out=out, cfg=81)
+    ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), act=1, out=out, cfg=cfg_named("ps:128x128(32x64) s4"))
     ref = np.maximum(O.conv2d(x, w, b), 0)
     assert_close(to_host(out.contiguous()), ref, cin)
     assert (big[..., :32] == 7).all() and (big[..., 96:] == 7).all()
@@ -1056,4 +1088,13 @@ def test_conv3x3_with_fused_expand_head_and_projection(n, hw, n3, act3):
     assert_close(to_host(y3), ref, 2 * cout)
     assert float((y3.float() - z.float()).abs().max()) <= 2e-2 * float(z.float().abs().max())
 
+
+def test_zz_every_tile_configuration_ran_unskipped():
+    """1880 of this file's parametrisations skip with "does not apply": a configuration whose predicate rejected EVERY shape of every test would be green
+    forever (VERDICT r3 item 4 ii).  ops.CFG_LOG holds the configurations that some *_cfg call in this process ran to SM_OK; after a complete run of this file
+    that must be all of them.  (A filtered run — `-k`, a single test — has not swept the pool: skipped, not judged.)"""
+    if len(CFGS_RUN) < len(ALL_CFGS) // 2:
+        pytest.skip("partial run of tests/test_gpu_ops.py: %d of %d configurations exercised" % (len(CFGS_RUN), len(ALL_CFGS)))
+    never = [(c, ops.config_name(c)) for c in ALL_CFGS if c not in CFGS_RUN]
+    assert not never, "tile configurations no test ran: %s" % never
 

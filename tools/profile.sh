@@ -22,7 +22,7 @@ for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" SQ_VALU_MFMA_BUSY_CY
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc/pass$i -o p -- python $ROOT/bench.py --model $MODEL --steps 5 --warmup 2 --no-cpu-baseline --no-roofline > $OUT/pmc_pass$i.log 2>&1
 done
 cd $ROOT
-python tools/rocprof_summary.py $(ls $OUT/prof_kt/*/r_results.db $OUT/prof_kt/r_results.db 2>/dev/null | head -1) --steps 20 > $OUT/${TAG}_kernel_stats${SUF}.txt 2>&1
+python tools/rocprof_summary.py $(ls $OUT/prof_kt/*/r_results.db $OUT/prof_kt/r_results.db 2>/dev/null | head -1) --steps 20 --model $MODEL > $OUT/${TAG}_kernel_stats${SUF}.txt 2>&1
 python tools/pmc_summary.py $(find $OUT/pmc -name "p_counter_collection.csv" | sort) --head $HEAD --out $OUT/${TAG}_pmc_traffic${SUF}.json > $OUT/${TAG}_pmc_per_op${SUF}.txt 2>&1
 cp $OUT/${TAG}_pmc_traffic${SUF}.json $ROOT/profiles/ 2>/dev/null   # bench.py quotes the newest profiles/r*_pmc_traffic<suffix>.json as roofline.traffic
 python bench.py --model $MODEL --steps 50 --warmup 10 > $OUT/${TAG}_bench${SUF}.json 2> $OUT/${TAG}_bench${SUF}.err

@@ -62,12 +62,20 @@ def step_starts(names, steps):
     return best
 
 
+# bs x 2 x MACs per image of the zoo models (smelter_amd/zoo.py return_macs; BASELINE.json batch sizes)
+FLOPS_PER_STEP = {"r50": 64 * 2 * 4089184256.0, "mbv2": 256 * 2 * 300774272.0, "unet": 16 * 2 * 65523417088.0}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("path")
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--flops-per-step", type=float, default=64 * 2 * 4089184256.0)
+    # algorithmic FLOPs of one step (2 * MACs of conv + fc) — per MODEL: the ResNet-50 default once put "496 TFLOP/s" under MobileNet-v2's table
+    ap.add_argument("--model", choices=sorted(FLOPS_PER_STEP), default="r50")
+    ap.add_argument("--flops-per-step", type=float, default=0.0, help="overrides --model")
     a = ap.parse_args()
+    if not a.flops_per_step:
+        a.flops_per_step = FLOPS_PER_STEP[a.model]
     rows = load(a.path)
     starts = step_starts([r[2] for r in rows], a.steps)
     assert len(starts) >= a.steps + 1, "found %d encode() calls" % len(starts)
@@ -87,9 +95,9 @@ def main():
     print("%-46s %8s %12s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
     for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         print("%-46s %8d %12.1f %10.2f %6.1f%%" % (k, c, t, t / c, 100 * t / total_us))
-    conv = [(c, t) for k, (c, t) in per.items() if k.startswith(("conv_igemm", "conv3x3_strip", "conv3x3_ws", "conv3x3_p9", "conv1x1_ps", "conv1x1_rw", "conv_stem_pool", "mbconv", "pw_thin")) or "splitk" in k]
+    conv = [(c, t) for k, (c, t) in per.items() if k.startswith(("conv_igemm", "conv3x3_strip", "conv3x3_ws", "conv3x3_p9", "conv1x1_ps", "conv1x1_rw", "conv3x3_kq", "conv_stem_pool", "mbconv", "pw_thin")) or "splitk" in k]
     cc, ct = sum(c for c, _ in conv), sum(t for _, t in conv)
-    print("# MFMA conv/FC family (conv_igemm*, conv3x3_strip/ws/wsx/p9, conv1x1_ps, split-K reduce): %d launches/step, avg %.2f us/launch, %.3f ms/step -> %.1f TFLOP/s (%.1f%% of 2500)" % (
+    print("# MFMA conv/FC family (conv_igemm*, conv3x3_strip/ws/wsx/p9, conv3x3_kq, conv1x1_ps / rw, split-K reduce): %d launches/step, avg %.2f us/launch, %.3f ms/step -> %.1f TFLOP/s (%.1f%% of 2500)" % (
         cc // a.steps, ct / cc, ct / 1e3 / a.steps, a.flops_per_step / (ct / a.steps * 1e-6) / 1e12, a.flops_per_step / (ct / a.steps * 1e-6) / 1e12 / 25))
 
 
