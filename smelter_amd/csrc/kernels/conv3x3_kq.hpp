@@ -54,7 +54,10 @@ typedef unsigned kq_u32x4 __attribute__((ext_vector_type(4)));
 // num_records gets zeros WITHOUT a memory access — the zero page of the other kernels, minus the 64-bit pointer select per lane.
 __device__ __forceinline__ void kq_bdma16(unsigned voff, kq_u32x4 rsrc, unsigned lds_dst, unsigned soff) {
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+#ifndef KQ_DMA_AUX      // cache-policy experiment (tools/kq_tl.sh): "" (default) | " nt" | " sc1" | " sc0 sc1"
+#define KQ_DMA_AUX ""
+#endif
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen" KQ_DMA_AUX " lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
 }
 

@@ -1066,7 +1066,7 @@ def test_conv3x3_with_fused_expand_head(n, hw, n3, act3, with_res, store_y, cfg)
     (1, (9, 70), 64, 0),         # two chunks (consumers 2 and 3 idle), no activation
 ])
 def test_conv3x3_with_fused_expand_head_and_projection(n, hw, n3, act3):
-    """sm_conv2d_xhead_proj_fwd_cfg (config 96): y3 = act3(w3 . y + ws . xs + b3 + bs).  The expand layer's output is never rounded, so the result is
+    """sm_conv2d_xhead_proj_fwd_cfg ("ws:64->64 w4+4 xhead side"): y3 = act3(w3 . y + ws . xs + b3 + bs).  The expand layer's output is never rounded, so the result is
     compared with the fp32 evaluation on the ROUNDED 3x3 output (what the three separate launches compute, minus one rounding)"""
     cin = cout = 64
     rng = np.random.default_rng(n3 + hw[0] + hw[1] + 7)
@@ -1078,7 +1078,8 @@ def test_conv3x3_with_fused_expand_head_and_projection(n, hw, n3, act3):
     slope3 = 0.25 if act3 == 2 else 0.0
     xd, wd, bd = to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda()
     w3d, wsd, xsd = torch.from_numpy(w3).cuda().half(), torch.from_numpy(ws).cuda().half(), to_dev(xs)
-    y3 = ops.conv2d_xhead_proj(xd, wd, bd, w3d, torch.from_numpy(b3 + bs).cuda(), xsd, wsd, act3=act3, slope3=slope3)
+    y3 = ops.conv2d_xhead_proj(xd, wd, bd, w3d, torch.from_numpy(b3 + bs).cuda(), xsd, wsd, act3=act3, slope3=slope3, cfg=cfg_named("ws:64->64 w4+4 xhead side"))
+    assert torch.equal(y3, ops.conv2d_xhead_proj(xd, wd, bd, w3d, torch.from_numpy(b3 + bs).cuda(), xsd, wsd, act3=act3, slope3=slope3))   # (the launcher's own pick is that configuration)
     yplain = ops.conv2d(xd, wd, bd, pads=(1, 1, 1, 1), act=1)
     y27 = ops.conv2d(yplain, w3d, torch.from_numpy(b3).cuda())                                          # the three separate launches
     z = ops.conv2d(xsd, wsd, torch.from_numpy(bs).cuda(), act=act3, slope=slope3, residual=y27)

@@ -4,7 +4,7 @@
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from smelter_amd import ops
+from smelter_amd import _native
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="64,56,56,64,64,3,1,1")
@@ -12,7 +12,11 @@ ap.add_argument("--cfg", default="all")
 ap.add_argument("--iters", type=int, default=30)
 ap.add_argument("--res", action="store_true")
 ap.add_argument("--ws", action="store_true", help="give the launcher a split-K workspace")
+ap.add_argument("--lib", default="", help="another build of the library, e.g. build/libsmelter_hip_tl.so (make ... EXTRA=-DSM_TIMELINE): sm_conv2d_time then prints per-block phase stamps to stderr")
 a = ap.parse_args()
+if a.lib:
+    _native.LIB_PATH = os.path.abspath(a.lib)
+from smelter_amd import ops  # noqa: E402
 n, h, w, cin, cout, k, s, p = map(int, a.shape.split(","))
 x = torch.randn((n, h, w, cin), device="cuda").half()
 wt = (torch.randn((cout, k, k, cin), device="cuda") * (2.0 / (cin * k * k)) ** 0.5).half()
