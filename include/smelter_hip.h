@@ -59,7 +59,8 @@ const char* smelter_version(void);
  * a = `slope`; ABS; SOFTPLUS log(1+e^x); SOFTSIGN x/(1+|x|); EXP e^x; LOG ln x.  (Pow is MPSCNNNeuronPowerNode(source:) with
  * its default exponent 1, i.e. the identity: the compiler aliases it.) */
 enum { SM_ACT_NONE = 0, SM_ACT_RELU = 1, SM_ACT_PRELU = 2, SM_ACT_SIGMOID = 3, SM_ACT_HARD_SIGMOID = 4, SM_ACT_TANH = 5, SM_ACT_ELU = 6,
-       SM_ACT_ABS = 7, SM_ACT_SOFTPLUS = 8, SM_ACT_SOFTSIGN = 9, SM_ACT_EXP = 10, SM_ACT_LOG = 11 };
+       SM_ACT_ABS = 7, SM_ACT_SOFTPLUS = 8, SM_ACT_SOFTSIGN = 9, SM_ACT_EXP = 10, SM_ACT_LOG = 11,
+       SM_ACT_CLIP = 12 /* min(max(x, 0), slope): ONNX Clip with lower bound 0 (ReLU6 = slope 6) — declared superset, not in the reference registry */ };
 /* NaN under SM_ACT_RELU is NOT specified: the epilogues that apply ReLU as a packed fp16 max after the rounding (v_pk_max_f16 returns the non-NaN
  * operand: NaN -> 0) and those that apply it as a select on the fp32 sum (NaN stays NaN) coexist, and the autotuner chooses between them per layer.
  * A diverged activation is therefore not guaranteed to surface as NaN in the output; -inf gives 0 everywhere, the sign of a zero result may differ.

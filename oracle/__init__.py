@@ -236,7 +236,7 @@ def add(a, b):
     return y
 
 
-NEURON = {"sigmoid": 3, "hardsigmoid": 4, "tanh": 5, "elu": 6, "abs": 7, "softplus": 8, "softsign": 9, "exp": 10, "log": 11}
+NEURON = {"sigmoid": 3, "hardsigmoid": 4, "tanh": 5, "elu": 6, "abs": 7, "softplus": 8, "softsign": 9, "exp": 10, "log": 11, "clip": 12}
 BINARY = {"add": 0, "sub": 1, "mul": 2, "div": 3}
 
 

@@ -306,6 +306,32 @@ static int leaky_conv(orc_graph* g, const orc_node* nd) {
     return ORC_OK;
 }
 
+/* SUPERSET (not in the reference registry, ONNXGraph.swift:110-155): ONNX Clip with lower bound 0 — bounds from the min / max attributes (opset 6) or from
+ * constant inputs 1 / 2 (opset 11; an empty name = unbounded); an infinite upper bound is plain ReLU; any other lower bound is refused */
+static int clip_conv(orc_graph* g, const orc_node* nd) {
+    value* in = nd->n_input >= 1 ? find_value(g, nd->input[0]) : NULL;
+    if (!in) return fail(ORC_ERR_NO_SUCH_OUTPUT, "Clip: input value missing");
+    float lo = -INFINITY, hi = INFINITY;
+    const orc_attr* a;
+    if ((a = find_attr(nd, "min"))) lo = a->f;
+    if ((a = find_attr(nd, "max"))) hi = a->f;
+    for (int k = 1; k <= 2 && k < nd->n_input; k++) {
+        if (nd->input[k].n == 0) continue;
+        const orc_tensor* t = find_tensor(g, nd->input[k]);
+        if (!t) return fail(ORC_ERR_INSUFFICIENT_INPUTS, "Clip: bound must be a constant tensor");
+        float v; if (orc_tensor_floats(t, NULL, 0) != 1) return fail(ORC_ERR_INCONSISTENT_STATE, "Clip: bound is not a scalar");
+        orc_tensor_floats(t, &v, 1);
+        if (k == 1) lo = v; else hi = v;
+    }
+    if (lo != 0.f) return fail(ORC_ERR_UNKNOWN_NODE_OP_TYPE, "Clip with lower bound %g", (double)lo);
+    if (!(hi > 0.f)) return fail(ORC_ERR_INCONSISTENT_STATE, "Clip: upper bound %g", (double)hi);
+    size_t cnt = (size_t)g->batch * in->c * in->h * in->w; float* y = malloc(sizeof(float) * cnt);
+    if (isinf(hi)) orc_relu(in->data, y, cnt, 0.f); else orc_neuron(12, in->data, y, cnt, hi);
+    if (wants_round(g, nd->output[0])) orc_round_to_half(y, cnt);
+    put_value(g, nd->output[0], y, in->c, in->h, in->w, in->ref);
+    return ORC_OK;
+}
+
 /* SUPERSET: ONNX MatMul, 2-D, Y[n][j] = sum_k A[n][k] * B[k][j] with B a constant tensor [K,N] */
 static int matmul_conv(orc_graph* g, const orc_node* nd) {
     value* in = nd->n_input >= 2 ? find_value(g, nd->input[0]) : NULL;
@@ -534,6 +560,7 @@ int orc_graph_run(orc_graph* g, const float* in_nchw, int batch, float** out, in
         else if (bis(op, "Dropout")) rc = dropout_conv(g, nd);
         else if (bis(op, "LeakyRelu")) rc = leaky_conv(g, nd);
         else if (bis(op, "MatMul")) rc = matmul_conv(g, nd);
+        else if (bis(op, "Clip")) rc = clip_conv(g, nd);
         else rc = fail(ORC_ERR_UNKNOWN_NODE_OP_TYPE, "%.*s", (int)op.n, op.p);                    /* :173-174 */
         if (rc) return rc;
     }

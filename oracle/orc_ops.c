@@ -151,6 +151,7 @@ void orc_neuron(int kind, const float* x, float* y, size_t n, float a) {
         case 9: r = v / (1.f + fabsf(v)); break;
         case 10: r = expf(v); break;
         case 11: r = logf(v); break;
+        case 12: r = fminf(fmaxf(v, 0.f), a); break;                       /* SUPERSET: ONNX Clip with lower bound 0 (ReLU6: a = 6) */
         }
         y[i] = r;
     }

@@ -11,6 +11,7 @@
 //            SM_ERR_UNSUPPORTED_DTYPE); the reference Shape bookkeeping incl. Concat depth*=2.
 //   dropped: BN epsilon attribute IS honoured (the reference never reads it); fp32 bias is also accepted from
 //            float_data; Concat's real channel count is the sum of its operands.
+#include <cmath>
 #include <string.h>
 
 #include "../kernels/common.hpp"
@@ -149,6 +150,34 @@ struct LeakyReluConverter : NodeConverter {
         const pb::Attribute* al = node.attr("alpha");
         const Value iv = graph.value(in);
         Op op; op.kind = OpKind::Neuron; op.inputs = {in}; op.act = SM_ACT_PRELU; op.slope = al ? al->f : 0.01f;
+        return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);
+    }
+};
+
+// ---- ClipConverter — NOT in the reference registry (a torchvision MobileNet-v2 export stops Smelter with unknownNodeOpType("Clip"), ONNXGraph.swift:173-174).
+// Declared superset: ONNX Clip with lower bound 0, i.e. the ReLU-N family (ReLU6 = Clip(0, 6)); bounds from the `min` / `max` attributes (opset 6) or from
+// constant inputs 1 / 2 (opset 11: initializer or Constant node; an empty name = unbounded).  max = +inf lowers to the node ReluConverter builds; a non-zero
+// lower bound is refused (no single MPSCNNNeuron node expresses it either).
+struct ClipConverter : NodeConverter {
+    int convert(ONNXGraph& graph, const pb::Node& node) override {
+        const int in = node.input.empty() ? -1 : graph.output(node.input[0]);
+        if (in < 0) SM_FAIL(SM_ERR_NO_SUCH_OUTPUT, "Clip: input is not a graph value");
+        float lo = -INFINITY, hi = INFINITY;
+        if (const pb::Attribute* a = node.attr("min")) lo = a->f;
+        if (const pb::Attribute* a = node.attr("max")) hi = a->f;
+        for (int k = 1; k <= 2 && k < (int)node.input.size(); k++) {
+            if (node.input[k].empty()) continue;
+            const pb::Tensor* t = graph.tensor(node.input[k]);
+            if (!t) SM_FAIL(SM_ERR_INSUFFICIENT_INPUTS, "Clip: bound '%.*s' must be a constant tensor", (int)node.input[k].size(), node.input[k].data());
+            std::vector<float> v; int rc = pb::tensor_floats(*t, &v); if (rc) return rc;
+            if (v.size() != 1) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Clip: bound '%.*s' has %zu elements (a scalar expected)", (int)node.input[k].size(), node.input[k].data(), v.size());
+            (k == 1 ? lo : hi) = v[0];
+        }
+        if (lo != 0.f) SM_FAIL(SM_ERR_UNKNOWN_NODE_OP_TYPE, "Clip with lower bound %g (only 0: the ReLU-N family is implemented)", (double)lo);
+        if (!(hi > 0.f)) SM_FAIL(SM_ERR_INCONSISTENT_STATE, "Clip: upper bound %g is not above the lower bound 0", (double)hi);
+        const Value iv = graph.value(in);
+        Op op; op.kind = OpKind::Neuron; op.inputs = {in};
+        if (std::isinf(hi)) { op.act = SM_ACT_RELU; op.slope = 0.f; } else { op.act = SM_ACT_CLIP; op.slope = hi; }
         return graph.addFilter(std::move(op), iv.c, iv.h, iv.w, iv.ref, node.output);
     }
 };
@@ -491,7 +520,8 @@ void registerDefaultConverters(ONNXGraph& g) {    // ONNXGraph.swift:110-155, ho
         .registerConverter("Pad", std::make_shared<PaddingConverter>())
         // declared supersets (not in the reference registry; BASELINE.json north_star names them)
         .registerConverter("LeakyRelu", std::make_shared<LeakyReluConverter>())
-        .registerConverter("MatMul", std::make_shared<MatMulConverter>());
+        .registerConverter("MatMul", std::make_shared<MatMulConverter>())
+        .registerConverter("Clip", std::make_shared<ClipConverter>());
 }
 
 }  // namespace smelter

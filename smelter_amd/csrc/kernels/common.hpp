@@ -54,6 +54,7 @@ __device__ __noinline__ static float sm_act_other(float v, int act, float slope)
     case SM_ACT_SOFTSIGN: return v / (1.f + fabsf(v));
     case SM_ACT_EXP: return expf(v);
     case SM_ACT_LOG: return logf(v);
+    case SM_ACT_CLIP: return fminf(fmaxf(v, 0.f), slope);
     }
     return v;
 }

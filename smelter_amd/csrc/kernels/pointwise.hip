@@ -340,7 +340,7 @@ int sm_relu(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int
     return sm_batchnorm(x, y, pixels, C, x_ld, y_ld, nullptr, nullptr, SM_ACT_PRELU, slope, st);
 }
 int sm_neuron(const void* x, void* y, int64_t pixels, int32_t C, int32_t x_ld, int32_t y_ld, int32_t act, float slope, sm_stream_t st) {
-    SM_REQUIRE(act >= SM_ACT_NONE && act <= SM_ACT_LOG, "sm_neuron: unknown activation");
+    SM_REQUIRE(act >= SM_ACT_NONE && act <= SM_ACT_CLIP, "sm_neuron: unknown activation");
     return sm_batchnorm(x, y, pixels, C, x_ld, y_ld, nullptr, nullptr, act, slope, st);
 }
 

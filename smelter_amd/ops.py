@@ -293,7 +293,7 @@ def add(a, b, act=ACT_NONE, slope=0.0, out=None):
     return out
 
 
-ACT_CODES = {"none": 0, "relu": 1, "prelu": 2, "sigmoid": 3, "hardsigmoid": 4, "tanh": 5, "elu": 6, "abs": 7, "softplus": 8, "softsign": 9, "exp": 10, "log": 11}
+ACT_CODES = {"none": 0, "relu": 1, "prelu": 2, "sigmoid": 3, "hardsigmoid": 4, "tanh": 5, "elu": 6, "abs": 7, "softplus": 8, "softsign": 9, "exp": 10, "log": 11, "clip": 12}
 BIN_CODES = {"add": 0, "sub": 1, "mul": 2, "div": 3}
 PAD_CODES = {"constant": 0, "reflect": 1, "edge": 2}
 

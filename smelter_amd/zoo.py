@@ -57,7 +57,15 @@ class _Net:
                                                             self.bn_params(c, gamma_scale))]
         return g.add_node("BatchNormalization", [x] + names, epsilon=1e-5, momentum=0.9)
 
+    relu6 = None                             # None: Relu nodes; "attr" / "input": every activation is ONNX Clip(0, 6) in its opset-6 / opset-11 form
+
     def relu(self, x):
+        if self.relu6 == "attr":
+            return self.g.add_node("Clip", [x], min=0.0, max=6.0)
+        if self.relu6 == "input":
+            lo = self.g.add_init(self.g.fresh("clip_min"), np.zeros((), np.float32))
+            hi = self.g.add_init(self.g.fresh("clip_max"), np.full((), 6.0, np.float32))
+            return self.g.add_node("Clip", [x, lo, hi])
         return self.g.add_node("Relu", [x])
 
     def conv_bn(self, x, hw, cin, cout, k, s=1, group=1, act=True, gamma_scale=1.0, p=None):
@@ -137,10 +145,13 @@ _MBV2 = ((1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 
 
 
 def mobilenet_v2(seed: int = 1, batch: int = 1, hw=(224, 224), classes: int = 1000, res_gamma: float = 0.5,
-                 dtype=np.float32, return_macs: bool = False):
-    """Config 3: MobileNet-v2 1.0, 52 Conv + 1 Gemm.  Relu stands in for ReLU6: `Clip` is not in the
-    reference registry (ONNXGraph.swift:110-155), see SURVEY.md §2a."""
+                 dtype=np.float32, return_macs: bool = False, relu6: str = None):
+    """Config 3: MobileNet-v2 1.0, 52 Conv + 1 Gemm.  By default Relu stands in for ReLU6: `Clip` is not in the
+    reference registry (ONNXGraph.swift:110-155), see SURVEY.md §2a.  relu6 = "attr" | "input": the real thing, every activation an ONNX
+    Clip(0, 6) with the bounds as attributes (opset 6) or as constant inputs (opset 11, what a torchvision export holds) — the
+    declared-superset ClipConverter (converters.cpp) takes both."""
     net = _Net("mobilenet_v2", seed, dtype)
+    net.relu6 = relu6
     x, cur = net.conv_bn("input", hw, 3, 32, 3, s=2)
     cin = 32
     for t, c, n, s in _MBV2:

@@ -418,14 +418,14 @@ def assert_close_f(got, ref, rel=2.0 ** -10, floor=1e-3):
     assert (np.abs(got - ref16) <= tol).all(), float(np.abs(got - ref16).max())
 
 
-@pytest.mark.parametrize("kind", ["sigmoid", "hardsigmoid", "tanh", "elu", "abs", "softplus", "softsign", "exp", "log"])
+@pytest.mark.parametrize("kind", ["sigmoid", "hardsigmoid", "tanh", "elu", "abs", "softplus", "softsign", "exp", "log", "clip"])
 @pytest.mark.parametrize("c", [16, 6])
 def test_neuron_family(kind, c):
     rng = np.random.default_rng(51)
     x = h(rng.standard_normal((2, c, 7, 9)) * 2)
     if kind == "log":
         x = h(np.abs(x) + 0.1)
-    a = 0.7 if kind == "elu" else 0.0
+    a = 0.7 if kind == "elu" else 1.25 if kind == "clip" else 0.0
     assert_close_f(to_host(ops.neuron(kind, to_dev(x), a)), O.neuron(kind, x, a))
 
 

@@ -96,6 +96,9 @@ ERRORS = [
     ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("Pad", ["y"], ["z"], mode=b"reflect")])),         # pads missing (:948-949)
     ("inconsistentState", _conv_model(FULL, extra_nodes=[ow.node("Pad", ["y"], ["z"], pads=[0, 0, 1, 1, 0, 0, 1, 1], mode=b"wrap")])),   # :966-967
     ("noSuchOutput", _conv_model(FULL, extra_nodes=[ow.node("InstanceNormalization", ["y", "w"], ["z"])])),   # 3 inputs required (:994-999)
+    ("unknownNodeOpType", _conv_model(FULL, extra_nodes=[ow.node("Clip", ["y"], ["z"], min=-1.0, max=1.0)])),     # Clip superset: only the lower bound 0 (ReLU-N family)
+    ("insufficientInputs", _conv_model(FULL, extra_nodes=[ow.node("Clip", ["y", "input", "w"], ["z"])])),        # opset-11 form: the bounds must be constant tensors
+    ("inconsistentState", _conv_model(FULL, extra_nodes=[ow.node("Clip", ["y"], ["z"], min=0.0, max=0.0)])),     # empty range
     ("inconsistentState", _conv_model(dict(FULL, group=2), op="ConvTranspose")),                  # outside the restated subset (group 1)
     ("notEnoughAttributes", _conv_model({k: v for k, v in FULL.items() if k != "strides"}, op="ConvTranspose")),
 ]

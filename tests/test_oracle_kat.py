@@ -255,6 +255,24 @@ def test_leaky_relu_and_matmul_supersets_against_numpy():
     assert np.abs(y.reshape(3, 4) - xf.reshape(3, 7).astype(np.float64) @ w.astype(np.float64)).max() < 1e-5
 
 
+def test_clip_superset_against_numpy():
+    """ONNX Clip with lower bound 0 (ReLU6 of a torchvision MobileNet-v2 export) — not in the reference registry; both opset forms, the unbounded
+    case = Relu, everything else refused"""
+    rng = np.random.default_rng(4)
+    x = (rng.standard_normal((2, 5, 3, 2)) * 5).astype(np.float32)
+    y = O.Graph(_one_op_model("Clip", [1, 5, 3, 2], [1, 5, 3, 2], min=0.0, max=6.0)).run(x)                     # opset 6: attributes
+    assert np.array_equal(y, np.clip(x, 0, 6))
+    y = O.Graph(_one_op_model("Clip", [1, 5, 3, 2], [1, 5, 3, 2], inits=[("lo", np.zeros((), np.float32)), ("hi", np.full((), 2.5, np.float32))])).run(x)   # opset 11: inputs
+    assert np.array_equal(y, np.clip(x, 0, 2.5))
+    y = O.Graph(_one_op_model("Clip", [1, 5, 3, 2], [1, 5, 3, 2], min=0.0)).run(x)                              # no upper bound: Relu
+    assert np.array_equal(y, np.maximum(x, 0))
+    assert np.array_equal(O.neuron("clip", x, 6.0), np.clip(x, 0, 6))
+    for kw, kind in ((dict(min=-1.0, max=1.0), "unknownNodeOpType"), (dict(max=6.0), "unknownNodeOpType"), (dict(min=0.0, max=-2.0), "inconsistentState")):
+        with pytest.raises(O.OracleError) as e:
+            O.Graph(_one_op_model("Clip", [1, 5, 3, 2], [1, 5, 3, 2], **kw)).run(x)
+        assert e.value.kind == kind
+
+
 def test_average_pool_converter_against_torch():
     torch = pytest.importorskip("torch")
     x = np.random.default_rng(1).standard_normal((2, 3, 9, 8)).astype(np.float32)
