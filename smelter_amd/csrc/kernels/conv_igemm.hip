@@ -726,6 +726,9 @@ const TileCfg kCfgs[] = {
     // ... flags = 2: two patch buffers, the next super-block's patch is copied while this one is multiplied (layers with Cin > 64 KG)
     {208, 64, 9, 256, nullptr, "kq:k2n2 196x64 b2", 2, 2, 2, 2},
     {208, 128, 9, 256, nullptr, "kq:k1n4 196x128 b2", 2, 1, 4, 2},
+    // kind 10 (conv3x3_kqp.hpp): persistent wave-split 3x3 with the whole weight tensor in registers, 16 x 14-pixel tiles; p0 = KG (Cin = 64 KG), p1 = NG (Cout = 32 NG)
+    {224, 64, 10, 256, nullptr, "kqp:k2n2 128->64", 0, 2, 2},
+    {224, 128, 10, 256, nullptr, "kqp:k1n4 64->128", 0, 1, 4},
     // ---- build-conditional entries stay BEHIND the product pool so that product indices do not depend on the build ----
 #ifdef SM_ABLATION   // the single-role expand head (conv3x3_ws.hpp HX): 16 of 55 us added to the 3x3; the two-role kernel replaced it
     {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead", CF_XHEAD, 64},
@@ -926,6 +929,10 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
                !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) &&
                ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && p.Cout == c.BN && wst_setup(q, c) > 0;
     }
+    if (c.kind == 10)    // persistent wave-split 3x3, weights in registers: exactly the instantiation's channel counts; an upsampled input needs even tile origins (14 is)
+        return same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && p.Cin == 64 * c.p0 && p.Cout == 32 * c.p1 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 &&
+               ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) &&
+               (long)p.N * p.H * p.W * p.x_ld * 2 < 0x7fff0000L && (long)p.N * p.H * p.W * p.y_ld * 2 < 0x7fff0000L && (long)p.N * ((p.H + 15) / 16) * ((p.W + 13) / 14) < (1L << 30);
     if (c.kind == 9) {   // wave-split 3x3: no residual, no upsampled input, dense 16-byte rows, ReLU family, 32-bit weight offsets
         ConvParams q = p;
         return same3x3 && !p.ups && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 &&
@@ -1054,11 +1061,11 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     if (p.ups && !mfma_eligible(d, p)) { sm_set_error("sm_conv2d_fwd: x_ups needs the MFMA path (Cin %% 8 == 0, aligned operands)"); return SM_ERR_INVALID_ARGUMENT; }
     if (cfg < 0 || cfg >= kNumCfgs) {
         cfg = pick_cfg(p);
-        if (p.ups) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if ((kCfgs[i].kind == 5 || kCfgs[i].kind == 4) && cfg_eligible(kCfgs[i], p)) cfg = i; }   // only the patch kernels gather through the upsampling
+        if (p.ups) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if ((kCfgs[i].kind == 5 || kCfgs[i].kind == 4 || kCfgs[i].kind == 10) && cfg_eligible(kCfgs[i], p)) cfg = i; }   // only the patch kernels gather through the upsampling
         if (cfg < 0) { sm_set_error("sm_conv2d_fwd: no kernel takes this shape with x_ups"); return SM_ERR_INVALID_ARGUMENT; }
     }
     const TileCfg& c = kCfgs[cfg];
-    if (p.ups && c.kind != 5 && c.kind != 4) { sm_set_error("conv tile config %d (%s) does not apply to an upsampled input", cfg, c.name); return SM_ERR_INVALID_ARGUMENT; }
+    if (p.ups && c.kind != 5 && c.kind != 4 && c.kind != 10) { sm_set_error("conv tile config %d (%s) does not apply to an upsampled input", cfg, c.name); return SM_ERR_INVALID_ARGUMENT; }
     if (!cfg_eligible(c, p)) { sm_set_error("conv tile config %d (%s) does not apply to Cin=%d", cfg, c.name, p.Cin); return SM_ERR_INVALID_ARGUMENT; }
     if (c.kind == 4 || c.kind == 6) {                                // persistent: one block per CU (two when the LDS allows), contiguous tile ranges
         const size_t lds = c.kind == 4 ? ws_setup(p, c) : wst_setup(p, c);
@@ -1090,6 +1097,10 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         const long tiles = (long)p.mt * p.nt;
         // (a whole number of blocks per XCD: XCD x owns tiles [xT/8, (x+1)T/8), at most ceil(T/8) of them)
         hipLaunchKernelGGL(c.fn, dim3((unsigned)std::min<long>((tiles + SM_NUM_XCD - 1) / SM_NUM_XCD * SM_NUM_XCD, SM_NUM_CU)), dim3(c.threads), ps_lds_bytes(p, c), s, p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
+    if (c.kind == 10) {
+        if (kqp_launch(c.p0, c.p1, p, s)) { sm_set_error("conv tile config %d (%s): no such instantiation", cfg, c.name); return SM_ERR_INVALID_ARGUMENT; }
         SM_LAUNCH_CHECK(); return SM_OK;
     }
     if (c.kind == 9) {

@@ -3,6 +3,7 @@
 
 namespace {
 #include "conv3x3_kq.hpp"
+#include "conv3x3_kqp.hpp"
 typedef void (*KqFn)(KqParams);
 struct KqVariant { int KG, NG, NF, NB; KqFn fn; };
 const KqVariant kVariants[] = {
@@ -15,6 +16,21 @@ const KqVariant kVariants[] = {
 };
 }  // namespace
 
+size_t kqp_lds_bytes(int KG) { return (size_t)2 * KG * (KQP_TH + 2) * 16 * 128 + 2048; }
+int kqp_launch(int KG, int NG, const ConvParams& p, hipStream_t s) {
+    KqpParams q;
+    q.x = p.x; q.w = p.w; q.bias = p.bias; q.y = p.y;
+    q.N = p.N; q.H = p.H; q.W = p.W; q.Cin = p.Cin; q.Cout = p.Cout; q.K = p.K; q.x_ld = p.x_ld; q.y_ld = p.y_ld; q.act = p.act; q.slope = p.slope; q.ups = p.ups;
+    q.tiles_x = (p.W + KQP_TW - 1) / KQP_TW; q.tiles_y = (p.H + KQP_TH - 1) / KQP_TH; q.ntiles = p.N * q.tiles_x * q.tiles_y;
+    const int grid = q.ntiles < SM_NUM_CU ? q.ntiles : SM_NUM_CU;
+    q.tpb = (q.ntiles + grid - 1) / grid;
+    sm_fastdiv_make((unsigned)q.tiles_x, &q.tx_mul, &q.tx_sh); sm_fastdiv_make((unsigned)(q.tiles_x * q.tiles_y), &q.txy_mul, &q.txy_sh);
+    const int blocks = (q.ntiles + q.tpb - 1) / q.tpb;
+    if (KG == 2 && NG == 2) hipLaunchKernelGGL((conv3x3_kqp_kernel<2, 2>), dim3(blocks), dim3(256), kqp_lds_bytes(2), s, q);
+    else if (KG == 1 && NG == 4) hipLaunchKernelGGL((conv3x3_kqp_kernel<1, 4>), dim3(blocks), dim3(256), kqp_lds_bytes(1), s, q);
+    else return -1;
+    return 0;
+}
 int kq_variant(int KG, int NG, int NF, int NB) {
     for (int i = 0; i < (int)(sizeof(kVariants) / sizeof(kVariants[0])); i++)
         if (kVariants[i].KG == KG && kVariants[i].NG == NG && kVariants[i].NF == NF && kVariants[i].NB == NB) return i;

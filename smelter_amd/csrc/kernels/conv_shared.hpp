@@ -67,3 +67,5 @@ template <int N> __device__ __forceinline__ void sm_wait_vmcnt() { asm volatile(
 // conv_kq.hip: launches instantiation `variant` (kq_variant(KG, NG, NF, NB)) of conv3x3_kq_kernel
 int kq_variant(int KG, int NG, int NF, int NB);
 void kq_launch(int variant, const ConvParams& p, unsigned grid, size_t lds, hipStream_t s);
+// ... and conv3x3_kqp_kernel<KG, NG> (persistent, weights in registers); -1: no such instantiation
+int kqp_launch(int KG, int NG, const ConvParams& p, hipStream_t s);

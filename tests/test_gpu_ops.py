@@ -604,6 +604,40 @@ def test_conv3x3_wave_split(case, cfg):
     assert_close(to_host(y), ref, cin * 9)
 
 
+KQP_CASES = [
+    # n, h, w, cin, cout, act, ups   -- conv3x3_kqp.hpp: persistent, whole weight tensor in registers, 14 x 14 tiles (h, w = the OUTPUT size; ups: the input is half of it)
+    (2, 28, 28, 128, 64, 1, False),    # exact tiles, two channel slices (the halves trade fragments through the released patch buffer)
+    (1, 33, 45, 128, 64, 2, False),    # ragged right / bottom tiles (5 rows, 3 columns), PRelu
+    (2, 30, 26, 64, 128, 1, False),    # one slice, four cout groups; ragged both ways
+    (3, 9, 7, 64, 128, 0, False),      # images smaller than a tile, no activation
+    (2, 28, 44, 128, 64, 1, True),     # fused nearest 2x upsampling of the input (14 x 22 source), ragged columns
+    (1, 36, 20, 64, 128, 1, True),     # ... one slice
+    (1, 150, 130, 128, 64, 1, False),  # 11 x 10 tiles: several tiles per block, buffers alternate
+]
+
+
+@pytest.mark.parametrize("case", KQP_CASES)
+@pytest.mark.parametrize("cfg", cfgs_named("kqp:"))
+def test_conv3x3_persistent_weights_in_registers(case, cfg):
+    n, hh, ww, cin, cout, act, ups = case
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    x = h(rng.standard_normal((n, cin, hh // 2, ww // 2) if ups else (n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * np.sqrt(2.0 / (cin * 9)))
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv2d(O.upsample(x, 2, 2) if ups else x, w, b, stride=(1, 1), pads=(1, 1, 1, 1))
+    slope = 0.25 if act == 2 else 0.0
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), act=act, slope=slope, cfg=cfg, ups=ups)
+    except SmelterError as e:
+        if "does not apply" in e.detail:                      # the other instantiation's channel counts
+            pytest.skip(e.detail)
+        raise
+    assert_close(to_host(y), ref, cin * 9)
+
+
 def test_conv3x3_wave_split_between_concat_slices():
     """pixel strides larger than the channel count on both sides, and nothing written outside the output slice"""
     rng = np.random.default_rng(6)
