@@ -20,7 +20,8 @@
 //  * fragment addresses are a register table (7 x 9 taps, built once: the tile shape is fixed); k16 step = an XOR, the buffer toggles by one add per table entry
 //    and tile;
 //  * reads run 8 fragments ahead in a ring of 9 (lgkmcnt counted) instead of a whole unit: 36 registers, which is what makes room for the weights;
-//  * epilogue: weight rows are assigned to couts so that a lane's 16 accumulator registers are 16 consecutive couts of one pixel: two 16-byte stores, no transpose.
+//  * epilogue: weight rows are assigned to couts so that 8 consecutive accumulator registers of a lane are 8 consecutive couts of its pixel and the other lane half
+//    holds the next 8: two 16-byte stores per lane, each writing 32 contiguous bytes per pixel, no transpose.
 //    KG = 2: the two channel halves trade half of their fragments through the patch buffer the tile has just released (accumulator layout, lane-linear).
 // Numerics: fp32 MFMA accumulation inside a channel slice over (tap, channel) ascending, then slice 0 + slice 1.
 #pragma once
@@ -54,11 +55,12 @@ __global__ __launch_bounds__(256) void conv3x3_kqp_kernel(KqpParams p) {
 
     // ---- weights -> registers, once.  A operand of tap, k16 step ks: lane (row rho = l31, channel group hi) holds channels 64 kg + 16 ks + 8 hi .. + 7 of the cout
     // that accumulator row rho stands for.  The 32x32 result layout gives lane half h the rows 8 q + 4 h + r (q = reg / 4, r = reg % 4): row rho is assigned cout
-    // co0 + 16 h + 4 q + r, so that a lane's 16 registers are 16 CONSECUTIVE couts of its pixel ----
+    // co0 + 16 (q / 2) + 8 h + 4 (q % 2) + r, so that registers 8 hf .. 8 hf + 7 of a lane are 8 consecutive couts and the two lane halves of a pixel are neighbours:
+    // store hf writes 32 contiguous bytes per pixel ----
     const int co0 = ng * 32;
     half8_t wreg[9][4];
     {
-        int co = co0 + 16 * ((l31 >> 2) & 1) + 4 * (l31 >> 3) + (l31 & 3); if (co >= p.Cout) co = p.Cout - 1;
+        int co = co0 + 16 * (l31 >> 4) + 8 * ((l31 >> 2) & 1) + 4 * ((l31 >> 3) & 1) + (l31 & 3); if (co >= p.Cout) co = p.Cout - 1;
         const unsigned wo = (unsigned)(co * p.K + kg * 64 + hi * 8) * 2u;
 #pragma unroll
         for (int tap = 0; tap < 9; tap++)
@@ -88,9 +90,9 @@ __global__ __launch_bounds__(256) void conv3x3_kqp_kernel(KqpParams p) {
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)((unsigned)p.N * (unsigned)(H * W) * yld2), 0x00020000);
     floatx4 bq[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) { const int co = co0 + 16 * hi + 4 * q; bq[q] = (p.bias && co + 3 < p.Cout) ? *(const floatx4*)(p.bias + co) : floatx4{0.f, 0.f, 0.f, 0.f}; }
+    for (int q = 0; q < 4; q++) { const int co = co0 + 16 * (q >> 1) + 8 * hi + 4 * (q & 1); bq[q] = (p.bias && co + 3 < p.Cout) ? *(const floatx4*)(p.bias + co) : floatx4{0.f, 0.f, 0.f, 0.f}; }
     const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;
-    const unsigned yco = (co0 + 16 * hi < p.Cout) ? (unsigned)(co0 + 16 * hi) * 2u : 0x80000000u;
+    const unsigned yco = (co0 + 8 * hi < p.Cout) ? (unsigned)(co0 + 8 * hi) * 2u : 0x80000000u;
 
     auto tile_origin = [&](int tile, int& n, int& y0, int& x0) {
         n = (int)sm_fastdiv((unsigned)tile, p.txy_mul, p.txy_sh);
@@ -158,7 +160,10 @@ __global__ __launch_bounds__(256) void conv3x3_kqp_kernel(KqpParams p) {
             __builtin_amdgcn_sched_barrier(0);
             acc[F] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wreg[TAP][KS], af[Q % RING], acc[F], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (F == 3 && U < DPW) {                        // one patch instruction of the next tile per unit (the last tile of the range copies nothing)
+            // one patch instruction of the next tile per unit (the last tile of the range copies nothing).  It costs the issuing wave ~150 clk (timeline): the copy is
+            // 72 KB per tile at the ~27 B/clk a CU fills at, and a wave waits in the address queue while its instruction is served — with one wave per SIMD that time
+            // is NOT overlapped with MFMAs.  Staggering the four waves' issue points over the unit made it worse (12.5 k instead of 11.2 k clk per tile).
+            if constexpr (F == 3 && U < DPW) {
                 if (more) issue_dma(std::integral_constant<int, U>(), nn, ny0, nx0, nbuf);
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -206,15 +211,22 @@ __global__ __launch_bounds__(256) void conv3x3_kqp_kernel(KqpParams p) {
                 const unsigned off = ok ? yorg + (unsigned)(ty * W + tx) * yld2 + yco : 0x80000000u;
                 typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
 #pragma unroll
-                for (int hf = 0; hf < 2; hf++) {                      // couts co0 + 16 hi + 8 hf .. + 7 = registers 8 hf .. 8 hf + 7
+                for (int hf = 0; hf < 2; hf++) {                      // couts co0 + 16 hf + 8 hi .. + 7 = registers 8 hf .. 8 hf + 7
                     half8_t ov;
+                    const floatx4 a0 = floatx4{acc[F][8 * hf], acc[F][8 * hf + 1], acc[F][8 * hf + 2], acc[F][8 * hf + 3]} + bq[2 * hf];
+                    const floatx4 a1 = floatx4{acc[F][8 * hf + 4], acc[F][8 * hf + 5], acc[F][8 * hf + 6], acc[F][8 * hf + 7]} + bq[2 * hf + 1];
+                    if (sl == 0.f) {                                  // ReLU (wave-uniform branch): one packed fp16 max per pair, after the rounding
 #pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const float v = acc[F][8 * hf + e] + bq[2 * hf + e / 4][e % 4];
-                        ov[e] = (half_t)(sl == 0.f ? v : (v < 0.f ? v * sl : v));
+                        for (int e = 0; e < 4; e++) { ov[e] = (half_t)a0[e]; ov[4 + e] = (half_t)a1[e]; }
+                        ov = __builtin_elementwise_max(ov, half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float v0 = a0[e] < 0.f ? a0[e] * sl : a0[e], v1 = a1[e] < 0.f ? a1[e] * sl : a1[e];
+                            ov[e] = (half_t)v0; ov[4 + e] = (half_t)v1;
+                        }
                     }
-                    if (sl == 0.f) ov = __builtin_elementwise_max(ov, half8_t{0, 0, 0, 0, 0, 0, 0, 0});   // ReLU: packed fp16 max after the rounding
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, ov), rs_y, (int)(off + 16u * hf), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, ov), rs_y, (int)(off + 32u * hf), 0, 0);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
