@@ -47,7 +47,9 @@ struct KqParams {
     const half_t* x; const half_t* w; const float* bias; half_t* y;
     int N, H, W, Cin, Cout, K, x_ld, y_ld, act; float slope;
     int nt, RS, NI, slice_bytes, TH, TI, mt, bands, mpx, nsb;
-    unsigned nt_mul, nt_sh, dhw_mul, dhw_sh, dw_mul, dw_sh, h1_mul, h1_sh, bands_mul, bands_sh;
+    unsigned nt_mul, nt_sh, dhw_mul, dhw_sh, dw_mul, dw_sh, h1_mul, h1_sh, bands_mul, bands_sh, rs_mul, rs_sh;
+    int ka, kb;                                                        // LDS swizzle: chunk c of patch slot (row r, column cc) sits at position c ^ ((ka (cc / 2) + kb r) & 7), kb in {0, 4};
+                                                                       // (1, (RS / 2) & 7) = the usual (slot / 2) & 7; the launcher picks a conflict-free pair where one exists (tools/lds_swizzle_search.py)
 };
 typedef unsigned kq_u32x4 __attribute__((ext_vector_type(4)));
 // LDS-DMA through a buffer descriptor: 16 bytes per lane from byte offset `voff` of the buffer to LDS address lds_dst + 16 lane; a lane whose offset is beyond
@@ -139,7 +141,7 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
         }
         const unsigned rowbase = (unsigned)(((n * H + y) * W - 1)) * ld2;                  // + cc * ld2: pixel (y, cc - 1)
         const int cc = 8 * k + l8;
-        const unsigned key = (unsigned)((((r * RS) >> 1) + (cc >> 1)) & 7);                 // swizzle key of slot r RS + cc (r RS % 8 == 0)
+        const unsigned key = (unsigned)((p.ka * (cc >> 1) + p.kb * r) & 7);                 // swizzle key of slot (r, cc)
         const bool ok = rok && (unsigned)(cc - 1) < (unsigned)W;
         return ok ? rowbase + (unsigned)cc * ld2 + (((unsigned)c8 ^ key) << 4) : 0x80000000u;
     };
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
     unsigned atab[TAB ? NFR : 1][3][2];                               // TAB: address of fragment f's slot under tap (0, kw), channel plane hp, in buffer 0: + kh RS 128 (+ the buffer) per read
     // (a row step of RS slots adds RS / 2 to slot / 2, i.e. flips bit 2 of the swizzle key when RS / 8 is odd: under an odd kh the two 64-byte planes of a slot trade
     // places — the unit then multiplies plane hp with the weights of channel half hp ^ 1)
-    const int kflip = (KPR & 1);
+    const int kflip = (p.kb >> 2) & 1;                                // (kb = 4: one patch row down flips bit 2 of the key)
     const unsigned G0 = (unsigned)g << 4;                             // chunk of half 0 this lane reads (half 1: chunk + 4 = address ^ 64)
     floatx4 acc[NFR][NF];
     half8_t af[2][NFR];
@@ -203,7 +205,8 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
                 if constexpr (TAB) {
 #pragma unroll
                     for (int kw = 0; kw < 3; kw++) {
-                        const unsigned pt = pf[f] + (unsigned)(kw << 7), a0 = pt ^ G0 ^ ((pt >> 4) & 0x70u);
+                        const int slot = vrow * RS + xx + kw, r = (int)sm_fastdiv((unsigned)slot, p.rs_mul, p.rs_sh), cc = slot - r * RS;
+                        const unsigned a0 = pf[f] + (unsigned)(kw << 7) + (((unsigned)g ^ (unsigned)((p.ka * (cc >> 1) + p.kb * r) & 7)) << 4);
                         atab[f][kw][0] = a0; atab[f][kw][1] = a0 ^ 64u;
                     }
                 }

@@ -47,6 +47,10 @@ void kq_launch(int variant, const ConvParams& p, unsigned grid, size_t lds, hipS
     q.N = p.N; q.H = p.H; q.W = p.W; q.Cin = p.Cin; q.Cout = p.Cout; q.K = p.K; q.x_ld = p.x_ld; q.y_ld = p.y_ld; q.act = p.act; q.slope = p.slope;
     q.nt = p.nt; q.RS = p.kq_RS; q.NI = p.kq_NI; q.slice_bytes = p.kq_slice_bytes; q.TH = p.kq_TH; q.TI = p.kq_TI; q.mt = p.kq_mt; q.bands = p.kq_bands; q.mpx = p.kq_mpx; q.nsb = p.kq_nsb;
     q.nt_mul = p.nt_mul; q.nt_sh = p.nt_sh; q.dhw_mul = p.dhw_mul; q.dhw_sh = p.dhw_sh; q.dw_mul = p.dw_mul; q.dw_sh = p.dw_sh;
-    q.h1_mul = p.kq_h1_mul; q.h1_sh = p.kq_h1_sh; q.bands_mul = p.kq_bands_mul; q.bands_sh = p.kq_bands_sh;
+    q.h1_mul = p.kq_h1_mul; q.h1_sh = p.kq_h1_sh; q.bands_mul = p.kq_bands_mul; q.bands_sh = p.kq_bands_sh; q.rs_mul = p.kq_rs_mul; q.rs_sh = p.kq_rs_sh;
+    // swizzle key: the usual one, except where the table-addressed instantiations (NF <= 2) have a conflict-free alternative — 28-pixel rows in 32-slot patch
+    // rows: (2 (cc / 2) + 4 r) & 7 serves every 16-lane group of every (fragment, tap) in 1.08 LDS cycles instead of 2.0 (tools/lds_swizzle_search.py --tw 28 --rs 32 --mfma 16 --pixels 196)
+    q.ka = 1; q.kb = (p.kq_RS / 2) & 7;
+    if (kVariants[variant].NF <= 2 && p.kq_RS == 32 && p.W == 28) { q.ka = 2; q.kb = 4; }
     hipLaunchKernelGGL(kVariants[variant].fn, dim3(grid), dim3(256), lds, s, q);
 }
