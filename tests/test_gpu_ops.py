@@ -638,6 +638,23 @@ def test_conv3x3_persistent_weights_in_registers(case, cfg):
     assert_close(to_host(y), ref, cin * 9)
 
 
+def test_conv3x3_persistent_weights_in_registers_between_concat_slices():
+    """pixel strides larger than the channel count on both sides, through the fused upsampling too, and nothing written outside the output slice"""
+    rng = np.random.default_rng(8)
+    for cin, cout, label in ((128, 64, "kqp:k2n2 128->64"), (64, 128, "kqp:k1n4 64->128")):
+        for ups in (False, True):
+            hh, ww = (18, 30)
+            x = h(rng.standard_normal((2, cin, hh // 2, ww // 2) if ups else (2, cin, hh, ww)))
+            w = h(rng.standard_normal((cout, 3, 3, cin)) * 0.04); b = rng.standard_normal(cout).astype(np.float32)
+            xin = torch.zeros(x.shape[:1] + x.shape[2:] + (cin + 48,), dtype=torch.float16, device="cuda"); xin[..., 16:16 + cin] = to_dev(x)
+            out = torch.full((2, hh, ww, cout + 24), 7.0, dtype=torch.float16, device="cuda")
+            ops.conv2d(xin[..., 16:16 + cin], torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(1, 1), pads=(1, 1, 1, 1), act=1, cfg=cfg_named(label),
+                       out=out[..., 8:8 + cout], ups=ups)
+            ref = np.maximum(O.conv2d(O.upsample(x, 2, 2) if ups else x, w, b, stride=(1, 1), pads=(1, 1, 1, 1)), 0)
+            assert_close(to_host(out[..., 8:8 + cout]), ref, cin * 9)
+            assert float(out[..., :8].min()) == 7.0 and float(out[..., 8 + cout:].max()) == 7.0
+
+
 def test_conv3x3_wave_split_between_concat_slices():
     """pixel strides larger than the channel count on both sides, and nothing written outside the output slice"""
     rng = np.random.default_rng(6)
