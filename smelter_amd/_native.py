@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsmelter_hip.so")
+# (SMELTER_LIB_PATH: another BUILD of the same library for same-box A/B runs and diagnostic builds — tools/lib_ab.sh; never a fallback: a missing file raises)
+LIB_PATH = os.environ.get("SMELTER_LIB_PATH") or os.path.join(_HERE, "libsmelter_hip.so")
 
 
 class SmelterError(RuntimeError):

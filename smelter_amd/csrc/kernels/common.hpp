@@ -12,6 +12,13 @@ typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// Cache policy of the OUTPUT stores of the convolution kernels (aux operand of __builtin_amdgcn_raw_buffer_store_*; 0 = default, 16 = sc1, 17 = sc0 sc1, 2 = nt).
+// A layer's output is never re-read through this launch's L2 — the next launch invalidates it — but with the default policy the last <= 32 MB of it sit DIRTY in the
+// L2s when the kernel ends, and the kernel boundary then waits for their write-back (MI355X_MICROARCH.md, boundary row: + B / 6 TB/s for B dirty bytes).  sc1 stores
+// write through and drop the line.  Build-time switch for the A/B (make EXTRA=-DSM_ST_AUX=16).
+#ifndef SM_ST_AUX
+#define SM_ST_AUX 0
+#endif
 #define SM_WAVE 64
 #define SM_NUM_XCD 8
 #define SM_NUM_CU 256

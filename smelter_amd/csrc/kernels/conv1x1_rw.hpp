@@ -203,7 +203,7 @@ __global__ __launch_bounds__(512) void conv1x1_rw_kernel(ConvParams p) {
                 for (int q = 0; q < 2; q++) {
                     sm_permlane32_swap(d[2 * q][0], d[2 * q + 1][0]);
                     sm_permlane32_swap(d[2 * q][1], d[2 * q + 1][1]);
-                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[2 * q][0], d[2 * q][1], d[2 * q + 1][0], d[2 * q + 1][1]}, rs_y, (int)(offy + (unsigned)(c * 64 + 32 * q)), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[2 * q][0], d[2 * q][1], d[2 * q + 1][0], d[2 * q + 1][1]}, rs_y, (int)(offy + (unsigned)(c * 64 + 32 * q)), 0, SM_ST_AUX);
                 }
             }
         });
@@ -449,7 +449,7 @@ __global__ __launch_bounds__((NCONS + 4) * 64) void conv1x1_rwl_kernel(ConvParam
             for (int q = 0; q < 2; q++) {
                 sm_permlane32_swap(d[2 * q][0], d[2 * q + 1][0]);
                 sm_permlane32_swap(d[2 * q][1], d[2 * q + 1][1]);
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[2 * q][0], d[2 * q][1], d[2 * q + 1][0], d[2 * q + 1][1]}, rs_y, (int)(offy + (unsigned)(32 * q)), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[2 * q][0], d[2 * q][1], d[2 * q + 1][0], d[2 * q + 1][1]}, rs_y, (int)(offy + (unsigned)(32 * q)), 0, SM_ST_AUX);
             }
         });
         if (++slot == NST) slot = 0;

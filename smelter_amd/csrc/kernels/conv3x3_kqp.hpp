@@ -226,7 +226,7 @@ __global__ __launch_bounds__(256) void conv3x3_kqp_kernel(KqpParams p) {
                             ov[e] = (half_t)v0; ov[4 + e] = (half_t)v1;
                         }
                     }
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, ov), rs_y, (int)(off + 32u * hf), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, ov), rs_y, (int)(off + 32u * hf), 0, SM_ST_AUX);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
                         for (int j = 0; j < 2; j++) {
                             sm_permlane32_swap(d[2 * j][0], d[2 * j + 1][0]);
                             sm_permlane32_swap(d[2 * j][1], d[2 * j + 1][1]);
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]}, rs_y3, (int)(offc + (unsigned)(cc * 64 + 32 * j)), 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]}, rs_y3, (int)(offc + (unsigned)(cc * 64 + 32 * j)), 0, SM_ST_AUX);
                         }
                     }
                 }

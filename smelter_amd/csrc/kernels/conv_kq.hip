@@ -1,4 +1,5 @@
 // conv_kq.hip — translation unit of the wave-split 3x3 convolution (conv3x3_kq.hpp, tile-config kind 9 of conv_igemm.hip's launcher).
+#include <stdlib.h>
 #include "conv_shared.hpp"
 
 namespace {

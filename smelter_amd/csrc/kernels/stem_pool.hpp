@@ -130,7 +130,7 @@ __global__ __launch_bounds__(512) void conv_stem_pool_kernel(ConvParams p) {
                     m = tp == 0 ? v : __builtin_elementwise_max(m, v);
                 }
                 const unsigned off = live ? (unsigned)((((n * POH + gy) * POW + gx) * p.y2_ld) * 2) + q_cv16[k] : DEAD;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), rs_y, (int)off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, m), rs_y, (int)off, 0, SM_ST_AUX);
             }
         };
         float va[LNI][2][4], vb[LNI][2][4];
