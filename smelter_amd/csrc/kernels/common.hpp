@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <type_traits>
 #include "../../../include/smelter_hip.h"
 
 typedef _Float16 half_t;
@@ -11,6 +12,10 @@ typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+template <int I, int N, class F> __device__ __forceinline__ void sm_static_for(F&& f) {       // f(integral_constant<int, I>) ... f(<N-1>)
+    if constexpr (I < N) { f(std::integral_constant<int, I>()); sm_static_for<I + 1, N>(f); }
+}
 
 // Cache policy of the OUTPUT stores of the convolution kernels (aux operand of __builtin_amdgcn_raw_buffer_store_*; 0 = default, 16 = sc1, 17 = sc0 sc1, 2 = nt).
 // A layer's output is never re-read through this launch's L2 — the next launch invalidates it — but with the default policy the last <= 32 MB of it sit DIRTY in the

@@ -59,9 +59,6 @@ __device__ __forceinline__ void ws_glds16(const void* gsrc, unsigned lds_dst) {
 }
 __device__ __forceinline__ unsigned ws_lds_addr(const void* p) { return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p; }
 
-template <int I, int N, class F> __device__ __forceinline__ void sm_static_for(F&& f) {       // f(integral_constant<int, I>) ... f(<N-1>)
-    if constexpr (I < N) { f(std::integral_constant<int, I>()); sm_static_for<I + 1, N>(f); }
-}
 template <int N> __device__ __forceinline__ void sm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // conv_kq.hip: launches instantiation `variant` (kq_variant(KG, NG, NF, NB)) of conv3x3_kq_kernel

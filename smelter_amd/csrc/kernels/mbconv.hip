@@ -465,6 +465,9 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
 // IMC: the expand layer is an image stem (3x3, 3 input planes, fp32 NCHW): the patch's B fragments are an im2col gather — lane = patch pixel of
 // the stem's output, its 16 k values per k step = taps (kh, kw, c) = k / 3 / 3, k / 3 % 3, k % 3 read from the planes (zero outside the image:
 // the stem's padding), k = 27, 28 the bias columns.  The stem's output (32 channels at full resolution: written once and read once) never exists.
+#ifndef MB3_BD
+#define MB3_BD 1
+#endif
 template <int S, int KS1, int NW, bool WREG, int TH = (S == 1 ? 4 : 2), bool WG = false, int NF = 2, bool IMC = false>
 __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     static_assert(!IMC || (KS1 == 2 && !WG), "image-stem form: K = 27 + 2 -> two k steps");
@@ -473,8 +476,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     constexpr int KP1 = KS1 * 16;
     const int ChP = p.ChP, NC = ChP >> 5, nfc = (p.Cout + 31) >> 5, CoP = nfc * 32, hs2 = ChP * 2 + 16;
     half_t* const w1l = (half_t*)mb_smem;                                // [ChP][KP1]   (absent with WG)
-    half_t* const wdl = w1l + (WG ? 0 : ChP * KP1);                      // [9][ChP]
-    unsigned char* const w2l = (unsigned char*)(wdl + 9 * ChP);          // [CoP] rows of hs2 bytes   (absent with WG)
+    unsigned* const wdl = (unsigned*)(w1l + (WG ? 0 : ChP * KP1));       // [10][ChP]: tap t of channel c as {w, w} (two halfs); row 9 = zeros (phase B's fifth k step holds one tap only)
+    unsigned char* const w2l = (unsigned char*)(wdl + 10 * ChP);         // [CoP] rows of hs2 bytes   (absent with WG)
     float* const bdl = (float*)(w2l + (WG ? 0 : CoP * hs2));             // [ChP]
     float* const b2l = bdl + ChP;                                        // [CoP]
     unsigned char* const wave_base = (unsigned char*)(b2l + CoP);
@@ -505,12 +508,12 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
             }
         }
     }
-    for (int i0 = tid; i0 < 9 * ChP; i0 += NT * PB) {
+    for (int i0 = tid; i0 < 10 * ChP; i0 += NT * PB) {
         half_t v[PB];
 #pragma unroll
         for (int j = 0; j < PB; j++) { const int i = i0 + j * NT, t = i / ChP, c = i - t * ChP; v[j] = (i < 9 * ChP && c < p.Ch) ? p.wd[(long)c * 9 + t] : (half_t)0.f; }
 #pragma unroll
-        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT; if (i < 9 * ChP) wdl[i] = v[j]; }
+        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT; if (i < 10 * ChP) wdl[i] = (unsigned)__builtin_bit_cast(unsigned short, v[j]) * 0x10001u; }
     }
     if constexpr (!WG) for (int i0 = tid; i0 < CoP * (hs2 / 2); i0 += NT * PB) {
         half_t v[PB];
@@ -544,6 +547,28 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
             }
         }
     };
+    // ---- phase B's lane constants: the depthwise layer as 16x16x32 MFMAs against DIAGONAL weight fragments ----------------------------------------------------
+    // D[channel i][pixel j] = sum_k A[i][k] B[k][j] with k = (tap pair member, channel of the 16-group): A[i][k] = wd[tap][i] where k's channel is i, else 0;
+    // B[k][j] = hidden value of that channel at pixel j shifted by that tap — a 16-byte LDS read per lane, exactly the slot layout phase A wrote.  Nine taps = five
+    // k steps of two taps (the tenth tap row of wdl is zero).  The fp32 accumulation, one rounding to fp16 and act2 are those of the vector-ALU form; only the
+    // ORDER of the nine fp32 additions differs.  1/16 of the MFMA's multipliers do work — they were idle: what it buys is 72 v_fma_mix + 18 LDS reads per
+    // (pixel, channel vector) turned into 5/16 MFMA + 5/16 reads (profiles/r04_pmc_mbconv_v3.txt: LDS 67 % and VALU 47 % busy before).
+    constexpr int NPG = OPX / 16;                                           // pixel groups of 16 = MFMA columns
+    const int n16 = lane & 15, g4 = lane >> 4;
+    unsigned amask[4];                                                      // lane (row i = n16, k group g4): the one half of its A fragment that is on the diagonal
+#pragma unroll
+    for (int d2 = 0; d2 < 4; d2++) amask[d2] = ((n16 >> 3) == (g4 & 1) && ((n16 & 7) >> 1) == d2) ? ((n16 & 1) ? 0xffff0000u : 0x0000ffffu) : 0u;
+    unsigned a_off[5], b_off[NPG][5];                                       // byte offsets into wdl (+ 4 * (chunk base + 16 cg)) / into hid (+ 32 cg)
+#pragma unroll
+    for (int s5 = 0; s5 < 5; s5++) {
+        const int tap = 2 * s5 + (g4 >> 1), tb = tap < 9 ? tap : 8, kh = tb / 3, kw = tb - 3 * kh;
+        a_off[s5] = (unsigned)((tap * ChP + n16) * 4);
+#pragma unroll
+        for (int pg = 0; pg < NPG; pg++) {
+            const int op = pg * 16 + n16, oy = op / TW, ox = op - oy * TW;
+            b_off[pg][s5] = (unsigned)(((oy * S + kh) * PW + ox * S + kw) * HS + (g4 & 1) * 16);
+        }
+    }
 #pragma unroll 1
     for (int t = t_begin; t < t_end; t++) {
         const int n = (int)fastdiv((unsigned)t, p.txy_mul, p.txy_sh);
@@ -671,47 +696,55 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
                     *(half4_t*)(hid + (mf * 32 + l31) * HS + (8 * q + 4 * hi) * 2) = o;
                 }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // (one wave: its LDS operations execute in order; this orders the compiler)
-            // ---- phase B: depthwise 3x3 on the chunk: 32 pixels x 4 channel vectors = two items per lane ----------------------------------
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            u32x4 wreg[WREG ? 9 : 1];                                    // a lane keeps its channel vector (lane & 3) for both items: nine taps in registers
-            floatx4 bd0, bd1;
-            const int chl = c * 32 + (lane & 3) * 8;
-            if (WREG) {
+            asm volatile("" ::: "memory");                                // (one wave: its LDS operations execute in order — no wait; this orders the compiler)
+            // ---- phase B: depthwise 3x3 on the chunk: NPG pixel groups x 2 channel groups of 16, five MFMAs each (lane constants above) -------------------
+            {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                floatx4 accB[NPG][2];
 #pragma unroll
-                for (int tp = 0; tp < 9; tp++) wreg[WREG ? tp : 0] = *(const u32x4*)(wdl + tp * ChP + chl);
-            }
-            bd0 = *(const floatx4*)(bdl + chl); bd1 = *(const floatx4*)(bdl + chl + 4);
+                for (int cg = 0; cg < 2; cg++) {
+                    const floatx4 b4 = *(const floatx4*)(bdl + c * 32 + cg * 16 + 4 * g4);
 #pragma unroll
-            for (int i2 = 0; i2 < OPX * 4 / 64; i2++) {
-                const int it = lane + 64 * i2, op = it >> 2, cv = it & 3, oy = op / TW, ox = op - oy * TW;
-                float a[8];
-#pragma unroll
-                for (int j = 0; j < 4; j++) { a[j] = bd0[j]; a[4 + j] = bd1[j]; }
-#pragma unroll
-                for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-                    for (int kw = 0; kw < 3; kw++) {
-                        const u32x4 xu = *(const u32x4*)(hid + ((oy * S + kh) * PW + ox * S + kw) * HS + cv * 16);
-                        const u32x4 wu = WREG ? wreg[WREG ? kh * 3 + kw : 0] : *(const u32x4*)(wdl + (kh * 3 + kw) * ChP + chl);
-#pragma unroll
-                        for (int d2 = 0; d2 < 4; d2++) {
-                            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2]) : "v"(xu[d2]), "v"(wu[d2]));
-                            asm("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,1,0]" : "+v"(a[2 * d2 + 1]) : "v"(xu[d2]), "v"(wu[d2]));
-                        }
-                    }
-                half8_t ov;
-                if (relu2) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) ov[j] = (half_t)a[j];
-                    ov = __builtin_elementwise_max(ov, hz);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+                    for (int pg = 0; pg < NPG; pg++) accB[pg][cg] = b4;
                 }
-                *(half8_t*)(dwo + op * HS + cv * 16) = ov;
+                // (a unit = one k step of one channel group: its reads are issued BD units ahead of the MFMAs that consume them, pinned: left alone, the scheduler
+                //  issues every read right in front of its MFMA and the wave sits out an LDS round trip per k step)
+                constexpr int BD = KS1 ? MB3_BD : 0, NU = 10;                 // (no read-ahead in the no-expand form: its 16-wave instantiations spill with it)
+                unsigned wv[BD + 1]; half8_t fb[BD + 1][NPG];
+                auto ld_b = [&](auto uc) {
+                    constexpr int u = decltype(uc)::value, s5 = u >> 1, cg = u & 1, buf = u % (BD + 1);
+                    wv[buf] = *(const unsigned*)((const unsigned char*)wdl + a_off[s5] + (c * 32 + cg * 16) * 4);
+#pragma unroll
+                    for (int pg = 0; pg < NPG; pg++) fb[buf][pg] = *(const half8_t*)(hid + b_off[pg][s5] + cg * 32);
+                };
+                sm_static_for<0, BD>([&](auto uc) { ld_b(uc); });
+                sm_static_for<0, NU>([&](auto uc) {
+                    constexpr int u = decltype(uc)::value, cg = u & 1, buf = u % (BD + 1);
+                    if constexpr (u + BD < NU) ld_b(std::integral_constant<int, u + BD>());
+                    __builtin_amdgcn_sched_barrier(0);
+                    const unsigned w = wv[buf];
+                    const half8_t fa = __builtin_bit_cast(half8_t, u32x4{w & amask[0], w & amask[1], w & amask[2], w & amask[3]});
+#pragma unroll
+                    for (int pg = 0; pg < NPG; pg++) accB[pg][cg] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa, fb[buf][pg], accB[pg][cg], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#pragma unroll
+                for (int pg = 0; pg < NPG; pg++)
+#pragma unroll
+                    for (int cg = 0; cg < 2; cg++) {
+                        half4_t o;
+                        if (relu2) {
+#pragma unroll
+                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)accB[pg][cg][r2];
+                            o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                        } else {
+#pragma unroll
+                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(accB[pg][cg][r2], p.sl2);
+                        }
+                        *(half4_t*)(dwo + (pg * 16 + n16) * HS + cg * 32 + g4 * 8) = o;
+                    }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            asm volatile("" ::: "memory");
             // ---- phase C: acc2 += W2[:, chunk] x depthwise chunk ---------------------------------------------------------------------
 #pragma unroll
             for (int ks = 0; ks < 2; ks++) {
@@ -724,7 +757,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
                         acc2[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw2, fy, acc2[a], 0, 0, 0);
                     }
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the chunk's readers are done before the next chunk overwrites hid / dwo
+            asm volatile("" ::: "memory");                                // the chunk's reads are issued before the next chunk's writes to hid / dwo (in-order LDS: no wait)
         }
         // ---- epilogue: + b2 (+ X), act3, 16-byte stores; lane = output pixel l31 of the tile ------------------------------------------
         const int oy = oy0 + l31 / TW, ox = ox0 + l31 % TW;
@@ -1129,7 +1162,7 @@ static size_t mb_v2_lds(const sm_mbconv_desc* d) {
 static size_t mb_v3_lds_nw(const sm_mbconv_desc* d, int nw, bool wg = false) {
     const int ChP = (d->Ch + 31) & ~31, KP1 = d->expand ? (d->Cin + 2 + 15) & ~15 : 0, CoP = (d->Cout + 31) & ~31;
     const int TH = d->stride == 1 ? 4 : 2, PH = (TH - 1) * d->stride + 3, PW = 7 * d->stride + 3, MFA = (PH * PW + 31) / 32;
-    return (wg ? 0 : (size_t)ChP * KP1 * 2 + (size_t)CoP * (ChP * 2 + 16)) + (size_t)9 * ChP * 2 + (size_t)(ChP + CoP) * 4 + (size_t)nw * (MFA * 32 + TH * 8) * 80;
+    return (wg ? 0 : (size_t)ChP * KP1 * 2 + (size_t)CoP * (ChP * 2 + 16)) + (size_t)10 * ChP * 4 + (size_t)(ChP + CoP) * 4 + (size_t)nw * (MFA * 32 + TH * 8) * 80;
 }
 // W1 / W2 as fragments from global memory (8-wave blocks): the expand form whose weights leave no room for 8 wave regions; instantiated for
 // K = Cin + 2 <= 80 | 112 (5 | 7 k steps) and Cout <= 64 | 96 | 160 — MobileNet-v2's 14 x 14 blocks
