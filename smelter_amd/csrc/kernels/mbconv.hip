@@ -791,6 +791,263 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     }
 }
 
+// ---- v5: the wave pipeline with the hidden patch in REGISTERS -------------------------------------------------------------------------------------------------------------
+// v3's phase B is bound by the LDS the four SIMDs share (profiles/r04_mbconv_v3_phases.txt): every hidden value is read back once per tap.  Here the expand GEMM is
+// turned around — D[patch pixel][channel] = X[pixel][k] W1[k][channel], the same two fragments with the MFMA's operands swapped — so a LANE holds one hidden channel and
+// its accumulator registers the pixels: the depthwise layer becomes a stencil over the lane's own registers (v_fma_mix_f32 on packed fp16 pairs, nine per output, fp32
+// accumulation, the same single rounding of the hidden tensor to fp16), and the hidden patch never touches the LDS at all.  The two halves of the wave (lanes 0..31 /
+// 32..63 = the two row groups of a 32x32 accumulator) own the left / right four output columns of the 4 x 8 (stride 2: 2 x 8) tile; the upper half keeps its window
+// MIRRORED (window column j = patch column PW-1-j, output column 7-j, taps read from a kw-mirrored copy of the depthwise weights), so both halves run the same
+// instructions on the same register numbers; the WC = 6 (stride 2: 9) window columns of a half overlap the other half's by 2 (1) columns that are computed twice —
+// MFMA work, which is idle here — instead of exchanged.  Only the depthwise OUTPUT passes the LDS (2 bytes per lane and pixel into the wave's [pixel][channel] region):
+// the transposition the projection GEMM's B operand needs; phase C and the epilogue are v3's.  Expand forms with W1 / W2 in the LDS (K = Cin + 2 <= 48), and the image-stem form.
+// (plain C, not an asm statement: behind a v_dot2c the hardware wants wait states before another vector-ALU instruction reads the result, and the compiler's
+//  hazard recogniser does not look into inline asm — a v_fma_mix_f32 written as asm read the accumulator one instruction too early)
+template <int X0, int X1> __device__ __forceinline__ void mb_fma_mix(float& a, unsigned x, unsigned w) {    // a += half X0 of x * half X1 of w, one v_fma_mix_f32
+    a = __builtin_fmaf((float)__builtin_bit_cast(half2_t, x)[X0], (float)__builtin_bit_cast(half2_t, w)[X1], a);
+}
+template <int S, int KS1, int NW, bool IMC = false, int NF = 1, bool RELU = true>   // RELU: act1 and act2 are ReLU (else any member of the leaky family, slopes p.sl1 / p.sl2)
+__global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
+    static_assert(!IMC || KS1 == 2, "image-stem form: K = 27 + 2 -> two k steps");
+    constexpr int TW = 8, TH = S == 1 ? 4 : 2, OPX = TH * TW, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, WC = 3 * S + 3, WPR = (WC + 1) / 2;
+    constexpr int PXH = PH * WC, MFA = (PXH + 15) / 16, HS = 80, NT = NW * 64, KP1 = KS1 * 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
+    const int ChP = p.ChP, NC = ChP >> 5, nfc = (p.Cout + 31) >> 5, CoP = nfc * 32, hs2 = ChP * 2 + 16;
+    half_t* const w1l = (half_t*)mb_smem;                                // [ChP][KP1]
+    half_t* const wdt = w1l + ChP * KP1;                                 // [ChP][2][3][4]: a channel's taps per kernel row as the pairs (w0, w1), (w1, w2), plain and kw-mirrored (three 8-byte reads)
+    unsigned char* const w2l = (unsigned char*)(wdt + ChP * 24);         // [CoP] rows of hs2 bytes
+    float* const bdl = (float*)(w2l + CoP * hs2);                        // [ChP]
+    float* const b2l = bdl + ChP;                                        // [CoP]
+    unsigned char* const wave_base = (unsigned char*)(b2l + CoP);
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* const dwo = wave_base + wave * (32 * HS);             // depthwise output chunk [32 pixels][HS] (stride 2: 16 pixels used)
+
+    constexpr int PB = 8;
+    for (int i0 = tid; i0 < ChP * KP1; i0 += NT * PB) {
+        half_t v[PB]; float bb[PB];
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+            const int i = i0 + j * NT, n = i / KP1, k = i - n * KP1;
+            const bool on = i < ChP * KP1 && n < p.Ch;
+            v[j] = (on && k < p.Cin) ? p.w1[(long)n * p.Cin + k] : (half_t)0.f;
+            bb[j] = (on && k >= p.Cin && k < p.Cin + 2 && p.b1) ? p.b1[n] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+            const int i = i0 + j * NT, n = i / KP1, k = i - n * KP1;
+            if (i < ChP * KP1) {
+                half_t o = v[j];
+                if (n < p.Ch && k >= p.Cin && k < p.Cin + 2) { const half_t bh = (half_t)bb[j]; o = k == p.Cin ? bh : (half_t)(bb[j] - (float)bh); }
+                w1l[i] = o;
+            }
+        }
+    }
+    for (int i0 = tid; i0 < ChP * 24; i0 += NT * PB) {
+        half_t v[PB];
+#pragma unroll
+        for (int j = 0; j < PB; j++) {
+            const int i = i0 + j * NT, c = i / 24, r = i - c * 24, mir = r >= 12, t = r - 12 * mir, kh = t >> 2, e = t & 3, kw = e < 2 ? e : e - 1;   // (w0, w1 | w1, w2) per kernel row
+            v[j] = (i < ChP * 24 && c < p.Ch) ? p.wd[(long)c * 9 + kh * 3 + (mir ? 2 - kw : kw)] : (half_t)0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT; if (i < ChP * 24) wdt[i] = v[j]; }
+    }
+    for (int i0 = tid; i0 < CoP * (hs2 / 2); i0 += NT * PB) {
+        half_t v[PB];
+#pragma unroll
+        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT, n = i / (hs2 / 2), k = i - n * (hs2 / 2); v[j] = (i < CoP * (hs2 / 2) && n < p.Cout && k < p.Ch) ? p.w2[(long)n * p.Ch + k] : (half_t)0.f; }
+#pragma unroll
+        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT; if (i < CoP * (hs2 / 2)) ((half_t*)w2l)[i] = v[j]; }
+    }
+    for (int i = tid; i < ChP; i += NT) bdl[i] = (p.bd && i < p.Ch) ? p.bd[i] : 0.f;
+    for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
+    __syncthreads();                                                     // the only barrier of the kernel
+
+    const long T = p.ntiles, GW = (long)gridDim.x * NW, gw = (long)blockIdx.x * NW + wave;
+    const int t_begin = (int)(gw * T / GW), t_end = (int)((gw + 1) * T / GW);
+    const half8_t hz = {0, 0, 0, 0, 0, 0, 0, 0};
+    half8_t ones = hz; ones[0] = (half_t)1.f; ones[1] = (half_t)1.f;
+    // row m = l31 of X fragment mf is accumulator element idx = 4 (m / 8) + m % 4 of the lanes of half (m / 4) % 2: window pixel q = 16 mf + idx = (row py, window column j)
+    int ppy[MFA], ppx[MFA];                                              // patch row / column of this lane's fragment rows; ppy < 0: the row is beyond the window
+#pragma unroll
+    for (int mf = 0; mf < MFA; mf++) {
+        const int hm = (l31 >> 2) & 1, q = mf * 16 + (l31 >> 3) * 4 + (l31 & 3), py = q / WC, j = q - py * WC;
+        ppy[mf] = q < PXH ? py : -1000000; ppx[mf] = hm ? PW - 1 - j : j;
+    }
+    unsigned woff[4];                                                    // depthwise-output slots of this lane's four output columns (+ row * TW * HS)
+#pragma unroll
+    for (int oxl = 0; oxl < 4; oxl++) woff[oxl] = (unsigned)((hi ? 7 - oxl : oxl) * HS + l31 * 2);
+    half8_t fw1[KS1];
+#pragma unroll 1
+    for (int t = t_begin; t < t_end; t++) {
+        const int n = (int)fastdiv((unsigned)t, p.txy_mul, p.txy_sh);
+        const int r = t - n * (p.tiles_x * p.tiles_y), by = (int)fastdiv((unsigned)r, p.tx_mul, p.tx_sh);
+        const int oy0 = by * TH, ox0 = (r - by * p.tiles_x) * TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+        const half_t* const xim = p.x + (long)n * p.H * p.W * p.x_ld;
+        // ---- X fragments of the window pixels: [fragment][k step], 16 bytes per lane, kept for all chunks ----------------------------------------------------------
+        half8_t fx[MFA][KS1];
+        if constexpr (IMC) {
+            constexpr unsigned DEAD = 0x80000000u;
+            const unsigned plane = (unsigned)p.in_H * (unsigned)p.in_W;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xf, 0, (int)((unsigned)p.N * 3u * plane * 4u), 0x00020000);
+#pragma unroll
+            for (int mf = 0; mf < MFA; mf++) {
+                const int iy = iy0 + ppy[mf], ix = ix0 + ppx[mf];
+                const bool inimg = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const int r0 = iy * p.st_s - p.st_p, c0 = ix * p.st_s - p.st_p;
+                const unsigned base = (((unsigned)n * 3u) * plane + (unsigned)r0 * (unsigned)p.in_W + (unsigned)c0) * 4u;
+                unsigned okbits = 0;
+#pragma unroll
+                for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+                    for (int kw = 0; kw < 3; kw++)
+                        okbits |= (unsigned)(inimg && (unsigned)(r0 + kh) < (unsigned)p.in_H && (unsigned)(c0 + kw) < (unsigned)p.in_W) << (kh * 3 + kw);
+#pragma unroll
+                for (int ks = 0; ks < KS1; ks++) {
+                    float g[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int k0 = ks * 16 + e, k1 = k0 + 8;
+                        const unsigned rel0 = (unsigned)(k0 % 3) * plane + (unsigned)(k0 / 9) * (unsigned)p.in_W + (unsigned)(k0 / 3 % 3);
+                        const unsigned rel1 = (unsigned)(k1 % 3) * plane + (unsigned)(k1 / 9 % 3) * (unsigned)p.in_W + (unsigned)(k1 / 3 % 3);
+                        const unsigned bit = hi ? (k1 < 27 ? 1u << (k1 / 3) : 0u) : (k0 < 27 ? 1u << (k0 / 3) : 0u);
+                        const unsigned off = (okbits & bit) ? base + (hi ? rel1 : rel0) * 4u : DEAD;
+                        g[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+                    }
+                    half8_t v;
+#pragma unroll
+                    for (int e = 0; e < 8; e++) {
+                        const int k = ks * 16 + hi * 8 + e;
+                        v[e] = (k == 27 || k == 28) ? (half_t)(inimg ? 1.f : 0.f) : (half_t)g[e];
+                    }
+                    fx[mf][ks] = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mf = 0; mf < MFA; mf++) {
+                const int iy = iy0 + ppy[mf], ix = ix0 + ppx[mf];
+                const bool inimg = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const half_t* src = xim + ((long)iy * p.W + ix) * p.x_ld;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ks++) {
+                    const int k = ks * 16 + hi * 8;
+                    half8_t v = hz;
+                    if (inimg) { if (k < p.Cin) v = *(const half8_t*)(src + k); else if (k == p.Cin) v = ones; }
+                    fx[mf][ks] = v;
+                }
+            }
+        }
+        floatx16 acc2[NF];
+#pragma unroll
+        for (int a = 0; a < NF; a++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc2[a][i] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < NC; c++) {
+            // ---- phase A: hidden[window pixel][channel] = act1(X W1[c]^T): lane = channel c*32 + l31 of its half's window -----------------------------------------------
+#pragma unroll
+            for (int ks = 0; ks < KS1; ks++) fw1[ks] = *(const half8_t*)(w1l + (c * 32 + l31) * KP1 + ks * 16 + hi * 8);
+            const int chl = c * 32 + l31;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            unsigned wqv[6];                                             // this lane's taps (its half's orientation): [2 kh] = (w0, w1), [2 kh + 1] = (w1, w2)
+#pragma unroll
+            for (int i = 0; i < 3; i++) { const u32x2 w2 = *(const u32x2*)(wdt + (chl * 2 + hi) * 12 + i * 4); wqv[2 * i] = w2[0]; wqv[2 * i + 1] = w2[1]; }
+            const float bdv = bdl[chl];
+            floatx16 accA[MFA];
+#pragma unroll
+            for (int mf = 0; mf < MFA; mf++) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) accA[mf][i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS1; ks++) accA[mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fx[mf][ks], fw1[ks], accA[mf], 0, 0, 0);
+            }
+            unsigned hw[PH][WPR];                                        // the window: row py, columns (2 q, 2 q + 1) as an fp16 pair
+#pragma unroll
+            for (int py = 0; py < PH; py++)
+#pragma unroll
+                for (int q = 0; q < WPR; q++) {
+                    const int q0 = py * WC + 2 * q, q1 = q0 + 1;
+                    const float a = accA[q0 >> 4][q0 & 15], b = (2 * q + 1 < WC) ? accA[q1 >> 4][q1 & 15] : 0.f;
+                    half2_t o;
+                    if constexpr (RELU) { o[0] = (half_t)a; o[1] = (half_t)b; o = __builtin_elementwise_max(o, half2_t{0, 0}); }
+                    else { o[0] = (half_t)relu_family(a, p.sl1); o[1] = (half_t)relu_family(b, p.sl1); }
+                    hw[py][q] = __builtin_bit_cast(unsigned, o);
+                }
+            // ---- phase B: depthwise 3x3 over the lane's window: TH x 4 outputs, nine fp32 FMAs each -------------------------------------------------------------------
+            asm volatile("" ::: "memory");                                // (phase C's reads of the previous chunk are issued before these writes: in-order LDS, no wait)
+            // (per kernel row one v_dot2c_f32_f16 — the two window columns that share a register against (w0, w1) or (w1, w2) — and one v_fma_mix_f32 for the third
+            //  column: 6 instead of 9 vector-ALU instructions per output, all accumulating in fp32)
+            sm_static_for<0, TH * 2>([&](auto oc) {
+                constexpr int oy = decltype(oc)::value >> 1, op2 = decltype(oc)::value & 1;
+                float a2[2];
+                sm_static_for<0, 2>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value, j0 = (2 * op2 + e) * S;                       // output column 2 op2 + e of the half: window columns j0 .. j0 + 2
+                    float a = bdv;
+                    sm_static_for<0, 3>([&](auto kc) {
+                        constexpr int kh = decltype(kc)::value, row = oy * S + kh;
+                        if constexpr ((j0 & 1) == 0) {
+                            a = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, hw[row][j0 >> 1]), __builtin_bit_cast(half2_t, wqv[2 * kh]), a, false);
+                            mb_fma_mix<0, 1>(a, hw[row][(j0 >> 1) + 1], wqv[2 * kh + 1]);
+                        } else {
+                            a = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, hw[row][(j0 + 1) >> 1]), __builtin_bit_cast(half2_t, wqv[2 * kh + 1]), a, false);
+                            mb_fma_mix<1, 0>(a, hw[row][j0 >> 1], wqv[2 * kh]);
+                        }
+                    });
+                    a2[e] = a;
+                });
+                half2_t o;
+                if constexpr (RELU) { o[0] = (half_t)a2[0]; o[1] = (half_t)a2[1]; o = __builtin_elementwise_max(o, half2_t{0, 0}); }
+                else { o[0] = (half_t)relu_family(a2[0], p.sl2); o[1] = (half_t)relu_family(a2[1], p.sl2); }
+                *(half_t*)(dwo + woff[2 * op2] + oy * TW * HS) = o[0];
+                *(half_t*)(dwo + woff[2 * op2 + 1] + oy * TW * HS) = o[1];
+            });
+            asm volatile("" ::: "memory");
+            // ---- phase C: acc2 += W2[:, chunk] x depthwise chunk -----------------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const half8_t fy = *(const half8_t*)(dwo + l31 * HS + (ks * 2 + hi) * 16);
+#pragma unroll
+                for (int a = 0; a < NF; a++)
+                    if (a < nfc) {
+                        const half8_t fw2 = *(const half8_t*)(w2l + (a * 32 + l31) * hs2 + (c * 32 + ks * 16 + hi * 8) * 2);
+                        acc2[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw2, fy, acc2[a], 0, 0, 0);
+                    }
+            }
+        }
+        // ---- epilogue: + b2 (+ X), act3, 16-byte stores; lane = output pixel l31 of the tile --------------------------------------------------------------------------
+        const int oy = oy0 + l31 / TW, ox = ox0 + l31 % TW;
+        const bool pin = l31 < OPX && oy < p.Ho && ox < p.Wo;
+        const long opix = ((long)n * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+        for (int a = 0; a < NF; a++)
+            if (a < nfc) {
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    float o[8];
+#pragma unroll
+                    for (int r2 = 0; r2 < 4; r2++) {
+                        unsigned ua = __builtin_bit_cast(unsigned, acc2[a][4 * (2 * j) + r2] + b2l[a * 32 + 8 * (2 * j) + 4 * hi + r2]);
+                        unsigned ub = __builtin_bit_cast(unsigned, acc2[a][4 * (2 * j + 1) + r2] + b2l[a * 32 + 8 * (2 * j + 1) + 4 * hi + r2]);
+                        sm_permlane32_swap(ua, ub);
+                        o[r2] = __builtin_bit_cast(float, ua); o[4 + r2] = __builtin_bit_cast(float, ub);
+                    }
+                    const int co = a * 32 + 16 * j + 8 * hi;
+                    if (pin && co < p.Cout) {
+                        if (p.res) { const half8_t rv = *(const half8_t*)(xim + ((long)oy * p.W + ox) * p.x_ld + co);
+#pragma unroll
+                            for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
+                        half8_t ov;
+#pragma unroll
+                        for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                        *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
+                    }
+                }
+            }
+    }
+}
+
 // ---- v4: one TILE per block, every hidden chunk shared by the block's eight waves ------------------------------------------------------------------
 // v3 is one wave per 4 x 8 tile walking its chunks in a single dependent chain (expand MFMAs -> LDS -> depthwise -> LDS -> project MFMAs): nothing in
 // a CU is busy, the 6 x 10 patch of a 4 x 8 tile computes the expand layer 1.9 times, and from Ch = 384 on the weights come from global memory per
@@ -1166,6 +1423,15 @@ static size_t mb_v3_lds_nw(const sm_mbconv_desc* d, int nw, bool wg = false) {
 }
 // W1 / W2 as fragments from global memory (8-wave blocks): the expand form whose weights leave no room for 8 wave regions; instantiated for
 // K = Cin + 2 <= 80 | 112 (5 | 7 k steps) and Cout <= 64 | 96 | 160 — MobileNet-v2's 14 x 14 blocks
+// v5 (hidden patch in registers): the expand form with W1 / W2 in the LDS, Cout <= 64
+static size_t mb_v5_lds_nw(const sm_mbconv_desc* d, int nw) {
+    const int ChP = (d->Ch + 31) & ~31, KP1 = (d->Cin + 2 + 15) & ~15, CoP = (d->Cout + 31) & ~31;
+    return (size_t)ChP * KP1 * 2 + (size_t)ChP * 24 * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)nw * 32 * 80;
+}
+static bool mb_v5_ok(const sm_mbconv_desc* d) {
+    static const int off = getenv("SMELTER_MBCONV_NO_V5") ? 1 : 0;          // experiment switch, read once
+    return !off && d->expand && d->Cin <= 30 && d->Cout <= 64 && mb_v5_lds_nw(d, 16) <= 160 * 1024;
+}
 static bool mb_v3_wg(const sm_mbconv_desc* d) { return d->expand && mb_v3_lds_nw(d, 8) > 160 * 1024; }
 // waves per block: 16 (one block per CU; its 128-register budget holds) when the LDS takes it, else 8, else 4
 static int mb_v3_waves(const sm_mbconv_desc* d) {
@@ -1238,7 +1504,7 @@ static int mb_pick(const sm_mbconv_desc* d) {                         // 4, 3, 1
 size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d) {
     if (!d) return 0;
     const int k = mb_pick(d);
-    return k == 4 ? mb_v4_lds(d) : k == 3 ? mb_v3_lds(d) : k == 1 ? mb_v1_lds(d) : mb_v2_lds(d);
+    return k == 4 ? mb_v4_lds(d) : k == 3 ? (mb_v5_ok(d) ? mb_v5_lds_nw(d, 16) : mb_v3_lds(d)) : k == 1 ? mb_v1_lds(d) : mb_v2_lds(d);
 }
 
 int sm_mbconv_supported(const sm_mbconv_desc* d) { return mb_pick(d) ? 1 : 0; }
@@ -1295,6 +1561,16 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
         SM_REQUIRE(nt3 < (1L << 31), "sm_mbconv_fwd: too many tiles");
         p.tiles_x = sm_ceil_div(d->Wo, 8); p.tiles_y = sm_ceil_div(d->Ho, th3); p.ntiles = (int)nt3;
         fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
+        if (mb_v5_ok(d)) {                                           // hidden patch in registers: 16-wave blocks, one per CU
+            const bool relu = p.sl1 == 0.f && p.sl2 == 0.f;
+            void (*f5)(MbParams) = nullptr;
+#define MB5_PICK(S_) (d->Cout <= 32 ? (relu ? mbconv5_kernel<S_, 2, 16, false, 1, true> : mbconv5_kernel<S_, 2, 16, false, 1, false>) \
+                                    : (relu ? mbconv5_kernel<S_, 2, 16, false, 2, true> : mbconv5_kernel<S_, 2, 16, false, 2, false>))
+            if (d->stride == 1) f5 = MB5_PICK(1); else f5 = MB5_PICK(2);
+#undef MB5_PICK
+            hipLaunchKernelGGL(f5, dim3((unsigned)std::min<long>((nt3 + 15) / 16, (long)SM_NUM_CU)), dim3(1024), mb_v5_lds_nw(d, 16), sm_s(stream), p);
+            SM_LAUNCH_CHECK(); return SM_OK;
+        }
         const int nw = mb_v3_waves(d), ks1 = d->expand ? ((d->Cin + 2 + 15) & ~15) >> 4 : 0;
         const int per_cu3 = (int)std::max<size_t>(1, std::min<size_t>(16 / nw, (size_t)(160 * 1024) / lds));
         const int grid3 = (int)std::min<long>((nt3 + nw - 1) / nw, (long)SM_NUM_CU * per_cu3);
