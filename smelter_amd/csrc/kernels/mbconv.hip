@@ -782,8 +782,13 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                         half8_t ov;
+                        if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
-                        for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
+                        } else {
+#pragma unroll
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                        }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }
                 }
@@ -1039,12 +1044,236 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                         half8_t ov;
+                        if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
-                        for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
+                        } else {
+#pragma unroll
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                        }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }
                 }
             }
+    }
+}
+
+// ---- v5 behind an image stem, the input patch STAGED: mbconv5s_kernel ---------------------------------------------------------------------------------------------------
+// The image-stem forms above gather the 27 taps of every patch pixel from the fp32 planes with 4-byte loads (32..48 per lane and tile, ~6 vector-ALU instructions of
+// address arithmetic each): MobileNet-v2's first block spent most of its 215 us there.  Here a block of eight waves owns a BLOCK TILE of 2 x 4 wave tiles ((2 TH) x 32
+// output pixels); the waves copy the input region under it — rows as coalesced segments, one (plane, row) per wave and step: scalar address arithmetic — into the LDS as
+// fp16 PIXEL SLOTS of 8 bytes (c0, c1, c2, -), so the three taps of a kernel row are 24 contiguous bytes and the expand GEMM's A fragment of a patch pixel is ONE
+// ds_read2_b64 per k step at a lane-constant address: K is laid out as (kh, kw in 0..3, c in 0..3) = 48 = three k steps, with zeros in W1 at the padding positions, and
+// the fourth "kw" slot of kernel row 1 — overwritten in registers — carries the two bias columns (1, 1 inside the hidden image: a hidden pixel outside is exactly 0, the
+// depthwise layer's padding).  Two blocks per CU (launch bounds): one stages while the other computes.  Phases A (operands swapped: lane = channel), B (register
+// stencil), C and the epilogue are mbconv5_kernel's.
+template <int S, int NF, bool RELU>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void mbconv5s_kernel(MbParams p) {   // (128 registers: two blocks per CU)
+    constexpr int NW = 8, TW = 8, TH = S == 1 ? 4 : 2, OPX = TH * TW, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, WC = 3 * S + 3, WPR = (WC + 1) / 2;
+    constexpr int PXH = PH * WC, MFA = (PXH + 15) / 16, HS = 80, NT = NW * 64, KP1 = 48, BWY = 2, BWX = 4;
+    constexpr int HR = (BWY * TH - 1) * S + 3, HC = (BWX * TW - 1) * S + 3;                 // hidden region of a block tile (rows, columns)
+    extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
+    const int ChP = p.ChP, nfc = (p.Cout + 31) >> 5, CoP = nfc * 32, hs2 = ChP * 2 + 16;
+    constexpr int NSG = 8, NPS = S == 1 ? 2 : 3, pitch = 64 * NPS + 2;     // staging: segments per wave (3 IR <= 64), 64-column passes (IC <= 64 NPS: checked by the launcher); LDS row pitch in pixel slots
+    const int st = p.st_s, IR = (HR - 1) * st + 3, IC = (HC - 1) * st + 3;              // input region (rows, columns); columns IC .. 64 NPS - 1 are staged as zeros, the last two stay zero
+    half_t* const w1l = (half_t*)mb_smem;                                // [ChP][48]: k = 16 kh + 4 kw + c
+    half_t* const wdt = w1l + ChP * KP1;                                 // [ChP][2][3][4] (mbconv5_kernel)
+    unsigned char* const w2l = (unsigned char*)(wdt + ChP * 24);         // [CoP] rows of hs2 bytes
+    float* const bdl = (float*)(w2l + CoP * hs2);                        // [ChP]
+    float* const b2l = bdl + ChP;                                        // [CoP]
+    unsigned char* const reg = (unsigned char*)(b2l + CoP);              // input region: [IR][pitch] pixel slots of 8 bytes
+    unsigned char* const wave_base = reg + (size_t)IR * pitch * 8;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), wy = wave >> 2, wx = wave & 3;
+    unsigned char* const dwo = wave_base + wave * (32 * HS);
+
+    for (int i = tid; i < ChP * KP1; i += NT) {
+        const int n = i / KP1, k = i - n * KP1, kh = k >> 4, kw = (k >> 2) & 3, c = k & 3;
+        half_t v = (half_t)0.f;
+        if (n < p.Ch) {
+            if (kw < 3 && c < 3) v = p.w1[(long)n * 27 + (kh * 3 + kw) * 3 + c];
+            else if (kh == 1 && kw == 3 && c < 2 && p.b1) { const float b = p.b1[n]; const half_t bh = (half_t)b; v = c == 0 ? bh : (half_t)(b - (float)bh); }
+        }
+        w1l[i] = v;
+    }
+    for (int i = tid; i < ChP * 24; i += NT) {
+        const int c = i / 24, r = i - c * 24, mir = r >= 12, t = r - 12 * mir, kh = t >> 2, e = t & 3, kw = e < 2 ? e : e - 1;
+        wdt[i] = c < p.Ch ? p.wd[(long)c * 9 + kh * 3 + (mir ? 2 - kw : kw)] : (half_t)0.f;
+    }
+    for (int i = tid; i < CoP * (hs2 / 2); i += NT) { const int n = i / (hs2 / 2), k = i - n * (hs2 / 2); ((half_t*)w2l)[i] = (n < p.Cout && k < p.Ch) ? p.w2[(long)n * p.Ch + k] : (half_t)0.f; }
+    for (int i = tid; i < ChP; i += NT) bdl[i] = (p.bd && i < p.Ch) ? p.bd[i] : 0.f;
+    for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
+    for (int i = tid; i < IR * pitch * 2; i += NT) ((unsigned*)reg)[i] = 0u;          // (the slots' fourth halfs and the spare column are never written again)
+
+    // window pixel (row py, patch column px) of this lane's fragment rows (mbconv5_kernel); rows beyond the window read pixel (0, 0) and are never used
+    int ppy[MFA], ppx[MFA]; bool pon[MFA];
+    unsigned abase[MFA][3];                                              // byte offset in `reg` of the lane's two slots (kw = 2 hi, 2 hi + 1) of kernel row kh, per fragment
+#pragma unroll
+    for (int mf = 0; mf < MFA; mf++) {
+        const int hm = (l31 >> 2) & 1, q = mf * 16 + (l31 >> 3) * 4 + (l31 & 3), py = q / WC, j = q - py * WC;
+        pon[mf] = q < PXH; ppy[mf] = pon[mf] ? py : 0; ppx[mf] = pon[mf] ? (hm ? PW - 1 - j : j) : 0;
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++)
+            abase[mf][kh] = (unsigned)((((wy * TH * S + ppy[mf]) * st + kh) * pitch + (wx * TW * S + ppx[mf]) * st + 2 * hi) * 8);
+    }
+    unsigned woff[4];
+#pragma unroll
+    for (int oxl = 0; oxl < 4; oxl++) woff[oxl] = (unsigned)((hi ? 7 - oxl : oxl) * HS + l31 * 2);
+    const unsigned plane = (unsigned)p.in_H * (unsigned)p.in_W;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xf, 0, (int)((unsigned)p.N * 3u * plane * 4u), 0x00020000);
+    const int nseg = 3 * IR;
+    __syncthreads();
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    half8_t fw1[3];                                                      // one chunk (Ch <= 32): the lane's weights stay in registers for the whole kernel
+#pragma unroll
+    for (int ks = 0; ks < 3; ks++) fw1[ks] = *(const half8_t*)(w1l + l31 * KP1 + ks * 16 + hi * 8);
+    unsigned wqv[6];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { const u32x2 w2 = *(const u32x2*)(wdt + (l31 * 2 + hi) * 12 + i * 4); wqv[2 * i] = w2[0]; wqv[2 * i + 1] = w2[1]; }
+    const float bdv = bdl[l31];
+
+#pragma unroll 1
+    for (int bt = blockIdx.x; bt < p.ntiles; bt += gridDim.x) {
+        const int n = (int)fastdiv((unsigned)bt, p.txy_mul, p.txy_sh);
+        const int r = bt - n * (p.tiles_x * p.tiles_y), by = (int)fastdiv((unsigned)r, p.tx_mul, p.tx_sh), bx = r - by * p.tiles_x;
+        const int hy0 = by * (BWY * TH) * S - 1, hx0 = bx * (BWX * TW) * S - 1;           // hidden pixel of the region's corner
+        const int iry0 = hy0 * st - p.st_p, irx0 = hx0 * st - p.st_p;                     // input pixel of the region's corner
+        // ---- stage the input region: wave w copies (plane, row) segments w, w + 8, ...; four segments in flight per lane and pass -------------------------------------
+        // (all of a lane's loads are issued before the first conversion: one memory round trip per block tile, not one per batch)
+        {
+            float g[NPS][NSG];
+#pragma unroll
+            for (int ps = 0; ps < NPS; ps++) {
+                const int x = lane + 64 * ps, gx = irx0 + x;
+                const bool colok = x < IC && (unsigned)gx < (unsigned)p.in_W;
+#pragma unroll
+                for (int i = 0; i < NSG; i++) {
+                    const int sg = wave + i * NW, c = sg >= 2 * IR ? 2 : sg >= IR ? 1 : 0, rr = sg - c * IR, gy = iry0 + rr;
+                    const bool ok = colok && sg < nseg && (unsigned)gy < (unsigned)p.in_H;
+                    const unsigned off = ok ? ((((unsigned)n * 3u + (unsigned)c) * (unsigned)p.in_H + (unsigned)gy) * (unsigned)p.in_W + (unsigned)gx) * 4u : 0x80000000u;
+                    g[ps][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+                }
+            }
+#pragma unroll
+            for (int ps = 0; ps < NPS; ps++) {
+                const int x = lane + 64 * ps;
+#pragma unroll
+                for (int i = 0; i < NSG; i++) {
+                    const int sg = wave + i * NW, c = sg >= 2 * IR ? 2 : sg >= IR ? 1 : 0, rr = sg - c * IR;
+                    if (sg < nseg) *(half_t*)(reg + ((rr * pitch + x) * 4 + c) * 2) = (half_t)g[ps][i];   // (wave-uniform condition; columns beyond IC were loaded as zeros)
+                }
+            }
+        }
+        __syncthreads();
+        const int oy0 = by * (BWY * TH) + wy * TH, ox0 = bx * (BWX * TW) + wx * TW, iy0 = oy0 * S - 1, ix0 = ox0 * S - 1;
+        if (oy0 < p.Ho && ox0 < p.Wo) {
+            // ---- phase A: hidden[window pixel][channel] = act1(X W1^T), X fragments straight from the staged region ------------------------------------------------
+            floatx16 accA[MFA];
+            const bool border = iy0 < 0 || ix0 < 0 || iy0 + PH > p.H || ix0 + PW > p.W;   // wave-uniform: only tiles on the image's edge pay for the masking
+#pragma unroll
+            for (int mf = 0; mf < MFA; mf++) {
+                const int iy = iy0 + ppy[mf], ix = ix0 + ppx[mf];
+                const bool inimg = pon[mf] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                const unsigned onesv = inimg ? 0x3c003c00u : 0u;            // (1, 1): the bias columns of a pixel inside the hidden image
+#pragma unroll
+                for (int i = 0; i < 16; i++) accA[mf][i] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 3; ks++) {
+                    const u32x2* const sl = (const u32x2*)(reg + abase[mf][ks]);          // two 8-byte slots: one ds_read2_b64
+                    const u32x2 s0v = sl[0], s1v = sl[1];
+                    u32x4 d = {s0v[0], s0v[1], s1v[0], s1v[1]};
+                    if (hi) { d[2] = ks == 1 ? onesv : 0u; d[3] = 0u; }       // the fourth "kw" slot: the bias columns in kernel row 1, zeros elsewhere (what the LDS holds there is the next pixel)
+                    if (border && !inimg) d = u32x4{0u, 0u, 0u, 0u};          // a hidden pixel beyond the right / lower edge still sees input pixels: it must be exactly 0 (the depthwise padding)
+                    accA[mf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(half8_t, d), fw1[ks], accA[mf], 0, 0, 0);
+                }
+            }
+            unsigned hw[PH][WPR];
+#pragma unroll
+            for (int py = 0; py < PH; py++)
+#pragma unroll
+                for (int q = 0; q < WPR; q++) {
+                    const int q0 = py * WC + 2 * q, q1 = q0 + 1;
+                    const float a = accA[q0 >> 4][q0 & 15], b = (2 * q + 1 < WC) ? accA[q1 >> 4][q1 & 15] : 0.f;
+                    half2_t o;
+                    if constexpr (RELU) { o[0] = (half_t)a; o[1] = (half_t)b; o = __builtin_elementwise_max(o, half2_t{0, 0}); }
+                    else { o[0] = (half_t)relu_family(a, p.sl1); o[1] = (half_t)relu_family(b, p.sl1); }
+                    hw[py][q] = __builtin_bit_cast(unsigned, o);
+                }
+            // ---- phase B (mbconv5_kernel) ----------------------------------------------------------------------------------------------------------------------------
+            sm_static_for<0, TH * 2>([&](auto oc) {
+                constexpr int oy = decltype(oc)::value >> 1, op2 = decltype(oc)::value & 1;
+                float a2[2];
+                sm_static_for<0, 2>([&](auto ec) {
+                    constexpr int e = decltype(ec)::value, j0 = (2 * op2 + e) * S;
+                    float a = bdv;
+                    sm_static_for<0, 3>([&](auto kc) {
+                        constexpr int kh = decltype(kc)::value, row = oy * S + kh;
+                        if constexpr ((j0 & 1) == 0) {
+                            a = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, hw[row][j0 >> 1]), __builtin_bit_cast(half2_t, wqv[2 * kh]), a, false);
+                            mb_fma_mix<0, 1>(a, hw[row][(j0 >> 1) + 1], wqv[2 * kh + 1]);
+                        } else {
+                            a = __builtin_amdgcn_fdot2(__builtin_bit_cast(half2_t, hw[row][(j0 + 1) >> 1]), __builtin_bit_cast(half2_t, wqv[2 * kh + 1]), a, false);
+                            mb_fma_mix<1, 0>(a, hw[row][j0 >> 1], wqv[2 * kh]);
+                        }
+                    });
+                    a2[e] = a;
+                });
+                half2_t o;
+                if constexpr (RELU) { o[0] = (half_t)a2[0]; o[1] = (half_t)a2[1]; o = __builtin_elementwise_max(o, half2_t{0, 0}); }
+                else { o[0] = (half_t)relu_family(a2[0], p.sl2); o[1] = (half_t)relu_family(a2[1], p.sl2); }
+                *(half_t*)(dwo + woff[2 * op2] + oy * TW * HS) = o[0];
+                *(half_t*)(dwo + woff[2 * op2 + 1] + oy * TW * HS) = o[1];
+            });
+            asm volatile("" ::: "memory");
+            // ---- phase C + epilogue (mbconv5_kernel; one chunk: Ch <= 32) -----------------------------------------------------------------------------------------------
+            floatx16 acc2[NF];
+#pragma unroll
+            for (int a = 0; a < NF; a++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc2[a][i] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ks++) {
+                const half8_t fy = *(const half8_t*)(dwo + l31 * HS + (ks * 2 + hi) * 16);
+#pragma unroll
+                for (int a = 0; a < NF; a++)
+                    if (a < nfc) {
+                        const half8_t fw2 = *(const half8_t*)(w2l + (a * 32 + l31) * hs2 + (ks * 16 + hi * 8) * 2);
+                        acc2[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw2, fy, acc2[a], 0, 0, 0);
+                    }
+            }
+            const int oy = oy0 + l31 / TW, ox = ox0 + l31 % TW;
+            const bool pin = l31 < OPX && oy < p.Ho && ox < p.Wo;
+            const long opix = ((long)n * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+            for (int a = 0; a < NF; a++)
+                if (a < nfc) {
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        float o[8];
+#pragma unroll
+                        for (int r2 = 0; r2 < 4; r2++) {
+                            unsigned ua = __builtin_bit_cast(unsigned, acc2[a][4 * (2 * j) + r2] + b2l[a * 32 + 8 * (2 * j) + 4 * hi + r2]);
+                            unsigned ub = __builtin_bit_cast(unsigned, acc2[a][4 * (2 * j + 1) + r2] + b2l[a * 32 + 8 * (2 * j + 1) + 4 * hi + r2]);
+                            sm_permlane32_swap(ua, ub);
+                            o[r2] = __builtin_bit_cast(float, ua); o[4 + r2] = __builtin_bit_cast(float, ub);
+                        }
+                        const int co = a * 32 + 16 * j + 8 * hi;
+                        if (pin && co < p.Cout) {
+                            half8_t ov;
+                            if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
+#pragma unroll
+                                for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
+                            } else {
+#pragma unroll
+                                for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                            }
+                            *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
+                        }
+                    }
+                }
+        }
+        mb_lds_barrier();                                                 // every wave has read its fragments: the region may be overwritten
     }
 }
 
@@ -1377,8 +1606,13 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
                             for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rres[i][j][r2];
                         }
                         half8_t ov;
+                        if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
-                        for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
+                        } else {
+#pragma unroll
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                        }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }
                 }
@@ -1430,7 +1664,7 @@ static size_t mb_v5_lds_nw(const sm_mbconv_desc* d, int nw) {
 }
 static bool mb_v5_ok(const sm_mbconv_desc* d) {
     static const int off = getenv("SMELTER_MBCONV_NO_V5") ? 1 : 0;          // experiment switch, read once
-    return !off && d->expand && d->Cin <= 30 && d->Cout <= 64 && mb_v5_lds_nw(d, 16) <= 160 * 1024;
+    return !off && d->expand && d->Cin <= 46 && d->Cout <= 64 && mb_v5_lds_nw(d, 16) <= 160 * 1024;
 }
 static bool mb_v3_wg(const sm_mbconv_desc* d) { return d->expand && mb_v3_lds_nw(d, 8) > 160 * 1024; }
 // waves per block: 16 (one block per CU; its 128-register budget holds) when the LDS takes it, else 8, else 4
@@ -1564,9 +1798,11 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
         if (mb_v5_ok(d)) {                                           // hidden patch in registers: 16-wave blocks, one per CU
             const bool relu = p.sl1 == 0.f && p.sl2 == 0.f;
             void (*f5)(MbParams) = nullptr;
-#define MB5_PICK(S_) (d->Cout <= 32 ? (relu ? mbconv5_kernel<S_, 2, 16, false, 1, true> : mbconv5_kernel<S_, 2, 16, false, 1, false>) \
-                                    : (relu ? mbconv5_kernel<S_, 2, 16, false, 2, true> : mbconv5_kernel<S_, 2, 16, false, 2, false>))
+#define MB5_PICK2(S_, K_) (d->Cout <= 32 ? (relu ? mbconv5_kernel<S_, K_, 16, false, 1, true> : mbconv5_kernel<S_, K_, 16, false, 1, false>) \
+                                         : (relu ? mbconv5_kernel<S_, K_, 16, false, 2, true> : mbconv5_kernel<S_, K_, 16, false, 2, false>))
+#define MB5_PICK(S_) (d->Cin <= 30 ? MB5_PICK2(S_, 2) : MB5_PICK2(S_, 3))
             if (d->stride == 1) f5 = MB5_PICK(1); else f5 = MB5_PICK(2);
+#undef MB5_PICK2
 #undef MB5_PICK
             hipLaunchKernelGGL(f5, dim3((unsigned)std::min<long>((nt3 + 15) / 16, (long)SM_NUM_CU)), dim3(1024), mb_v5_lds_nw(d, 16), sm_s(stream), p);
             SM_LAUNCH_CHECK(); return SM_OK;
@@ -1643,6 +1879,32 @@ int sm_mbconv_stem_fwd(const sm_mbconv_desc* d, const float* x_nchw, int32_t C, 
     const int per_cu3 = (int)std::max<size_t>(1, std::min<size_t>(16 / nw, (size_t)(160 * 1024) / lds));
     const int grid3 = (int)std::min<long>((nt3 + nw - 1) / nw, (long)SM_NUM_CU * per_cu3);
     void (*fn)(MbParams) = nullptr;
+    static const int v5s = getenv("SMELTER_MBCONV_STEM_STAGED") ? atoi(getenv("SMELTER_MBCONV_STEM_STAGED")) : 1;   // experiment switch (0: the gathering kernels below), read once
+    if (v5s && d->Ch <= 32 && d->Cout <= 64) {
+        const int S = d->stride, TH = S == 1 ? 4 : 2, HR = (2 * TH - 1) * S + 3, HC = 31 * S + 3, IR = (HR - 1) * st_stride + 3, IC = (HC - 1) * st_stride + 3, pitch = 64 * (S == 1 ? 2 : 3) + 2;
+        const int ChP = p.ChP, CoP = (d->Cout + 31) & ~31;
+        const size_t lds5 = (size_t)ChP * 48 * 2 + (size_t)ChP * 24 * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)IR * pitch * 8 + (size_t)8 * 32 * 80;
+        p.tiles_x = sm_ceil_div(d->Wo, 32); p.tiles_y = sm_ceil_div(d->Ho, 2 * TH);
+        const long nbt = (long)d->N * p.tiles_x * p.tiles_y;
+        SM_REQUIRE(nbt < (1L << 31) && lds5 <= 80 * 1024 && 3 * IR <= 64 && IC <= 64 * (S == 1 ? 2 : 3), "sm_mbconv_stem_fwd: too many tiles");
+        p.ntiles = (int)nbt;
+        fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
+        const bool relu = p.sl1 == 0.f && p.sl2 == 0.f;
+        void (*f5)(MbParams) = nullptr;
+#define MB5S_PICK(S_) (d->Cout <= 32 ? (relu ? mbconv5s_kernel<S_, 1, true> : mbconv5s_kernel<S_, 1, false>) : (relu ? mbconv5s_kernel<S_, 2, true> : mbconv5s_kernel<S_, 2, false>))
+        if (S == 1) f5 = MB5S_PICK(1); else f5 = MB5S_PICK(2);
+#undef MB5S_PICK
+        hipLaunchKernelGGL(f5, dim3((unsigned)std::min<long>(nbt, 2L * SM_NUM_CU)), dim3(512), lds5, sm_s(stream), p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
+    static const int v5nw = getenv("SMELTER_MBCONV_STEM_V5") ? atoi(getenv("SMELTER_MBCONV_STEM_V5")) : 0;   // experiment switch: 8 | 16 = the register-window kernel with that many waves
+    if ((v5nw == 8 || v5nw == 12 || v5nw == 16) && d->Cout <= 32 && p.sl1 == 0.f && p.sl2 == 0.f) {
+        void (*f5)(MbParams) = d->stride == 1 ? (v5nw == 16 ? mbconv5_kernel<1, 2, 16, true, 1, true> : v5nw == 12 ? mbconv5_kernel<1, 2, 12, true, 1, true> : mbconv5_kernel<1, 2, 8, true, 1, true>)
+                                              : (v5nw == 16 ? mbconv5_kernel<2, 2, 16, true, 1, true> : v5nw == 12 ? mbconv5_kernel<2, 2, 12, true, 1, true> : mbconv5_kernel<2, 2, 8, true, 1, true>);
+        sm_mbconv_desc d5 = dl; d5.expand = 1; d5.Cin = 27;
+        hipLaunchKernelGGL(f5, dim3((unsigned)std::min<long>((nt3 + v5nw - 1) / v5nw, (long)SM_NUM_CU)), dim3(v5nw * 64), mb_v5_lds_nw(&d5, v5nw), sm_s(stream), p);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
     if (d->stride == 2) fn = nw == 16 ? mbconv3_kernel<2, 2, 16, false, 2, false, 2, true> : nw == 8 ? mbconv3_kernel<2, 2, 8, false, 2, false, 2, true> : mbconv3_kernel<2, 2, 4, false, 2, false, 2, true>;
     else fn = nw == 16 ? mbconv3_kernel<1, 2, 16, false, 4, false, 2, true> : nw == 8 ? mbconv3_kernel<1, 2, 8, true, 4, false, 2, true> : mbconv3_kernel<1, 2, 4, true, 4, false, 2, true>;
     hipLaunchKernelGGL(fn, dim3(grid3), dim3(nw * 64), lds, sm_s(stream), p);
