@@ -36,8 +36,8 @@ struct MbParams {
     int tiles_x, tiles_y, ntiles;
     int tile_o;                      // v4: side of the square output tile (14 at stride 1, 7 at stride 2; <= the image)
     unsigned tx_mul, tx_sh, txy_mul, txy_sh, pw_mul, pw_sh;
-    // v3 IMC (the block behind an image stem): the "expand" layer is the stem's 3x3 convolution of the fp32 NCHW image `xf` (3 planes of in_H x in_W,
-    // stride st_s, padding st_p): K = 27 taps (kh, kw, c) + the two bias columns, gathered per patch pixel; H x W above = the stem's OUTPUT image
+    // mbconv5s_kernel (the block behind an image stem): the "expand" layer is the stem's 3x3 convolution of the fp32 NCHW image `xf` (3 planes of in_H x in_W,
+    // stride st_s, padding st_p): K = 27 taps (kh, kw, c) + the two bias columns; H x W above = the stem's OUTPUT image
     const float* xf; int in_H, in_W, st_s, st_p;
 };
 
@@ -462,15 +462,11 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
 // WG: W1 and W2 do not fit the LDS (Ch = 384 / 576): their MFMA fragments are read from global memory (L2-resident) — W1's for chunk c+1
 // right behind the MFMAs that consumed chunk c's, W2's at the top of the chunk that multiplies them two phases later; the bias columns of W1
 // are made in registers from b1.  NF = cout blocks of 32 (accumulator sets).
-// IMC: the expand layer is an image stem (3x3, 3 input planes, fp32 NCHW): the patch's B fragments are an im2col gather — lane = patch pixel of
-// the stem's output, its 16 k values per k step = taps (kh, kw, c) = k / 3 / 3, k / 3 % 3, k % 3 read from the planes (zero outside the image:
-// the stem's padding), k = 27, 28 the bias columns.  The stem's output (32 channels at full resolution: written once and read once) never exists.
 #ifndef MB3_BD
 #define MB3_BD 1
 #endif
-template <int S, int KS1, int NW, bool WREG, int TH = (S == 1 ? 4 : 2), bool WG = false, int NF = 2, bool IMC = false>
+template <int S, int KS1, int NW, bool WREG, int TH = (S == 1 ? 4 : 2), bool WG = false, int NF = 2>
 __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
-    static_assert(!IMC || (KS1 == 2 && !WG), "image-stem form: K = 27 + 2 -> two k steps");
     constexpr int TW = 8, OPX = TH * TW, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, HP = PH * PW, MFA = (HP + 31) / 32, HS = 80, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
     constexpr int KP1 = KS1 * 16;
@@ -577,49 +573,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
         const half_t* const xim = p.x + (long)n * p.H * p.W * p.x_ld;
         // ---- X fragments of the whole patch: [row block][k step], 16 bytes per lane, kept for all chunks ------------------------------
         half8_t fx[MFA][KS1 ? KS1 : 1];
-        if constexpr (IMC) {
-            constexpr unsigned DEAD = 0x80000000u;
-            const unsigned plane = (unsigned)p.in_H * (unsigned)p.in_W;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xf, 0, (int)((unsigned)p.N * 3u * plane * 4u), 0x00020000);
 #pragma unroll
-            for (int mf = 0; mf < MFA; mf++) {
-                const int pp = mf * 32 + l31, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px;
-                const bool inimg = pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const int r0 = iy * p.st_s - p.st_p, c0 = ix * p.st_s - p.st_p;
-                // byte offset of tap (0, 0) of plane 0 (wraps when r0 / c0 are negative: only in-bounds taps use it), and one bit per tap that is inside the image
-                const unsigned base = (((unsigned)n * 3u) * plane + (unsigned)r0 * (unsigned)p.in_W + (unsigned)c0) * 4u;
-                unsigned okbits = 0;
-#pragma unroll
-                for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-                    for (int kw = 0; kw < 3; kw++)
-                        okbits |= (unsigned)(inimg && (unsigned)(r0 + kh) < (unsigned)p.in_H && (unsigned)(c0 + kw) < (unsigned)p.in_W) << (kh * 3 + kw);
-#pragma unroll
-                for (int ks = 0; ks < KS1; ks++) {
-                    float g[8];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        // k = 16 ks + 8 hi + e = (kh*3 + kw)*3 + c: both candidates are compile-time constants (their plane / row / column offsets wave-uniform
-                        // scalars), the lane's half-wave picks one; k >= 27 (bias columns, padding) reads nothing
-                        const int k0 = ks * 16 + e, k1 = k0 + 8;
-                        const unsigned rel0 = (unsigned)(k0 % 3) * plane + (unsigned)(k0 / 9) * (unsigned)p.in_W + (unsigned)(k0 / 3 % 3);
-                        const unsigned rel1 = (unsigned)(k1 % 3) * plane + (unsigned)(k1 / 9 % 3) * (unsigned)p.in_W + (unsigned)(k1 / 3 % 3);
-                        const unsigned bit = hi ? (k1 < 27 ? 1u << (k1 / 3) : 0u) : (k0 < 27 ? 1u << (k0 / 3) : 0u);
-                        const unsigned off = (okbits & bit) ? base + (hi ? rel1 : rel0) * 4u : DEAD;
-                        g[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
-                    }
-                    half8_t v;
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int k = ks * 16 + hi * 8 + e;
-                        v[e] = (k == 27 || k == 28) ? (half_t)(inimg ? 1.f : 0.f) : (half_t)g[e];
-                    }
-                    fx[mf][ks] = v;
-                }
-            }
-        }
-#pragma unroll
-        for (int mf = 0; mf < ((KS1 && !IMC) ? MFA : 0); mf++) {
+        for (int mf = 0; mf < (KS1 ? MFA : 0); mf++) {
             const int pp = mf * 32 + l31, py = pp / PW, px = pp - py * PW, iy = iy0 + py, ix = ix0 + px;
             const bool inimg = pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
             const half_t* src = xim + ((long)iy * p.W + ix) * p.x_ld;
@@ -811,9 +766,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 template <int X0, int X1> __device__ __forceinline__ void mb_fma_mix(float& a, unsigned x, unsigned w) {    // a += half X0 of x * half X1 of w, one v_fma_mix_f32
     a = __builtin_fmaf((float)__builtin_bit_cast(half2_t, x)[X0], (float)__builtin_bit_cast(half2_t, w)[X1], a);
 }
-template <int S, int KS1, int NW, bool IMC = false, int NF = 1, bool RELU = true>   // RELU: act1 and act2 are ReLU (else any member of the leaky family, slopes p.sl1 / p.sl2)
+template <int S, int KS1, int NW, int NF = 1, bool RELU = true>   // RELU: act1 and act2 are ReLU (else any member of the leaky family, slopes p.sl1 / p.sl2)
 __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
-    static_assert(!IMC || KS1 == 2, "image-stem form: K = 27 + 2 -> two k steps");
     constexpr int TW = 8, TH = S == 1 ? 4 : 2, OPX = TH * TW, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, WC = 3 * S + 3, WPR = (WC + 1) / 2;
     constexpr int PXH = PH * WC, MFA = (PXH + 15) / 16, HS = 80, NT = NW * 64, KP1 = KS1 * 16;
     extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
@@ -892,58 +846,20 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
         const half_t* const xim = p.x + (long)n * p.H * p.W * p.x_ld;
         // ---- X fragments of the window pixels: [fragment][k step], 16 bytes per lane, kept for all chunks ----------------------------------------------------------
         half8_t fx[MFA][KS1];
-        if constexpr (IMC) {
-            constexpr unsigned DEAD = 0x80000000u;
-            const unsigned plane = (unsigned)p.in_H * (unsigned)p.in_W;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.xf, 0, (int)((unsigned)p.N * 3u * plane * 4u), 0x00020000);
 #pragma unroll
-            for (int mf = 0; mf < MFA; mf++) {
-                const int iy = iy0 + ppy[mf], ix = ix0 + ppx[mf];
-                const bool inimg = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const int r0 = iy * p.st_s - p.st_p, c0 = ix * p.st_s - p.st_p;
-                const unsigned base = (((unsigned)n * 3u) * plane + (unsigned)r0 * (unsigned)p.in_W + (unsigned)c0) * 4u;
-                unsigned okbits = 0;
+        for (int mf = 0; mf < MFA; mf++) {
+            const int iy = iy0 + ppy[mf], ix = ix0 + ppx[mf];
+            const bool inimg = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const half_t* src = xim + ((long)iy * p.W + ix) * p.x_ld;
 #pragma unroll
-                for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-                    for (int kw = 0; kw < 3; kw++)
-                        okbits |= (unsigned)(inimg && (unsigned)(r0 + kh) < (unsigned)p.in_H && (unsigned)(c0 + kw) < (unsigned)p.in_W) << (kh * 3 + kw);
-#pragma unroll
-                for (int ks = 0; ks < KS1; ks++) {
-                    float g[8];
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int k0 = ks * 16 + e, k1 = k0 + 8;
-                        const unsigned rel0 = (unsigned)(k0 % 3) * plane + (unsigned)(k0 / 9) * (unsigned)p.in_W + (unsigned)(k0 / 3 % 3);
-                        const unsigned rel1 = (unsigned)(k1 % 3) * plane + (unsigned)(k1 / 9 % 3) * (unsigned)p.in_W + (unsigned)(k1 / 3 % 3);
-                        const unsigned bit = hi ? (k1 < 27 ? 1u << (k1 / 3) : 0u) : (k0 < 27 ? 1u << (k0 / 3) : 0u);
-                        const unsigned off = (okbits & bit) ? base + (hi ? rel1 : rel0) * 4u : DEAD;
-                        g[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
-                    }
-                    half8_t v;
-#pragma unroll
-                    for (int e = 0; e < 8; e++) {
-                        const int k = ks * 16 + hi * 8 + e;
-                        v[e] = (k == 27 || k == 28) ? (half_t)(inimg ? 1.f : 0.f) : (half_t)g[e];
-                    }
-                    fx[mf][ks] = v;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int mf = 0; mf < MFA; mf++) {
-                const int iy = iy0 + ppy[mf], ix = ix0 + ppx[mf];
-                const bool inimg = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-                const half_t* src = xim + ((long)iy * p.W + ix) * p.x_ld;
-#pragma unroll
-                for (int ks = 0; ks < KS1; ks++) {
-                    const int k = ks * 16 + hi * 8;
-                    half8_t v = hz;
-                    if (inimg) { if (k < p.Cin) v = *(const half8_t*)(src + k); else if (k == p.Cin) v = ones; }
-                    fx[mf][ks] = v;
-                }
+            for (int ks = 0; ks < KS1; ks++) {
+                const int k = ks * 16 + hi * 8;
+                half8_t v = hz;
+                if (inimg) { if (k < p.Cin) v = *(const half8_t*)(src + k); else if (k == p.Cin) v = ones; }
+                fx[mf][ks] = v;
             }
         }
+    
         floatx16 acc2[NF];
 #pragma unroll
         for (int a = 0; a < NF; a++)
@@ -1798,8 +1714,8 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
         if (mb_v5_ok(d)) {                                           // hidden patch in registers: 16-wave blocks, one per CU
             const bool relu = p.sl1 == 0.f && p.sl2 == 0.f;
             void (*f5)(MbParams) = nullptr;
-#define MB5_PICK2(S_, K_) (d->Cout <= 32 ? (relu ? mbconv5_kernel<S_, K_, 16, false, 1, true> : mbconv5_kernel<S_, K_, 16, false, 1, false>) \
-                                         : (relu ? mbconv5_kernel<S_, K_, 16, false, 2, true> : mbconv5_kernel<S_, K_, 16, false, 2, false>))
+#define MB5_PICK2(S_, K_) (d->Cout <= 32 ? (relu ? mbconv5_kernel<S_, K_, 16, 1, true> : mbconv5_kernel<S_, K_, 16, 1, false>) \
+                                         : (relu ? mbconv5_kernel<S_, K_, 16, 2, true> : mbconv5_kernel<S_, K_, 16, 2, false>))
 #define MB5_PICK(S_) (d->Cin <= 30 ? MB5_PICK2(S_, 2) : MB5_PICK2(S_, 3))
             if (d->stride == 1) f5 = MB5_PICK(1); else f5 = MB5_PICK(2);
 #undef MB5_PICK2
@@ -1841,20 +1757,29 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
     SM_LAUNCH_CHECK(); return SM_OK;
 }
 
-// The block behind an image stem, stem included: 3x3 convolution of the fp32 NCHW image (3 planes, stride st_stride, padding st_pad, ReLU-family
-// activation d->act1) -> depthwise 3x3 (d->stride) -> 1x1 project, ONE launch (mbconv3_kernel IMC).  d->H x d->W = the stem's OUTPUT image,
-// d->Ch = the stem's output channels (<= 32: one hidden chunk), w1 = the stem's weights [Ch][3][3][3] (OHWI) fp16, d->Cin is ignored.
+// The block behind an image stem, stem included: x_nchw [N, 3, in_H, in_W] fp32 -> 3x3 convolution (w1 = the stem's OHWI weights [Ch][3][3][3] fp16; stride st_stride, padding
+// st_pad, ReLU-family activation d->act1) -> depthwise 3x3 (d->stride) -> 1x1 project, ONE launch (mbconv5s_kernel: the input region of a block tile staged in the LDS).
+// d->H x d->W = the stem's OUTPUT image, d->Ch = its channels (<= 32: one hidden chunk), d->Cin is ignored.
+static void mb_stem_geometry(int S, int st, int* IR, int* IC, int* pitch) {                 // input region of a block tile of 2 x 4 wave tiles (mbconv5s_kernel)
+    const int TH = S == 1 ? 4 : 2, HR = (2 * TH - 1) * S + 3, HC = 31 * S + 3;
+    *IR = (HR - 1) * st + 3; *IC = (HC - 1) * st + 3; *pitch = 64 * (S == 1 ? 2 : 3) + 2;
+}
+static size_t mb_stem_lds(const sm_mbconv_desc* d, int st) {
+    int IR, IC, pitch; mb_stem_geometry(d->stride, st, &IR, &IC, &pitch);
+    const int ChP = (d->Ch + 31) & ~31, CoP = (d->Cout + 31) & ~31;
+    return (size_t)ChP * 48 * 2 + (size_t)ChP * 24 * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)IR * pitch * 8 + (size_t)8 * 32 * 80;
+}
 int sm_mbconv_stem_supported(const sm_mbconv_desc* d, int32_t C, int32_t in_H, int32_t in_W, int32_t st_stride, int32_t st_pad) {
     if (!d || C != 3 || d->Ch > 32 || (d->Ch & 7) || d->Cout > 64 || (d->Cout & 7) || d->residual || in_H <= 0 || in_W <= 0 || st_stride < 1 || st_stride > 2 || st_pad < 0 || st_pad > 1) return 0;
     if (d->H != (in_H + 2 * st_pad - 3) / st_stride + 1 || d->W != (in_W + 2 * st_pad - 3) / st_stride + 1) return 0;
     if ((long)d->N * 3 * in_H * in_W * 4 >= 0x7fff0000L) return 0;
-    sm_mbconv_desc dl = *d; dl.Cin = 24; dl.expand = 1;               // (K = 27 + 2 -> the LDS / wave budget of a Cin = 24 expand block)
-    return mb_common_ok(&dl) && !mb_v3_wg(&dl) && mb_v3_lds(&dl) <= 160 * 1024;
+    sm_mbconv_desc dl = *d; dl.Cin = 24; dl.expand = 1;               // (the remaining geometry checks are those of an expand block)
+    int IR, IC, pitch; mb_stem_geometry(d->stride, st_stride, &IR, &IC, &pitch);
+    return mb_common_ok(&dl) && 3 * IR <= 64 && IC <= pitch - 2 && mb_stem_lds(d, st_stride) <= 80 * 1024;     // (eight segments per wave, the passes cover the region's columns, two blocks per CU)
 }
 int sm_mbconv_stem_fwd(const sm_mbconv_desc* d, const float* x_nchw, int32_t C, int32_t in_H, int32_t in_W, int32_t st_stride, int32_t st_pad, const void* w1, const float* b1,
                        const void* wd, const float* bd, const void* w2, const float* b2, void* y, sm_stream_t stream) {
     SM_REQUIRE(sm_mbconv_stem_supported(d, C, in_H, in_W, st_stride, st_pad) && x_nchw && w1 && wd && w2 && y, "sm_mbconv_stem_fwd: unsupported geometry");
-    sm_mbconv_desc dl = *d; dl.Cin = 24; dl.expand = 1;
     MbParams p{};
     p.xf = x_nchw; p.in_H = in_H; p.in_W = in_W; p.st_s = st_stride; p.st_p = st_pad;
     p.x = nullptr; p.y = (half_t*)y; p.w1 = (const half_t*)w1; p.wd = (const half_t*)wd; p.w2 = (const half_t*)w2; p.b1 = b1; p.bd = bd; p.b2 = b2;
@@ -1866,48 +1791,18 @@ int sm_mbconv_stem_fwd(const sm_mbconv_desc* d, const float* x_nchw, int32_t C, 
     p.sl2 = d->act2 == SM_ACT_NONE ? 1.f : d->act2 == SM_ACT_RELU ? 0.f : d->slope2;
     p.sl3 = d->act3 == SM_ACT_NONE ? 1.f : d->act3 == SM_ACT_RELU ? 0.f : d->slope3;
     p.ChP = (d->Ch + 31) & ~31; p.hstride = p.ChP * 2 + 16;
-    const int th3 = d->stride == 1 ? 4 : 2;
-    const long nt3 = (long)d->N * sm_ceil_div(d->Ho, th3) * sm_ceil_div(d->Wo, 8);
-    SM_REQUIRE(nt3 < (1L << 31), "sm_mbconv_stem_fwd: too many tiles");
-    p.tiles_x = sm_ceil_div(d->Wo, 8); p.tiles_y = sm_ceil_div(d->Ho, th3); p.ntiles = (int)nt3;
+    const int S = d->stride, TH = S == 1 ? 4 : 2;
+    p.tiles_x = sm_ceil_div(d->Wo, 32); p.tiles_y = sm_ceil_div(d->Ho, 2 * TH);                // block tiles of (2 TH) x 32 output pixels
+    const long nbt = (long)d->N * p.tiles_x * p.tiles_y;
+    SM_REQUIRE(nbt < (1L << 31), "sm_mbconv_stem_fwd: too many tiles");
+    p.ntiles = (int)nbt;
     fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
-    fastdiv_make((unsigned)(7 * d->stride + 3), &p.pw_mul, &p.pw_sh);
-    // (8-wave blocks at most: the gather's address arithmetic does not fit the 16-wave blocks' 128-register budget — 436 us spilling against 282)
-    static const int force16 = getenv("SMELTER_MBCONV_STEM_WAVES") ? atoi(getenv("SMELTER_MBCONV_STEM_WAVES")) : 0;   // experiment switch, read once
-    const int nw = (force16 == 16 && mb_v3_lds_nw(&dl, 16) <= 160 * 1024) ? 16 : std::min(mb_v3_waves(&dl), 8);
-    const size_t lds = mb_v3_lds_nw(&dl, nw);
-    const int per_cu3 = (int)std::max<size_t>(1, std::min<size_t>(16 / nw, (size_t)(160 * 1024) / lds));
-    const int grid3 = (int)std::min<long>((nt3 + nw - 1) / nw, (long)SM_NUM_CU * per_cu3);
+    const bool relu = p.sl1 == 0.f && p.sl2 == 0.f;
     void (*fn)(MbParams) = nullptr;
-    static const int v5s = getenv("SMELTER_MBCONV_STEM_STAGED") ? atoi(getenv("SMELTER_MBCONV_STEM_STAGED")) : 1;   // experiment switch (0: the gathering kernels below), read once
-    if (v5s && d->Ch <= 32 && d->Cout <= 64) {
-        const int S = d->stride, TH = S == 1 ? 4 : 2, HR = (2 * TH - 1) * S + 3, HC = 31 * S + 3, IR = (HR - 1) * st_stride + 3, IC = (HC - 1) * st_stride + 3, pitch = 64 * (S == 1 ? 2 : 3) + 2;
-        const int ChP = p.ChP, CoP = (d->Cout + 31) & ~31;
-        const size_t lds5 = (size_t)ChP * 48 * 2 + (size_t)ChP * 24 * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)IR * pitch * 8 + (size_t)8 * 32 * 80;
-        p.tiles_x = sm_ceil_div(d->Wo, 32); p.tiles_y = sm_ceil_div(d->Ho, 2 * TH);
-        const long nbt = (long)d->N * p.tiles_x * p.tiles_y;
-        SM_REQUIRE(nbt < (1L << 31) && lds5 <= 80 * 1024 && 3 * IR <= 64 && IC <= 64 * (S == 1 ? 2 : 3), "sm_mbconv_stem_fwd: too many tiles");
-        p.ntiles = (int)nbt;
-        fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
-        const bool relu = p.sl1 == 0.f && p.sl2 == 0.f;
-        void (*f5)(MbParams) = nullptr;
 #define MB5S_PICK(S_) (d->Cout <= 32 ? (relu ? mbconv5s_kernel<S_, 1, true> : mbconv5s_kernel<S_, 1, false>) : (relu ? mbconv5s_kernel<S_, 2, true> : mbconv5s_kernel<S_, 2, false>))
-        if (S == 1) f5 = MB5S_PICK(1); else f5 = MB5S_PICK(2);
+    if (S == 1) fn = MB5S_PICK(1); else fn = MB5S_PICK(2);
 #undef MB5S_PICK
-        hipLaunchKernelGGL(f5, dim3((unsigned)std::min<long>(nbt, 2L * SM_NUM_CU)), dim3(512), lds5, sm_s(stream), p);
-        SM_LAUNCH_CHECK(); return SM_OK;
-    }
-    static const int v5nw = getenv("SMELTER_MBCONV_STEM_V5") ? atoi(getenv("SMELTER_MBCONV_STEM_V5")) : 0;   // experiment switch: 8 | 16 = the register-window kernel with that many waves
-    if ((v5nw == 8 || v5nw == 12 || v5nw == 16) && d->Cout <= 32 && p.sl1 == 0.f && p.sl2 == 0.f) {
-        void (*f5)(MbParams) = d->stride == 1 ? (v5nw == 16 ? mbconv5_kernel<1, 2, 16, true, 1, true> : v5nw == 12 ? mbconv5_kernel<1, 2, 12, true, 1, true> : mbconv5_kernel<1, 2, 8, true, 1, true>)
-                                              : (v5nw == 16 ? mbconv5_kernel<2, 2, 16, true, 1, true> : v5nw == 12 ? mbconv5_kernel<2, 2, 12, true, 1, true> : mbconv5_kernel<2, 2, 8, true, 1, true>);
-        sm_mbconv_desc d5 = dl; d5.expand = 1; d5.Cin = 27;
-        hipLaunchKernelGGL(f5, dim3((unsigned)std::min<long>((nt3 + v5nw - 1) / v5nw, (long)SM_NUM_CU)), dim3(v5nw * 64), mb_v5_lds_nw(&d5, v5nw), sm_s(stream), p);
-        SM_LAUNCH_CHECK(); return SM_OK;
-    }
-    if (d->stride == 2) fn = nw == 16 ? mbconv3_kernel<2, 2, 16, false, 2, false, 2, true> : nw == 8 ? mbconv3_kernel<2, 2, 8, false, 2, false, 2, true> : mbconv3_kernel<2, 2, 4, false, 2, false, 2, true>;
-    else fn = nw == 16 ? mbconv3_kernel<1, 2, 16, false, 4, false, 2, true> : nw == 8 ? mbconv3_kernel<1, 2, 8, true, 4, false, 2, true> : mbconv3_kernel<1, 2, 4, true, 4, false, 2, true>;
-    hipLaunchKernelGGL(fn, dim3(grid3), dim3(nw * 64), lds, sm_s(stream), p);
+    hipLaunchKernelGGL(fn, dim3((unsigned)std::min<long>(nbt, 2L * SM_NUM_CU)), dim3(512), mb_stem_lds(d, st_stride), sm_s(stream), p);
     SM_LAUNCH_CHECK(); return SM_OK;
 }
 

@@ -708,6 +708,10 @@ def test_conv3x3_reads_through_fused_nearest_upsampling(case, cfg):
     (2, (7, 7), 160, 960, 320, 1, False, True),    # ten cout fragments
     (2, (6, 9), 96, 200, 72, 1, False, True),      # ragged everything: 54 pixels, Ch not a multiple of the chunk, Cout not of 32
     (1, (13, 15), 48, 136, 48, 1, True, True),     # 195 pixels (6.1 fragments), Cin = 48 on the four-k-step instantiation
+    (2, (21, 43), 24, 72, 48, 1, False, True),     # register-window kernel (mbconv5): two cout blocks, ragged tiles, Ch not a multiple of 32
+    (1, (37, 19), 16, 40, 56, 2, False, True),     # ... at stride 2 on odd sizes
+    (2, (40, 36), 40, 80, 40, 1, True, True),      # ... with three k steps (Cin = 40) + residual
+    (1, (33, 70), 32, 64, 24, 2, False, True),     # ... three k steps at stride 2, image larger than four 14 x 14 tiles
 ])
 @pytest.mark.parametrize("kernel", [None, 1, 2, 3, 4])
 def test_mbconv_fused_block_equals_the_three_layers(n, hw, cin, ch, cout, stride, res, expand, kernel, monkeypatch):
@@ -744,6 +748,28 @@ def test_mbconv_fused_block_equals_the_three_layers(n, hw, cin, ch, cout, stride
     # fp16 ulp of the LARGEST magnitude in play -> per-element bound of 2 ulp + one ulp of max|ref|
     assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
     assert np.mean(got != ref16) < 0.2                                  # the vast majority of the elements is bit-identical
+
+
+@pytest.mark.parametrize("hw,cin,ch,cout,stride,acts", [
+    ((30, 26), 24, 96, 24, 1, (ops.ACT_NONE, ops.ACT_NONE, ops.ACT_NONE)),     # purely linear block
+    ((30, 26), 24, 96, 40, 2, (ops.ACT_RELU, ops.ACT_NONE, ops.ACT_RELU)),     # mixed: the generic (slope) instantiation, ReLU behind the projection
+    ((22, 34), 40, 64, 16, 1, (ops.ACT_NONE, ops.ACT_RELU, ops.ACT_NONE)),
+])
+def test_mbconv_register_window_kernel_other_activations(hw, cin, ch, cout, stride, acts):
+    """mbconv5_kernel's RELU = false instantiations (act1 / act2 by slope) and act3 != none: same oracle as above with the activations as configured"""
+    rng = np.random.default_rng(cin + ch + cout)
+    act = lambda a, v: np.maximum(v, 0) if a == ops.ACT_RELU else v
+    x = h(rng.standard_normal((2, cin, hw[0], hw[1])))
+    w1 = h(rng.standard_normal((ch, 1, 1, cin)) * np.sqrt(2.0 / cin)); b1 = rng.standard_normal(ch).astype(np.float32) * 0.1
+    wd = h(rng.standard_normal((ch, 3, 3, 1)) * np.sqrt(2.0 / 9)); bd = rng.standard_normal(ch).astype(np.float32) * 0.1
+    w2 = h(rng.standard_normal((cout, 1, 1, ch)) * np.sqrt(1.0 / ch)); b2 = rng.standard_normal(cout).astype(np.float32) * 0.1
+    hid = h(act(acts[0], O.conv2d(x, w1, b1)))
+    hid2 = h(act(acts[1], O.conv2d(hid, wd, bd, stride=(stride, stride), pads=(1, 1, 1, 1), groups=ch)))
+    ref16 = h(act(acts[2], O.conv2d(hid2, w2, b2)))
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    got = to_host(ops.mbconv(to_dev(x), dev(w1).half(), dev(b1), dev(wd.reshape(ch, 3, 3)).half(), dev(bd), dev(w2).half(), dev(b2), stride=stride, residual=False, acts=acts))
+    assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
+    assert np.mean(got != ref16) < 0.2
 
 
 @pytest.mark.parametrize("n,hw,ch,cout,st_stride,stride", [

@@ -17,8 +17,11 @@ def timed(fn, reps=6):
         a.record(); fn(); e.record(); torch.cuda.synchronize()
         if i: ts.append(a.elapsed_time(e) * 1e3)
     ts.sort(); return ts[len(ts) // 2]
-t_stem = timed(lambda: ops.stem_conv(x, ws.cpu(), bs, stride=2, pads=(1, 1, 1, 1), act=1, cfg=98))
-h1 = ops.stem_conv(x, ws.cpu(), bs, stride=2, pads=(1, 1, 1, 1), act=1, cfg=98)
+L = ops.lib()
+# (the separate stem: the first loader-wave configuration for 32 output channels, by its label — indices move when configurations are added)
+lw = [c for c in range(L.sm_conv2d_num_configs()) if L.sm_conv2d_config_loader_waves(c) > 0 and "->32" in ops.config_name(c)][0]
+t_stem = timed(lambda: ops.stem_conv(x, ws.cpu(), bs, stride=2, pads=(1, 1, 1, 1), act=1, cfg=lw))
+h1 = ops.stem_conv(x, ws.cpu(), bs, stride=2, pads=(1, 1, 1, 1), act=1, cfg=lw)
 t_blk = timed(lambda: ops.mbconv(h1, None, None, wd, bd, w2, b2, stride=1, residual=False))
 t_fused = timed(lambda: ops.mbconv_stem(x, ws.half(), bs, wd, bd, w2, b2))
-print("stem (loader waves) %.1f us + block %.1f us = %.1f us ; fused %.1f us" % (t_stem, t_blk, t_stem + t_blk, t_fused))
+print("stem (%s) %.1f us + block %.1f us = %.1f us ; fused %.1f us" % (ops.config_name(lw), t_stem, t_blk, t_stem + t_blk, t_fused))
