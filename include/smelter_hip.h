@@ -194,6 +194,14 @@ int sm_mbconv_stem_fwd(const sm_mbconv_desc* d, const float* x_nchw, int32_t C, 
                        const void* w1, const float* b1, const void* wd, const float* bd, const void* w2, const float* b2, void* y,
                        sm_stream_t stream);
 
+/* 3x3 IMAGE STEM: the first MPSCNNConvolutionNode (Converters.swift:253) of a graph whose input is an image with C <= 3 planes, straight from the fp32
+ * NCHW batch — no converted copy of the image: y [N, Ho, Wo, Cout] fp16 (pixel stride y_ld halfs, % 8 == 0, 16-byte aligned) =
+ * act(conv3x3(x_nchw [N, C, in_H, in_W], w [Cout][3][3][C] fp16 (OHWI), stride 1 | 2, padding `pad` (0 | 1) on all four sides) + bias), Cout <= 64 (% 8 == 0),
+ * act in {SM_ACT_NONE, SM_ACT_RELU, leaky / PReLU with one `slope`}.  The image is rounded to fp16 first (as the converted copy was), fp32 accumulation. */
+int sm_stem3x3_f32_supported(int32_t N, int32_t C, int32_t in_H, int32_t in_W, int32_t Cout, int32_t stride, int32_t pad);
+int sm_stem3x3_f32_fwd(const float* x_nchw, int32_t N, int32_t C, int32_t in_H, int32_t in_W, const void* w_ohwi, const float* bias, int32_t Cout,
+                       int32_t stride, int32_t pad, int32_t act, float slope, void* y, int32_t y_ld, sm_stream_t stream);
+
 /* MPSCNNConvolutionTransposeNode (Converters.swift:277) + ONNX_ConvolutionPadding(isTranspose) (:66-71, :97-103).
  * `w_ohwi_flipped` is what ConvDataSource hands MPS: out[oc][kH-1-kh][kW-1-kw][ic] = W[ic][oc][kh][kw]
  * (Array+Extensions.swift:71-76).  y[n,oy,ox,oc] = act(bias[oc] + sum x[n,iy,ix,ic] * W[ic,oc,kh,kw]) over
@@ -340,7 +348,7 @@ typedef struct smelter_config {
 } smelter_config;
 /* Executor behaviour is decided by THIS struct, read once at smelter_graph_create / _compile — no environment variable is consulted after that.
  * smelter_config_default() is where the bench / A/B tools' environment overrides enter (each read there, once): SMELTER_MBCONV=0, SMELTER_XHEAD=0,
- * SMELTER_XHEAD_PROJ=0, SMELTER_KCAT=0|copy, SMELTER_MBCONV_STEM=0, SMELTER_STEM_F32=0, SMELTER_STEM_POOL=0 clear / set the matching SM_FUSE_* bit;
+ * SMELTER_XHEAD_PROJ=0, SMELTER_KCAT=0|copy, SMELTER_MBCONV_STEM=0, SMELTER_STEM_F32=0, SMELTER_STEM_POOL=0, SMELTER_STEM3=0 clear / set the matching SM_FUSE_* bit;
  * SMELTER_AUTOTUNE=cold, SMELTER_AUTOTUNE_MAXCFG=n, SMELTER_MBCONV_DOMAIN="cin,hidden,cout" fill the fields above.  A host that fills the struct itself
  * (the Swift shim of INTEGRATION.md) is not affected by the environment at all. */
 enum { SM_FUSE_MBCONV = 1,        /* expand -> depthwise -> project in one launch (mbconv.hip) */
@@ -351,7 +359,8 @@ enum { SM_FUSE_MBCONV = 1,        /* expand -> depthwise -> project in one launc
        SM_FUSE_MBCONV_STEM = 32,  /* image stem inside the first inverted-residual block */
        SM_FUSE_STEM_F32 = 64,     /* input conversion inside the stem launch (loader waves) */
        SM_FUSE_STEM_POOL = 128,   /* stem + max-pool 3x3 / 2 in one launch (stem_pool.hpp) */
-       SM_FUSE_DEFAULT = 1 | 2 | 4 | 8 | 32 | 64 | 128 };
+       SM_FUSE_STEM3 = 256,       /* a 3x3 stem on <= 3 planes as the staged kernel of stem3.hip (needs SM_FUSE_STEM_F32: it reads the fp32 batch) */
+       SM_FUSE_DEFAULT = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 256 };
 enum { SM_TUNE_IN_SITU = 0, SM_TUNE_COLD = 1 };
 void smelter_config_default(smelter_config* c);
 

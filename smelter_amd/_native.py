@@ -88,6 +88,8 @@ SYMBOLS = {
     "sm_mbconv_fwd": (_i32, [C.POINTER(MbConvDesc)] + [_vp] * 9),
     "sm_mbconv_stem_supported": (_i32, [C.POINTER(MbConvDesc)] + [_i32] * 5),
     "sm_mbconv_stem_fwd": (_i32, [C.POINTER(MbConvDesc), _vp] + [_i32] * 5 + [_vp] * 8),
+    "sm_stem3x3_f32_supported": (_i32, [_i32] * 7),
+    "sm_stem3x3_f32_fwd": (_i32, [_vp] + [_i32] * 4 + [_vp, _vp] + [_i32] * 4 + [_f, _vp, _i32, _vp]),
     "sm_conv_transpose2d_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp]),
     "sm_conv2d_time": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp, C.POINTER(_f)]),
     "sm_batchnorm": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp]),

@@ -332,7 +332,9 @@ int Executor::plan(ONNXGraph& g, int batch) {
                             w[((size_t)co * P + kh / 2) * 64 + kw * 8 + (kh & 1) * 4 + c] = op.weight[(((size_t)co * op.kh + kh) * op.kw + kw) * C + c];
             stem_ = true; stem_pt_ = op.pt; stem_pl_ = op.pl;
             stem_h_ = (ov.h - 1) * op.sh + 2 * (P - 1) + 1; stem_w_ = (ov.w - 1) * op.sw + 8;
-            st.stem_s = op.sh; st.stem_p = (op.pt == op.pl && op.pt == op.pb && op.pt == op.pr && op.sh == op.sw && op.kh == 3 && op.kw == 3 && C == 3) ? op.pt : -1;   // (-1: not a form pass 3g takes)
+            const bool sym3 = op.pt == op.pl && op.pt == op.pb && op.pt == op.pr && op.sh == op.sw && op.kh == 3 && op.kw == 3;
+            st.stem_s = op.sh; st.stem_p = (sym3 && C == 3) ? op.pt : -1;   // (-1: not a form pass 3g takes)
+            st.stem3_p = (sym3 && C <= 3 && op.pt <= 1) ? op.pt : -1;      // (-1: not a form pass 3j takes)
             op.weight.swap(w); op.cin = 64; op.kh = P; op.kw = 1; op.dh = 2; op.dw = 1; op.pt = op.pl = op.pb = op.pr = 0;
             st.stem_w = std::move(w);                                  // the original [Cout][kH][kW][C] weights
             st.stem = true; input_ld_ = 8; place_[input_value_].ld = 8;
@@ -652,6 +654,15 @@ int Executor::plan(ONNXGraph& g, int batch) {
             break;
         }
     }
+    // ---- 3j. 3x3 image stem straight from the fp32 batch (stem3.hip): the layer is bound by its output write, which the staged kernel does at ~80 % of the loader-wave
+    // form's time (U-Net 512^2: 110 -> 68 us); taken whenever the stem is a 3x3 on <= 3 planes that neither pass 3g nor 3i fused away
+    if (stem_ && !stem_in_block_ && cfg_.fuse && !cfg_.keepIntermediates && cfg_.allows(SM_FUSE_STEM_F32) && cfg_.allows(SM_FUSE_STEM3))
+        for (Step& st : steps_) {
+            if (!st.stem || st.has_mb || st.pool3_out >= 0 || st.pool_out >= 0 || st.has_head || st.stem3_p < 0 || st.op.residual >= 0 || st.op.act > SM_ACT_PRELU || !vecOk(st.op.output)) continue;
+            const Value& iv = values_[input_value_];
+            if (!sm_stem3x3_f32_supported(batch, iv.c, iv.h, iv.w, st.op.cout, st.stem_s, st.stem3_p)) continue;
+            st.stem3 = true; stem_f32_ = true;
+        }
     if (stem_f32_) launches_ -= 1;
 
     // ---- 4. memory plan ------------------------------------------------------------------------------------
@@ -726,6 +737,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             st.w_off = off; off = alignUp(off + op.weight.size() * 2);
             st.has_bias = !op.bias.empty();
             if (st.has_bias) { st.b_off = off; off = alignUp(off + op.bias.size() * 4); }
+            if (st.stem3) { st.ws_off = off; off = alignUp(off + st.stem_w.size() * 2); }       // the original [Cout][3][3][C] weights (the row-pair packing stays at w_off: unused by this launch)
             if (st.has_mb && st.mb_stem) {
                 st.ws_off = off; off = alignUp(off + st.stem_w.size() * 2);
                 if (!st.stem_b.empty()) { st.bs_off = off; off = alignUp(off + st.stem_b.size() * 4); }
@@ -782,7 +794,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         char buf[256];
         if (isConvLike(op.kind))
             snprintf(buf, sizeof buf, "%s %s M=%d N=%d K=%d k=%dx%d s=%d g=%d%s%s%s", kindName(op.kind), op.name.c_str(), st.M, op.cout, op.kh * op.kw * (op.cin / op.groups),
-                     st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem ? " stem" : op.grid_h ? " convT-phase" : op.x_ups ? " +ups2x" : "");
+                     st.real_kh, st.real_kw, op.sh, op.groups, op.residual >= 0 ? " +res" : "", op.act ? " +act" : "", st.stem3 ? " stem (fp32 image, staged 3x3)" : st.stem ? " stem" : op.grid_h ? " convT-phase" : op.x_ups ? " +ups2x" : "");
         else snprintf(buf, sizeof buf, "%s %s pixels=%d C=%d%s", kindName(op.kind), op.name.c_str(), st.M, values_[op.output].c, op.act ? " +act" : "");
         st.desc = buf;
         if (st.pool3_out >= 0) { const Value& pv = values_[st.pool3_out]; st.desc += " >> MaxPool 3x3/2 (same launch)";
@@ -865,6 +877,7 @@ int Executor::packWeights(std::vector<uint8_t>* host) const {
                 sm_float_to_half(op.weight.data(), dst, op.weight.size());   // fp16 cast, RNE (ONNX2MPS.py:27 numpy astype(float16))
             }
             if (st.has_bias) memcpy(host->data() + st.b_off, op.bias.data(), op.bias.size() * 4);
+            if (st.stem3) sm_float_to_half(st.stem_w.data(), (uint16_t*)(host->data() + st.ws_off), st.stem_w.size());
             if (st.has_mb && st.mb_stem) {
                 sm_float_to_half(st.stem_w.data(), (uint16_t*)(host->data() + st.ws_off), st.stem_w.size());
                 if (!st.stem_b.empty()) memcpy(host->data() + st.bs_off, st.stem_b.data(), st.stem_b.size() * 4);
@@ -1000,6 +1013,9 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
         if (st.stem && stem_f32_) {
             if (!cur_in_) { sm_set_error("stem step launched before any input was bound"); return SM_ERR_INCONSISTENT_STATE; }
             const Value& iv = values_[input_value_];
+            if (st.stem3)
+                return sm_stem3x3_f32_fwd(cur_in_, batch_, iv.c, iv.h, iv.w, arena_ + st.ws_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, op.cout, st.stem_s, st.stem3_p,
+                                          op.act, op.slope, y, y_ld, ss);
             if (st.pool3_out >= 0) {
                 const Value& pv = values_[st.pool3_out];
                 return sm_conv2d_stem_f32_pool_fwd(&d, cur_in_, iv.c, iv.h, iv.w, stem_pt_, stem_pl_, arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr,
@@ -1256,7 +1272,7 @@ int Executor::autotune(hipStream_t s) {
     }
     for (size_t i = 0; i < steps_.size() && !rc; i++) {
         Step& st = steps_[i];
-        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8) || st.has_mb || st.pool3_out >= 0) continue;
+        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8) || st.has_mb || st.pool3_out >= 0 || st.stem3) continue;
         if (st.op.kind != OpKind::ConvTranspose) { const sm_conv_desc cd = convDesc(st); if (!sm_conv2d_uses_tile_config(&cd)) continue; }   // dedicated kernel, nothing to tune
         // one config: `reps` timed launches after an untimed first one (code fetch); returns false if the config does not apply
         auto timeCfg = [&](int c, int reps, std::vector<float>& samples) -> bool {

@@ -29,6 +29,7 @@ struct Step {                // one op after fusion, with everything resolved
     int real_cin = 0;        // before first-layer channel padding (FLOP accounting)
     int fc_h = 1, fc_w = 1;  // FullyConnected over a flattened HxW map: weight columns permuted NCHW->NHWC order
     bool stem = false;       // first-layer conv running on the row-pair image (executor.cpp "image stem")
+    bool stem3 = false; int stem3_p = -1;   // ... launched as sm_stem3x3_f32_fwd instead (pass 3j: 3x3, C <= 3, symmetric padding stem3_p in {0, 1}); weights = stem_w at ws_off
     int real_k = 0;          // kH*kW*Cin/groups of the model (FLOP / byte accounting, description)
     int real_kh = 0, real_kw = 0;
     // branch concurrency (executor.cpp "side branch"): a conv whose result is only read as the residual operand of a later

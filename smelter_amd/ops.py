@@ -416,6 +416,18 @@ def nhwc_f16_to_float_array(x):
     return out
 
 
+def stem3x3(x_nchw, w_ohwi, bias=None, stride=1, pad=1, act=ACT_NONE, slope=0.0):
+    """3x3 image stem straight from the fp32 NCHW batch (sm_stem3x3_f32_fwd): w_ohwi [Cout,3,3,C] fp16, C <= 3; returns NHWC fp16"""
+    assert x_nchw.is_cuda and x_nchw.dtype == torch.float32 and x_nchw.is_contiguous() and w_ohwi.dtype == torch.float16 and w_ohwi.is_contiguous()
+    n, c, ih, iw = x_nchw.shape
+    cout = w_ohwi.shape[0]
+    assert tuple(w_ohwi.shape[1:]) == (3, 3, c)
+    ho, wo = (ih + 2 * pad - 3) // stride + 1, (iw + 2 * pad - 3) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x_nchw.device)
+    check(lib().sm_stem3x3_f32_fwd(_ptr(x_nchw), n, c, ih, iw, _ptr(w_ohwi), _ptr(bias), cout, stride, pad, act, slope, _ptr(y), _ld(y), _stream()))
+    return y
+
+
 def mbconv_stem(x_nchw, w_stem_ohwi, b_stem, wd, bd, w2, b2, st_stride=2, st_pad=1, stride=1, acts=(ACT_RELU, ACT_RELU, ACT_NONE)):
     """image stem (3x3 on the fp32 NCHW batch) -> depthwise 3x3 -> 1x1 project in one launch (sm_mbconv_stem_fwd); w_stem_ohwi [Ch,3,3,3] fp16"""
     from ._native import MbConvDesc

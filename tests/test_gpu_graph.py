@@ -546,6 +546,8 @@ def test_resnet50_projection_shortcuts_are_concatenated_along_k(form, monkeypatc
     ("SMELTER_XHEAD_PROJ", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 1),        # pass 3e: the first block's shortcut as the head's second GEMM
     ("SMELTER_STEM_F32", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 2),          # pass 3f: no input-conversion launch (and no pool fusion, which needs it)
     ("SMELTER_STEM_F32", lambda: zoo.unet(hw=(64, 48)), (2, 3, 64, 48), 1),
+    ("SMELTER_STEM3", lambda: zoo.unet(hw=(64, 48)), (2, 3, 64, 48), 0),                 # pass 3j: the staged 3x3 stem instead of the loader-wave form (same launch count)
+    ("SMELTER_STEM3", lambda: zoo.unet(hw=(48, 80), levels=2), (1, 3, 48, 80), 0),
     ("SMELTER_STEM_POOL", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 1),         # pass 3i: the 3x3 / 2 max-pool inside the stem launch (bit-identical: max is exact)
     ("SMELTER_MBCONV_STEM", lambda: zoo.mobilenet_v2(hw=(96, 96)), (2, 3, 96, 96), 1),   # pass 3g: the stem inside the first block (the stem launch goes;
 ])                                                                                          # the conversion launch is gone either way: loader-wave stem)
@@ -557,9 +559,10 @@ def test_fusion_pass_switches_keep_the_function(env, make, shape, fewer_launches
     monkeypatch.setenv(env, "0")
     ex0, plain = run_hip(model, x)
     assert ex0.numLaunches == ex.numLaunches + fewer_launches
-    # (MobileNet-v2: the stem's fp32 summation order differs between the two forms and a flipped fp16 rounding travels through 52 layers — the
-    #  bound of the block-fusion test above)
-    assert nerr(got, plain) <= (2e-3 if env == "SMELTER_MBCONV_STEM" else 1e-3)
+    # (MobileNet-v2, and the U-Net whose 3x3 stem runs on stem3.hip when the switch is on: the stem's fp32 summation order differs between the two forms
+    #  and a flipped fp16 rounding travels through 52 / 23 layers — the bound of the block-fusion test above; the U-Net's max-norm floor is 2e-3)
+    loose = env == "SMELTER_MBCONV_STEM" or (env in ("SMELTER_STEM_F32", "SMELTER_STEM3") and "unet" in make.__code__.co_names)
+    assert nerr(got, plain) <= (2e-3 if loose else 1e-3)
     if env == "SMELTER_STEM_POOL":
         assert np.array_equal(got, plain)
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3

@@ -772,6 +772,26 @@ def test_mbconv_register_window_kernel_other_activations(hw, cin, ch, cout, stri
     assert np.mean(got != ref16) < 0.2
 
 
+@pytest.mark.parametrize("n,c,hw,cout,stride,pad,act,slope", [
+    (2, 1, (70, 45), 32, 1, 1, ops.ACT_RELU, 0.0),     # U-Net's first layer (one plane), ragged block tiles
+    (1, 1, (512, 512), 32, 1, 1, ops.ACT_RELU, 0.0),   # ... at its real size
+    (2, 3, (64, 64), 32, 2, 1, ops.ACT_RELU, 0.0),     # RGB, stride 2
+    (1, 3, (37, 83), 64, 1, 0, ops.ACT_NONE, 0.0),     # no padding, two cout blocks, no activation
+    (3, 2, (33, 31), 16, 2, 0, ops.ACT_PRELU, 0.2),    # two planes, stride 2 without padding, leaky, 16 outputs
+    (1, 3, (18, 130), 24, 2, 1, ops.ACT_RELU, 0.0),    # three 64-column staging passes
+])
+def test_image_stem_3x3_from_the_fp32_batch(n, c, hw, cout, stride, pad, act, slope):
+    """sm_stem3x3_f32_fwd against the oracle's convolution of the fp16-rounded image (what the converted copy held)"""
+    rng = np.random.default_rng(c * 100 + cout + stride)
+    x = rng.standard_normal((n, c, hw[0], hw[1])).astype(np.float32)
+    w = h(rng.standard_normal((cout, 3, 3, c)) * np.sqrt(2.0 / (9 * c))); b = rng.standard_normal(cout).astype(np.float32) * 0.3
+    ref = O.conv2d(h(x), w, b, stride=(stride, stride), pads=(pad, pad, pad, pad))
+    ref = np.maximum(ref, 0) if act == ops.ACT_RELU else np.where(ref < 0, ref * slope, ref) if act == ops.ACT_PRELU else ref
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    y = ops.stem3x3(dev(x), dev(w).half(), dev(b), stride=stride, pad=pad, act=act, slope=slope)
+    assert_close(to_host(y), ref, 9 * c)
+
+
 @pytest.mark.parametrize("n,hw,ch,cout,st_stride,stride", [
     (2, (64, 64), 32, 16, 2, 1),      # MobileNet-v2's first three layers: 3x3/2 stem 3 -> 32, depthwise 3x3, project 32 -> 16
     (1, (45, 51), 32, 16, 2, 1),      # odd image, ragged tiles
