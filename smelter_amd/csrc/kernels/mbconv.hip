@@ -781,24 +781,27 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* const dwo = wave_base + wave * (32 * HS);             // depthwise output chunk [32 pixels][HS] (stride 2: 16 pixels used)
+    const half8_t hz0 = {0, 0, 0, 0, 0, 0, 0, 0};
 
     constexpr int PB = 8;
-    for (int i0 = tid; i0 < ChP * KP1; i0 += NT * PB) {
-        half_t v[PB]; float bb[PB];
+    // W1 rows as 16-byte vectors (Cin % 8 == 0, rows 16-byte aligned: checked by the launcher), the two bias columns behind them: with 2-byte loads the prologue
+    // of a 384 x 64 layer was fourteen memory round trips (28 of the block's 65 us)
+    for (int i0 = tid; i0 < ChP * (KP1 / 8); i0 += NT * PB) {
+        half8_t v[PB]; float bb[PB];
 #pragma unroll
         for (int j = 0; j < PB; j++) {
-            const int i = i0 + j * NT, n = i / KP1, k = i - n * KP1;
-            const bool on = i < ChP * KP1 && n < p.Ch;
-            v[j] = (on && k < p.Cin) ? p.w1[(long)n * p.Cin + k] : (half_t)0.f;
-            bb[j] = (on && k >= p.Cin && k < p.Cin + 2 && p.b1) ? p.b1[n] : 0.f;
+            const int i = i0 + j * NT, n = i / (KP1 / 8), k = (i - n * (KP1 / 8)) * 8;
+            const bool on = i < ChP * (KP1 / 8) && n < p.Ch;
+            v[j] = (on && k < p.Cin) ? *(const half8_t*)(p.w1 + (long)n * p.Cin + k) : hz0;
+            bb[j] = (on && k == p.Cin && p.b1) ? p.b1[n] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < PB; j++) {
-            const int i = i0 + j * NT, n = i / KP1, k = i - n * KP1;
-            if (i < ChP * KP1) {
-                half_t o = v[j];
-                if (n < p.Ch && k >= p.Cin && k < p.Cin + 2) { const half_t bh = (half_t)bb[j]; o = k == p.Cin ? bh : (half_t)(bb[j] - (float)bh); }
-                w1l[i] = o;
+            const int i = i0 + j * NT, n = i / (KP1 / 8), k = (i - n * (KP1 / 8)) * 8;
+            if (i < ChP * (KP1 / 8)) {
+                half8_t o = v[j];
+                if (n < p.Ch && k == p.Cin) { const half_t bh = (half_t)bb[j]; o[0] = bh; o[1] = (half_t)(bb[j] - (float)bh); }
+                *(half8_t*)(w1l + n * KP1 + k) = o;
             }
         }
     }
@@ -812,12 +815,12 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
 #pragma unroll
         for (int j = 0; j < PB; j++) { const int i = i0 + j * NT; if (i < ChP * 24) wdt[i] = v[j]; }
     }
-    for (int i0 = tid; i0 < CoP * (hs2 / 2); i0 += NT * PB) {
-        half_t v[PB];
+    for (int i0 = tid; i0 < CoP * (hs2 / 16); i0 += NT * PB) {             // W2 rows, 16 bytes at a time (the row's last slot is the padding)
+        half8_t v[PB];
 #pragma unroll
-        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT, n = i / (hs2 / 2), k = i - n * (hs2 / 2); v[j] = (i < CoP * (hs2 / 2) && n < p.Cout && k < p.Ch) ? p.w2[(long)n * p.Ch + k] : (half_t)0.f; }
+        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT, n = i / (hs2 / 16), k = (i - n * (hs2 / 16)) * 8; v[j] = (i < CoP * (hs2 / 16) && n < p.Cout && k < p.Ch) ? *(const half8_t*)(p.w2 + (long)n * p.Ch + k) : hz0; }
 #pragma unroll
-        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT; if (i < CoP * (hs2 / 2)) ((half_t*)w2l)[i] = v[j]; }
+        for (int j = 0; j < PB; j++) { const int i = i0 + j * NT, n = i / (hs2 / 16), k = (i - n * (hs2 / 16)) * 8; if (i < CoP * (hs2 / 16)) *(half8_t*)(w2l + n * hs2 + k * 2) = v[j]; }
     }
     for (int i = tid; i < ChP; i += NT) bdl[i] = (p.bd && i < p.Ch) ? p.bd[i] : 0.f;
     for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
@@ -1642,6 +1645,7 @@ static int mb_pick(const sm_mbconv_desc* d) {                         // 4, 3, 1
     // eleven k steps, 15 chunks, spills), which stay where they were
     // => v4 for images of at most four tiles (56^2 -> 28^2 has sixteen 7 x 7 tiles: 107 vs 90 us)
     // (7^2 blocks: with the row blocks of a chunk dealt to different waves — AS — 50 vs 63 us as three launches, cold)
+    // (28^2, stride 1: the register-window kernel ties it with the vectorised prologue — 42.6 vs 45.6 us cold, no difference in the graph)
     if (ok4 && !force && sm_ceil_div(d->Ho, mb_v4_tile(d)) * sm_ceil_div(d->Wo, mb_v4_tile(d)) <= 4) return 4;
     // measured on MobileNet-v2 bs = 256 (tools/mbconv_bench.py): the wave pipelines win everywhere (112^2 -> 56^2: 125 vs 307 us, 56^2: 143 vs 245,
     // 56^2 -> 28^2: 92 vs 122, 28^2: 60 vs 93) except on the 28^2 -> 14^2 block (58 vs 53: one or two ragged tiles per wave)
@@ -1712,6 +1716,7 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
         p.tiles_x = sm_ceil_div(d->Wo, 8); p.tiles_y = sm_ceil_div(d->Ho, th3); p.ntiles = (int)nt3;
         fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
         if (mb_v5_ok(d)) {                                           // hidden patch in registers: 16-wave blocks, one per CU
+            SM_REQUIRE(((((uintptr_t)w1) | ((uintptr_t)w2)) & 15) == 0, "sm_mbconv_fwd: weights must be 16-byte aligned");
             const bool relu = p.sl1 == 0.f && p.sl2 == 0.f;
             void (*f5)(MbParams) = nullptr;
 #define MB5_PICK2(S_, K_) (d->Cout <= 32 ? (relu ? mbconv5_kernel<S_, K_, 16, 1, true> : mbconv5_kernel<S_, K_, 16, 1, false>) \
