@@ -14,6 +14,15 @@
 // LDS, LDS -> MFMA -> store), so the tile time is latency, not throughput — 4-wave blocks took 20 k clk per tile, 16 waves spread the
 // (row block, channel block) pairs of phase A and the pixel x channel-vector items of phase B over the whole CU.
 // Numerics = the three separate launches: same fp32 accumulation order over k, the same two intermediate roundings to fp16.
+//
+// Kernels in this file, in the order they were built (mb_pick() / sm_mbconv_stem_fwd choose; DESIGN.md 4.4, DESIGN_APPENDIX.md A4.8, A4.14):
+//   mbconv_kernel   (v1)  16-wave blocks, whole hidden patch in LDS, block barriers between the phases           — small Cin / Ch where nothing else applies
+//   mbconv2_kernel  (v2)  the same chunked over 32 hidden channels in 4-wave blocks                              — shapes nothing else takes
+//   mbconv3_kernel  (v3)  every wave its own pipeline over a 4 x 8 tile, hidden chunk in a wave-private LDS region, depthwise on MFMAs against diagonal
+//                         weight fragments                                                                       — no-expand blocks, wide blocks with W1 / W2 read from global memory
+//   mbconv4_kernel  (v4)  one 14 x 14 tile per 8-wave block, the waves share every 64-channel chunk              — images of at most four tiles (28^2, 14^2, 7^2)
+//   mbconv5_kernel  (v5)  v3's pipeline with the hidden patch in REGISTERS (lane = channel, depthwise = register stencil with v_dot2c) — expand blocks on large images
+//   mbconv5s_kernel       v5 behind an image stem, the input region staged in the LDS                            — MobileNet-v2's first three layers
 #include <algorithm>
 
 #include "common.hpp"
