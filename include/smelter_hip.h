@@ -202,6 +202,35 @@ int sm_stem3x3_f32_supported(int32_t N, int32_t C, int32_t in_H, int32_t in_W, i
 int sm_stem3x3_f32_fwd(const float* x_nchw, int32_t N, int32_t C, int32_t in_H, int32_t in_W, const void* w_ohwi, const float* bias, int32_t Cout,
                        int32_t stride, int32_t pad, int32_t act, float slope, void* y, int32_t y_ld, sm_stream_t stream);
 
+/* A RUN of MPSCNNConvolutionNodes at one resolution — the bottleneck blocks of a residual stage: 1x1 reduce -> 3x3 -> 1x1 expand (+ MPSNNAdditionNode
+ * + MPSCNNNeuronReLUNode; Converters.swift:187-338, :430-451, :342-359) — as ONE persistent launch of 256 blocks (csrc/kernels/stage.hip).  Each phase is the
+ * convolution sm_conv2d_fwd (or, with x2 != NULL, sm_conv2d_dual_fwd_cfg) would run on the same operands: 1x1 / stride 1 / no padding or 3x3 / stride 1 /
+ * padding 1, groups 1, Cin % 128 == 0, Cout % 8 == 0, images of at most 208 pixels, fp16 NHWC.  An operand of phase i that lies inside the output of an earlier
+ * phase of the run is read from it once the producing tiles of the SAME image have published (the batch has no cross-sample dependency: BN uses stored
+ * statistics, Converters.swift:760-773); everything else must be complete before the launch.  No phase may overwrite a tensor another phase of the run reads or
+ * writes.  The blocks of one XCD form a team that keeps N/8 images for the whole run, so a phase's output is read back from that XCD's L2.
+ * `ctl`: sm_stage_ctl_bytes(ph, n) bytes of device memory, zeroed once by the caller; the kernel leaves it zeroed (but for the status words).
+ * Same numerics per phase as a phase launched alone through this entry (bit-identical); fp32 accumulation, one rounding to fp16 per phase output. */
+#define SM_STAGE_MAX_PHASES 18
+typedef struct sm_stage_phase {
+    sm_conv_desc d;                 /* d.N = the batch (the same in every phase); d.Cin = K1 + K2 */
+    const void* x; const void* w_ohwi; const float* bias; const void* residual; void* y;
+    const void* w_packed;           /* optional (NULL: none): the same weights in the run's fragment order (sm_stage_pack_weights), device memory — the kernel then streams them
+                                     * as contiguous 1 KB requests instead of 64-byte row pieces (about twice the weight bandwidth per compute unit) */
+    const void* x2; int32_t K2, x2_ld, x2_H, x2_W, x2_stride;   /* second source, as in sm_conv2d_dual_fwd_cfg (x2 = NULL: none) */
+    int32_t form;                   /* 0 = the planner picks the tile form (fewest bytes through a CU's L1); k + 1 = tile form k if it takes the phase (tests, tuning) */
+} sm_stage_phase;
+int sm_stage_supported(const sm_stage_phase* ph, int32_t n);
+int sm_stage_phase_kind(const sm_stage_phase* ph, int32_t n, int32_t i);   /* tile form phase i runs on (0 .. 5; logs and tests), -1 = run not supported */
+size_t sm_stage_ctl_bytes(const sm_stage_phase* ph, int32_t n);
+int sm_stage_fwd(const sm_stage_phase* ph, int32_t n, void* ctl, sm_stream_t stream);
+/* HOST side, once per model: phase i's OHWI weights (host memory) re-ordered for the tile form the planner gives the phase in THIS run (the phase list and the batch decide it) */
+size_t sm_stage_packed_weight_bytes(const sm_stage_phase* ph, int32_t n, int32_t i);
+int sm_stage_pack_weights(const sm_stage_phase* ph, int32_t n, int32_t i, const void* w_ohwi_host, void* dst_host);
+/* After a run (synchronises `stream`): error_bits 1 = the 256 blocks did not become co-resident within the spin bound, 2 = a hand-off wait ran out (results are
+ * undefined in both cases); mode 1 = XCD-local hand-off (every XCD held 32 blocks), 2 = the fenced fallback (agent-scope release / acquire).  Clears both words. */
+int sm_stage_status(void* ctl, sm_stream_t stream, int32_t* error_bits, int32_t* mode);
+
 /* MPSCNNConvolutionTransposeNode (Converters.swift:277) + ONNX_ConvolutionPadding(isTranspose) (:66-71, :97-103).
  * `w_ohwi_flipped` is what ConvDataSource hands MPS: out[oc][kH-1-kh][kW-1-kw][ic] = W[ic][oc][kh][kw]
  * (Array+Extensions.swift:71-76).  y[n,oy,ox,oc] = act(bias[oc] + sum x[n,iy,ix,ic] * W[ic,oc,kh,kw]) over

@@ -33,6 +33,12 @@ class ConvDesc(C.Structure):
                [("slope", C.c_float)] + [(n, C.c_int32) for n in ("x_ld", "y_ld", "res_ld", "y_sH", "y_sW", "y_oH", "y_oW", "y_H", "y_W", "x_ups")]
 
 
+class StagePhase(C.Structure):
+    """sm_stage_phase (include/smelter_hip.h): one convolution of a persistent run"""
+    _fields_ = [("d", ConvDesc), ("x", C.c_void_p), ("w_ohwi", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p), ("w_packed", C.c_void_p),
+                ("x2", C.c_void_p), ("K2", C.c_int32), ("x2_ld", C.c_int32), ("x2_H", C.c_int32), ("x2_W", C.c_int32), ("x2_stride", C.c_int32), ("form", C.c_int32)]
+
+
 class MbConvDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("N", "H", "W", "Ho", "Wo", "stride", "Cin", "Ch", "Cout", "expand", "residual")] + \
                [("act1", C.c_int32), ("slope1", C.c_float), ("act2", C.c_int32), ("slope2", C.c_float), ("act3", C.c_int32), ("slope3", C.c_float),
@@ -70,6 +76,13 @@ SYMBOLS = {
     "sm_conv2d_config_loader_waves": (_i32, [_i32]),
     "sm_conv2d_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sm_conv2d_dual_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "sm_stage_supported": (_i32, [C.POINTER(StagePhase), _i32]),
+    "sm_stage_phase_kind": (_i32, [C.POINTER(StagePhase), _i32, _i32]),
+    "sm_stage_ctl_bytes": (_sz, [C.POINTER(StagePhase), _i32]),
+    "sm_stage_fwd": (_i32, [C.POINTER(StagePhase), _i32, _vp, _vp]),
+    "sm_stage_packed_weight_bytes": (_sz, [C.POINTER(StagePhase), _i32, _i32]),
+    "sm_stage_pack_weights": (_i32, [C.POINTER(StagePhase), _i32, _i32, _vp, _vp]),
+    "sm_stage_status": (_i32, [_vp, _vp, _pi32, _pi32]),
     "sm_conv2d_pool_supported": (_i32, [C.POINTER(ConvDesc)]),
     "sm_conv2d_pool_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "sm_conv2d_head_supported": (_i32, [C.POINTER(ConvDesc), _i32]),

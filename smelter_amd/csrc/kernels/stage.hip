@@ -1,0 +1,708 @@
+// stage.hip — a RUN of convolution layers at one resolution (the bottleneck blocks of a ResNet stage: 1x1 reduce -> 3x3 -> 1x1 expand + residual, ...) as ONE
+// persistent launch: sm_stage_fwd (include/smelter_hip.h).  Replaces, per phase, an MPSCNNConvolutionNode (+ MPSNNAdditionNode + MPSCNNNeuronReLUNode) of the
+// reference (/root/reference/Sources/Smelter/Converters.swift:187-338, :430-451, :342-359) — the same arithmetic as sm_conv2d_fwd / sm_conv2d_dual_fwd_cfg.
+//
+// Why: at batch 64 every late layer of ResNet-50 gives a CU ONE tile, so every launch pays kernel entry + a cold first fill (operands the
+// previous launch wrote come from the Infinity Cache at ~13 B/clk/CU: the L2 is invalidated at the kernel boundary) + epilogue + drain, 7.7 us per launch, 48 times.
+// Inference has no cross-sample dependency (BN uses stored statistics, Converters.swift:760-773), so:
+//   * 256 blocks (one per CU) form 8 TEAMS of 32 — the blocks of one XCD (HW_REG_XCC_ID + a per-XCD ticket; placement is verified at kernel entry, see below);
+//   * team t owns images [t N/8, (t+1) N/8) for the WHOLE run: what a phase writes is read by the next phase from the SAME XCD's L2 (~27 B/clk/CU), with plain
+//     stores on the producer side and L1-bypassing (sc1) loads on the consumer side — no cache write-back, no invalidate (tools/ubench/xcdphase.hip: 0 stale words of 168 M);
+//   * hand-off = one counter per (phase, image): a tile adds 1 to the counters of the images it covers once its stores are drained (s_waitcnt vmcnt(0) in every wave,
+//     barrier, one relaxed agent-scope atomic); a consumer tile polls the counters of ITS images only (one lane, sc1 loads, s_sleep, bounded) — no team-wide barrier,
+//     images advance independently; weights of the next tile are requested before the poll;
+//   * a phase's tile = TP output pixels (whole images or an aligned part of one) x BN couts, K reduction in "units" of 32 channels:
+//       kinds R (1x1, many input channels, few couts) and T (3x3): K split over the four waves (each wave owns the whole tile, partial sums meet in LDS);
+//       kinds E (1x1, few input channels, many couts; optionally a second source = projection shortcut concatenated along K): couts split over the four waves;
+//     the input patch goes HBM/L2 -> LDS by buffer LDS-DMA (out-of-range lanes = zeros without a memory access: padding, halo, dead pixels), 64-channel slices
+//     [slot][128 B] XOR-swizzled by slot/2, NB buffers deep; weights go global -> registers in fragment layout (never through the LDS), two units per request so that
+//     both halves of a 128-byte line are asked for together; v_mfma_f32_16x16x32_f16, fp32 accumulators; bias + residual + activation + one rounding in the epilogue.
+// Numerics: fp32 accumulation over (channel block, tap, channel) ascending inside a wave's K slice, slices added in ascending order — the same as the wave-split
+// per-layer kernel (conv3x3_kq.hpp); a phase launched ALONE through this file is bit-identical to the same phase inside a run (tests/test_gpu_stage.py).
+//
+// Placement check: every block takes a ticket from its XCD's counter and all wait (bounded) until 256 tickets are out; if every XCD holds exactly 32 blocks the run is
+// XCD-local as above.  Otherwise (partitioned device, foreign work on some CUs) teams are formed in arrival order and every hand-off uses the architecturally sanctioned
+// agent-scope release / acquire (buffer_wbl2 sc1 / buffer_inv sc1, MI355X_MICROARCH.md §Workgroup dispatch) — slower, never wrong.  Every spin is bounded; a timeout sets
+// an error word the host reads with sm_stage_status.
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <vector>
+#include "conv_shared.hpp"
+
+namespace {
+
+typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int ST_MAXPH = SM_STAGE_MAX_PHASES, ST_TEAM = 32, ST_NTEAM = 8, ST_GRID = ST_TEAM * ST_NTEAM;
+constexpr int ST_CTL_HDR = 16;                  // ctl words: [0..7] tickets per XCD, [8] arrived, [9] done, [10] error bits, [11] mode seen (1 = XCD-local, 2 = fenced), then cnt[phase][cnt_ld]
+
+struct StPhase {
+    const half_t* x; const half_t* x2; const half_t* w; const half_t* wp; const float* bias; const half_t* res; half_t* y;   // wp: the weights in fragment order (sm_stage_pack_weights) or nullptr
+    int kind, H, W, HW, K1, K, Cout;            // K1 = channels of x (per tap); K = row length of w = TAPS K1 (+ K2)
+    int x_ld, x2_ld, res_ld, y_ld, x2_W, x2_HW, x2_s;
+    int act; float slope;
+    int TP, TI, MT, NT, nsb1, nsb, RS, NI;      // pixels / whole images per tile; tiles per team; super-blocks from x / in all; patch row slots; DMA instructions per 64-channel slice
+    int dep0, dep1, dep2, expect;               // producing phase of x / x2 / res (-1: outside the run); arrivals per image that complete THIS phase's output
+    unsigned x_bytes, x2_bytes, res_bytes, y_bytes;
+    unsigned hw_mul, hw_sh, w_mul, w_sh, h1_mul, h1_sh, kpr_mul, kpr_sh;
+};
+struct StArgs { unsigned* ctl; int nphase, N, ipt, spin_limit, cnt_ld, lds_bytes; StPhase ph[ST_MAXPH]; };
+static_assert(sizeof(StArgs) <= 4096, "kernel argument block");
+
+// KG x NG = 4 waves: KG = K groups (a wave multiplies channels [kg WCH, (kg + 1) WCH) of every super-block of KG WCH channels), NG = cout groups of NF 16-cout fragments;
+// NFR = 16-pixel fragments per tile; TAPS = 1 | 9; SBG = super-blocks per unrolled loop body; NB = patch buffers.
+template <int KG_, int NG_, int NF_, int NFR_, int TAPS_, int WCH_, int SBG_, int NB_>
+struct StKind {
+    static constexpr int KG = KG_, NG = NG_, NF = NF_, NFR = NFR_, TAPS = TAPS_, WCH = WCH_, SBG = SBG_, NB = NB_;
+    static constexpr int QPW = WCH / 32, UPS = TAPS * QPW, UB = SBG * UPS, NSL = WCH / 64, SBCH = KG * WCH, WN = NF * 16, BN = NG * WN, PD = NB - 1;
+    static constexpr int RW = TAPS == 9 ? 6 : 4, PA = RW - 2;                 // weight ring (units) and how many units ahead a PAIR of units is requested
+    static constexpr int NI_MAX = TAPS == 1 ? NFR * 2 : (NFR <= 7 ? 18 : 37);  // DMA instructions per slice the kind can take
+    static constexpr int NIW_MAX = (NSL * NI_MAX + NG - 1) / NG;               // ... per wave and super-block
+    static constexpr int DPU = NB > 1 ? (NIW_MAX + UPS - 1) / UPS : 0, V = NF + DPU;   // DMA slots per unit; VMEM operations per unit
+    static constexpr bool DUAL = TAPS == 1 && KG == 1, SHARED = NG > 1;
+    static constexpr int TPMAX = NFR * 16;
+    static_assert(KG * NG == 4 && UB % RW == 0 && UB % 2 == 0 && QPW % 2 == 0 && (NB > 1 || DPU == 0), "shape of the loop body");
+    static_assert(PA * NF + (PA + 1) * DPU + NF <= 63 && (PD <= 1 || true), "counted waits must be expressible");
+};
+typedef StKind<4, 1, 4, 7, 1, 64, 2, 3> StR7;     // 0: 1x1, K % 512 == 0, tile <= 112 px x 64 couts      (7x7: 2048 -> 512)
+typedef StKind<4, 1, 4, 7, 9, 64, 1, 2> StT7;     // 1: 3x3, K1 % 256 == 0, images of <= 56 px, 2+ per tile x 64 couts (7x7 512 -> 512)
+typedef StKind<1, 4, 4, 7, 1, 128, 1, 3> StE7;    // 2: 1x1 (+ second source), K % 128 == 0, <= 112 px x 256 couts (7x7: 512 -> 2048)
+typedef StKind<2, 2, 4, 7, 1, 128, 1, 3> StR14;   // 3: 1x1, K % 256 == 0, <= 112 px x 128 couts          (14x14: 1024 -> 256)
+typedef StKind<1, 4, 4, 13, 1, 128, 1, 3> StE14;  // 4: 1x1 (+ second source), <= 208 px x 256 couts       (14x14: 256 -> 1024)
+typedef StKind<4, 1, 4, 13, 9, 64, 1, 1> StT14;   // 5: 3x3, one image of <= 208 px x 64 couts, patch single-buffered (14x14 256 -> 256)
+constexpr int ST_NKINDS = 6;
+
+#ifdef SM_STAGE_TL   // diagnostic build (tools/stage_tl.py): per block and tile, wall clock (100 MHz, the same on every XCD) at 8 points
+__device__ unsigned long long g_st_tl[ST_GRID * 64 * 8];
+__device__ unsigned g_st_tl_n[ST_GRID];
+#define ST_TL(i) do { if (threadIdx.x == 0 && tl_slot < 64) g_st_tl[(blockIdx.x * 64 + tl_slot) * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define ST_TL(i)
+#endif
+
+#ifndef ST_DMA_AUX
+#define ST_DMA_AUX " sc1"
+#endif
+__device__ __forceinline__ void st_bdma16(unsigned voff, st_u32x4 rsrc, unsigned lds_dst, unsigned soff) {   // 16 bytes per lane, buffer -> LDS, L1 bypassed (sc1): the producer may be another CU of this XCD
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen" ST_DMA_AUX " lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+__device__ __forceinline__ void st_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ unsigned st_ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <int N> __device__ __forceinline__ void st_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory"); }
+
+// One tile of one phase: output pixels pix0 .. pix0 + PTe - 1 (global pixel index n HW + y W + x), couts of cout tile `ntile`.
+template <class KD, class Sync>
+__device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const int PTe, const int ntile, const unsigned lds0, unsigned char* const smem, const unsigned smem_lds, Sync&& sync, const int tl_slot) {
+    constexpr int KG = KD::KG, NG = KD::NG, NF = KD::NF, NFR = KD::NFR, TAPS = KD::TAPS, WCH = KD::WCH, SBG = KD::SBG, NB = KD::NB;
+    constexpr int QPW = KD::QPW, UPS = KD::UPS, UB = KD::UB, NSL = KD::NSL, SBCH = KD::SBCH, WN = KD::WN, BN = KD::BN, PD = KD::PD, RW = KD::RW, PA = KD::PA, DPU = KD::DPU, V = KD::V;
+    constexpr bool DUAL = KD::DUAL, SHARED = KD::SHARED, T3 = TAPS == 9;
+    constexpr int NTAB = DPU * UPS;                                    // DMA slots of one super-block (per wave)
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4, c8 = lane & 7, l8 = lane >> 3;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = wave / NG, ng = wave % NG;
+    const int H = p.H, W = p.W, HW = p.HW, RS = p.RS, NI = p.NI, K1 = p.K1, K = p.K, Cout = p.Cout, nsb = p.nsb, nsb1 = p.nsb1;
+    const unsigned SLB = (unsigned)NI * 1024u, BUFB = (unsigned)(KG * NSL) * SLB, sink = lds0 + (unsigned)NB * BUFB;
+    const unsigned myslices = lds0 + (unsigned)(kg * NSL) * SLB;       // this K group's slices inside buffer 0
+    const int co0 = ntile * BN + ng * WN;
+    const int n0 = (int)sm_fastdiv((unsigned)pix0, p.hw_mul, p.hw_sh), imgs = T3 ? (int)sm_fastdiv((unsigned)PTe, p.hw_mul, p.hw_sh) : 1;
+
+    // ---- weight fragments: lane (l15, g) of fragment j holds one cout row, channels 8 g .. 8 g + 7 of the unit's 32.  KG == 1 (register epilogue): row l15 of fragment j is
+    // cout (j/2) 32 + (l15/4) 8 + (j%2) 4 + l15%4, so that an accumulator lane holds eight CONSECUTIVE couts across fragments 2 jp, 2 jp + 1 (one 16-byte store) ----
+    unsigned boff[NF];
+#pragma unroll
+    for (int j = 0; j < NF; j++) {
+        int co = KG == 1 ? co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) : co0 + j * 16 + l15;
+        if (co >= Cout) co = Cout - 1;
+        boff[j] = (unsigned)(co * K + g * 8) * 2u;
+    }
+    half8_t wb[RW][NF];
+    // Packed weights (sm_stage_pack_weights): the fragments of this wave, unit after unit, are ONE linear stream — [cout tile][ng][kg][super-block][unit][fragment][lane] x 16 bytes:
+    // a request is 1 KB contiguous (8 full lines) instead of 16 row pieces of 64 bytes, which cost a request each (measured: 24-30 GB/s per CU against 55 for the patch stream)
+    const bool packed = p.wp != nullptr;
+    const half_t* const wstream = p.wp + ((size_t)((ntile * NG + ng) * KG + kg) * (size_t)(nsb * UPS)) * (size_t)(NF * 512);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto load_b = [&](auto slotc, int sb, int ul) {                   // weight fragments of unit `ul` of super-block `sb` -> ring slot
+        constexpr int SLOT = decltype(slotc)::value;
+        if (packed) {
+            const half_t* ub = wstream + (size_t)(sb * UPS + ul) * (size_t)(NF * 512);
+            static_assert(NF == 4, "four fragments per unit");
+            { half8_t& d = wb[SLOT][0]; asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(lane16), "s"(ub) : "memory"); }
+            { half8_t& d = wb[SLOT][1]; asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(d) : "v"(lane16), "s"(ub) : "memory"); }
+            { half8_t& d = wb[SLOT][2]; asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(d) : "v"(lane16), "s"(ub) : "memory"); }
+            { half8_t& d = wb[SLOT][3]; asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(d) : "v"(lane16), "s"(ub) : "memory"); }
+            return;
+        }
+        int k1o = K1; asm volatile("" : "+s"(k1o));                  // (opaque: the nine tap offsets are NOT loop invariants worth 18 scalar registers)
+        const half_t* ub = p.w + ((ul / QPW) * k1o + sb * SBCH + kg * WCH + (ul % QPW) * 32);
+#ifdef ST_ABL_NOW
+        for (int j = 0; j < NF; j++) { half8_t& d = wb[SLOT][j]; const unsigned bo = 0x80000000u; const st_u32x4 rz = {0u, 0u, 0u, 0x00020000u}; asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(d) : "v"(bo), "s"(rz) : "memory"); }
+#else
+#pragma unroll
+        for (int j = 0; j < NF; j++) { half8_t& d = wb[SLOT][j]; const unsigned bo = boff[j]; asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(bo), "s"(ub) : "memory"); }
+#endif
+    };
+    // requests of the first PA units: nothing here depends on another tile
+    sm_static_for<0, PA>([&](auto uc) { constexpr int U = decltype(uc)::value; load_b(uc, U / UPS, U % UPS); });
+    sync();                                                           // the producers of this tile's inputs have published; the block is through with the previous tile's LDS
+
+    // ---- patch geometry ----
+    const unsigned ld2 = (unsigned)p.x_ld * 2u;
+    const st_u32x4 rs_x = {(unsigned)(uintptr_t)p.x, (unsigned)((uintptr_t)p.x >> 32) & 0xffffu, p.x_bytes, 0x00020000u};
+    st_u32x4 rs_x2 = rs_x;
+    if constexpr (DUAL) { if (p.x2) rs_x2 = st_u32x4{(unsigned)(uintptr_t)p.x2, (unsigned)((uintptr_t)p.x2 >> 32) & 0xffffu, p.x2_bytes, 0x00020000u}; }
+    // byte offset (channel base excluded) of this lane's 16 bytes of DMA instruction i of a slice: slots 8 i .. 8 i + 7, lane = (slot 8 i + l8, chunk c8); dead: beyond the buffer.
+    // 1x1, first source: slot = pixel, the offset is (pix0 + 8 i) ld2 + [l8 ld2 + swizzled chunk], and the swizzle key (slot / 2) & 7 = (l8 / 2) | 4 (i & 1): two lane constants, no
+    // table (slots beyond the tile copy whatever follows it — their pixels are never stored; beyond the tensor the descriptor returns zeros)
+    const unsigned lo0 = (unsigned)l8 * ld2 + ((((unsigned)c8) ^ (unsigned)(l8 >> 1)) << 4), lo1 = (unsigned)l8 * ld2 + ((((unsigned)c8) ^ (unsigned)((l8 >> 1) | 4)) << 4);
+    auto dma_off = [&](int i) -> unsigned {
+        if constexpr (T3) {
+            const int s = 8 * i + l8;
+            const unsigned chunk = (((unsigned)c8 ^ (unsigned)((s >> 1) & 7)) << 4);
+            const int r = (int)sm_fastdiv((unsigned)i, p.kpr_mul, p.kpr_sh), k = i - r * (RS >> 3);
+            const int vr = r - 1, im = vr < 0 ? 0 : (int)sm_fastdiv((unsigned)vr, p.h1_mul, p.h1_sh), y = vr - im * (H + 1), cc = 8 * k + l8;
+            const bool ok = vr >= 0 && y < H && im < imgs && (unsigned)(cc - 1) < (unsigned)W;
+            return ok ? (unsigned)(((n0 + im) * H + y) * W + cc - 1) * ld2 + chunk : 0x80000000u;
+        } else {
+            return (unsigned)(pix0 + 8 * i) * ld2 + ((i & 1) ? lo1 : lo0);
+        }
+    };
+    auto dma_off2 = [&](int i) -> unsigned {                          // second source: output pixel (n, oy, ox) reads pixel (n, oy s, ox s) of x2
+        const int s = 8 * i + l8;
+        const unsigned chunk = (((unsigned)c8 ^ (unsigned)((s >> 1) & 7)) << 4);
+        const unsigned P = (unsigned)(pix0 + (s < PTe ? s : 0));
+        const unsigned n = sm_fastdiv(P, p.hw_mul, p.hw_sh), r = P - n * (unsigned)HW, oy = sm_fastdiv(r, p.w_mul, p.w_sh), ox = r - oy * (unsigned)W;
+        return s < PTe ? (n * (unsigned)p.x2_HW + (oy * (unsigned)p.x2_W + ox) * (unsigned)p.x2_s) * ((unsigned)p.x2_ld * 2u) + chunk : 0x80000000u;
+    };
+    // DMA slot m of a super-block (this wave): instruction idx = ng + m NG of the K group's NSL NI instructions.  Tables (one register per slot): 3x3 patches and second sources
+    constexpr int NTAB1 = T3 ? NTAB : 0, NTAB2 = DUAL ? NTAB : 0;
+    unsigned dmo[NTAB1 > 0 ? NTAB1 : 1], dmo2[NTAB2 > 0 ? NTAB2 : 1];
+    const int nidx = NSL * NI;
+    auto issue_slot = [&](auto mc, int sbn, unsigned bufo) {           // one DMA slot: real if the super-block and the instruction exist, else zeros into the sink (the counted waits see every slot)
+        constexpr int M = decltype(mc)::value;
+        const int idx = ng + M * NG;
+#ifdef ST_ABL_NODMA
+        const bool real = false;
+#else
+        const bool real = sbn < nsb && idx < nidx;
+#endif
+        const bool second = DUAL && sbn >= nsb1;
+        const int sl = idx >= NI ? 1 : 0;
+        const unsigned chb = (unsigned)(((second ? sbn - nsb1 : sbn) * SBCH + kg * WCH + sl * 64) * 2);
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(real ? myslices + bufo + (unsigned)idx * 1024u : sink));
+        if constexpr (DUAL) {
+            if (second) { st_bdma16(real ? dmo2[M] : 0x80000000u, rs_x2, dst, chb); return; }
+        }
+        unsigned vo;
+        if constexpr (T3) vo = dmo[M]; else vo = dma_off(idx - sl * NI);
+        st_bdma16(real ? vo : 0x80000000u, rs_x, dst, chb);
+    };
+
+    // ---- prologue: the patches of the first PD super-blocks ----
+    if constexpr (NB > 1) {
+        sm_static_for<0, NTAB>([&](auto mc) {
+            constexpr int M = decltype(mc)::value;
+            const int idx = ng + M * NG, sl = idx >= NI ? 1 : 0, i = idx - sl * NI;
+            if constexpr (T3) dmo[M] = idx < nidx ? dma_off(i) : 0x80000000u;
+            if constexpr (DUAL) dmo2[M] = (idx < nidx && nsb1 < nsb) ? dma_off2(i) : 0x80000000u;
+            issue_slot(mc, 0, 0u);
+        });
+        sm_static_for<1, PD>([&](auto sc) {
+            constexpr int S = decltype(sc)::value;
+            sm_static_for<0, NTAB>([&](auto mc) { issue_slot(mc, S, (unsigned)S * BUFB); });
+        });
+    }
+    // (while they are in flight) pixel fragments: slice-relative LDS byte offset of this lane's slot — 1x1: swizzled, channel half 0; 3x3: slot of tap (0, 0), before the swizzle
+    unsigned pf[NFR];
+    floatx4 acc[NFR][NF];
+#pragma unroll
+    for (int f = 0; f < NFR; f++) {
+        const int t = f * 16 + l15, tc = t < PTe ? t : 0;
+        if constexpr (T3) {
+            const int im = (int)sm_fastdiv((unsigned)tc, p.hw_mul, p.hw_sh), rr = tc - im * HW, yy = (int)sm_fastdiv((unsigned)rr, p.w_mul, p.w_sh), xx = rr - yy * W;
+            pf[f] = (unsigned)(((im * (H + 1) + yy) * RS + xx) << 7);
+        } else pf[f] = ((unsigned)tc << 7) + ((((unsigned)g) ^ (unsigned)((tc >> 1) & 7)) << 4);
+#pragma unroll
+        for (int j = 0; j < NF; j++) acc[f][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    }
+    const unsigned G0 = (unsigned)g << 4;
+    half8_t af[NFR];                                                   // ONE buffer: fragment F of the next unit is requested into slot F right behind the last MFMA that reads it (an MFMA takes its operands at issue)
+    unsigned ad[NFR];
+    // LDS address of fragment F under unit `ul` (tap ul / QPW, 32-channel piece ul % QPW) of the buffer at `bufo`
+    auto frag_addr = [&](int F, int ul, unsigned bufo) -> unsigned {
+        const int tap = ul / QPW, q = ul % QPW;
+        const unsigned base = myslices + bufo + (unsigned)(q >> 1) * SLB;
+        if constexpr (T3) {
+            unsigned to = (unsigned)(((tap / 3) * RS + tap % 3) << 7); asm volatile("" : "+s"(to));
+            const unsigned rel = pf[F] + to;
+            return ((rel ^ G0 ^ ((rel >> 4) & 0x70u)) ^ (unsigned)((q & 1) << 6)) + base;
+        } else return (pf[F] ^ (unsigned)((q & 1) << 6)) + base;
+    };
+
+    // ---- main loop.  VMEM operations per unit, in program order: [even units: 2 NF weight loads of the pair PA units ahead] then DPU patch slots of super-block sb + PD ----
+    int bcur = 0;                                                      // buffer of the current super-block
+#pragma unroll 1
+    for (int sb0 = 0; sb0 < nsb; sb0 += SBG) {
+        sm_static_for<0, UB>([&](auto uc) {
+            constexpr int U = decltype(uc)::value, UL = U % UPS, SBL = U / UPS;
+            const int sb = sb0 + SBL;
+            const unsigned bufo = (unsigned)bcur * BUFB;
+            if constexpr (UL == 0) {                                   // ---- super-block boundary: its patch has landed, everybody has left the buffer the next patch goes to ----
+                if constexpr (NB == 1) {
+                    if (sb > 0) st_lds_barrier();
+#pragma unroll 1
+                    for (int idx = ng; idx < nidx; idx += NG) {
+                        const int sl = idx >= NI ? 1 : 0;
+                        st_bdma16(dma_off(idx - sl * NI), rs_x, (unsigned)__builtin_amdgcn_readfirstlane((int)(myslices + (unsigned)idx * 1024u)), (unsigned)((sb * SBCH + kg * WCH + sl * 64) * 2));
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (SHARED) __builtin_amdgcn_s_barrier();
+                } else {
+                    // younger than the last slot of this patch: the slots of the PD - 1 later prologue patches (first super-blocks) or everything issued during the PD - 1 super-blocks since
+                    if (sb0 == 0 && SBL == 0) st_wait_vm<(PD - 1) * NTAB>();
+                    else st_wait_vm<(PD - 1) * UPS * V + (UPS / 2) * 0>();
+                    if (SHARED) __builtin_amdgcn_s_barrier();
+                }
+                if (sb0 == 0 && SBL == 0) ST_TL(2);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int f = 0; f < NFR; f++) { ad[f] = frag_addr(f, 0, bufo); half8_t& d = af[f]; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad[f])); }
+            }
+            if constexpr (U % 2 == 0) {                                // weights of the pair PA units ahead (beyond the last unit: a harmless reload keeps the counted waits exact)
+                constexpr int U2 = U + PA;
+                int sb2 = sb0 + (U2 % UB) / UPS + (U2 >= UB ? SBG : 0);
+                if (sb2 >= nsb) sb2 = sb;
+                load_b(std::integral_constant<int, U2 % RW>(), sb2, U2 % UPS);
+                load_b(std::integral_constant<int, (U2 + 1) % RW>(), sb2, (U2 + 1) % UPS);
+                st_wait_vm<NF + PA * DPU + PA * NF>();                 // unit U's fragments: younger = its partner's NF, the slots of units U - PA .. U - 1, the pairs requested since
+            } else st_wait_vm<(PA + 1) * DPU + PA * NF>();
+            __builtin_amdgcn_sched_barrier(0);
+            sm_static_for<0, NFR>([&](auto fc) {
+                constexpr int F = decltype(fc)::value;
+                constexpr bool LASTU = UL == UPS - 1;                  // the last unit of a super-block fetches nothing
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(LASTU ? NFR - 1 - F : NFR - 1) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < NF; j++) {
+#ifdef ST_ABL_NOMFMA
+                    asm volatile("" ::"v"(wb[U % RW][j]), "v"(af[F]));
+#else
+                    acc[F][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[U % RW][j], af[F], acc[F][j], 0, 0, 0);
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (!LASTU) {
+                        if (j == 0) {
+                            constexpr int VL = UL + 1;
+                            if constexpr ((VL % QPW) % 2 == 1) ad[F] ^= 64u;       // same tap, same slice, other channel half
+                            else ad[F] = frag_addr(F, VL, bufo);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (j == NF - 1) {
+                            half8_t& d = af[F];
+                            asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad[F]));
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                if constexpr (DPU > 0) {
+                    sm_static_for<0, DPU>([&](auto dc) {
+                        constexpr int D = decltype(dc)::value;
+                        if constexpr (F == ((2 * D + 1) * NFR) / (2 * DPU)) {
+                            constexpr int M = UL * DPU + D;
+                            int bn = bcur + PD; if (bn >= NB) bn -= NB;
+                            issue_slot(std::integral_constant<int, M>(), sb + PD, (unsigned)bn * BUFB);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                }
+            });
+            if constexpr (UL == UPS - 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); bcur = bcur + 1 == NB ? 0 : bcur + 1; }
+        });
+    }
+
+    // ---- epilogue ----
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    ST_TL(3);
+    // (ring slots requested beyond the last unit are never multiplied: keep them allocated up to here, behind the wait — to the register allocator an asm output is
+    // written when the statement executes, and a dead destination would be handed out while its load is in flight)
+#pragma unroll
+    for (int q = 0; q < RW; q++)
+#pragma unroll
+        for (int j = 0; j < NF; j++) asm volatile("" ::"v"(wb[q][j]));
+    const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, (int)(p.res ? p.res_bytes : 0u), 0x00020000);
+    typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    auto finish = [&](floatx4 a0, floatx4 a1, half8_t rv) -> u32x4s {   // 8 consecutive couts of one pixel: + residual, activation, one rounding
+        half8_t ov;
+#pragma unroll
+        for (int e = 0; e < 4; e++) { a0[e] += (float)rv[e]; a1[e] += (float)rv[4 + e]; }
+#pragma unroll
+        for (int e = 0; e < 4; e++) { ov[e] = (half_t)(a0[e] < 0.f ? a0[e] * sl : a0[e]); ov[4 + e] = (half_t)(a1[e] < 0.f ? a1[e] * sl : a1[e]); }
+        return __builtin_bit_cast(u32x4s, ov);
+    };
+    const unsigned ybase = (unsigned)pix0 * (unsigned)p.y_ld * 2u, rbase = (unsigned)pix0 * (unsigned)p.res_ld * 2u;
+    if constexpr (KG == 1) {
+        // registers -> memory: lane (l15, g) of fragments 2 jp, 2 jp + 1 holds couts co0 + 32 jp + 8 g .. + 7 of pixel 16 F + l15
+        floatx4 bq[NF];
+#pragma unroll
+        for (int j = 0; j < NF; j++) {
+            const int co = co0 + (j >> 1) * 32 + g * 8 + (j & 1) * 4;
+            bq[j] = (p.bias && co + 3 < Cout) ? *(const floatx4*)(p.bias + co) : floatx4{0.f, 0.f, 0.f, 0.f};
+        }
+        // every residual load of the tile is in flight before the first sum: ONE memory latency per tile, not one per fragment (the weight ring and the pixel
+        // fragments are dead by now: NFR NF / 2 x 4 registers are there)
+        half8_t rv[NFR][NF / 2];
+        if (p.res) {
+#pragma unroll
+            for (int f = 0; f < NFR; f++)
+#pragma unroll
+                for (int jp = 0; jp < NF / 2; jp++) {
+                    const int t = f * 16 + l15, co = co0 + jp * 32 + g * 8;
+                    rv[f][jp] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((t < PTe && co < Cout) ? rbase + (unsigned)t * (unsigned)p.res_ld * 2u + (unsigned)co * 2u : 0x80000000u), 0, 16));
+                }
+        } else {
+#pragma unroll
+            for (int f = 0; f < NFR; f++)
+#pragma unroll
+                for (int jp = 0; jp < NF / 2; jp++) rv[f][jp] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        sm_static_for<0, NFR>([&](auto fc) {
+            constexpr int F = decltype(fc)::value;
+            const int t = F * 16 + l15;
+#pragma unroll
+            for (int jp = 0; jp < NF / 2; jp++) {
+                const int co = co0 + jp * 32 + g * 8;
+                const bool ok = t < PTe && co < Cout;
+                const u32x4s ov = finish(acc[F][2 * jp] + bq[2 * jp], acc[F][2 * jp + 1] + bq[2 * jp + 1], rv[F][jp]);
+                __builtin_amdgcn_raw_buffer_store_b128(ov, rs_y, (int)(ok ? ybase + (unsigned)t * (unsigned)p.y_ld * 2u + (unsigned)co * 2u : 0x80000000u), 0, 0);
+            }
+        });
+    } else {
+        // the KG partial sums meet in LDS (fp32 rows [pixel][WN + 4] per wave, in rounds of <= RFR fragments), are added in the order kg = 0 .. KG - 1, then as above
+        constexpr int RFR = NFR > 7 ? 7 : NFR, ROUNDS = (NFR + RFR - 1) / RFR, RLD = WN + 4, RROWS = RFR * 16, OCT = WN / 8, PPS = 64 / OCT;
+        st_lds_barrier();                                             // everybody has left the patch: its LDS becomes the exchange area
+        float* const red = (float*)(smem + (lds0 - smem_lds));
+        const int o = lane % OCT, co = co0 + o * 8;
+        floatx4 bq0 = {0.f, 0.f, 0.f, 0.f}, bq1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && co + 7 < Cout) { bq0 = *(const floatx4*)(p.bias + co); bq1 = *(const floatx4*)(p.bias + co + 4); }
+        sm_static_for<0, ROUNDS>([&](auto rc) {
+            constexpr int RND = decltype(rc)::value, F0 = RND * RFR, NFRR = (NFR - F0) < RFR ? (NFR - F0) : RFR;
+#pragma unroll
+            for (int fi = 0; fi < NFRR; fi++)
+#pragma unroll
+                for (int j = 0; j < NF; j++) *(floatx4*)&red[(wave * RROWS + fi * 16 + l15) * RLD + j * 16 + g * 4] = acc[F0 + fi][j];
+            st_lds_barrier();
+            constexpr int ITS = (NFRR * 16 + KG * PPS - 1) / (KG * PPS);
+#pragma unroll
+            for (int it = 0; it < ITS; it++) {
+                const int pp = kg * PPS + lane / OCT + it * KG * PPS, ppc = pp < NFRR * 16 ? pp : 0, t = F0 * 16 + pp;
+                const bool ok = pp < NFRR * 16 && t < PTe && co < Cout;
+                half8_t rv = {0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.res) rv = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(ok ? rbase + (unsigned)t * (unsigned)p.res_ld * 2u + (unsigned)co * 2u : 0x80000000u), 0, 16));
+                floatx4 a0 = *(const floatx4*)&red[((0 * NG + ng) * RROWS + ppc) * RLD + o * 8], a1 = *(const floatx4*)&red[((0 * NG + ng) * RROWS + ppc) * RLD + o * 8 + 4];
+#pragma unroll
+                for (int k = 1; k < KG; k++) {
+                    a0 += *(const floatx4*)&red[((k * NG + ng) * RROWS + ppc) * RLD + o * 8];
+                    a1 += *(const floatx4*)&red[((k * NG + ng) * RROWS + ppc) * RLD + o * 8 + 4];
+                }
+                const u32x4s ov = finish(a0 + bq0, a1 + bq1, rv);
+                __builtin_amdgcn_raw_buffer_store_b128(ov, rs_y, (int)(ok ? ybase + (unsigned)t * (unsigned)p.y_ld * 2u + (unsigned)co * 2u : 0x80000000u), 0, 0);
+            }
+            if (RND + 1 < ROUNDS) st_lds_barrier();
+        });
+    }
+}
+
+__global__ __launch_bounds__(256) void stage_kernel(const StArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char st_smem[];
+    __shared__ int s_info[4];
+    const int tid = threadIdx.x;
+    unsigned* const ctl = a.ctl;
+    unsigned* const cnt = ctl + ST_CTL_HDR;
+    if (tid == 0) {
+        unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 7u;
+        const unsigned slot = __hip_atomic_fetch_add(&ctl[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned gi = __hip_atomic_fetch_add(&ctl[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0; bool to = false;
+        while (st_ld_sc1(&ctl[8]) < (unsigned)ST_GRID) { __builtin_amdgcn_s_sleep(1); if (++spins > a.spin_limit) { to = true; break; } }
+        bool local = !to;
+        for (int i = 0; i < ST_NTEAM; i++) local = local && st_ld_sc1(&ctl[i]) == (unsigned)ST_TEAM;
+        s_info[0] = local ? (int)xcc : (int)(gi / ST_TEAM); s_info[1] = local ? (int)slot : (int)(gi % ST_TEAM); s_info[2] = local ? 1 : 0;
+        if (to) __hip_atomic_fetch_or(&ctl[10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_or(&ctl[11], local ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const int team = s_info[0], member = s_info[1]; const bool local = s_info[2] != 0;
+    const int i0 = team * a.ipt, i1 = min(a.N, i0 + a.ipt);
+    const unsigned smem_lds = ws_lds_addr(st_smem), lds0 = (smem_lds + 1023u) & ~1023u;
+    int tl_slot = 0;                                                  // (tiles this block has run: index of the diagnostic build's stamps)
+#pragma unroll 1
+    for (int ph = 0; ph < a.nphase; ph++) {
+        const StPhase& p = a.ph[ph];
+        const int ntiles = p.MT * p.NT, HW = p.HW;
+#pragma unroll 1
+        for (int j = member; j < ntiles; j += ST_TEAM) {
+            const int mt = (int)((unsigned)j / (unsigned)p.NT), nt = j - mt * p.NT;
+            const int pix0 = i0 * HW + mt * p.TP, PTe = min(p.TP, i1 * HW - pix0);
+            if (PTe <= 0) continue;
+            const int ia = (int)sm_fastdiv((unsigned)pix0, p.hw_mul, p.hw_sh), ib = (int)sm_fastdiv((unsigned)(pix0 + PTe - 1), p.hw_mul, p.hw_sh);
+            ST_TL(0);
+            // ---- wait for the tiles that produce this tile's inputs (wave 0, lane 0), called by the tile body behind its first weight requests ----
+            auto sync = [&]() {
+                if (tid == 0) {
+                    const int deps[3] = {p.dep0, p.dep1, p.dep2};
+                    bool waited = false;
+                    for (int d = 0; d < 3; d++) {
+                        if (deps[d] < 0) continue;
+                        const unsigned want = (unsigned)a.ph[deps[d]].expect;
+                        for (int im = ia; im <= ib; im++) {
+                            int spins = 0;
+                            while (st_ld_sc1(&cnt[deps[d] * a.cnt_ld + im]) < want) {
+                                __builtin_amdgcn_s_sleep(1);
+                                if (++spins > a.spin_limit) { __hip_atomic_fetch_or(&ctl[10], 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                            }
+                            waited = true;
+                        }
+                    }
+                    if (waited && !local) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                ST_TL(1);
+            };
+#ifdef ST_ONLY_KIND
+#define ST_CASE(k) if constexpr (ST_ONLY_KIND == k)
+#else
+#define ST_CASE(k)
+#endif
+            switch (p.kind) {
+            case 0: ST_CASE(0) st_tile<StR7>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
+            case 1: ST_CASE(1) st_tile<StT7>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
+            case 2: ST_CASE(2) st_tile<StE7>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
+            case 3: ST_CASE(3) st_tile<StR14>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
+            case 4: ST_CASE(4) st_tile<StE14>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
+            default: ST_CASE(5) st_tile<StT14>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
+            }
+            ST_TL(4);
+            // ---- publish: every wave's stores are drained, then one arrival per covered image ----
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                if (!local) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+                for (int im = ia; im <= ib; im++) __hip_atomic_fetch_add(&cnt[ph * a.cnt_ld + im], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            ST_TL(5);
+#ifdef SM_STAGE_TL
+            if (tid == 0 && tl_slot < 64) { g_st_tl[(blockIdx.x * 64 + tl_slot) * 8 + 7] = ((unsigned long long)ph << 32) | (unsigned)j | ((unsigned long long)team << 48); }
+#endif
+            tl_slot++;
+        }
+    }
+#ifdef SM_STAGE_TL
+    if (tid == 0) g_st_tl_n[blockIdx.x] = (unsigned)tl_slot;
+#endif
+    // ---- exit: the last block out resets the control words for the next launch ----
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned d = __hip_atomic_fetch_add(&ctl[9], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_info[3] = d == (unsigned)ST_GRID - 1u;
+    }
+    __syncthreads();
+    if (s_info[3]) {
+        for (int i = tid; i < a.nphase * a.cnt_ld; i += 256) __hip_atomic_store(&cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < 10) __hip_atomic_store(&ctl[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (error bits [10] and the mode word [11] stay for sm_stage_status)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct KindInfo { int KG, NG, NF, NFR, TAPS, WCH, SBG, NB, NI_MAX; };
+template <class KD> constexpr KindInfo kind_info() { return {KD::KG, KD::NG, KD::NF, KD::NFR, KD::TAPS, KD::WCH, KD::SBG, KD::NB, KD::NI_MAX}; }
+const KindInfo kKinds[ST_NKINDS] = {kind_info<StR7>(), kind_info<StT7>(), kind_info<StE7>(), kind_info<StR14>(), kind_info<StE14>(), kind_info<StT14>()};
+
+bool overlap(const void* a, size_t an, const void* b, size_t bn) { return a && b && (const char*)a < (const char*)b + bn && (const char*)b < (const char*)a + an; }
+
+// largest tile (pixels) <= cap that is a whole number of images, or an aligned part of one image
+int tile_pixels(int HW, int cap) {
+    if (HW <= cap) return cap / HW * HW;
+    for (int d = cap; d >= 16; d--) if (HW % d == 0) return d;
+    return 0;
+}
+
+// fills `a` from the caller's phase list; returns SM_OK or an error code with the reason in smelter_last_error_string
+int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
+#define ST_REQ(cond, ...) do { if (!(cond)) { if (!quiet) sm_set_error(__VA_ARGS__); return SM_ERR_INVALID_ARGUMENT; } } while (0)
+    ST_REQ(ph && n >= 1 && n <= ST_MAXPH, "sm_stage: 1 .. %d phases, got %d", ST_MAXPH, n);
+    memset(&a, 0, sizeof a);
+    const int N = ph[0].d.N;
+    ST_REQ(N >= 1 && N <= 4096, "sm_stage: batch %d", N);
+    a.nphase = n; a.N = N; a.ipt = sm_ceil_div(N, ST_NTEAM); a.spin_limit = 1000000; a.cnt_ld = (N + 15) / 16 * 16;
+    size_t lds = 0;
+    struct Range { const void* p; size_t n; };
+    std::vector<Range> ys(n);
+    for (int i = 0; i < n; i++) {
+        const sm_conv_desc& d = ph[i].d; StPhase& q = a.ph[i];
+        const bool dual = ph[i].x2 != nullptr;
+        const int K2 = dual ? ph[i].K2 : 0, K1 = d.Cin - K2;
+        ST_REQ(d.N == N && d.groups == 1 && d.dH == 1 && d.dW == 1 && d.sH == 1 && d.sW == 1 && d.Ho == d.H && d.Wo == d.W && !d.x_ups && !d.y_sH && !d.y_sW && !d.y_H,
+               "sm_stage: phase %d is not a stride-1, same-size, dense convolution", i);
+        const bool t3 = d.kH == 3 && d.kW == 3 && d.pt == 1 && d.pl == 1 && d.pb == 1 && d.pr == 1, t1 = d.kH == 1 && d.kW == 1 && d.pt == 0 && d.pl == 0 && d.pb == 0 && d.pr == 0;
+        ST_REQ(t1 || t3, "sm_stage: phase %d: 1x1 / no padding or 3x3 / padding 1 only", i);
+        ST_REQ(d.act >= SM_ACT_NONE && d.act <= SM_ACT_PRELU, "sm_stage: phase %d: activation %d (none, ReLU, leaky / PReLU only)", i, d.act);
+        ST_REQ(!(t3 && dual) && K1 > 0, "sm_stage: phase %d: a second source needs a 1x1 phase", i);
+        const int HW = d.H * d.W, x_ld = d.x_ld ? d.x_ld : K1, y_ld = d.y_ld ? d.y_ld : d.Cout, res_ld = d.res_ld ? d.res_ld : d.Cout, x2_ld = dual ? (ph[i].x2_ld ? ph[i].x2_ld : K2) : 0;
+        ST_REQ((d.Cout & 7) == 0 && (x_ld & 7) == 0 && (y_ld & 7) == 0 && (res_ld & 7) == 0 && (x2_ld & 7) == 0 && !((uintptr_t)ph[i].x & 15) && !((uintptr_t)ph[i].y & 15) && !((uintptr_t)ph[i].w_ohwi & 15) &&
+               !((uintptr_t)ph[i].w_packed & 15) && !((uintptr_t)ph[i].bias & 15) && !((uintptr_t)ph[i].residual & 15) && !((uintptr_t)ph[i].x2 & 15) && ph[i].x && ph[i].y && ph[i].w_ohwi, "sm_stage: phase %d: 16-byte aligned operands, channel counts and strides % 8", i);
+        const long xb = (long)N * HW * x_ld * 2, yb = (long)N * HW * y_ld * 2, rb = ph[i].residual ? (long)N * HW * res_ld * 2 : 0, wb = (long)d.Cout * d.kH * d.kW * d.Cin * 2;
+        const long x2b = dual ? (long)N * ph[i].x2_H * ph[i].x2_W * x2_ld * 2 : 0;
+        ST_REQ(xb < 0x7fff0000L && yb < 0x7fff0000L && rb < 0x7fff0000L && wb < 0x7fff0000L && x2b < 0x7fff0000L, "sm_stage: phase %d: a tensor of 2 GB or more", i);
+        if (dual) ST_REQ(ph[i].x2_stride >= 1 && (long)(d.H - 1) * ph[i].x2_stride < ph[i].x2_H && (long)(d.W - 1) * ph[i].x2_stride < ph[i].x2_W && K2 > 0, "sm_stage: phase %d: second source geometry", i);
+        // ---- kind: the cheapest by bytes a CU pulls through its L1 (tiles per CU x (pixels + couts) x K x 2) ----
+        const int team_px = a.ipt * HW;
+        int best = -1, best_tp = 0; double best_cost = 0;
+        for (int k = 0; k < ST_NKINDS; k++) {
+            const KindInfo& ki = kKinds[k];
+            if ((ki.TAPS == 9) != t3 || (ph[i].form > 0 && ph[i].form != k + 1)) continue;
+            const int sbch = ki.KG * ki.WCH;
+            if (K1 % sbch || (dual && (K2 % sbch || !(ki.TAPS == 1 && ki.KG == 1))) || ((K1 + K2) / sbch) % ki.SBG) continue;
+            int tp, ni;
+            if (t3) {
+                if (HW > ki.NFR * 16) continue;
+                const int rs = (d.W + 1 + 7) / 8 * 8, extra = rs == d.W + 1 ? 1 : 0;
+                int ti = ki.NFR * 16 / HW;                               // whole images per tile: as many as the fragments and the patch instructions allow
+                while (ti > 1 && (ti * (d.H + 1) + 1) * (rs / 8) + extra > ki.NI_MAX) ti--;
+                tp = ti * HW; ni = (ti * (d.H + 1) + 1) * (rs / 8) + extra;
+            } else { tp = tile_pixels(HW, ki.NFR * 16); if (!tp) continue; ni = (tp + 7) / 8; }
+            if (ni > ki.NI_MAX) continue;
+            const size_t need = (size_t)ki.NB * ki.KG * (ki.WCH / 64) * ni * 1024 + 1024 + 1024;
+            const size_t red = ki.KG > 1 ? (size_t)4 * std::min(ki.NFR, 7) * 16 * (ki.NF * 16 + 4) * 4 + 1024 : 0;
+            if (std::max(need, red) > 160 * 1024 - 64) continue;
+            const int mt = sm_ceil_div(team_px, tp), nt = sm_ceil_div(d.Cout, (4 / ki.KG) * ki.NF * 16);
+            const double cost = (double)sm_ceil_div(mt * nt, ST_TEAM) * ((double)tp + (4 / ki.KG) * ki.NF * 16) * (K1 + K2) * (t3 ? 1.0 : 1.0) * 2 * (ki.KG > 1 ? 1.05 : 1.0);
+            if (best < 0 || cost < best_cost) { best = k; best_cost = cost; best_tp = tp; }
+        }
+        ST_REQ(best >= 0, "sm_stage: phase %d (%dx%d, %d -> %d channels, %dx%d kernel): no tile form takes it", i, d.H, d.W, d.Cin, d.Cout, d.kH, d.kW);
+        const KindInfo& ki = kKinds[best];
+        q.x = (const half_t*)ph[i].x; q.x2 = (const half_t*)ph[i].x2; q.w = (const half_t*)ph[i].w_ohwi; q.wp = (const half_t*)ph[i].w_packed; q.bias = ph[i].bias; q.res = (const half_t*)ph[i].residual; q.y = (half_t*)ph[i].y;
+        q.kind = best; q.H = d.H; q.W = d.W; q.HW = HW; q.K1 = K1; q.K = d.kH * d.kW * K1 + K2; q.Cout = d.Cout;
+        q.x_ld = x_ld; q.x2_ld = x2_ld; q.res_ld = res_ld; q.y_ld = y_ld; q.x2_W = dual ? ph[i].x2_W : 0; q.x2_HW = dual ? ph[i].x2_H * ph[i].x2_W : 0; q.x2_s = dual ? ph[i].x2_stride : 1;
+        q.act = d.act; q.slope = d.act == SM_ACT_RELU ? 0.f : d.slope;
+        q.TP = best_tp; q.TI = t3 ? best_tp / HW : 0; q.MT = sm_ceil_div(team_px, best_tp); q.NT = sm_ceil_div(d.Cout, (4 / ki.KG) * ki.NF * 16);
+        const int sbch = ki.KG * ki.WCH;
+        q.nsb1 = K1 / sbch; q.nsb = (K1 + K2) / sbch;
+        q.RS = t3 ? (d.W + 1 + 7) / 8 * 8 : 8; q.NI = t3 ? (q.TI * (d.H + 1) + 1) * (q.RS / 8) + (q.RS == d.W + 1 ? 1 : 0) : (best_tp + 7) / 8;
+        q.x_bytes = (unsigned)xb; q.x2_bytes = (unsigned)x2b; q.res_bytes = (unsigned)rb; q.y_bytes = (unsigned)yb;
+        sm_fastdiv_make((unsigned)HW, &q.hw_mul, &q.hw_sh); sm_fastdiv_make((unsigned)d.W, &q.w_mul, &q.w_sh); sm_fastdiv_make((unsigned)(d.H + 1), &q.h1_mul, &q.h1_sh);
+        sm_fastdiv_make((unsigned)(q.RS / 8), &q.kpr_mul, &q.kpr_sh);
+        // arrivals per image: every cout tile of every pixel tile that overlaps the image
+        q.expect = q.NT * (HW > best_tp ? HW / best_tp : 1);
+        lds = std::max(lds, std::max((size_t)ki.NB * ki.KG * (ki.WCH / 64) * q.NI * 1024 + 1024, ki.KG > 1 ? (size_t)4 * std::min(ki.NFR, 7) * 16 * (ki.NF * 16 + 4) * 4 : (size_t)0) + 1024);
+        ys[i] = {ph[i].y, (size_t)yb};
+        // ---- producers: the LATEST earlier phase whose output holds the operand ----
+        q.dep0 = q.dep1 = q.dep2 = -1;
+        for (int e = 0; e < i; e++) {
+            if (overlap(ph[i].x, (size_t)xb, ys[e].p, ys[e].n)) q.dep0 = e;
+            if (dual && overlap(ph[i].x2, (size_t)x2b, ys[e].p, ys[e].n)) q.dep1 = e;
+            if (ph[i].residual && overlap(ph[i].residual, (size_t)rb, ys[e].p, ys[e].n)) q.dep2 = e;
+        }
+        // a producer hands over whole images: its image grid must be this phase's (same N is given; a second source at another resolution is still per image)
+    }
+    // ---- no phase may overwrite what another phase of the run reads or writes (images advance independently: there is no run-wide order between phases) ----
+    for (int i = 0; i < n; i++)
+        for (int e = 0; e < n; e++) {
+            if (e == i) {
+                const sm_conv_desc& d = ph[i].d; const int HW = d.H * d.W; const bool dual = ph[i].x2 != nullptr; const int K2 = dual ? ph[i].K2 : 0, K1 = d.Cin - K2;
+                ST_REQ(!overlap(ys[i].p, ys[i].n, ph[i].x, (size_t)N * HW * (d.x_ld ? d.x_ld : K1) * 2) && !overlap(ys[i].p, ys[i].n, ph[i].residual, ph[i].residual ? (size_t)N * HW * (d.res_ld ? d.res_ld : d.Cout) * 2 : 0) &&
+                       !overlap(ys[i].p, ys[i].n, ph[i].x2, dual ? (size_t)N * ph[i].x2_H * ph[i].x2_W * (ph[i].x2_ld ? ph[i].x2_ld : K2) * 2 : 0), "sm_stage: phase %d works in place", i);
+                continue;
+            }
+            const sm_conv_desc& d = ph[e].d;
+            const int HW = d.H * d.W;
+            const bool dual = ph[e].x2 != nullptr; const int K2 = dual ? ph[e].K2 : 0, K1 = d.Cin - K2;
+            const size_t xb = (size_t)N * HW * (d.x_ld ? d.x_ld : K1) * 2, rb = ph[e].residual ? (size_t)N * HW * (d.res_ld ? d.res_ld : d.Cout) * 2 : 0;
+            const size_t x2b = dual ? (size_t)N * ph[e].x2_H * ph[e].x2_W * (ph[e].x2_ld ? ph[e].x2_ld : K2) * 2 : 0;
+            const bool reads = overlap(ys[i].p, ys[i].n, ph[e].x, xb) || overlap(ys[i].p, ys[i].n, ph[e].x2, x2b) || overlap(ys[i].p, ys[i].n, ph[e].residual, rb);
+            ST_REQ(!(reads && e < i), "sm_stage: phase %d overwrites an input of phase %d", i, e);
+            ST_REQ(!(reads && e > i && a.ph[e].dep0 != i && a.ph[e].dep1 != i && a.ph[e].dep2 != i), "sm_stage: phase %d's output is overwritten before phase %d reads it", i, e);
+            ST_REQ(!overlap(ys[i].p, ys[i].n, ys[e].p, ys[e].n), "sm_stage: phases %d and %d write overlapping tensors", i, e);
+        }
+    a.lds_bytes = (int)lds;
+    ST_REQ(lds <= 160 * 1024 - 64, "sm_stage: %zu bytes of LDS", lds);   // (+ 16 bytes of static LDS)
+    return SM_OK;
+#undef ST_REQ
+}
+
+}  // namespace
+
+extern "C" int sm_stage_supported(const sm_stage_phase* ph, int32_t n) { StArgs a; return stage_plan(ph, n, a, true) == SM_OK ? 1 : 0; }
+extern "C" size_t sm_stage_ctl_bytes(const sm_stage_phase* ph, int32_t n) {
+    if (!ph || n < 1) return 0;
+    return (size_t)(ST_CTL_HDR + (size_t)ST_MAXPH * ((ph[0].d.N + 15) / 16 * 16)) * 4;
+}
+extern "C" int sm_stage_phase_kind(const sm_stage_phase* ph, int32_t n, int32_t i) { StArgs a; if (stage_plan(ph, n, a, true) != SM_OK || i < 0 || i >= n) return -1; return a.ph[i].kind; }
+// phase i's weights in the fragment order its tile form reads: [cout tile][ng][kg][super-block][unit = (tap, 32-channel piece)][fragment j][lane (l15, g)][8 halfs],
+// element e of lane (l15, g) = w[cout(tile, ng, j, l15)][tap][channel sb SBCH + kg WCH + piece 32 + 8 g + e]; couts beyond Cout are zero rows.  Host memory on both sides.
+extern "C" size_t sm_stage_packed_weight_bytes(const sm_stage_phase* ph, int32_t n, int32_t i) {
+    StArgs a;
+    if (stage_plan(ph, n, a, true) != SM_OK || i < 0 || i >= n) return 0;
+    const KindInfo& ki = kKinds[a.ph[i].kind];
+    return (size_t)a.ph[i].NT * (4 / ki.KG) * ki.NF * 16 * (size_t)a.ph[i].K * 2;
+}
+extern "C" int sm_stage_pack_weights(const sm_stage_phase* ph, int32_t n, int32_t i, const void* w_ohwi_host, void* dst_host) {
+    StArgs a;
+    const int rc = stage_plan(ph, n, a, false);
+    if (rc) return rc;
+    SM_REQUIRE(i >= 0 && i < n && w_ohwi_host && dst_host, "sm_stage_pack_weights: phase %d of %d", i, n);
+    const StPhase& q = a.ph[i]; const KindInfo& ki = kKinds[q.kind];
+    const int KG = ki.KG, NG = 4 / ki.KG, NF = ki.NF, WCH = ki.WCH, QPW = WCH / 32, UPS = ki.TAPS * QPW, SBCH = KG * WCH, BN = NG * NF * 16;
+    const uint16_t* w = (const uint16_t*)w_ohwi_host; uint16_t* dst = (uint16_t*)dst_host;
+    size_t o = 0;
+    for (int nt = 0; nt < q.NT; nt++)
+        for (int ng = 0; ng < NG; ng++)
+            for (int kg = 0; kg < KG; kg++)
+                for (int sb = 0; sb < q.nsb; sb++)
+                    for (int ul = 0; ul < UPS; ul++)
+                        for (int j = 0; j < NF; j++)
+                            for (int lane = 0; lane < 64; lane++) {
+                                const int l15 = lane & 15, g = lane >> 4, co0 = nt * BN + ng * NF * 16;
+                                const int co = KG == 1 ? co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) : co0 + j * 16 + l15;
+                                const size_t k = (size_t)(ul / QPW) * q.K1 + (size_t)sb * SBCH + kg * WCH + (ul % QPW) * 32 + g * 8;
+                                if (co < q.Cout) memcpy(dst + o, w + (size_t)co * q.K + k, 16); else memset(dst + o, 0, 16);
+                                o += 8;
+                            }
+    return SM_OK;
+}
+extern "C" int sm_stage_fwd(const sm_stage_phase* ph, int32_t n, void* ctl, sm_stream_t stream) {
+    StArgs a;
+    const int rc = stage_plan(ph, n, a, false);
+    if (rc) return rc;
+    SM_REQUIRE(ctl && !((uintptr_t)ctl & 15), "sm_stage_fwd: ctl = %p (sm_stage_ctl_bytes of zeroed device memory, 16-byte aligned)", ctl);
+    a.ctl = (unsigned*)ctl;
+    static int cu_count = 0;
+    if (!cu_count) {
+        int dev = 0; hipDeviceProp_t prop;
+        SM_HIP_CHECK(hipGetDevice(&dev)); SM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cu_count = prop.multiProcessorCount;
+    }
+    // co-residency: one block per CU (the kernel's LDS and registers admit no second block), every block of the grid must be resident for the hand-offs to complete
+    SM_REQUIRE(cu_count >= ST_GRID, "sm_stage_fwd: %d compute units, the persistent grid needs %d resident blocks", cu_count, ST_GRID);
+    hipLaunchKernelGGL(stage_kernel, dim3(ST_GRID), dim3(256), (size_t)a.lds_bytes, sm_s(stream), a);
+    SM_LAUNCH_CHECK();
+    return SM_OK;
+}
+// bit 0: the blocks did not all become resident in time; bit 1: a hand-off wait ran out.  mode: 1 = XCD-local hand-off, 2 = fenced (placement was not 32 blocks per XCD), 3 = both seen.
+// Synchronises the stream.  Clears the words.
+extern "C" int sm_stage_status(void* ctl, sm_stream_t stream, int32_t* error_bits, int32_t* mode) {
+    unsigned h[2] = {0, 0};
+    SM_HIP_CHECK(hipMemcpyAsync(h, (char*)ctl + 10 * 4, 8, hipMemcpyDeviceToHost, sm_s(stream)));
+    SM_HIP_CHECK(hipStreamSynchronize(sm_s(stream)));
+    SM_HIP_CHECK(hipMemsetAsync((char*)ctl + 10 * 4, 0, 8, sm_s(stream)));
+    if (error_bits) *error_bits = (int32_t)h[0];
+    if (mode) *mode = (int32_t)h[1];
+    return SM_OK;
+}
+#ifdef SM_STAGE_TL
+extern "C" int sm_stage_timeline_read(unsigned long long* dst, unsigned* counts) {
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_st_tl), sizeof(unsigned long long) * ST_GRID * 64 * 8) != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_st_tl_n), sizeof(unsigned) * ST_GRID) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -10,7 +10,7 @@ import ctypes as C
 
 import torch
 
-from ._native import ConvDesc, PoolDesc, check, lib
+from ._native import ConvDesc, PoolDesc, StagePhase, check, lib
 
 ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
 
@@ -106,6 +106,76 @@ def conv2d_dual(x, x2, w_ohwi, bias=None, stride2=1, act=ACT_NONE, slope=0.0, cf
     check(lib().sm_conv2d_dual_fwd_cfg(C.byref(d), cfg, _ptr(x), _ptr(x2), k2, x2_ld, h2, w2, stride2, _ptr(w_ohwi), _ptr(bias), _ptr(out), _stream()))
     _ran(cfg)
     return out
+
+
+class Stage:
+    """A run of convolutions as ONE persistent launch (sm_stage_fwd).  `add(...)` appends a phase with the operands of `conv2d` / `conv2d_dual`;
+    tensors are kept alive by the object.  `run()` enqueues the launch, `status()` reads (error_bits, mode) after synchronising."""
+
+    def __init__(self):
+        self.phases, self.keep, self.ctl = [], [], None
+
+    def add(self, x, w_ohwi, bias=None, residual=None, act=ACT_NONE, slope=0.0, out=None, x2=None, stride2=1, kind=None):
+        n, h, w, k1, x_ld = _check_nhwc(x)
+        cout, kh, kw, kk = w_ohwi.shape
+        k2 = 0
+        if x2 is not None:
+            n2, h2, w2, k2, x2_ld = _check_nhwc(x2)
+            assert n2 == n
+        assert kk == k1 + k2 and w_ohwi.dtype == torch.float16 and w_ohwi.is_contiguous()
+        pad = (kh - 1) // 2
+        if out is None:
+            out = torch.empty((n, h, w, cout), dtype=torch.float16, device=x.device)
+        res_ld = _ld(residual) if residual is not None else 0
+        ph = StagePhase()
+        ph.d = ConvDesc(n, h, w, k1 + k2, cout, kh, kw, 1, 1, 1, 1, pad, pad, pad, pad, 1, h, w, act, slope, x_ld, _ld(out), res_ld)
+        ph.x, ph.w_ohwi, ph.bias, ph.residual, ph.y = x.data_ptr(), w_ohwi.data_ptr(), bias.data_ptr() if bias is not None else None, \
+            residual.data_ptr() if residual is not None else None, out.data_ptr()
+        if x2 is not None:
+            ph.x2, ph.K2, ph.x2_ld, ph.x2_H, ph.x2_W, ph.x2_stride = x2.data_ptr(), k2, x2_ld, h2, w2, stride2
+        ph.form = 0 if kind is None else kind + 1
+        self.phases.append(ph)
+        self.keep += [x, w_ohwi, bias, residual, out, x2]
+        return out
+
+    def _array(self, sel=None):
+        ph = self.phases if sel is None else [self.phases[i] for i in sel]
+        return (StagePhase * len(ph))(*ph), len(ph)
+
+    def supported(self):
+        arr, n = self._array()
+        return bool(lib().sm_stage_supported(arr, n))
+
+    def kinds(self):
+        arr, n = self._array()
+        return [lib().sm_stage_phase_kind(arr, n, i) for i in range(n)]
+
+    def pack(self):
+        """re-order every phase's weights for the tile form the planner gave it (sm_stage_pack_weights, host side) and hand the kernel the packed copies"""
+        arr, n = self._array()
+        self.packed = []
+        ws = [t for t in self.keep[1::6]]
+        for i in range(n):
+            nb = lib().sm_stage_packed_weight_bytes(arr, n, i)
+            wh = ws[i].cpu().contiguous()
+            dst = torch.empty(nb // 2, dtype=torch.float16)
+            check(lib().sm_stage_pack_weights(arr, n, i, C.c_void_p(wh.data_ptr()), C.c_void_p(dst.data_ptr())))
+            d = dst.cuda()
+            self.packed.append(d)
+            self.phases[i].w_packed = d.data_ptr()
+
+    def run(self, sel=None):
+        """sel: indices of the phases to launch as one run (default: all)"""
+        arr, n = self._array(sel)
+        if self.ctl is None:
+            full, nf = self._array()
+            self.ctl = torch.zeros(lib().sm_stage_ctl_bytes(full, nf) // 4, dtype=torch.int32, device="cuda")
+        check(lib().sm_stage_fwd(arr, n, _ptr(self.ctl), _stream()))
+
+    def status(self):
+        e, m = C.c_int32(), C.c_int32()
+        check(lib().sm_stage_status(_ptr(self.ctl), _stream(), C.byref(e), C.byref(m)))
+        return e.value, m.value
 
 
 def stem_conv(x_nchw, w_ohwi_f32, bias=None, stride=1, pads=(0, 0, 0, 0), act=ACT_NONE, slope=0.0, cfg=None):

@@ -1,0 +1,256 @@
+"""sm_stage_fwd — a run of convolutions as ONE persistent launch (csrc/kernels/stage.hip) — on a real MI355X, through the C ABI, against the CPU oracle.
+
+What is checked, and why in this form:
+  * every tile form ("kind") alone, at the channel counts / image sizes of ResNet-50's stages 3 and 4, against `O.conv2d` on identical fp16-rounded inputs
+    (tolerance of tests/test_gpu_ops.py: 1 fp16 ulp + an accumulation-order floor);
+  * a whole run against the oracle PHASE BY PHASE: every intermediate tensor the run wrote is read back and each phase is re-computed by the oracle from the
+    run's OWN inputs to that phase — a stale or early read of a hand-off shows up as a gross error of exactly that phase, not as a blur over the chain;
+  * the hand-off itself: the run in one launch must be BIT-IDENTICAL to the same phases launched one at a time (each launch boundary is a full
+    synchronisation); repeated, so that a control word the kernel failed to reset would surface;
+  * ragged shapes: batches that are not a multiple of 8 (teams with fewer / no images), Cout that is not a multiple of the cout tile, non-dense pixel strides;
+  * the real shapes (64 x 7^2 x 2048, 64 x 14^2 x 1024): bit-identity as above + the oracle on sampled pixels (1x1) / on whole images {0, N-1} (3x3).
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from smelter_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def h(a):
+    return O.round_to_half(np.asarray(a, np.float32))
+
+
+def dev(a_nchw):
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a_nchw, np.float32).transpose(0, 2, 3, 1))).cuda().half()
+
+
+def host(t_nhwc):
+    torch.cuda.synchronize()
+    return t_nhwc.float().cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def assert_close(got, ref, k):
+    ref16 = h(ref)
+    tol = np.abs(ref16) * 2.0 ** -10 + np.abs(ref).max() * 2.0 ** -11 * max(1.0, np.sqrt(k)) * 1e-2 + 1e-7
+    bad = np.abs(got - ref16) > tol
+    assert not bad.any(), "max err %g (max |ref| %g) at %d of %d elements" % (np.abs(got - ref16).max(), np.abs(ref).max(), bad.sum(), bad.size)
+
+
+def act_ref(v, act, slope):
+    return v if act == 0 else np.where(v >= 0, v, v * (0.0 if act == 1 else slope))
+
+
+def weights(rng, cout, k, cin):
+    return h(rng.standard_normal((cout, k, k, cin)) * np.sqrt(2.0 / (k * k * cin)))
+
+
+class Net:
+    """a run under construction: device tensors for sm_stage_fwd + what the oracle needs to redo each phase"""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.st = ops.Stage()
+        self.recs = []
+
+    def phase(self, x, cout, k=1, res=None, act=1, slope=0.0, x2=None, stride2=1, bias=True, out=None, kind=None):
+        cin = x.shape[3] + (x2.shape[3] if x2 is not None else 0)
+        w = weights(self.rng, cout, k, cin)
+        b = self.rng.standard_normal(cout).astype(np.float32) * 0.1 if bias else None
+        wd = torch.from_numpy(w).cuda().half()
+        bd = torch.from_numpy(b).cuda() if bias else None
+        y = self.st.add(x, wd, bd, residual=res, act=act, slope=slope, x2=x2, stride2=stride2, out=out, kind=kind)
+        self.recs.append(dict(x=x, x2=x2, stride2=stride2, w=w, b=b, res=res, act=act, slope=slope, y=y, k=k))
+        return y
+
+    def oracle_phase(self, i, imgs=None):
+        """phase i re-computed by the oracle from the tensors the GPU run read (optionally only images `imgs`)"""
+        r = self.recs[i]
+        sel = slice(None) if imgs is None else imgs
+        x = host(r["x"])[sel]
+        pad = (r["k"] - 1) // 2
+        if r["x2"] is not None:
+            x2 = host(r["x2"])[sel][:, :, ::r["stride2"], ::r["stride2"]][:, :, :x.shape[2], :x.shape[3]]
+            x = np.concatenate([x, x2], axis=1)
+        ref = O.conv2d(x, r["w"], r["b"], pads=(pad, pad, pad, pad))
+        if r["res"] is not None:
+            ref = ref + host(r["res"])[sel]
+        return act_ref(ref, r["act"], r["slope"]), x.shape[1] * r["k"] ** 2
+
+
+def bottleneck_run(n, hw, cin, mid, blocks, seed, head_src=None):
+    """ResNet bottleneck blocks at one resolution: [1x1 cin -> mid, 3x3 mid -> mid, 1x1 mid -> cin + residual] x blocks; with `head_src` (the previous stage's output at twice
+    the resolution, cin / 2 channels) the run starts with the K-concatenated expand + projection shortcut of a stage's first block (executor pass 3h)"""
+    net = Net(seed)
+    rng = np.random.default_rng(seed + 1000)
+    if head_src:
+        t0 = dev(h(np.abs(rng.standard_normal((n, mid, hw, hw)))))
+        xin = dev(h(np.abs(rng.standard_normal((n, cin // 2, 2 * hw, 2 * hw)))))
+        cur = net.phase(t0, cin, 1, x2=xin, stride2=2)
+    else:
+        cur = dev(h(np.abs(rng.standard_normal((n, cin, hw, hw)))))
+    for _ in range(blocks):
+        r = net.phase(cur, mid, 1)
+        t = net.phase(r, mid, 3)
+        cur = net.phase(t, cin, 1, res=cur)
+    return net
+
+
+def run_and_snapshot(net, sel=None):
+    net.st.run(sel)
+    torch.cuda.synchronize()
+    return [r["y"].clone() for r in net.recs]
+
+
+def check_status(net, want_local=True):
+    err, mode = net.st.status()
+    assert err == 0, "sm_stage_status error bits %d" % err
+    if want_local:
+        assert mode == 1, "the run did not take the XCD-local hand-off (mode %d)" % mode
+
+
+# (n, hw, cin, cout, k, dual, res, act, tile form or None = the planner's choice)
+SINGLE = [
+    (16, 7, 2048, 512, 1, False, False, 1, 0),     # R7   K split, 98 px x 64 couts
+    (16, 7, 512, 512, 3, False, False, 1, 1),      # T7   3x3, two images per tile
+    (16, 7, 512, 2048, 1, False, True, 1, 2),      # E7   cout split, residual
+    (16, 7, 512, 2048, 1, True, False, 1, 2),      # E7   second source (stride 2)
+    (8, 14, 1024, 256, 1, False, False, 1, 3),     # R14  half-image tiles
+    (8, 14, 256, 1024, 1, False, True, 1, 4),      # E14  residual
+    (8, 14, 256, 1024, 1, True, False, 2, 4),      # E14  second source, PReLU
+    (8, 14, 256, 256, 3, False, False, 1, 5),      # T14  one image per tile
+    (13, 7, 512, 200, 1, False, True, 0, None),    # ragged batch (teams 0-5 two images, 6 one, 7 none), Cout % 64 != 0, no activation
+    (5, 14, 256, 72, 3, False, False, 2, 5),       # five images: teams 5-7 idle; Cout = 72 (second cout tile mostly dead)
+    (3, 5, 256, 64, 3, False, False, 1, 1),        # 5 x 5 images: four per 3x3 tile, RS = 8 > W + 1
+    (9, 10, 128, 256, 1, False, False, 1, None),   # 100-pixel images, K = 128: one super-block
+    (2, 12, 256, 256, 3, False, True, 1, 5),       # 144-pixel images, residual on a 3x3 phase
+]
+
+
+@pytest.mark.parametrize("case", SINGLE)
+def test_single_phase_vs_oracle(case):
+    n, hw, cin, cout, k, dual, res, act, kind = case
+    rng = np.random.default_rng(hash(case) & 0xffff)
+    net = Net(7)
+    x = dev(h(rng.standard_normal((n, cin, hw, hw))))
+    x2 = dev(h(rng.standard_normal((n, 2 * cin, 2 * hw, 2 * hw)))) if dual else None     # second source: twice the channels at twice the resolution, read at stride 2
+    r = dev(h(rng.standard_normal((n, cout, hw, hw)))) if res else None
+    y = net.phase(x, cout, k, res=r, act=act, slope=0.25, x2=x2, stride2=2, kind=kind)     # (the tile form is forced: at these small batches the planner would pick by tile count)
+    assert net.st.supported()
+    if kind is not None:
+        assert net.st.kinds() == [kind]
+    net.st.run()
+    ref, kk = net.oracle_phase(0)
+    assert_close(host(y), ref, kk)
+    first = y.clone()
+    net.st.pack(); y.zero_(); net.st.run(); torch.cuda.synchronize()
+    assert torch.equal(y, first), "packed weights: %d elements differ from the OHWI run" % int((y != first).sum())
+    check_status(net)
+
+
+def test_pixel_strides_and_channel_slices():
+    """operands that are channel slices of wider tensors (concat placement): x_ld, y_ld, res_ld differ from the channel counts"""
+    rng = np.random.default_rng(3)
+    n, hw = 8, 7
+    xw = dev(h(rng.standard_normal((n, 640, hw, hw)))); x = xw[..., 64:576]
+    rw = dev(h(rng.standard_normal((n, 2048 + 64, hw, hw)))); r = rw[..., 64:]
+    yw = torch.zeros((n, hw, hw, 2048 + 128), dtype=torch.float16, device="cuda"); y = yw[..., 128:]
+    net = Net(4)
+    net.phase(x, 2048, 1, res=r, out=y)
+    net.st.run()
+    ref, kk = net.oracle_phase(0)
+    assert_close(host(y), ref, kk)
+    assert float(yw[..., :128].abs().max()) == 0.0   # nothing written outside the slice
+    check_status(net)
+
+
+@pytest.mark.parametrize("shape", [(16, 7, 2048, 512, True), (8, 14, 1024, 256, True), (16, 7, 2048, 512, False), (11, 14, 1024, 256, False)])
+def test_run_phase_by_phase_vs_oracle_and_bit_identical_to_single_launches(shape):
+    n, hw, cin, mid, head = shape
+    net = bottleneck_run(n, hw, cin, mid, 2, seed=hw + n, head_src=head)
+    assert net.st.supported()
+    fused = run_and_snapshot(net)
+    check_status(net)
+    for i in range(len(net.recs)):                       # each phase against the oracle on the run's own inputs
+        ref, kk = net.oracle_phase(i)
+        assert_close(host(fused[i]), ref, kk)
+    for r in net.recs:
+        r["y"].zero_()
+    for i in range(len(net.recs)):                       # the same phases, one launch each
+        net.st.run([i])
+    torch.cuda.synchronize()
+    for i, r in enumerate(net.recs):
+        assert torch.equal(r["y"], fused[i]), "phase %d: one launch per phase and the single run differ in %d elements" % (i, int((r["y"] != fused[i]).sum()))
+    for rep in range(5):                                 # again and again: the kernel must leave its control words as it found them
+        again = run_and_snapshot(net)
+        for i in range(len(net.recs)):
+            assert torch.equal(again[i], fused[i]), "repeat %d, phase %d differs" % (rep, i)
+    net.st.pack()                                        # the weights in fragment order (sm_stage_pack_weights): another memory layout, the same sums in the same order
+    packed = run_and_snapshot(net)
+    for i in range(len(net.recs)):
+        assert torch.equal(packed[i], fused[i]), "packed weights, phase %d: differs from the OHWI run in %d elements" % (i, int((packed[i] != fused[i]).sum()))
+    check_status(net)
+
+
+@pytest.mark.parametrize("stage", ["stage4", "stage3"])
+def test_real_shape_run(stage):
+    """ResNet-50 bs 64: stage 4 = 64 x 7^2 x 2048 (mid 512, head + 2 blocks: 7 phases), stage 3 = 64 x 14^2 x 1024 (mid 256, head + 5 blocks: 16 phases)"""
+    n = 64
+    hw, cin, mid, blocks = (7, 2048, 512, 2) if stage == "stage4" else (14, 1024, 256, 5)
+    net = bottleneck_run(n, hw, cin, mid, blocks, seed=11, head_src=True)
+    assert net.st.supported()
+    want = {"stage4": [2] + [0, 1, 2] * 2, "stage3": [4] + [3, 5, 4] * 5}[stage]
+    assert net.st.kinds() == want
+    fused = run_and_snapshot(net)
+    check_status(net)
+    rng = np.random.default_rng(5)
+    for i, r in enumerate(net.recs):
+        got = host(fused[i])
+        if r["k"] == 3:                                  # whole images: the first and the LAST of the batch (the last tile of the last team)
+            ref, kk = net.oracle_phase(i, imgs=[0, n - 1])
+            assert_close(got[[0, n - 1]], ref, kk)
+        else:                                            # 1x1: per pixel — sampled pixels through the same oracle code
+            P = 2048
+            flat = rng.choice(n * hw * hw, size=P, replace=False)
+            ni, rem = np.divmod(flat, hw * hw); oy, ox = np.divmod(rem, hw)
+            x = host(r["x"])[ni, :, oy, ox]
+            if r["x2"] is not None:
+                x = np.concatenate([x, host(r["x2"])[ni, :, oy * 2, ox * 2]], axis=1)
+            ref = O.conv2d(np.ascontiguousarray(x.T[None, :, None, :]), r["w"], r["b"])[0, :, 0, :]
+            if r["res"] is not None:
+                ref = ref + host(r["res"])[ni, :, oy, ox].T
+            assert_close(got[ni, :, oy, ox].T, act_ref(ref, r["act"], r["slope"]), x.shape[1])
+    for r in net.recs:
+        r["y"].zero_()
+    for i in range(len(net.recs)):
+        net.st.run([i])
+    torch.cuda.synchronize()
+    for i, r in enumerate(net.recs):
+        assert torch.equal(r["y"], fused[i]), "phase %d: one launch per phase and the single run differ in %d elements" % (i, int((r["y"] != fused[i]).sum()))
+    net.st.pack()
+    for rep in range(3):
+        again = run_and_snapshot(net)
+        assert all(torch.equal(again[i], fused[i]) for i in range(len(net.recs))), "repeat %d (packed weights) differs" % rep
+    check_status(net)
+
+
+def test_rejected_runs():
+    """what sm_stage_supported must refuse: strides, aliasing, in-place phases"""
+    x = torch.zeros((8, 7, 7, 512), dtype=torch.float16, device="cuda")
+    w = torch.zeros((512, 1, 1, 512), dtype=torch.float16, device="cuda")
+    st = ops.Stage(); y = st.add(x, w); st.add(y, w, out=x)          # phase 1 overwrites phase 0's input
+    assert not st.supported()
+    st = ops.Stage(); st.add(x, w, out=x)                             # in place
+    assert not st.supported()
+    st = ops.Stage(); y = st.add(x, w); st.add(x, w, out=y)           # two phases write the same tensor
+    assert not st.supported()
+    w5 = torch.zeros((512, 5, 5, 512), dtype=torch.float16, device="cuda")
+    st = ops.Stage(); st.add(x, w5)
+    assert not st.supported()
+    big = torch.zeros((8, 28, 28, 512), dtype=torch.float16, device="cuda")   # 784-pixel images: no tile form yet
+    w3 = torch.zeros((512, 3, 3, 512), dtype=torch.float16, device="cuda")
+    st = ops.Stage(); st.add(big, w3)
+    assert not st.supported()

@@ -1,0 +1,48 @@
+"""Per-phase timeline of ONE sm_stage_fwd run (diagnostic build: tools/stage_tl.sh, SMELTER_LIB_PATH=build/libsmelter_hip_stagetl.so).
+Every block stamps the 100 MHz wall clock (the same counter on every XCD) per tile: 0 tile start (weights requested), 1 producers published + block synchronised,
+2 first patch landed, 3 main loop done, 4 epilogue done (stores issued), 5 stores drained + published.  Printed per phase: when the first / last tile of the phase starts and
+ends (us after the first stamp of the kernel), and the average length of each segment.  Usage: python tools/stage_tl.py [stage4|stage3] [reps]"""
+import ctypes as C
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+sys.path.insert(0, "tools")
+from smelter_amd import ops
+from smelter_amd._native import lib
+from stage_bench import build
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "stage4"
+    hw, cin, mid, blocks = (7, 2048, 512, 2) if which == "stage4" else (14, 1024, 256, 5)
+    st, layers = build(64, hw, cin, mid, blocks, pack="nopack" not in sys.argv)
+    L = lib()
+    L.sm_stage_timeline_read.argtypes = [C.c_void_p, C.c_void_p]; L.sm_stage_timeline_read.restype = C.c_int
+    for _ in range(5):
+        st.run()
+    torch.cuda.synchronize()
+    tl = np.zeros((256, 64, 8), np.uint64); cnt = np.zeros(256, np.uint32)
+    assert L.sm_stage_timeline_read(tl.ctypes.data, cnt.ctypes.data) == 0
+    print("status", st.status(), "kinds", st.kinds())
+    rows = []
+    for b in range(256):
+        for t in range(int(cnt[b])):
+            e = tl[b, t]; tag = int(e[7]); rows.append((tag >> 32 & 0xffff, tag >> 48, tag & 0xffffffff, b, [int(v) for v in e[:6]]))
+    t0 = min(r[4][0] for r in rows)
+    us = lambda v: (v - t0) / 100.0
+    print("%-5s %-5s %9s %9s %9s | %8s %8s %8s %8s %8s  (us; averages over the phase's tiles)" % ("phase", "tiles", "first in", "last in", "last out", "wait", "1st fill", "main", "epilogue", "drain"))
+    for ph in sorted(set(r[0] for r in rows)):
+        rs = [r[4] for r in rows if r[0] == ph]
+        seg = lambda a, b: np.mean([(r[b] - r[a]) / 100.0 for r in rs])
+        print("%-5d %-5d %9.2f %9.2f %9.2f | %8.2f %8.2f %8.2f %8.2f %8.2f" % (ph, len(rs), us(min(r[0] for r in rs)), us(max(r[0] for r in rs)), us(max(r[5] for r in rs)),
+                                                                               seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4), seg(4, 5)))
+    print("kernel: first stamp -> last stamp %.2f us" % us(max(r[4][5] for r in rows)))
+    # one team in detail: team 0's blocks, start and end of each tile
+    if "detail" in sys.argv:
+        for r in sorted((r for r in rows if r[1] == 0), key=lambda r: (r[3], r[4][0])):
+            print("team0 block %3d phase %2d tile %3d:" % (r[3], r[0], r[2]), " ".join("%7.2f" % us(v) for v in r[4]))
+
+
+if __name__ == "__main__":
+    main()
