@@ -156,7 +156,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t1
+    shard_check = None
     if world > 1:
+        # self-validation of the shard job ("rank r runs the identical single-GPU exec"): every rank reports its own clock, the checksum of the weight arena
+        # its kernels read and of the execution plan it runs; rank 0 prints whether they agree next to the ranks the process group really has
+        mine = dict(sd.shard_fingerprint(ex), rank=rank, ms_per_step=elapsed / a.steps * 1e3, device=torch.cuda.current_device(), launches=ex.numLaunches)
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        allr.sort(key=lambda d: d["rank"])
+        shard_check = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "ranks_reporting": [d["rank"] for d in allr],
+                       "per_rank_ms_per_step": [round(d["ms_per_step"], 4) for d in allr], "per_rank_device": [d["device"] for d in allr],
+                       "arena_crc_equal": len({d["arena"] for d in allr}) == 1 and allr[0]["arena"] is not None, "plan_equal": len({d["plan"] for d in allr}) == 1,
+                       "launches_equal": len({d["launches"] for d in allr}) == 1}
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -189,6 +200,8 @@ def main():
                           "launches_per_step": ex.numLaunches, "hip_graph": True, "compile_s": round(compile_s, 2)},
                "timing": {"regions": len(regions), "steps_per_region": a.steps, "ms_per_step_median": round(regions[len(regions) // 2], 4),
                           "ms_per_step_min": round(regions[0], 4), "ms_per_step_max": round(regions[-1], 4), "clock": "HIP events on the launch stream"}}
+        if shard_check is not None:
+            out["shard_check"] = shard_check
         # ---- roofline of the dominant kernel family, HIP events on the launch stream ----
         if not a.no_roofline:
             # in-situ: full eager passes over the real launch sequence, HIP events between consecutive launches on the

@@ -389,7 +389,9 @@ enum { SM_FUSE_MBCONV = 1,        /* expand -> depthwise -> project in one launc
        SM_FUSE_STEM_F32 = 64,     /* input conversion inside the stem launch (loader waves) */
        SM_FUSE_STEM_POOL = 128,   /* stem + max-pool 3x3 / 2 in one launch (stem_pool.hpp) */
        SM_FUSE_STEM3 = 256,       /* a 3x3 stem on <= 3 planes as the staged kernel of stem3.hip (needs SM_FUSE_STEM_F32: it reads the fp32 batch) */
-       SM_FUSE_DEFAULT = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 256 };
+       SM_FUSE_STAGE = 512,       /* runs of consecutive 1x1 / 3x3 stride-1 convolutions at one resolution as ONE persistent launch (sm_stage_fwd, stage.hip) — images of <= 112 pixels */
+       SM_FUSE_STAGE_WIDE = 1024, /* ... also at images of 113 .. 208 pixels (the tile forms with 208 accumulator registers: behind the per-layer kernels on ResNet-50's 14 x 14 stage, off by default) */
+       SM_FUSE_DEFAULT = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 256 | 512 };
 enum { SM_TUNE_IN_SITU = 0, SM_TUNE_COLD = 1 };
 void smelter_config_default(smelter_config* c);
 

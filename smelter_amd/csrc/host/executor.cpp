@@ -66,6 +66,7 @@ const Roctx& roctx() { static const Roctx r; return r; }
 }  // namespace
 
 Executor::~Executor() {
+    if (stage_ctl_) (void)hipFree(stage_ctl_);
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
     if (graph_) (void)hipGraphDestroy(graph_);
     if (own_arena_ && arena_) (void)hipFree(arena_);
@@ -665,6 +666,46 @@ int Executor::plan(ONNXGraph& g, int batch) {
         }
     if (stem_f32_) launches_ -= 1;
 
+    // ---- 3k. persistent runs: consecutive plain convolutions (1x1 / no padding or 3x3 / padding 1, stride 1, groups 1, ReLU family, dense operands) at ONE resolution of at most
+    // 208 pixels per image — the bottleneck blocks of a residual stage — become one launch of sm_stage_fwd: the blocks of an XCD keep batch / 8 images for the whole run and hand
+    // tensors over through that XCD's L2 (csrc/kernels/stage.hip).  The steps stay in the list (profiling, SM_FUSE_STAGE off, a run the A/B of `autotune` turns down launch them one
+    // by one); every tensor a run touches stays alive for the whole run (pass 4): inside it the images advance independently, there is no run-wide order between its phases.
+    runs_.clear(); step_run_.assign(steps_.size(), -1);
+    if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && cfg_.allows(SM_FUSE_STAGE)) {
+        auto dense = [&](int v) { return v >= 0 && place_[v].root == v && place_[v].c_off == 0 && place_[v].ld == values_[v].c; };
+        auto eligible = [&](const Step& st) {
+            const Op& op = st.op;
+            if (op.kind != OpKind::Conv || st.has_mb || st.has_head || st.has_side || st.stem || st.stem3 || st.pool_out >= 0 || st.pool3_out >= 0 || st.gather || op.x_ups || op.grid_h) return false;
+            if (op.groups != 1 || op.sh != 1 || op.sw != 1 || op.dh != 1 || op.dw != 1 || op.act > SM_ACT_PRELU || (op.cout & 7)) return false;
+            const bool t1 = op.kh == 1 && op.kw == 1 && !op.pt && !op.pl && !op.pb && !op.pr, t3 = op.kh == 3 && op.kw == 3 && op.pt == 1 && op.pl == 1 && op.pb == 1 && op.pr == 1;
+            if (!t1 && !t3) return false;
+            const Value& iv = values_[op.inputs[0]]; const Value& ov = values_[op.output];
+            if (iv.h != ov.h || iv.w != ov.w || ov.h * ov.w > 208 || !dense(op.inputs[0]) || !dense(op.output) || (op.residual >= 0 && !dense(op.residual))) return false;
+            if (st.dual_src >= 0 && (!t1 || !dense(st.dual_src))) return false;
+            return true;
+        };
+        for (size_t t = 0; t < steps_.size();) {
+            if (!eligible(steps_[t])) { t++; continue; }
+            const Value& v0 = values_[steps_[t].op.output];
+            size_t e = t + 1;
+            while (e < steps_.size() && e - t < SM_STAGE_MAX_PHASES && eligible(steps_[e]) && values_[steps_[e].op.output].h == v0.h && values_[steps_[e].op.output].w == v0.w) e++;
+            StageRun r; r.first = (int)t; r.count = (int)(e - t); r.wide = v0.h * v0.w > 112;
+            // kernel-level check on a synthetic address map (every tensor of the run in a range of its own; the real map comes out of pass 4 with the same property)
+            bool ok = r.count >= 2 && (!r.wide || cfg_.allows(SM_FUSE_STAGE_WIDE));
+            if (ok) {
+                const int keep = batch_; batch_ = batch;
+                std::vector<size_t> save(root_offset_); root_offset_.assign(nv, 0);
+                size_t o = 0; for (int v = 0; v < nv; v++) { root_offset_[v] = o; o += alignUp((size_t)batch * values_[v].h * values_[v].w * std::max(place_[v].ld, 8) * 2 + 64); }
+                size_t wo = 0; for (size_t q = t; q < e; q++) { steps_[q].w_off = wo; wo += alignUp(steps_[q].op.weight.size() * 2); steps_[q].b_off = wo; wo += alignUp(steps_[q].op.bias.size() * 4 + 64); steps_[q].has_bias = !steps_[q].op.bias.empty(); }
+                const std::vector<sm_stage_phase> ph = runPhases(r, (const char*)(uintptr_t)0x100000000ull, (const char*)(uintptr_t)0x4000000000ull, false);
+                ok = sm_stage_supported(ph.data(), (int)ph.size()) != 0;
+                root_offset_ = save; batch_ = keep;
+            }
+            if (ok) { for (size_t q = t; q < e; q++) step_run_[q] = (int)runs_.size(); runs_.push_back(r); }
+            t = ok ? e : t + 1;
+        }
+    }
+
     // ---- 4. memory plan ------------------------------------------------------------------------------------
     const int ns = (int)steps_.size();
     std::vector<int> first(nv, INT32_MAX), last(nv, -1);   // per ROOT value: live step interval
@@ -705,6 +746,13 @@ int Executor::plan(ONNXGraph& g, int batch) {
         touch(op.output, t);
         if (steps_[t].pool_out >= 0) touch(steps_[t].pool_out, t);
     }
+    for (const StageRun& r : runs_)                          // a run's tensors: all alive from its first to its last step
+        for (int t = r.first; t < r.first + r.count; t++) {
+            const Op& op = steps_[t].op;
+            auto span = [&](int v) { if (v >= 0) { touch(v, r.first); touch(v, r.first + r.count - 1); } };
+            for (int u : op.inputs) span(u);
+            span(op.residual); span(steps_[t].dual_src); span(op.output);
+        }
     touch(output_value_, ns);                               // result image must survive until read back
     if (cfg_.keepIntermediates) for (int v = 0; v < nv; v++) if (last[v] >= 0) { first[v] = -1; last[v] = ns; }
     // storage = the value's root buffer got a lifetime; the image input of a stem launch is never stored as an NHWC fp16 tensor (row-pair image, or nothing at all)
@@ -737,6 +785,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             st.w_off = off; off = alignUp(off + op.weight.size() * 2);
             st.has_bias = !op.bias.empty();
             if (st.has_bias) { st.b_off = off; off = alignUp(off + op.bias.size() * 4); }
+            if (step_run_[&st - steps_.data()] >= 0) { st.has_wp = true; st.wp_off = off; off = alignUp(off + (size_t)((op.cout + 255) / 256 * 256) * op.weight.size() / op.cout * 2); }   // fragment-order copy for the run (couts padded to the widest cout tile)
             if (st.stem3) { st.ws_off = off; off = alignUp(off + st.stem_w.size() * 2); }       // the original [Cout][3][3][C] weights (the row-pair packing stays at w_off: unused by this launch)
             if (st.has_mb && st.mb_stem) {
                 st.ws_off = off; off = alignUp(off + st.stem_w.size() * 2);
@@ -901,6 +950,18 @@ int Executor::packWeights(std::vector<uint8_t>* host) const {
             memcpy(host->data() + st.t_off, op.shift.data(), op.shift.size() * 4);
         }
     }
+    // the runs' weights once more, in the fragment order of the tile form the kernel-level planner gives each phase (the same deterministic choice it makes at launch:
+    // it depends on the shapes and the batch only — the addresses here are stand-ins with the real layout's offsets)
+    for (const StageRun& r : runs_) {
+        const std::vector<sm_stage_phase> ph = runPhases(r, (const char*)(uintptr_t)0x100000000ull, (const char*)(uintptr_t)0x4000000000ull, false);
+        for (int i = 0; i < r.count; i++) {
+            const Step& st = steps_[r.first + i];
+            const size_t need = sm_stage_packed_weight_bytes(ph.data(), r.count, i);
+            if (!need || st.wp_off + need > host->size()) { sm_set_error("persistent run at step %d: packed weights of phase %d need %zu bytes", r.first, i, need); return SM_ERR_INCONSISTENT_STATE; }
+            const int rc = sm_stage_pack_weights(ph.data(), r.count, i, host->data() + st.w_off, host->data() + st.wp_off);
+            if (rc) return rc;
+        }
+    }
     return SM_OK;
 }
 
@@ -920,23 +981,59 @@ int Executor::packWeightsHost(ONNXGraph& g, int batch, void* dst, size_t cap) {
 }
 
 static const int32_t kPlanMagic = 0x4e414c50;   // "PLAN"
+// fingerprint of the step list a plan was made for: two compiles of one graph with different fusion masks, batches or library builds can agree in the NUMBER of steps
+static int32_t stepsFingerprint(const std::vector<Step>& steps) {
+    uint32_t h = 2166136261u;
+    auto mix = [&](uint32_t v) { h = (h ^ v) * 16777619u; };
+    for (const Step& st : steps) {
+        mix((uint32_t)st.op.kind); mix((uint32_t)st.M); mix((uint32_t)st.op.cout); mix((uint32_t)st.op.cin); mix((uint32_t)(st.op.kh * 16 + st.op.kw)); mix((uint32_t)(st.op.sh * 16 + st.op.groups));
+        mix((uint32_t)((st.has_mb ? 1 : 0) | (st.has_head ? 2 : 0) | (st.has_side ? 4 : 0) | (st.stem ? 8 : 0) | (st.stem3 ? 16 : 0) | (st.dual_src >= 0 ? 32 : 0) | (st.pool_out >= 0 ? 64 : 0) | (st.pool3_out >= 0 ? 128 : 0) | (st.op.residual >= 0 ? 256 : 0)));
+    }
+    return (int32_t)h;
+}
+// [0] 'PLAN', [1] tile configurations in this build, [2] steps S, [3 .. 3 + S) conv_cfg per step, then R = persistent runs, R x (first step, steps, 1 = launched as a run), then the
+// fingerprint of the step list
 std::vector<int32_t> Executor::exportPlan() const {
     std::vector<int32_t> p{kPlanMagic, (int32_t)sm_conv2d_num_configs(), (int32_t)steps_.size()};
     for (const Step& st : steps_) p.push_back(st.conv_cfg);
+    p.push_back((int32_t)runs_.size());
+    for (const StageRun& r : runs_) { p.push_back(r.first); p.push_back(r.count); p.push_back(r.on ? 1 : 0); }
+    p.push_back(stepsFingerprint(steps_));
     return p;
 }
 int Executor::importPlan(const int32_t* plan, size_t words) {
     if (!plan || words < 3 || plan[0] != kPlanMagic) { sm_set_error("execution plan: not a plan (bad header)"); return SM_ERR_INVALID_ARGUMENT; }
     if (plan[1] != sm_conv2d_num_configs()) { sm_set_error("execution plan: made by a library with %d tile configurations, this one has %d", plan[1], sm_conv2d_num_configs()); return SM_ERR_INVALID_ARGUMENT; }
-    if ((size_t)plan[2] != steps_.size() || words != 3 + steps_.size()) {
-        sm_set_error("execution plan: %d steps (%zu words), this graph / batch compiles to %zu steps", plan[2], words, steps_.size()); return SM_ERR_INVALID_ARGUMENT; }
-    for (size_t i = 0; i < steps_.size(); i++) {
+    const size_t nst = steps_.size(), want = 3 + nst + 1 + 3 * runs_.size() + 1;
+    if ((size_t)plan[2] != nst || words != want) {
+        sm_set_error("execution plan: %d steps (%zu words), this graph / batch compiles to %zu steps and %zu persistent runs (%zu words)", plan[2], words, nst, runs_.size(), want); return SM_ERR_INVALID_ARGUMENT; }
+    if (plan[words - 1] != stepsFingerprint(steps_)) { sm_set_error("execution plan: made for another step list (fusion mask, batch or graph differ)"); return SM_ERR_INVALID_ARGUMENT; }
+    const int32_t* q = plan + 3 + nst;
+    if ((size_t)q[0] != runs_.size()) { sm_set_error("execution plan: %d persistent runs, this compile has %zu", q[0], runs_.size()); return SM_ERR_INVALID_ARGUMENT; }
+    for (size_t i = 0; i < runs_.size(); i++)
+        if (q[1 + 3 * i] != runs_[i].first || q[2 + 3 * i] != runs_[i].count) { sm_set_error("execution plan: persistent run %zu covers other steps", i); return SM_ERR_INVALID_ARGUMENT; }
+    for (size_t i = 0; i < nst; i++) {
         const int c = plan[3 + i];
         if (c < -1 || c >= sm_conv2d_num_configs()) { sm_set_error("execution plan: step %zu names tile configuration %d", i, c); return SM_ERR_INVALID_ARGUMENT; }
         steps_[i].conv_cfg = c;
         if (c >= 0) steps_[i].desc += " cfg=" + std::to_string(c);
     }
+    for (size_t i = 0; i < runs_.size(); i++) runs_[i].on = q[3 + 3 * i] != 0;
+    annotateRuns();
     return SM_OK;
+}
+// the step descriptions say which steps leave in one launch (the same text whether the decision was measured here, imported with a plan or is the default)
+void Executor::annotateRuns() {
+    for (const StageRun& r : runs_)
+        for (int t = r.first; t < r.first + r.count; t++) {
+            std::string& d = steps_[t].desc;
+            const size_t at = d.find(" [persistent run");
+            if (at != std::string::npos) d.erase(at, d.find(']', at) - at + 1);
+            char buf[96];
+            if (r.on) snprintf(buf, sizeof buf, t == r.first ? " [persistent run: this and the next %d layers are ONE launch]" : " [persistent run: launched with step %d]", t == r.first ? r.count - 1 : r.first);
+            else snprintf(buf, sizeof buf, " [persistent run turned down: layer by layer]");
+            d += buf;
+        }
 }
 int Executor::defaultPlanHost(ONNXGraph& g, int batch, std::vector<int32_t>* out) {
     if (batch <= 0) { sm_set_error("batch must be positive"); return SM_ERR_INVALID_ARGUMENT; }
@@ -973,6 +1070,16 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     SM_HIP_CHECK(hipMalloc((void**)&e->out_f32_, e->out_f32_count_ * 4));
     for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit();
                                  st.head.weight.clear(); st.head.weight.shrink_to_fit(); st.side.weight.clear(); st.side.weight.shrink_to_fit(); st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
+    if (!e->runs_.empty()) {
+        size_t ctl = 0;
+        for (StageRun& r : e->runs_) {                                // the real address map: the kernel-level planner must take every run (pass 4 keeps a run's tensors apart)
+            const std::vector<sm_stage_phase> ph = e->runPhases(r, e->arena_, e->act_, true);
+            if (!sm_stage_supported(ph.data(), (int)ph.size())) { sm_set_error("persistent run at step %d: rejected on the real address map", r.first); return SM_ERR_INCONSISTENT_STATE; }
+            ctl = std::max(ctl, sm_stage_ctl_bytes(ph.data(), (int)ph.size()));
+        }
+        SM_HIP_CHECK(hipMalloc(&e->stage_ctl_, ctl)); SM_HIP_CHECK(hipMemset(e->stage_ctl_, 0, ctl));
+    }
+    e->annotateRuns();
     if (plan) { rc = e->importPlan(plan, plan_words); if (rc) return rc; }   // another executor's picks (rank 0 of a batch-shard job): identical kernels on every rank
     else if (e->cfg_.autotune) {   // with an external arena and upload == 0 the caller filled it before compiling
         hipStream_t s; SM_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -982,6 +1089,33 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     }
     *out = e.release();
     return SM_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+std::vector<sm_stage_phase> Executor::runPhases(const StageRun& r, const char* arena, const char* act, bool packed) const {
+    std::vector<sm_stage_phase> ph(r.count);
+    auto ptr = [&](int v) -> const void* { return act + root_offset_[place_[v].root] + (size_t)place_[v].c_off * 2; };
+    for (int i = 0; i < r.count; i++) {
+        const Step& st = steps_[r.first + i]; const Op& op = st.op; sm_stage_phase& q = ph[i];
+        memset(&q, 0, sizeof q);
+        q.d = convDesc(st);
+        q.x = ptr(op.inputs[0]); q.w_ohwi = arena + st.w_off; q.bias = st.has_bias ? (const float*)(arena + st.b_off) : nullptr;
+        q.residual = op.residual >= 0 ? ptr(op.residual) : nullptr; q.y = (void*)ptr(op.output);
+        q.w_packed = (packed && st.has_wp) ? arena + st.wp_off : nullptr;
+        if (st.dual_src >= 0) { const Value& xv = values_[st.dual_src]; q.x2 = ptr(st.dual_src); q.K2 = xv.c; q.x2_ld = valueLd(st.dual_src); q.x2_H = xv.h; q.x2_W = xv.w; q.x2_stride = st.dual_stride; }
+    }
+    return ph;
+}
+
+int Executor::launchRun(const StageRun& r, hipStream_t s) const {
+    const std::vector<sm_stage_phase> ph = runPhases(r, arena_, act_, true);
+    return sm_stage_fwd(ph.data(), (int)ph.size(), stage_ctl_, (sm_stream_t)s);
+}
+
+int Executor::numLaunchesNow() const {
+    int n = launches_;
+    for (const StageRun& r : runs_) if (r.on) n -= r.count - 1;
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1130,7 +1264,13 @@ int Executor::launchAll(hipStream_t s, const float* in) const {
     if (rx.on) rx.pop();
     if (rc) return rc;
     struct Range { const Roctx& r; Range(const Roctx& r_, const char* n) : r(r_) { if (r.on) r.push(n); } ~Range() { if (r.on) r.pop(); } };
-    for (auto& st : steps_) {
+    for (size_t si = 0; si < steps_.size(); si++) {
+        const Step& st = steps_[si];
+        if (step_run_[si] >= 0 && runs_[step_run_[si]].on) {      // a persistent run: one launch at its first step
+            const StageRun& r = runs_[step_run_[si]];
+            if ((int)si == r.first) { Range range(rx, ("persistent run: " + st.desc).c_str()); rc = launchRun(r, s); if (rc) return rc; }
+            continue;
+        }
         Range range(rx, st.desc.c_str());
         if (st.join >= 0 && side_) {                            // fork: the side stream sees everything enqueued so far
             SM_HIP_CHECK(hipEventRecord(ev_fork_, s));
@@ -1240,7 +1380,12 @@ int Executor::profile(hipStream_t s, const float* in, int iters, float* ms, int 
         SM_HIP_CHECK(hipEventRecord(ev[0], s));
         rc = convertInput(s, in);
         SM_HIP_CHECK(hipEventRecord(ev[1], s));
-        for (int i = 0; i < n - 1 && !rc; i++) { rc = launchStep(steps_[i], s); SM_HIP_CHECK(hipEventRecord(ev[i + 2], s)); }
+        for (int i = 0; i < n - 1 && !rc; i++) {
+            const int ri = step_run_[i];
+            if (ri >= 0 && runs_[ri].on) { if (i == runs_[ri].first) rc = launchRun(runs_[ri], s); }   // (the whole run under its first step, zeros under the others)
+            else rc = launchStep(steps_[i], s);
+            SM_HIP_CHECK(hipEventRecord(ev[i + 2], s));
+        }
         SM_HIP_CHECK(hipStreamSynchronize(s));
         if (it > 0) for (int i = 0; i < n; i++) { float t = 0; SM_HIP_CHECK(hipEventElapsedTime(&t, ev[i], ev[i + 1])); acc[i] += t; }
     }
@@ -1309,6 +1454,32 @@ int Executor::autotune(hipStream_t s) {
         st.conv_cfg = best_cfg;
         st.desc += " cfg=" + std::to_string(best_cfg);
     }
+    // Persistent runs (pass 3k): ONE launch against its layers launched one by one with the configurations just chosen, both behind the two real predecessor launches;
+    // median of 7.  The faster form is kept; a run whose kernel reports a timeout or fell back to the fenced hand-off is turned down.
+    for (size_t ri = 0; ri < runs_.size() && !rc; ri++) {
+        StageRun& r = runs_[ri];
+        auto timeForm = [&](bool as_run) -> float {
+            std::vector<float> smp;
+            for (int it = 0; it < 8 && !rc; it++) {
+                for (int q = std::max(0, r.first - 2); q < r.first && !rc; q++) rc = launchStep(steps_[q], s);
+                if (rc || hipEventRecord(a, s) != hipSuccess) { rc = rc ? rc : SM_ERR_HIP; return 0.f; }
+                if (as_run) rc = launchRun(r, s);
+                else for (int q = r.first; q < r.first + r.count && !rc; q++) rc = launchStep(steps_[q], s);
+                float t = 0;
+                if (rc || hipEventRecord(b, s) != hipSuccess || hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&t, a, b) != hipSuccess) { rc = rc ? rc : SM_ERR_HIP; return 0.f; }
+                if (it > 0) smp.push_back(t);
+            }
+            std::sort(smp.begin(), smp.end());
+            return smp.empty() ? 0.f : smp[smp.size() / 2];
+        };
+        const float t_layers = timeForm(false), t_run = timeForm(true);
+        if (rc) break;
+        int32_t err = 0, mode = 0;
+        rc = sm_stage_status(stage_ctl_, (sm_stream_t)s, &err, &mode); if (rc) break;
+        r.on = err == 0 && mode == 1 && t_run < t_layers;
+        if (getenv("SMELTER_DEBUG_PLAN")) fprintf(stderr, "[plan] persistent run at step %d (%d layers): %.1f us as one launch, %.1f us layer by layer -> %s\n", r.first, r.count, t_run * 1e3f, t_layers * 1e3f, r.on ? "run" : "layers");
+    }
+    annotateRuns();
     (void)hipStreamSynchronize(s);
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     if (tune_in) { (void)hipFree(tune_in); cur_in_ = nullptr; }

@@ -58,9 +58,13 @@ struct Step {                // one op after fusion, with everything resolved
     // layer's input (a MaxPool 1x1 step the graph does not hold: not accounted)
     int dual_src = -1, dual_stride = 1;   // >= 0: value id of the SECOND source of a K-concatenated pointwise convolution, read in place at this pixel stride (sm_conv2d_dual_fwd_cfg)
     bool kcat = false, gather = false; double kcat_extra_elems = 0;   // elements the two graph layers move beyond the merged layer's own operands
+    size_t wp_off = 0; bool has_wp = false;   // member of a persistent run (executor.cpp pass 3k): the weights once more, in the fragment order of the run's tile form (sm_stage_pack_weights)
     bool mb_noexp = false;   // the block has no expand layer: this step IS the depthwise convolution (mb_dw is a copy of it), mb_proj follows
     std::string desc;
 };
+
+// pass 3k: steps [first, first + count) — plain 1x1 / 3x3 stride-1 convolutions at one resolution — run as ONE persistent launch (sm_stage_fwd) when `on`
+struct StageRun { int first = 0, count = 0; bool on = true, wide = false; };
 
 class Executor {
    public:
@@ -88,7 +92,7 @@ class Executor {
     int batch() const { return batch_; }
     void outputDims(int* n, int* c, int* h, int* w) const;
     const void* outputDevice() const;
-    int numLaunches() const { return launches_; }
+    int numLaunches() const { return numLaunchesNow(); }
     int numOps() const { return (int)steps_.size(); }
     size_t weightBytesUsed() const { return arena_bytes_; }
     void* weightArena() const { return arena_; }
@@ -107,6 +111,11 @@ class Executor {
     int plan(ONNXGraph& g, int batch);                   // fusion + placement + memory plan + arena layout
     int packWeights(std::vector<uint8_t>* host) const;   // fold/cast/pad -> arena image
     int launchStep(const Step& st, hipStream_t s) const;
+    int launchRun(const StageRun& r, hipStream_t s) const;
+    // the phase list of a run over the given arena / activation base addresses (real ones, or any two disjoint fake ranges for host-side planning and packing)
+    std::vector<sm_stage_phase> runPhases(const StageRun& r, const char* arena, const char* act, bool packed) const;
+    int numLaunchesNow() const;
+    void annotateRuns();
     sm_conv_desc convDesc(const Step& st) const;
     int convertInput(hipStream_t s, const float* in) const;
     int launchAll(hipStream_t s, const float* in) const;
@@ -120,6 +129,8 @@ class Executor {
     std::vector<Placement> place_;
     std::vector<size_t> root_offset_;    // per value id (roots only), byte offset in the activation arena
     std::vector<Step> steps_;
+    std::vector<StageRun> runs_; std::vector<int> step_run_;   // per step: index into runs_ or -1
+    void* stage_ctl_ = nullptr;
     int input_value_ = -1, output_value_ = -1, input_ld_ = 0;
     float* resized_ = nullptr;       // forceInputScale: the resampled batch (NCHW fp32), allocated on first use
     bool stem_ = false; int stem_h_ = 0, stem_w_ = 0, stem_pt_ = 0, stem_pl_ = 0;   // row-pair image geometry

@@ -3,6 +3,7 @@
 // C++.  Where the reference's converters create an MPSNNFilterNode, ours append one `Op` record; the executor
 // (executor.cpp) turns the records into gfx950 kernel launches through the sm_* C ABI.
 #pragma once
+#include "../../../include/smelter_hip.h"
 #include <map>
 #include <memory>
 #include <string>
@@ -26,7 +27,7 @@ struct Configuration {
     std::map<int, int> dims;             // per-axis input-dim override (:25, :200-202)
     // executor options (no reference counterpart)
     bool fuse = true, useHipGraph = true, autotune = false, keepIntermediates = false, branchConcurrency = false;
-    int fusions = 0xEF;                  // SM_FUSE_DEFAULT (smelter_hip.h): which fusion passes may run
+    int fusions = SM_FUSE_DEFAULT;       // (smelter_hip.h): which fusion passes may run
     int autotuneMode = 0, autotuneMaxCfg = 0, mbconvDomain[3] = {0, 0, 0};
     bool allows(int bit) const { return (fusions & bit) != 0; }
 };

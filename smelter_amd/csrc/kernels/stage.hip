@@ -51,25 +51,30 @@ static_assert(sizeof(StArgs) <= 4096, "kernel argument block");
 
 // KG x NG = 4 waves: KG = K groups (a wave multiplies channels [kg WCH, (kg + 1) WCH) of every super-block of KG WCH channels), NG = cout groups of NF 16-cout fragments;
 // NFR = 16-pixel fragments per tile; TAPS = 1 | 9; SBG = super-blocks per unrolled loop body; NB = patch buffers.
-template <int KG_, int NG_, int NF_, int NFR_, int TAPS_, int WCH_, int SBG_, int NB_>
+template <int KG_, int NG_, int NF_, int NFR_, int TAPS_, int WCH_, int SBG_, int NB_, int RW_>
 struct StKind {
     static constexpr int KG = KG_, NG = NG_, NF = NF_, NFR = NFR_, TAPS = TAPS_, WCH = WCH_, SBG = SBG_, NB = NB_;
     static constexpr int QPW = WCH / 32, UPS = TAPS * QPW, UB = SBG * UPS, NSL = WCH / 64, SBCH = KG * WCH, WN = NF * 16, BN = NG * WN, PD = NB - 1;
-    static constexpr int RW = TAPS == 9 ? 6 : 4, PA = RW - 2;                 // weight ring (units) and how many units ahead a PAIR of units is requested
+    static constexpr int RW = RW_, PA = RW - 2;                 // weight ring (units) and how many units ahead a PAIR of units is requested.  (Requesting unit U + PA fragment by
+                                                                // fragment between the MFMAs of unit U instead of as a burst at its top: 136 -> 155 us on the 7x7 stage, profiles/r05_stage_ablation.txt)
     static constexpr int NI_MAX = TAPS == 1 ? NFR * 2 : (NFR <= 7 ? 18 : 37);  // DMA instructions per slice the kind can take
     static constexpr int NIW_MAX = (NSL * NI_MAX + NG - 1) / NG;               // ... per wave and super-block
     static constexpr int DPU = NB > 1 ? (NIW_MAX + UPS - 1) / UPS : 0, V = NF + DPU;   // DMA slots per unit; VMEM operations per unit
     static constexpr bool DUAL = TAPS == 1 && KG == 1, SHARED = NG > 1;
     static constexpr int TPMAX = NFR * 16;
     static_assert(KG * NG == 4 && UB % RW == 0 && UB % 2 == 0 && QPW % 2 == 0 && (NB > 1 || DPU == 0), "shape of the loop body");
-    static_assert(PA * NF + (PA + 1) * DPU + NF <= 63 && (PD <= 1 || true), "counted waits must be expressible");
 };
-typedef StKind<4, 1, 4, 7, 1, 64, 2, 3> StR7;     // 0: 1x1, K % 512 == 0, tile <= 112 px x 64 couts      (7x7: 2048 -> 512)
-typedef StKind<4, 1, 4, 7, 9, 64, 1, 2> StT7;     // 1: 3x3, K1 % 256 == 0, images of <= 56 px, 2+ per tile x 64 couts (7x7 512 -> 512)
-typedef StKind<1, 4, 4, 7, 1, 128, 1, 3> StE7;    // 2: 1x1 (+ second source), K % 128 == 0, <= 112 px x 256 couts (7x7: 512 -> 2048)
-typedef StKind<2, 2, 4, 7, 1, 128, 1, 3> StR14;   // 3: 1x1, K % 256 == 0, <= 112 px x 128 couts          (14x14: 1024 -> 256)
-typedef StKind<1, 4, 4, 13, 1, 128, 1, 3> StE14;  // 4: 1x1 (+ second source), <= 208 px x 256 couts       (14x14: 256 -> 1024)
-typedef StKind<4, 1, 4, 13, 9, 64, 1, 1> StT14;   // 5: 3x3, one image of <= 208 px x 64 couts, patch single-buffered (14x14 256 -> 256)
+#ifndef ST_RW1
+#define ST_RW1 4          // weight ring of the 1x1 forms, in units (a pair is requested ST_RW1 - 2 units ahead); 8 needs loop bodies of 8 units
+#endif
+#define ST_SBG1 (ST_RW1 / 4)
+#define ST_SBG_R7 (ST_RW1 / 2)
+typedef StKind<4, 1, 4, 7, 1, 64, ST_SBG_R7, 3, ST_RW1> StR7;     // 0: 1x1, K % 512 == 0, tile <= 112 px x 64 couts      (7x7: 2048 -> 512)
+typedef StKind<4, 1, 4, 7, 9, 64, 1, 2, 6> StT7;     // 1: 3x3, K1 % 256 == 0, images of <= 56 px, 2+ per tile x 64 couts (7x7 512 -> 512)
+typedef StKind<1, 4, 4, 7, 1, 128, ST_SBG1, 3, ST_RW1> StE7;    // 2: 1x1 (+ second source), K % 128 == 0, <= 112 px x 256 couts (7x7: 512 -> 2048)
+typedef StKind<2, 2, 4, 7, 1, 128, ST_SBG1, 3, ST_RW1> StR14;   // 3: 1x1, K % 256 == 0, <= 112 px x 128 couts          (14x14: 1024 -> 256)
+typedef StKind<1, 4, 4, 13, 1, 128, 1, 3, 4> StE14;  // 4: 1x1 (+ second source), <= 208 px x 256 couts       (14x14: 256 -> 1024)
+typedef StKind<4, 1, 4, 13, 9, 64, 1, 1, 6> StT14;   // 5: 3x3, one image of <= 208 px x 64 couts, patch single-buffered (14x14 256 -> 256)
 constexpr int ST_NKINDS = 6;
 
 #ifdef SM_STAGE_TL   // diagnostic build (tools/stage_tl.py): per block and tile, wall clock (100 MHz, the same on every XCD) at 8 points
@@ -88,6 +93,7 @@ __device__ __forceinline__ void st_bdma16(unsigned voff, st_u32x4 rsrc, unsigned
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen" ST_DMA_AUX " lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
 }
+template <int OFF> __device__ __forceinline__ void st_gload16(half8_t& d, unsigned voff, const half_t* sbase) { asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(d) : "v"(voff), "s"(sbase), "n"(OFF) : "memory"); }
 __device__ __forceinline__ void st_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ unsigned st_ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int N> __device__ __forceinline__ void st_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory"); }
@@ -124,6 +130,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     const unsigned lane16 = (unsigned)lane * 16u;
     auto load_b = [&](auto slotc, int sb, int ul) {                   // weight fragments of unit `ul` of super-block `sb` -> ring slot
         constexpr int SLOT = decltype(slotc)::value;
+#ifndef ST_ABL_NOW
         if (packed) {
             const half_t* ub = wstream + (size_t)(sb * UPS + ul) * (size_t)(NF * 512);
             static_assert(NF == 4, "four fragments per unit");
@@ -133,6 +140,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
             { half8_t& d = wb[SLOT][3]; asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(d) : "v"(lane16), "s"(ub) : "memory"); }
             return;
         }
+#endif
         int k1o = K1; asm volatile("" : "+s"(k1o));                  // (opaque: the nine tap offsets are NOT loop invariants worth 18 scalar registers)
         const half_t* ub = p.w + ((ul / QPW) * k1o + sb * SBCH + kg * WCH + (ul % QPW) * 32);
 #ifdef ST_ABL_NOW
@@ -155,17 +163,19 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     // 1x1, first source: slot = pixel, the offset is (pix0 + 8 i) ld2 + [l8 ld2 + swizzled chunk], and the swizzle key (slot / 2) & 7 = (l8 / 2) | 4 (i & 1): two lane constants, no
     // table (slots beyond the tile copy whatever follows it — their pixels are never stored; beyond the tensor the descriptor returns zeros)
     const unsigned lo0 = (unsigned)l8 * ld2 + ((((unsigned)c8) ^ (unsigned)(l8 >> 1)) << 4), lo1 = (unsigned)l8 * ld2 + ((((unsigned)c8) ^ (unsigned)((l8 >> 1) | 4)) << 4);
-    auto dma_off = [&](int i) -> unsigned {
-        if constexpr (T3) {
-            const int s = 8 * i + l8;
-            const unsigned chunk = (((unsigned)c8 ^ (unsigned)((s >> 1) & 7)) << 4);
-            const int r = (int)sm_fastdiv((unsigned)i, p.kpr_mul, p.kpr_sh), k = i - r * (RS >> 3);
-            const int vr = r - 1, im = vr < 0 ? 0 : (int)sm_fastdiv((unsigned)vr, p.h1_mul, p.h1_sh), y = vr - im * (H + 1), cc = 8 * k + l8;
-            const bool ok = vr >= 0 && y < H && im < imgs && (unsigned)(cc - 1) < (unsigned)W;
-            return ok ? (unsigned)(((n0 + im) * H + y) * W + cc - 1) * ld2 + chunk : 0x80000000u;
-        } else {
-            return (unsigned)(pix0 + 8 * i) * ld2 + ((i & 1) ? lo1 : lo0);
-        }
+    auto dma_off = [&](int i) -> unsigned { return (unsigned)(pix0 + 8 * i) * ld2 + ((i & 1) ? lo1 : lo0); };   // (1x1, first source)
+    // 3x3: the instructions of a slice in order — patch row r = 0 .. (row 0 = halo above the first image; images H + 1 rows apart: the row between two images is zero), 8-slot group k
+    // of the row.  Which image row a patch row is, whether it exists, its byte offset: wave-uniform running counters (no division); per lane only the column test and the add.
+    // Swizzle key of slot r RS + 8 k + l8 = ((r RS / 2 + 4 k) & 4) | l8 / 2 (RS % 8 == 0): the two lane constants of the 1x1 case.
+    int t3_k = 0, t3_y = -1, t3_im = 0, t3_r = 0;
+    auto t3_next = [&]() -> unsigned {
+        const bool rok = t3_y >= 0 && t3_y < H && t3_im < imgs;
+        const int cc0 = 8 * t3_k;
+        const unsigned rowb = (unsigned)(((n0 + t3_im) * H + t3_y) * W - 1 + cc0) * ld2;
+        const bool okc = (unsigned)(cc0 + l8 - 1) < (unsigned)W;
+        const unsigned v = rowb + ((((t3_r * (RS >> 1) + 4 * t3_k) & 4) != 0) ? lo1 : lo0);
+        if (++t3_k == (RS >> 3)) { t3_k = 0; t3_r++; if (++t3_y == H + 1) { t3_y = 0; t3_im++; } }
+        return (rok && okc) ? v : 0x80000000u;
     };
     auto dma_off2 = [&](int i) -> unsigned {                          // second source: output pixel (n, oy, ox) reads pixel (n, oy s, ox s) of x2
         const int s = 8 * i + l8;
@@ -203,8 +213,8 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
         sm_static_for<0, NTAB>([&](auto mc) {
             constexpr int M = decltype(mc)::value;
             const int idx = ng + M * NG, sl = idx >= NI ? 1 : 0, i = idx - sl * NI;
-            if constexpr (T3) dmo[M] = idx < nidx ? dma_off(i) : 0x80000000u;
-            if constexpr (DUAL) dmo2[M] = (idx < nidx && nsb1 < nsb) ? dma_off2(i) : 0x80000000u;
+            if constexpr (T3) { static_assert(!T3 || (NG == 1 && NSL == 1), "3x3 forms: a wave issues its slice's instructions in order"); const unsigned v = t3_next(); dmo[M] = idx < nidx ? v : 0x80000000u; }
+            if constexpr (DUAL) { dmo2[M] = 0x80000000u; if (idx < nidx && nsb1 < nsb) dmo2[M] = dma_off2(i); }
             issue_slot(mc, 0, 0u);
         });
         sm_static_for<1, PD>([&](auto sc) {
@@ -249,11 +259,13 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
             const unsigned bufo = (unsigned)bcur * BUFB;
             if constexpr (UL == 0) {                                   // ---- super-block boundary: its patch has landed, everybody has left the buffer the next patch goes to ----
                 if constexpr (NB == 1) {
-                    if (sb > 0) st_lds_barrier();
+                    if (sb > 0) { st_lds_barrier(); t3_k = 0; t3_y = -1; t3_im = 0; t3_r = 0; }
 #pragma unroll 1
                     for (int idx = ng; idx < nidx; idx += NG) {
                         const int sl = idx >= NI ? 1 : 0;
-                        st_bdma16(dma_off(idx - sl * NI), rs_x, (unsigned)__builtin_amdgcn_readfirstlane((int)(myslices + (unsigned)idx * 1024u)), (unsigned)((sb * SBCH + kg * WCH + sl * 64) * 2));
+                        unsigned vo;
+                        if constexpr (T3) vo = t3_next(); else vo = dma_off(idx - sl * NI);
+                        st_bdma16(vo, rs_x, (unsigned)__builtin_amdgcn_readfirstlane((int)(myslices + (unsigned)idx * 1024u)), (unsigned)((sb * SBCH + kg * WCH + sl * 64) * 2));
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     if (SHARED) __builtin_amdgcn_s_barrier();
@@ -414,6 +426,9 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     }
 }
 
+// MASK: the tile forms this instantiation holds (bit k = form k).  One kernel with all six pays for the union of their registers (the 208-accumulator forms push the
+// others' lane constants to scratch memory); a run of forms 0-2 or 3-5 only gets a kernel of its own.
+template <int MASK>
 __global__ __launch_bounds__(256) void stage_kernel(const StArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char st_smem[];
     __shared__ int s_info[4];
@@ -470,11 +485,7 @@ __global__ __launch_bounds__(256) void stage_kernel(const StArgs a) {
                 __syncthreads();
                 ST_TL(1);
             };
-#ifdef ST_ONLY_KIND
-#define ST_CASE(k) if constexpr (ST_ONLY_KIND == k)
-#else
-#define ST_CASE(k)
-#endif
+#define ST_CASE(k) if constexpr ((MASK >> k) & 1)
             switch (p.kind) {
             case 0: ST_CASE(0) st_tile<StR7>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
             case 1: ST_CASE(1) st_tile<StT7>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
@@ -685,7 +696,11 @@ extern "C" int sm_stage_fwd(const sm_stage_phase* ph, int32_t n, void* ctl, sm_s
     }
     // co-residency: one block per CU (the kernel's LDS and registers admit no second block), every block of the grid must be resident for the hand-offs to complete
     SM_REQUIRE(cu_count >= ST_GRID, "sm_stage_fwd: %d compute units, the persistent grid needs %d resident blocks", cu_count, ST_GRID);
-    hipLaunchKernelGGL(stage_kernel, dim3(ST_GRID), dim3(256), (size_t)a.lds_bytes, sm_s(stream), a);
+    int mask = 0;
+    for (int i = 0; i < n; i++) mask |= 1 << a.ph[i].kind;
+    if ((mask & ~0x7) == 0) hipLaunchKernelGGL(stage_kernel<0x7>, dim3(ST_GRID), dim3(256), (size_t)a.lds_bytes, sm_s(stream), a);
+    else if ((mask & ~0x38) == 0) hipLaunchKernelGGL(stage_kernel<0x38>, dim3(ST_GRID), dim3(256), (size_t)a.lds_bytes, sm_s(stream), a);
+    else hipLaunchKernelGGL(stage_kernel<0x3f>, dim3(ST_GRID), dim3(256), (size_t)a.lds_bytes, sm_s(stream), a);
     SM_LAUNCH_CHECK();
     return SM_OK;
 }

@@ -89,10 +89,19 @@ def compile_sharded(graph, per_rank_batch: int, local_device: int = 0, src: int 
     Configuration asks for it — and its execution plan is broadcast: every rank runs the identical kernels with the identical tile configurations, so a
     shard's outputs are bit-identical to the one-GPU run of the same images."""
     import torch.distributed as dist
+    if not dist.is_initialized():
+        src = 0                                       # one process: it is the source whatever the caller named
     arena = broadcast_weight_arena(graph, per_rank_batch, src=src)
     rank = dist.get_rank() if dist.is_initialized() else 0
     ex = graph.hipGraph(local_device, per_rank_batch, weight_arena=arena, upload_weights=False) if rank == src else None
     plan = broadcast_plan(ex.plan if ex is not None else None, src=src)
     if ex is None:
         ex = graph.hipGraph(local_device, per_rank_batch, weight_arena=arena, upload_weights=False, plan=plan)
+    ex.shard_arena = arena                            # (what this rank's kernels read: bench.py checksums it per rank)
     return ex
+
+
+def shard_fingerprint(ex) -> dict:
+    """what a batch-shard job compares across ranks: the bytes of the weight arena this rank's kernels read and the execution plan it runs"""
+    import zlib
+    return {"arena": arena_checksum(ex.shard_arena) if getattr(ex, "shard_arena", None) is not None else None, "plan": zlib.crc32(np.ascontiguousarray(ex.plan).tobytes())}

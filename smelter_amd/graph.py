@@ -32,6 +32,17 @@ class Shape:  # TypeDefinitions.swift:1-33
         return [self.channels, self.width, self.height, self.depth]
 
 
+# SM_FUSE_* bits of Configuration.fusions a caller may want to flip (smelter_hip.h has the full list)
+FUSE_STAGE, FUSE_STAGE_WIDE = 512, 1024
+
+
+def default_fusions() -> int:
+    """SM_FUSE_DEFAULT as smelter_config_default() returns it (the SMELTER_* environment overrides applied)"""
+    c = N.Config()
+    N.lib().smelter_config_default(C.byref(c))
+    return int(c.fusions)
+
+
 @dataclass
 class Configuration:  # ONNXGraph.swift:6-36 (+ executor options)
     inputConstraint: str = "none"            # "none" | "lanczos" | "bilinear" (.forceInputScale: source images of any size)

@@ -73,7 +73,7 @@ def test_weight_arena_broadcast_world2_gloo():
     (r0, c0, n0, packs0, s0, p0), (r1, c1, n1, packs1, s1, p1) = res
     assert p0 == p1 and len(p0) > 12                   # the plan bytes are identical on both ranks ...
     words = np.frombuffer(p0, np.int32)
-    assert words[0] == 0x4e414c50 and words[2] == len(words) - 3 and words[4] == 7 and words[5] == 13   # ... and are rank 0's
+    assert words[0] == 0x4e414c50 and 0 < words[2] < len(words) - 3 and words[4] == 7 and words[5] == 13   # ... and are rank 0's (header, one word per step, the persistent runs, a fingerprint)
     assert (r0, r1) == (0, 1)
     assert n0 == n1 > 5e6 and c0 == c1                 # byte-identical weights on both ranks
     assert packs0 == 1 and packs1 == 0                 # only the source rank runs the CPU weight preparation
@@ -86,8 +86,10 @@ def test_default_plan_is_host_only_and_self_describing():
     from smelter_amd import ops
     g = ONNXGraph(zoo.resnet50(hw=(32, 32)))
     p = g.defaultPlan(8)
-    assert p.dtype == np.int32 and p[0] == 0x4e414c50 and p[1] == ops.num_conv_configs() and p[2] == len(p) - 3
-    assert (p[3:] == -1).all()                          # no autotuning happened: every step on its heuristic
+    assert p.dtype == np.int32 and p[0] == 0x4e414c50 and p[1] == ops.num_conv_configs()
+    steps, runs = int(p[2]), int(p[3 + p[2]])
+    assert len(p) == 3 + steps + 1 + 3 * runs + 1      # header, one word per step, the persistent runs (first step, steps, on), the step list's fingerprint
+    assert (p[3:3 + steps] == -1).all()                 # no autotuning happened: every step on its heuristic
     assert np.array_equal(sd.broadcast_plan(p), p)      # no process group: the plan comes back as it is
 
 

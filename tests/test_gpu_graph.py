@@ -92,8 +92,38 @@ def test_fusion_counts_resnet50():
     # 53 convs (BN folded, Add/Relu in epilogues) + MaxPool + GlobalAveragePool + FC = 56 ops, of which the three 1x1 expand convolutions of the
     # first stage run inside the 3x3 launch in front of them (pass 3d, expand head) and so does the first block's projection shortcut (pass 3e);
     # + input conversion; the max-pool runs inside the stem launch (pass 3i)
-    assert ex.numOps == 48 and ex.numLaunches in (48, 49)         # (no input-conversion launch: the stem's loader waves read the fp32 batch, pass 3f)
+    # (no input-conversion launch: the stem's loader waves read the fp32 batch, pass 3f).  At 64 x 64 input every stage's images are <= 256 pixels, and stages 2-4
+    # (8 x 8, 4 x 4, 2 x 2) are persistent runs (pass 3k): the eight bottleneck tails of stage 1 stay launches (fused heads are not run members), 3 + 3 stride-2 / reduce
+    # layers in front of the runs, 3 runs, stem, pool + FC
+    from smelter_amd.graph import FUSE_STAGE, default_fusions
+    assert ex.numOps == 48 and ex.numLaunches == 25, ex.numLaunches
+    ex0, _ = run_hip(zoo.resnet50(hw=(64, 64)), zoo.synthetic_images(1, 3, (64, 64)), fusions=default_fusions() & ~FUSE_STAGE)
+    assert ex0.numOps == 48 and ex0.numLaunches in (48, 49)
     assert abs(ex.flops - 2 * 4089184256 * (64 * 64) / (224 * 224)) / ex.flops < 0.2      # scaled MAC count, FC unscaled
+
+
+@pytest.mark.parametrize("batch", [16, 3])
+def test_persistent_runs_same_function_as_layer_by_layer(batch):
+    """executor pass 3k: the bottleneck layers of a stage at <= 112-pixel images as ONE launch (sm_stage_fwd).  Same tensors stored, same function: against the oracle
+    with the same rounding list, and against the layer-by-layer launches (not bit-identical: the run's kernels add their K slices in another order than the per-layer tile
+    configurations — each kernel alone is bit-identical inside and outside a run, tests/test_gpu_stage.py)"""
+    from smelter_amd.graph import FUSE_STAGE, default_fusions
+    model = onnx2mps.optimize_model(zoo.resnet50(hw=(96, 96)), half=True)       # stages at 24 x 24 (not a run: 576 pixels), 12 x 12, 6 x 6, 3 x 3
+    x = zoo.synthetic_images(batch, 3, (96, 96))
+    ex, got = run_hip(model, x)
+    ex0, plain = run_hip(model, x, fusions=default_fusions() & ~FUSE_STAGE)
+    assert ex.numLaunches < ex0.numLaunches and ex.numOps == ex0.numOps and ex.valueNames == ex0.valueNames
+    ref_g = O.Graph(model); ref_g.set_round_list(ex.valueNames)
+    ref = ref_g.run(x)
+    O.set_acc64(True)
+    try:
+        floor = nerr(ref_g.run(x), ref)
+    finally:
+        O.set_acc64(False)
+    assert nerr(got, ref) <= 1e-3 + floor and nerr(plain, ref) <= 1e-3 + floor, (nerr(got, ref), nerr(plain, ref), floor)
+    assert nerr(got, plain) <= 1e-3 + floor, nerr(got, plain)
+    ex.encode(torch.from_numpy(x).cuda())                                       # again: the run's control words were left clean
+    assert np.array_equal(ex.toFloatArray(), got)
 
 
 def test_resnet50_runs_its_first_stage_bottleneck_tails_as_one_launch_each(monkeypatch):
@@ -249,7 +279,9 @@ def test_execution_plan_makes_autotuned_shards_bit_identical():
     g0 = ONNXGraph(model, Configuration(autotune=True))
     ex0 = g0.hipGraph(0, 2)                                            # "rank 0": autotunes
     plan = ex0.plan
-    assert plan[0] == 0x4e414c50 and plan[2] == len(plan) - 3 and (plan[3:] >= 0).sum() >= 20, "an autotuned ResNet-50 names a tile configuration for its conv steps"
+    steps = int(plan[2]); runs = int(plan[3 + steps])
+    assert plan[0] == 0x4e414c50 and len(plan) == 3 + steps + 1 + 3 * runs + 1 and (plan[3:3 + steps] >= 0).sum() >= 20, "an autotuned ResNet-50 names a tile configuration for its conv steps"
+    assert runs == 3                                                  # the persistent runs (pass 3k) and whether rank 0's in-situ A/B kept each travel with the plan
     g1 = ONNXGraph(model, Configuration(autotune=True))               # "rank 1": same Configuration, but the plan wins — no autotune sweep
     arena = torch.from_numpy(g1.packWeights(2)).cuda()
     ex1 = g1.hipGraph(0, 2, weight_arena=arena, upload_weights=False, plan=plan.copy())
@@ -261,6 +293,12 @@ def test_execution_plan_makes_autotuned_shards_bit_identical():
     bad = plan.copy(); bad[2] += 1
     with pytest.raises(SmelterError):
         g1.hipGraph(0, 2, plan=bad)
+    other = plan.copy(); other[-1] ^= 1                               # the fingerprint of the step list: another fusion mask can give the same NUMBER of steps
+    with pytest.raises(SmelterError):
+        g1.hipGraph(0, 2, plan=other)
+    from smelter_amd.graph import FUSE_STAGE, default_fusions
+    with pytest.raises(SmelterError):                                # ... and a compile without the runs does not take a plan that has them
+        ONNXGraph(model, Configuration(fusions=default_fusions() & ~FUSE_STAGE)).hipGraph(0, 2, plan=plan)
     with pytest.raises(SmelterError):
         ONNXGraph(zoo.toy()).hipGraph(0, 2, plan=plan)
     worse = plan.copy(); worse[1] += 1

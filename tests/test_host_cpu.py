@@ -239,7 +239,9 @@ def test_mps_flavor_round_trip_same_function_as_unfused():
 def test_weight_bytes_resnet50():
     g = ONNXGraph(zoo.resnet50(hw=(32, 32)))
     nbytes = g.weightBytes(4)
-    assert 51.0e6 < nbytes < 51.5e6                    # 25.5 M fp16 weights + fp32 biases
+    # 25.5 M fp16 weights + fp32 biases = 51.1 MB, + the fragment-order copies of the layers that sit in persistent runs (executor pass 3k; at 32 x 32 input every stage's
+    # images are <= 64 pixels, so nearly every 1x1 / 3x3 stride-1 layer is in one): less than as much again
+    assert 51.0e6 < nbytes < 2 * 51.5e6
     assert nbytes == g.weightBytes(64)                 # independent of batch
 
 
