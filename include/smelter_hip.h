@@ -168,7 +168,8 @@ int sm_conv2d_stem_f32_fwd_cfg(const sm_conv_desc* d, int cfg, const float* x_nc
 /* Three MPSCNNConvolutionNodes in a row — [1x1 expand + act1] -> depthwise 3x3 (pad 1, stride 1|2) + act2 -> 1x1 project + act3
  * (+ the block input as residual) — in ONE launch; the two hidden tensors stay in LDS (the "inverted residual" block of
  * MobileNet-v2).  expand = 0: no 1x1 in front (Ch == Cin).  Weights: w1 [Ch][Cin], wd [Ch][3][3] (the depthwise data source's
- * OHWI image), w2 [Cout][Ch], fp16; biases fp32 or NULL.  All channel counts % 8 == 0; ReLU-family activations.  Four kernels behind it
+ * OHWI image), w2 [Cout][Ch], fp16; biases fp32 or NULL.  All channel counts % 8 == 0; activations: the ReLU family (none / ReLU / leaky with slopeN) or SM_ACT_CLIP
+ * (min(max(x, 0), slopeN): ReLU6 as a torchvision MobileNet-v2 export holds it).  Four kernels behind it
  * (sm_mbconv_kernel_kind: 1 = all-in-LDS, Cin <= 32, Ch <= 192, Cout <= 64; 2 = chunked; 3 = one wave per tile, Cin <= 46 or weights from
  * global memory up to Cin 110 / Cout 96; 4 = one IMAGE per block for H * W <= 224 at stride 1: Cin % 16 == 0, Cin <= 96 / Cout <= 96 above
  * 64 pixels, Cin <= 160 / Cout <= 384 up to 64 pixels, Ch >= 128, everything within 160 KB of LDS — MobileNet-v2's 14 x 14 and 7 x 7 blocks); sm_mbconv_supported = any of them.

@@ -32,6 +32,8 @@ namespace {
 
 constexpr size_t kAlign = 256;
 size_t alignUp(size_t v, size_t a = kAlign) { return (v + a - 1) / a * a; }
+// activations the fused block kernels (mbconv.hip, stem3.hip) apply: the ReLU family and ONNX Clip(0, hi) (ReLU6) — ADVICE r4: a torchvision MobileNet-v2 export holds Clip
+bool blockAct(int act) { return act <= SM_ACT_PRELU || act == SM_ACT_CLIP; }
 bool isConvLike(OpKind k) { return k == OpKind::Conv || k == OpKind::FullyConnected || k == OpKind::ConvTranspose; }
 const char* kindName(OpKind k) {
     switch (k) {
@@ -379,7 +381,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     {
         auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
         auto pointwise = [&](const Step& q) { const Op& o = q.op; return o.kind == OpKind::Conv && o.kh == 1 && o.kw == 1 && o.sh == 1 && o.sw == 1 && !o.pt && !o.pl && !o.pb && !o.pr && o.groups == 1 &&
-                                                     o.act <= SM_ACT_PRELU && !q.stem && !o.grid_h && !o.x_ups && q.pool_out < 0 && !q.has_mb; };
+                                                     blockAct(o.act) && !q.stem && !o.grid_h && !o.x_ups && q.pool_out < 0 && !q.has_mb; };
         if (cfg_.allows(SM_FUSE_MBCONV) && cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency)
             for (size_t t = 0; t < steps_.size(); t++) {
                 Step& e = steps_[t];
@@ -389,7 +391,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 if (!ud) continue;
                 const Op& dw = steps_[ud].op;
                 if (dw.kind != OpKind::Conv || dw.groups != dw.cin || dw.cin != dw.cout || dw.cin != e.op.cout || dw.kh != 3 || dw.kw != 3 || dw.dh != 1 || dw.dw != 1 || dw.sh != dw.sw ||
-                    (dw.sh != 1 && dw.sh != 2) || dw.pt != 1 || dw.pl != 1 || dw.residual >= 0 || dw.act > SM_ACT_PRELU || steps_[ud].pool_out >= 0 || readers(dw.output) != 1) continue;
+                    (dw.sh != 1 && dw.sh != 2) || dw.pt != 1 || dw.pl != 1 || dw.residual >= 0 || !blockAct(dw.act) || steps_[ud].pool_out >= 0 || readers(dw.output) != 1) continue;
                 for (size_t u = ud + 1; u < steps_.size() && !up; u++) if (!steps_[u].op.inputs.empty() && steps_[u].op.inputs[0] == dw.output) up = u;
                 if (!up || !pointwise(steps_[up])) continue;
                 const Op& pj = steps_[up].op;
@@ -412,7 +414,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 Step& e = steps_[t];
                 const Op& dw = e.op;
                 if (e.has_mb || e.pool_out >= 0 || e.stem || dw.kind != OpKind::Conv || dw.groups != dw.cin || dw.cin != dw.cout || dw.groups < 8 || dw.kh != 3 || dw.kw != 3 || dw.dh != 1 ||
-                    dw.dw != 1 || dw.sh != dw.sw || (dw.sh != 1 && dw.sh != 2) || dw.pt != 1 || dw.pl != 1 || dw.residual >= 0 || dw.act > SM_ACT_PRELU || dw.grid_h || dw.x_ups || readers(dw.output) != 1) continue;
+                    dw.dw != 1 || dw.sh != dw.sw || (dw.sh != 1 && dw.sh != 2) || dw.pt != 1 || dw.pl != 1 || dw.residual >= 0 || !blockAct(dw.act) || dw.grid_h || dw.x_ups || readers(dw.output) != 1) continue;
                 size_t up = 0;
                 for (size_t u = t + 1; u < steps_.size() && !up; u++) if (!steps_[u].op.inputs.empty() && steps_[u].op.inputs[0] == dw.output) up = u;
                 if (!up || !pointwise(steps_[up]) || steps_[up].op.residual >= 0 || steps_[up].op.cin != dw.cout) continue;
@@ -604,7 +606,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         auto readers = [&](int v) { int n = v == output_value_ ? 2 : 0; for (const Step& q : steps_) { for (int u : q.op.inputs) if (u == v) n++; if (q.op.residual == v) n++; } return n; };
         for (size_t t = 0; t + 1 < steps_.size(); t++) {
             Step& sc = steps_[t];
-            if (!sc.stem || sc.stem_p < 0 || sc.op.act > SM_ACT_PRELU || sc.op.residual >= 0 || readers(sc.op.output) != 1) continue;
+            if (!sc.stem || sc.stem_p < 0 || !blockAct(sc.op.act) || sc.op.residual >= 0 || readers(sc.op.output) != 1) continue;
             size_t ub = 0;
             for (size_t u = t + 1; u < steps_.size() && !ub; u++) if (!steps_[u].op.inputs.empty() && steps_[u].op.inputs[0] == sc.op.output) ub = u;
             if (!ub || !steps_[ub].has_mb || !steps_[ub].mb_noexp) continue;
@@ -659,7 +661,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     // form's time (U-Net 512^2: 110 -> 68 us); taken whenever the stem is a 3x3 on <= 3 planes that neither pass 3g nor 3i fused away
     if (stem_ && !stem_in_block_ && cfg_.fuse && !cfg_.keepIntermediates && cfg_.allows(SM_FUSE_STEM_F32) && cfg_.allows(SM_FUSE_STEM3))
         for (Step& st : steps_) {
-            if (!st.stem || st.has_mb || st.pool3_out >= 0 || st.pool_out >= 0 || st.has_head || st.stem3_p < 0 || st.op.residual >= 0 || st.op.act > SM_ACT_PRELU || !vecOk(st.op.output)) continue;
+            if (!st.stem || st.has_mb || st.pool3_out >= 0 || st.pool_out >= 0 || st.has_head || st.stem3_p < 0 || st.op.residual >= 0 || !blockAct(st.op.act) || !vecOk(st.op.output)) continue;
             const Value& iv = values_[input_value_];
             if (!sm_stem3x3_f32_supported(batch, iv.c, iv.h, iv.w, st.op.cout, st.stem_s, st.stem3_p)) continue;
             st.stem3 = true; stem_f32_ = true;

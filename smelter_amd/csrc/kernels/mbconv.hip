@@ -40,7 +40,7 @@ struct MbParams {
     const half_t* x; half_t* y; const half_t *w1, *wd, *w2; const float *b1, *bd, *b2;
     int N, H, W, Ho, Wo, s, Cin, Ch, Cout, x_ld, y_ld;
     int expand, res;                 // expand = 0: no 1x1 in front (the depthwise layer reads X itself, Ch == Cin)
-    int act1, act2, act3; float sl1, sl2, sl3;
+    int act1, act2, act3; float sl1, sl2, sl3, hi1, hi2, hi3;   // hiN = +inf unless actN is SM_ACT_CLIP
     int ChP, hstride;                // Ch rounded up to 32; LDS bytes per hidden pixel = ChP*2 + 16 (an odd number of 16-byte slots: conflict-free b128 columns)
     int tiles_x, tiles_y, ntiles;
     int tile_o;                      // v4: side of the square output tile (14 at stride 1, 7 at stride 2; <= the image)
@@ -52,7 +52,9 @@ struct MbParams {
 
 inline void fastdiv_make(unsigned d, unsigned* mul, unsigned* sh) { unsigned s = 0; while ((1ull << s) < d) s++; *mul = (unsigned)(((1ull << (31 + s)) / d) + 1); *sh = 31 + s; }
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned mul, unsigned sh) { return (unsigned)(((unsigned long long)n * mul) >> sh); }
-__device__ __forceinline__ float relu_family(float v, float sl) { return v < 0.f ? v * sl : v; }
+// the activations a fused block takes: x >= 0 ? x : sl x (none: sl = 1, ReLU: sl = 0, leaky / PReLU), then min(., hi) — hi = +inf but for SM_ACT_CLIP (ONNX Clip(0, hi), ReLU6 = 6:
+// sl = 0).  The packed-max fast paths below serve plain ReLU only (hi = +inf); a clipped activation takes the general path with one v_min more per value.
+__device__ __forceinline__ float relu_family(float v, float sl, float hi) { return fminf(v < 0.f ? v * sl : v, hi); }
 // Barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0): inside the tile loop that made every barrier wait for the
 // X-patch prefetch of the NEXT tile (a full HBM round trip) and for the previous tile's output stores.
 __device__ __forceinline__ void mb_lds_barrier() {
@@ -107,7 +109,9 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
     for (int i = tid; i < OP * (hs / 2); i += NT) ((half_t*)hid2)[i] = (half_t)0.f;      // (the pad channels / pad slot of the hidden tile stay zero for good)
     if (!p.expand) for (int i = tid; i < 2 * HIDB / 2; i += NT) ((half_t*)hid0)[i] = (half_t)0.f;   // (pad channels of the copied patch)
 
-    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;            // block-uniform: plain ReLU takes the packed-max path
+    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;           // block-uniform: (clipped) ReLU takes the packed-max path ...
+    const bool clip1 = p.hi1 != INFINITY, clip2 = p.hi2 != INFINITY;   // ... + a packed min when the activation is ONNX Clip(0, hi); min commutes with the rounding (monotone)
+    const half_t hh1 = (half_t)p.hi1, hh2 = (half_t)p.hi2;            // block-uniform: plain ReLU takes the packed-max path
     const int T = p.ntiles, G = gridDim.x;
     const int t_begin = (int)((long)blockIdx.x * T / G), t_end = (int)((long)(blockIdx.x + 1) * T / G);
     const int nfa = ChP >> 5, ks1 = KP1 >> 4, ks2 = ChP >> 4, nfc = CoP >> 5, cvn = p.Ch >> 3;
@@ -176,9 +180,10 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
 #pragma unroll
                     for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[4 * q + r2];
                     o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                    if (clip1) o = __builtin_elementwise_min(o, half4_t{hh1, hh1, hh1, hh1});
                 } else {
 #pragma unroll
-                    for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[4 * q + r2], p.sl1);
+                    for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[4 * q + r2], p.sl1, p.hi1);
                 }
                 *(half4_t*)(hid + pp * hs + (nf * 32 + 8 * q + 4 * hi) * 2) = o;
             }
@@ -216,9 +221,10 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) ov[j] = (half_t)a[j];
                 ov = __builtin_elementwise_max(ov, half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+                if (clip2) ov = __builtin_elementwise_min(ov, half8_t{hh2, hh2, hh2, hh2, hh2, hh2, hh2, hh2});
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+                for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2, p.hi2);
             }
             *(half8_t*)(hid2 + op * hs + cv * 16) = ov;
         }
@@ -259,7 +265,7 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
                         for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                     half8_t ov;
 #pragma unroll
-                    for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                    for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
                     *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                 }
             }
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
                     for (int q = 0; q < 4; q++) {
                         half4_t o;
 #pragma unroll
-                        for (int r2 = 0; r2 < 4; r2++) o[r2] = inimg ? (half_t)relu_family(acc[4 * q + r2] + bq[q][r2], p.sl1) : (half_t)0.f;
+                        for (int r2 = 0; r2 < 4; r2++) o[r2] = inimg ? (half_t)relu_family(acc[4 * q + r2] + bq[q][r2], p.sl1, p.hi1) : (half_t)0.f;
                         *(half4_t*)(hid + pp * HS + (8 * q + 4 * hi) * 2) = o;
                     }
                 }
@@ -405,7 +411,7 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
                     }
                 half8_t ov;
 #pragma unroll
-                for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+                for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2, p.hi2);
                 *(half8_t*)(dwo + op * HS + cv * 16) = ov;
             }
             MB_TL(3);
@@ -444,7 +450,7 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
                         for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                     half8_t ov;
 #pragma unroll
-                    for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                    for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
                     *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                 }
             }
@@ -531,7 +537,9 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
     __syncthreads();                                                     // the only barrier of the kernel
 
-    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;
+    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;           // block-uniform: (clipped) ReLU takes the packed-max path ...
+    const bool clip1 = p.hi1 != INFINITY, clip2 = p.hi2 != INFINITY;   // ... + a packed min when the activation is ONNX Clip(0, hi); min commutes with the rounding (monotone)
+    const half_t hh1 = (half_t)p.hi1, hh2 = (half_t)p.hi2;
     const long T = p.ntiles, GW = (long)gridDim.x * NW, gw = (long)blockIdx.x * NW + wave;
     const int t_begin = (int)(gw * T / GW), t_end = (int)((gw + 1) * T / GW);
     const half8_t hz = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -653,9 +661,10 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 #pragma unroll
                         for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[4 * q + r2];
                         o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                        if (clip1) o = __builtin_elementwise_min(o, half4_t{hh1, hh1, hh1, hh1});
                     } else {
 #pragma unroll
-                        for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[4 * q + r2], p.sl1);
+                        for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[4 * q + r2], p.sl1, p.hi1);
                     }
                     *(half4_t*)(hid + (mf * 32 + l31) * HS + (8 * q + 4 * hi) * 2) = o;
                 }
@@ -701,9 +710,10 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)accB[pg][cg][r2];
                             o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                            if (clip2) o = __builtin_elementwise_min(o, half4_t{hh2, hh2, hh2, hh2});
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(accB[pg][cg][r2], p.sl2);
+                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(accB[pg][cg][r2], p.sl2, p.hi2);
                         }
                         *(half4_t*)(dwo + (pg * 16 + n16) * HS + cg * 32 + g4 * 8) = o;
                     }
@@ -746,12 +756,12 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                         half8_t ov;
-                        if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
+                        if (p.sl3 == 1.f && p.hi3 == INFINITY) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
                         }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }
@@ -775,7 +785,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 template <int X0, int X1> __device__ __forceinline__ void mb_fma_mix(float& a, unsigned x, unsigned w) {    // a += half X0 of x * half X1 of w, one v_fma_mix_f32
     a = __builtin_fmaf((float)__builtin_bit_cast(half2_t, x)[X0], (float)__builtin_bit_cast(half2_t, w)[X1], a);
 }
-template <int S, int KS1, int NW, int NF = 1, bool RELU = true>   // RELU: act1 and act2 are ReLU (else any member of the leaky family, slopes p.sl1 / p.sl2)
+template <int S, int KS1, int NW, int NF = 1, int RELU = 1>   // RELU: 1 = act1 and act2 are ReLU, 2 = ReLU with an upper bound (ONNX Clip(0, hi): packed max, packed min), 0 = any member of the leaky family (slopes p.sl1 / p.sl2, bounds p.hi1 / p.hi2)
 __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
     constexpr int TW = 8, TH = S == 1 ? 4 : 2, OPX = TH * TW, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, WC = 3 * S + 3, WPR = (WC + 1) / 2;
     constexpr int PXH = PH * WC, MFA = (PXH + 15) / 16, HS = 80, NT = NW * 64, KP1 = KS1 * 16;
@@ -904,8 +914,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
                     const int q0 = py * WC + 2 * q, q1 = q0 + 1;
                     const float a = accA[q0 >> 4][q0 & 15], b = (2 * q + 1 < WC) ? accA[q1 >> 4][q1 & 15] : 0.f;
                     half2_t o;
-                    if constexpr (RELU) { o[0] = (half_t)a; o[1] = (half_t)b; o = __builtin_elementwise_max(o, half2_t{0, 0}); }
-                    else { o[0] = (half_t)relu_family(a, p.sl1); o[1] = (half_t)relu_family(b, p.sl1); }
+                    if constexpr (RELU != 0) { o[0] = (half_t)a; o[1] = (half_t)b; o = __builtin_elementwise_max(o, half2_t{0, 0}); if constexpr (RELU == 2) o = __builtin_elementwise_min(o, half2_t{(half_t)p.hi1, (half_t)p.hi1}); }
+                    else { o[0] = (half_t)relu_family(a, p.sl1, p.hi1); o[1] = (half_t)relu_family(b, p.sl1, p.hi1); }
                     hw[py][q] = __builtin_bit_cast(unsigned, o);
                 }
             // ---- phase B: depthwise 3x3 over the lane's window: TH x 4 outputs, nine fp32 FMAs each -------------------------------------------------------------------
@@ -931,8 +941,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
                     a2[e] = a;
                 });
                 half2_t o;
-                if constexpr (RELU) { o[0] = (half_t)a2[0]; o[1] = (half_t)a2[1]; o = __builtin_elementwise_max(o, half2_t{0, 0}); }
-                else { o[0] = (half_t)relu_family(a2[0], p.sl2); o[1] = (half_t)relu_family(a2[1], p.sl2); }
+                if constexpr (RELU != 0) { o[0] = (half_t)a2[0]; o[1] = (half_t)a2[1]; o = __builtin_elementwise_max(o, half2_t{0, 0}); if constexpr (RELU == 2) o = __builtin_elementwise_min(o, half2_t{(half_t)p.hi2, (half_t)p.hi2}); }
+                else { o[0] = (half_t)relu_family(a2[0], p.sl2, p.hi2); o[1] = (half_t)relu_family(a2[1], p.sl2, p.hi2); }
                 *(half_t*)(dwo + woff[2 * op2] + oy * TW * HS) = o[0];
                 *(half_t*)(dwo + woff[2 * op2 + 1] + oy * TW * HS) = o[1];
             });
@@ -972,12 +982,12 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                         half8_t ov;
-                        if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
+                        if (p.sl3 == 1.f && p.hi3 == INFINITY) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
                         }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }
@@ -995,7 +1005,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
 // the fourth "kw" slot of kernel row 1 — overwritten in registers — carries the two bias columns (1, 1 inside the hidden image: a hidden pixel outside is exactly 0, the
 // depthwise layer's padding).  Two blocks per CU (launch bounds): one stages while the other computes.  Phases A (operands swapped: lane = channel), B (register
 // stencil), C and the epilogue are mbconv5_kernel's.
-template <int S, int NF, bool RELU>
+template <int S, int NF, int RELU>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void mbconv5s_kernel(MbParams p) {   // (128 registers: two blocks per CU)
     constexpr int NW = 8, TW = 8, TH = S == 1 ? 4 : 2, OPX = TH * TW, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, WC = 3 * S + 3, WPR = (WC + 1) / 2;
     constexpr int PXH = PH * WC, MFA = (PXH + 15) / 16, HS = 80, NT = NW * 64, KP1 = 48, BWY = 2, BWX = 4;
@@ -1124,8 +1134,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     const int q0 = py * WC + 2 * q, q1 = q0 + 1;
                     const float a = accA[q0 >> 4][q0 & 15], b = (2 * q + 1 < WC) ? accA[q1 >> 4][q1 & 15] : 0.f;
                     half2_t o;
-                    if constexpr (RELU) { o[0] = (half_t)a; o[1] = (half_t)b; o = __builtin_elementwise_max(o, half2_t{0, 0}); }
-                    else { o[0] = (half_t)relu_family(a, p.sl1); o[1] = (half_t)relu_family(b, p.sl1); }
+                    if constexpr (RELU != 0) { o[0] = (half_t)a; o[1] = (half_t)b; o = __builtin_elementwise_max(o, half2_t{0, 0}); if constexpr (RELU == 2) o = __builtin_elementwise_min(o, half2_t{(half_t)p.hi1, (half_t)p.hi1}); }
+                    else { o[0] = (half_t)relu_family(a, p.sl1, p.hi1); o[1] = (half_t)relu_family(b, p.sl1, p.hi1); }
                     hw[py][q] = __builtin_bit_cast(unsigned, o);
                 }
             // ---- phase B (mbconv5_kernel) ----------------------------------------------------------------------------------------------------------------------------
@@ -1148,8 +1158,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     a2[e] = a;
                 });
                 half2_t o;
-                if constexpr (RELU) { o[0] = (half_t)a2[0]; o[1] = (half_t)a2[1]; o = __builtin_elementwise_max(o, half2_t{0, 0}); }
-                else { o[0] = (half_t)relu_family(a2[0], p.sl2); o[1] = (half_t)relu_family(a2[1], p.sl2); }
+                if constexpr (RELU != 0) { o[0] = (half_t)a2[0]; o[1] = (half_t)a2[1]; o = __builtin_elementwise_max(o, half2_t{0, 0}); if constexpr (RELU == 2) o = __builtin_elementwise_min(o, half2_t{(half_t)p.hi2, (half_t)p.hi2}); }
+                else { o[0] = (half_t)relu_family(a2[0], p.sl2, p.hi2); o[1] = (half_t)relu_family(a2[1], p.sl2, p.hi2); }
                 *(half_t*)(dwo + woff[2 * op2] + oy * TW * HS) = o[0];
                 *(half_t*)(dwo + woff[2 * op2 + 1] + oy * TW * HS) = o[1];
             });
@@ -1189,12 +1199,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                         const int co = a * 32 + 16 * j + 8 * hi;
                         if (pin && co < p.Cout) {
                             half8_t ov;
-                            if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
+                            if (p.sl3 == 1.f && p.hi3 == INFINITY) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
                                 for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                             } else {
 #pragma unroll
-                                for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                                for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
                             }
                             *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                         }
@@ -1333,7 +1343,9 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
     }
     const int rlong = TO % RP, rbase = TO / RP;
     const int ty0 = rp * rbase + (rp < rlong ? rp : rlong), ty1 = task_on ? ty0 + rbase + (rp < rlong ? 1 : 0) : 0;
-    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;
+    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;           // block-uniform: (clipped) ReLU takes the packed-max path ...
+    const bool clip1 = p.hi1 != INFINITY, clip2 = p.hi2 != INFINITY;   // ... + a packed min when the activation is ONNX Clip(0, hi); min commutes with the rounding (monotone)
+    const half_t hh1 = (half_t)p.hi1, hh2 = (half_t)p.hi2;
 
     int g = 0;                                                            // chunks done since the launch (buffer parity); the chunk's channels = g % NC
 #pragma unroll 1
@@ -1388,9 +1400,10 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[cf][4 * qq + r2];
                             o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                            if (clip1) o = __builtin_elementwise_min(o, half4_t{hh1, hh1, hh1, hh1});
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[cf][4 * qq + r2], p.sl1);
+                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[cf][4 * qq + r2], p.sl1, p.hi1);
                         }
                         *(half4_t*)(hid + pp * HSB + ((cfa0 + cf) * 32 + 8 * qq + 4 * hi) * 2) = o;
                     }
@@ -1430,9 +1443,10 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
 #pragma unroll
                         for (int j = 0; j < 8; j++) ov[j] = (half_t)a[j];
                         ov = __builtin_elementwise_max(ov, hz);
+                        if (clip2) ov = __builtin_elementwise_min(ov, half8_t{hh2, hh2, hh2, hh2, hh2, hh2, hh2, hh2});
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2);
+                        for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2, p.hi2);
                     }
                     *(half8_t*)(dwo + (y * TO + tx) * HSB + cv * 16) = ov;
                 };
@@ -1534,12 +1548,12 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
                             for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rres[i][j][r2];
                         }
                         half8_t ov;
-                        if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
+                        if (p.sl3 == 1.f && p.hi3 == INFINITY) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
                         }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }
@@ -1611,7 +1625,8 @@ static bool mb_common_ok(const sm_mbconv_desc* d) {
     if ((d->Cin & 7) || (d->Ch & 7) || (d->Cout & 7) || d->Cin <= 0 || d->Ch <= 0 || d->Cout <= 0) return false;
     if (!d->expand && d->Ch != d->Cin) return false;
     if (d->residual && (d->stride != 1 || d->Cin != d->Cout)) return false;
-    if (d->act1 > SM_ACT_PRELU || d->act2 > SM_ACT_PRELU || d->act3 > SM_ACT_PRELU) return false;
+    auto act_ok = [](int a) { return a <= SM_ACT_PRELU || a == SM_ACT_CLIP; };
+    if (!act_ok(d->act1) || !act_ok(d->act2) || !act_ok(d->act3)) return false;
     return d->Ho == (d->H + 2 - 3) / d->stride + 1 && d->Wo == (d->W + 2 - 3) / d->stride + 1;
 }
 static bool mb_v1_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && d->Cin <= 32 && d->Ch <= 192 && d->Cout <= 64 && mb_v1_lds(d) <= 160 * 1024; }
@@ -1683,9 +1698,9 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
     SM_REQUIRE((p.x_ld & 7) == 0 && (p.y_ld & 7) == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0, "sm_mbconv_fwd: operands must be 16-byte aligned, pixel strides % 8 == 0");
     SM_REQUIRE((long)d->N * d->H * d->W < (1L << 31), "sm_mbconv_fwd: too many pixels");
     p.act1 = d->act1; p.act2 = d->act2; p.act3 = d->act3;
-    p.sl1 = d->act1 == SM_ACT_NONE ? 1.f : d->act1 == SM_ACT_RELU ? 0.f : d->slope1;
-    p.sl2 = d->act2 == SM_ACT_NONE ? 1.f : d->act2 == SM_ACT_RELU ? 0.f : d->slope2;
-    p.sl3 = d->act3 == SM_ACT_NONE ? 1.f : d->act3 == SM_ACT_RELU ? 0.f : d->slope3;
+    p.sl1 = d->act1 == SM_ACT_NONE ? 1.f : (d->act1 == SM_ACT_RELU || d->act1 == SM_ACT_CLIP) ? 0.f : d->slope1; p.hi1 = d->act1 == SM_ACT_CLIP ? d->slope1 : INFINITY;
+    p.sl2 = d->act2 == SM_ACT_NONE ? 1.f : (d->act2 == SM_ACT_RELU || d->act2 == SM_ACT_CLIP) ? 0.f : d->slope2; p.hi2 = d->act2 == SM_ACT_CLIP ? d->slope2 : INFINITY;
+    p.sl3 = d->act3 == SM_ACT_NONE ? 1.f : (d->act3 == SM_ACT_RELU || d->act3 == SM_ACT_CLIP) ? 0.f : d->slope3; p.hi3 = d->act3 == SM_ACT_CLIP ? d->slope3 : INFINITY;
     p.ChP = (d->Ch + 31) & ~31; p.hstride = p.ChP * 2 + 16;
     const int TH = d->stride == 1 ? 8 : 4, TW = 8, PW = (TW - 1) * d->stride + 3;
     p.tiles_x = sm_ceil_div(d->Wo, TW); p.tiles_y = sm_ceil_div(d->Ho, TH);
@@ -1726,10 +1741,10 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
         fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
         if (mb_v5_ok(d)) {                                           // hidden patch in registers: 16-wave blocks, one per CU
             SM_REQUIRE(((((uintptr_t)w1) | ((uintptr_t)w2)) & 15) == 0, "sm_mbconv_fwd: weights must be 16-byte aligned");
-            const bool relu = p.sl1 == 0.f && p.sl2 == 0.f;
+            const int relu = (p.sl1 == 0.f && p.sl2 == 0.f) ? ((p.hi1 == INFINITY && p.hi2 == INFINITY) ? 1 : 2) : 0;   // (a bound on one of the two: the other's is +inf, a no-op min)
             void (*f5)(MbParams) = nullptr;
-#define MB5_PICK2(S_, K_) (d->Cout <= 32 ? (relu ? mbconv5_kernel<S_, K_, 16, 1, true> : mbconv5_kernel<S_, K_, 16, 1, false>) \
-                                         : (relu ? mbconv5_kernel<S_, K_, 16, 2, true> : mbconv5_kernel<S_, K_, 16, 2, false>))
+#define MB5_PICK2(S_, K_) (d->Cout <= 32 ? (relu == 1 ? mbconv5_kernel<S_, K_, 16, 1, 1> : relu == 2 ? mbconv5_kernel<S_, K_, 16, 1, 2> : mbconv5_kernel<S_, K_, 16, 1, 0>) \
+                                         : (relu == 1 ? mbconv5_kernel<S_, K_, 16, 2, 1> : relu == 2 ? mbconv5_kernel<S_, K_, 16, 2, 2> : mbconv5_kernel<S_, K_, 16, 2, 0>))
 #define MB5_PICK(S_) (d->Cin <= 30 ? MB5_PICK2(S_, 2) : MB5_PICK2(S_, 3))
             if (d->stride == 1) f5 = MB5_PICK(1); else f5 = MB5_PICK(2);
 #undef MB5_PICK2
@@ -1801,9 +1816,9 @@ int sm_mbconv_stem_fwd(const sm_mbconv_desc* d, const float* x_nchw, int32_t C, 
     p.x_ld = 8; p.y_ld = d->y_ld ? d->y_ld : d->Cout; p.expand = 1; p.res = 0;
     SM_REQUIRE((p.y_ld & 7) == 0 && (((uintptr_t)y) & 15) == 0, "sm_mbconv_stem_fwd: output must be 16-byte aligned, pixel stride % 8 == 0");
     p.act1 = d->act1; p.act2 = d->act2; p.act3 = d->act3;
-    p.sl1 = d->act1 == SM_ACT_NONE ? 1.f : d->act1 == SM_ACT_RELU ? 0.f : d->slope1;
-    p.sl2 = d->act2 == SM_ACT_NONE ? 1.f : d->act2 == SM_ACT_RELU ? 0.f : d->slope2;
-    p.sl3 = d->act3 == SM_ACT_NONE ? 1.f : d->act3 == SM_ACT_RELU ? 0.f : d->slope3;
+    p.sl1 = d->act1 == SM_ACT_NONE ? 1.f : (d->act1 == SM_ACT_RELU || d->act1 == SM_ACT_CLIP) ? 0.f : d->slope1; p.hi1 = d->act1 == SM_ACT_CLIP ? d->slope1 : INFINITY;
+    p.sl2 = d->act2 == SM_ACT_NONE ? 1.f : (d->act2 == SM_ACT_RELU || d->act2 == SM_ACT_CLIP) ? 0.f : d->slope2; p.hi2 = d->act2 == SM_ACT_CLIP ? d->slope2 : INFINITY;
+    p.sl3 = d->act3 == SM_ACT_NONE ? 1.f : (d->act3 == SM_ACT_RELU || d->act3 == SM_ACT_CLIP) ? 0.f : d->slope3; p.hi3 = d->act3 == SM_ACT_CLIP ? d->slope3 : INFINITY;
     p.ChP = (d->Ch + 31) & ~31; p.hstride = p.ChP * 2 + 16;
     const int S = d->stride, TH = S == 1 ? 4 : 2;
     p.tiles_x = sm_ceil_div(d->Wo, 32); p.tiles_y = sm_ceil_div(d->Ho, 2 * TH);                // block tiles of (2 TH) x 32 output pixels
@@ -1811,9 +1826,9 @@ int sm_mbconv_stem_fwd(const sm_mbconv_desc* d, const float* x_nchw, int32_t C, 
     SM_REQUIRE(nbt < (1L << 31), "sm_mbconv_stem_fwd: too many tiles");
     p.ntiles = (int)nbt;
     fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
-    const bool relu = p.sl1 == 0.f && p.sl2 == 0.f;
+    const int relu = (p.sl1 == 0.f && p.sl2 == 0.f) ? ((p.hi1 == INFINITY && p.hi2 == INFINITY) ? 1 : 2) : 0;
     void (*fn)(MbParams) = nullptr;
-#define MB5S_PICK(S_) (d->Cout <= 32 ? (relu ? mbconv5s_kernel<S_, 1, true> : mbconv5s_kernel<S_, 1, false>) : (relu ? mbconv5s_kernel<S_, 2, true> : mbconv5s_kernel<S_, 2, false>))
+#define MB5S_PICK(S_) (d->Cout <= 32 ? (relu == 1 ? mbconv5s_kernel<S_, 1, 1> : relu == 2 ? mbconv5s_kernel<S_, 1, 2> : mbconv5s_kernel<S_, 1, 0>) : (relu == 1 ? mbconv5s_kernel<S_, 2, 1> : relu == 2 ? mbconv5s_kernel<S_, 2, 2> : mbconv5s_kernel<S_, 2, 0>))
     if (S == 1) fn = MB5S_PICK(1); else fn = MB5S_PICK(2);
 #undef MB5S_PICK
     hipLaunchKernelGGL(fn, dim3((unsigned)std::min<long>(nbt, 2L * SM_NUM_CU)), dim3(512), mb_stem_lds(d, st_stride), sm_s(stream), p);

@@ -19,7 +19,7 @@ namespace {
 
 struct Stem3Params {
     const float* x; const half_t* w; const float* bias; half_t* y;
-    int N, C, in_H, in_W, Ho, Wo, Cout, s, pad, y_ld; float slope;   // slope: 0 = ReLU, 1 = none, else leaky
+    int N, C, in_H, in_W, Ho, Wo, Cout, s, pad, y_ld; float slope, hi;   // slope: 0 = ReLU, 1 = none, else leaky; hi: upper bound (+inf but for SM_ACT_CLIP: ONNX Clip(0, hi), ReLU6)
     int tiles_x, tiles_y, ntiles, IR, IC, pitch, nelem;              // block tiles; input region (rows, columns), LDS row pitch in pixel slots, C * IR * IC
     unsigned tx_mul, tx_sh, txy_mul, txy_sh, ic_mul, ic_sh, pl_mul, pl_sh;   // fastdiv by tiles_x, tiles_x * tiles_y, IC, IR * IC
 };
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                             ov = __builtin_elementwise_max(ov, half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+                            if (p.hi != INFINITY) { const half_t hh = (half_t)p.hi; ov = __builtin_elementwise_min(ov, half8_t{hh, hh, hh, hh, hh, hh, hh, hh}); }   // (min commutes with the rounding: it is monotone)
                         } else {
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)(o[r2] < 0.f ? o[r2] * p.slope : o[r2]);
@@ -162,16 +163,16 @@ int sm_stem3x3_f32_supported(int32_t N, int32_t C, int32_t in_H, int32_t in_W, i
 }
 
 // y [N, Ho, Wo, Cout] fp16 (pixel stride y_ld halfs, 16-byte aligned, y_ld % 8 == 0) = act(conv3x3(x_nchw fp32 [N, C, in_H, in_W], w [Cout][3][3][C] fp16 (OHWI), stride,
-// padding pad on all four sides) + bias); act in the ReLU family (SM_ACT_NONE | SM_ACT_RELU | leaky with `slope`).
+// padding pad on all four sides) + bias); act in the ReLU family (SM_ACT_NONE | SM_ACT_RELU | leaky with `slope`) or SM_ACT_CLIP (min(max(x, 0), slope)).
 int sm_stem3x3_f32_fwd(const float* x_nchw, int32_t N, int32_t C, int32_t in_H, int32_t in_W, const void* w_ohwi, const float* bias, int32_t Cout, int32_t stride, int32_t pad,
                        int32_t act, float slope, void* y, int32_t y_ld, sm_stream_t stream) {
-    SM_REQUIRE(x_nchw && w_ohwi && y && sm_stem3x3_f32_supported(N, C, in_H, in_W, Cout, stride, pad) && act <= SM_ACT_PRELU, "sm_stem3x3_f32_fwd: unsupported geometry");
+    SM_REQUIRE(x_nchw && w_ohwi && y && sm_stem3x3_f32_supported(N, C, in_H, in_W, Cout, stride, pad) && (act <= SM_ACT_PRELU || act == SM_ACT_CLIP), "sm_stem3x3_f32_fwd: unsupported geometry");
     Stem3Params p{};
     p.x = x_nchw; p.w = (const half_t*)w_ohwi; p.bias = bias; p.y = (half_t*)y;
     p.N = N; p.C = C; p.in_H = in_H; p.in_W = in_W; p.Cout = Cout; p.s = stride; p.pad = pad; p.y_ld = y_ld ? y_ld : Cout;
     p.Ho = (in_H + 2 * pad - 3) / stride + 1; p.Wo = (in_W + 2 * pad - 3) / stride + 1;
     SM_REQUIRE((p.y_ld & 7) == 0 && (((uintptr_t)y) & 15) == 0, "sm_stem3x3_f32_fwd: output must be 16-byte aligned, pixel stride % 8 == 0");
-    p.slope = act == SM_ACT_NONE ? 1.f : act == SM_ACT_RELU ? 0.f : slope;
+    p.slope = act == SM_ACT_NONE ? 1.f : (act == SM_ACT_RELU || act == SM_ACT_CLIP) ? 0.f : slope; p.hi = act == SM_ACT_CLIP ? slope : INFINITY;
     s3_geometry(stride, &p.IR, &p.IC, &p.pitch); p.nelem = C * p.IR * p.IC;
     p.tiles_x = sm_ceil_div(p.Wo, S3_COLS); p.tiles_y = sm_ceil_div(p.Ho, S3_NW * s3_wr(stride));
     const long nbt = (long)N * p.tiles_x * p.tiles_y;

@@ -12,7 +12,7 @@ import torch
 
 from ._native import ConvDesc, PoolDesc, StagePhase, check, lib
 
-ACT_NONE, ACT_RELU, ACT_PRELU = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_PRELU, ACT_CLIP = 0, 1, 2, 12
 
 
 def _stream():
@@ -290,14 +290,14 @@ def conv2d_xhead_proj(x, w_ohwi, bias, w3, b3sum, xs, ws, act=ACT_RELU, slope=0.
     return y3
 
 
-def mbconv(x, w1, b1, wd, bd, w2, b2, stride=1, residual=False, acts=(ACT_RELU, ACT_RELU, ACT_NONE)):
+def mbconv(x, w1, b1, wd, bd, w2, b2, stride=1, residual=False, acts=(ACT_RELU, ACT_RELU, ACT_NONE), slopes=(0.0, 0.0, 0.0)):
     """fused inverted-residual block (sm_mbconv_fwd): [1x1 expand w1 (None = absent)] -> depthwise 3x3 wd [Ch,3,3] -> 1x1 project w2 (+ x)"""
     from ._native import MbConvDesc
     n, h, w, cin, x_ld = _check_nhwc(x)
     ch, cout = wd.shape[0], w2.shape[0]
     ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
     y = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x.device)
-    d = MbConvDesc(n, h, w, ho, wo, stride, cin, ch, cout, 1 if w1 is not None else 0, 1 if residual else 0, acts[0], 0.0, acts[1], 0.0, acts[2], 0.0, x_ld, _ld(y))
+    d = MbConvDesc(n, h, w, ho, wo, stride, cin, ch, cout, 1 if w1 is not None else 0, 1 if residual else 0, acts[0], slopes[0], acts[1], slopes[1], acts[2], slopes[2], x_ld, _ld(y))
     check(lib().sm_mbconv_fwd(C.byref(d), _ptr(x), _ptr(w1), _ptr(b1), _ptr(wd), _ptr(bd), _ptr(w2), _ptr(b2), _ptr(y), _stream()))
     return y
 

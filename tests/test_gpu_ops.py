@@ -772,7 +772,42 @@ def test_mbconv_register_window_kernel_other_activations(hw, cin, ch, cout, stri
     assert np.mean(got != ref16) < 0.2
 
 
+@pytest.mark.parametrize("hw,cin,ch,cout,stride,res", [
+    ((56, 56), 24, 144, 24, 1, True),      # MobileNet-v2 block 3: register-window kernel (kind 5)
+    ((56, 56), 24, 144, 32, 2, False),     # ... stride 2
+    ((28, 28), 32, 192, 32, 1, True),      # 28 x 28
+    ((14, 14), 64, 384, 64, 1, True),      # one image per block (kind 4)
+    ((14, 14), 96, 576, 160, 2, False),    # stride 2 into 7 x 7
+    ((7, 7), 160, 960, 160, 1, True),      # 7 x 7
+    ((20, 24), 16, 96, 24, 1, False),      # all-in-LDS / chunked domain
+])
+def test_mbconv_relu6_clip(hw, cin, ch, cout, stride, res):
+    """a torchvision MobileNet-v2 export holds ONNX Clip(0, 6) where the stand-in model has Relu.  The fused block kernels take SM_ACT_CLIP (upper bound in
+    `slope`): min(max(x, 0), 6) behind the expand and the depthwise layer, on inputs scaled so that the bound bites"""
+    import ctypes
+    from smelter_amd._native import MbConvDesc
+    so = lambda v: (v + 2 - 3) // stride + 1
+    dsc = MbConvDesc(2, hw[0], hw[1], so(hw[0]), so(hw[1]), stride, cin, ch, cout, 1, 1 if res else 0, 12, 6.0, 12, 6.0, 0, 0.0, cin, cout)
+    if not ops.lib().sm_mbconv_supported(ctypes.byref(dsc)):
+        pytest.skip("no fused kernel takes this geometry (the executor keeps the three launches)")
+    rng = np.random.default_rng(cin + ch + cout + stride)
+    x = h(rng.standard_normal((2, cin, hw[0], hw[1])) * 3)
+    w1 = h(rng.standard_normal((ch, 1, 1, cin)) * np.sqrt(2.0 / cin)); b1 = rng.standard_normal(ch).astype(np.float32)
+    wd = h(rng.standard_normal((ch, 3, 3, 1)) * np.sqrt(2.0 / 9) * 2); bd = rng.standard_normal(ch).astype(np.float32)
+    w2 = h(rng.standard_normal((cout, 1, 1, ch)) * np.sqrt(1.0 / ch)); b2 = rng.standard_normal(cout).astype(np.float32) * 0.1
+    hid = h(np.clip(O.conv2d(x, w1, b1), 0, 6))
+    hid2 = h(np.clip(O.conv2d(hid, wd, bd, stride=(stride, stride), pads=(1, 1, 1, 1), groups=ch), 0, 6))
+    assert (hid == 6).mean() > 0.02 and (hid2 == 6).mean() > 0.02, "the test data must reach the upper bound"
+    ref = O.conv2d(hid2, w2, b2) + (x if res else 0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    got = to_host(ops.mbconv(to_dev(x), dev(w1).half(), dev(b1), dev(wd.reshape(ch, 3, 3)).half(), dev(bd), dev(w2).half(), dev(b2), stride=stride, residual=res,
+                             acts=(ops.ACT_CLIP, ops.ACT_CLIP, ops.ACT_NONE), slopes=(6.0, 6.0, 0.0)))
+    ref16 = h(ref)
+    assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
+
+
 @pytest.mark.parametrize("n,c,hw,cout,stride,pad,act,slope", [
+    (2, 3, (64, 64), 32, 2, 1, 12, 6.0),               # ReLU6 behind the stem (SM_ACT_CLIP), as MobileNet-v2's first layer holds it
     (2, 1, (70, 45), 32, 1, 1, ops.ACT_RELU, 0.0),     # U-Net's first layer (one plane), ragged block tiles
     (1, 1, (512, 512), 32, 1, 1, ops.ACT_RELU, 0.0),   # ... at its real size
     (2, 3, (64, 64), 32, 2, 1, ops.ACT_RELU, 0.0),     # RGB, stride 2
@@ -783,10 +818,10 @@ def test_mbconv_register_window_kernel_other_activations(hw, cin, ch, cout, stri
 def test_image_stem_3x3_from_the_fp32_batch(n, c, hw, cout, stride, pad, act, slope):
     """sm_stem3x3_f32_fwd against the oracle's convolution of the fp16-rounded image (what the converted copy held)"""
     rng = np.random.default_rng(c * 100 + cout + stride)
-    x = rng.standard_normal((n, c, hw[0], hw[1])).astype(np.float32)
+    x = rng.standard_normal((n, c, hw[0], hw[1])).astype(np.float32) * (8 if act == ops.ACT_CLIP else 1)      # (clipped: scaled so that the upper bound bites)
     w = h(rng.standard_normal((cout, 3, 3, c)) * np.sqrt(2.0 / (9 * c))); b = rng.standard_normal(cout).astype(np.float32) * 0.3
     ref = O.conv2d(h(x), w, b, stride=(stride, stride), pads=(pad, pad, pad, pad))
-    ref = np.maximum(ref, 0) if act == ops.ACT_RELU else np.where(ref < 0, ref * slope, ref) if act == ops.ACT_PRELU else ref
+    ref = np.maximum(ref, 0) if act == ops.ACT_RELU else np.where(ref < 0, ref * slope, ref) if act == ops.ACT_PRELU else np.clip(ref, 0, slope) if act == ops.ACT_CLIP else ref
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     y = ops.stem3x3(dev(x), dev(w).half(), dev(b), stride=stride, pad=pad, act=act, slope=slope)
     assert_close(to_host(y), ref, 9 * c)
