@@ -185,6 +185,10 @@ int sm_mbconv_kernel_kind(const sm_mbconv_desc* d);   /* 0 = none, else the kern
 size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d);
 int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const float* b1, const void* wd, const float* bd,
                   const void* w2, const float* b2, void* y, sm_stream_t stream);
+/* the same with the kernel named (sm_mbconv_kernel_kind's numbering; 0 = the launcher's choice = sm_mbconv_fwd): a kernel outside whose domain the block lies is not forced — the
+ * launcher's choice runs instead.  Tests and tuning; replaces the SMELTER_MBCONV_KERNEL environment switch of rounds 2-4. */
+int sm_mbconv_fwd_kind(const sm_mbconv_desc* d, int32_t kind, const void* x, const void* w1, const float* b1, const void* wd, const float* bd,
+                       const void* w2, const float* b2, void* y, sm_stream_t stream);
 
 /* The same block directly behind an image stem, the stem included (MobileNet-v2's first three layers): 3x3 convolution of the fp32 NCHW batch
  * (`C` = 3 planes of in_H x in_W, stride st_stride, padding st_pad, activation d->act1) -> depthwise 3x3 -> 1x1 project, ONE launch; neither the
@@ -378,9 +382,13 @@ typedef struct smelter_config {
 } smelter_config;
 /* Executor behaviour is decided by THIS struct, read once at smelter_graph_create / _compile — no environment variable is consulted after that.
  * smelter_config_default() is where the bench / A/B tools' environment overrides enter (each read there, once): SMELTER_MBCONV=0, SMELTER_XHEAD=0,
- * SMELTER_XHEAD_PROJ=0, SMELTER_KCAT=0|copy, SMELTER_MBCONV_STEM=0, SMELTER_STEM_F32=0, SMELTER_STEM_POOL=0, SMELTER_STEM3=0 clear / set the matching SM_FUSE_* bit;
+ * SMELTER_XHEAD_PROJ=0, SMELTER_KCAT=0|copy, SMELTER_MBCONV_STEM=0, SMELTER_STEM_F32=0, SMELTER_STEM_POOL=0, SMELTER_STEM3=0, SMELTER_STAGE=0|wide clear / set the matching SM_FUSE_* bit;
  * SMELTER_AUTOTUNE=cold, SMELTER_AUTOTUNE_MAXCFG=n, SMELTER_MBCONV_DOMAIN="cin,hidden,cout" fill the fields above.  A host that fills the struct itself
- * (the Swift shim of INTEGRATION.md) is not affected by the environment at all. */
+ * (the Swift shim of INTEGRATION.md) is not affected by the environment at all.
+ * The kernel-level `sm_*` launchers consult NO environment variable (round 5): which kernel runs is a pure function of the descriptor and the explicit arguments
+ * (`cfg`, sm_mbconv_fwd_kind's `kind`, sm_stage_phase.form).  The experiment switches of rounds 1-4 (SMELTER_MBCONV_WAVES / _NO_V5, SMELTER_NO_PW_THIN / _PW_THIN_RES /
+ * _PW_THIN_K64, SMELTER_DW_STRIP, SM_CONV_ORDER, SM_HX_DEBUG, SM_SP_DEBUG, SM_TIME_COLD, SM_TL_DUMP) exist only in diagnostic builds (`make EXTRA=-DSM_ABLATION`).  Left in the
+ * product library, read-only diagnostics that change no kernel choice: SMELTER_ROCTX (trace ranges), SMELTER_DEBUG_SYNC, SMELTER_DEBUG_PLAN (stderr notes). */
 enum { SM_FUSE_MBCONV = 1,        /* expand -> depthwise -> project in one launch (mbconv.hip) */
        SM_FUSE_XHEAD = 2,         /* 3x3 -> 1x1 expand (+ residual) in one launch (conv3x3_wsx.hpp) */
        SM_FUSE_XHEAD_PROJ = 4,    /* ... with the projection shortcut as its second GEMM */

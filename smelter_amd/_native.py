@@ -99,6 +99,7 @@ SYMBOLS = {
     "sm_mbconv_kernel_kind": (_i32, [C.POINTER(MbConvDesc)]),
     "sm_mbconv_lds_bytes": (_sz, [C.POINTER(MbConvDesc)]),
     "sm_mbconv_fwd": (_i32, [C.POINTER(MbConvDesc)] + [_vp] * 9),
+    "sm_mbconv_fwd_kind": (_i32, [C.POINTER(MbConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sm_mbconv_stem_supported": (_i32, [C.POINTER(MbConvDesc)] + [_i32] * 5),
     "sm_mbconv_stem_fwd": (_i32, [C.POINTER(MbConvDesc), _vp] + [_i32] * 5 + [_vp] * 8),
     "sm_stem3x3_f32_supported": (_i32, [_i32] * 7),

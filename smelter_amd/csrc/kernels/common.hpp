@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <type_traits>
 #include "../../../include/smelter_hip.h"
@@ -23,6 +24,13 @@ template <int I, int N, class F> __device__ __forceinline__ void sm_static_for(F
 // write through and drop the line.  Build-time switch for the A/B (make EXTRA=-DSM_ST_AUX=16).
 #ifndef SM_ST_AUX
 #define SM_ST_AUX 0
+#endif
+// Experiment / ablation switches by environment variable exist in DIAGNOSTIC builds only (make EXTRA=-DSM_ABLATION; tools/lib_ab.sh): the product library's kernel
+// launchers consult no environment variable (smelter_hip.h: everything a caller can set is a field of smelter_config or an argument).
+#ifdef SM_ABLATION
+#define SM_ABL_ENV(name) getenv(name)
+#else
+#define SM_ABL_ENV(name) ((const char*)nullptr)
 #endif
 #define SM_WAVE 64
 #define SM_NUM_XCD 8

@@ -596,43 +596,21 @@ const TileCfg kCfgs[] = {
     {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 4, 2>, "k64w8:128x64(32x32)"},     // 18
     {256, 128, 1, 512, conv_igemm64_kernel<256, 128, 4, 2, 3>, "k64w8s3:256x128"},    // 19
     // 4-deep rings: every K tile of a K <= 256 layer in flight at once
-    {128, 64, 1, 256, conv_igemm64_kernel<128, 64, 2, 2, 4>, "k64s4:128x64"},         // 20
     {64, 64, 1, 256, conv_igemm64_kernel<64, 64, 2, 2, 4>, "k64s4:64x64"},            // 21
-    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 4>, "k64w8s4:128x128"},    // 22
-    {64, 128, 1, 256, conv_igemm64_kernel<64, 128, 2, 2, 4>, "k64s4:64x128"},         // 23
     // single LDS stage for K == 64: half the LDS, twice the resident blocks (memory-level parallelism)
-    {128, 128, 2, 256, conv_igemm64_kernel<128, 128, 2, 2, 1>, "k64s1:128x128"},      // 24
-    {128, 128, 2, 512, conv_igemm64_kernel<128, 128, 4, 2, 1>, "k64w8s1:128x128"},    // 25
-    {128, 64, 2, 256, conv_igemm64_kernel<128, 64, 2, 2, 1>, "k64s1:128x64"},         // 26
     {64, 64, 2, 256, conv_igemm64_kernel<64, 64, 2, 2, 1>, "k64s1:64x64"},            // 27
-    {256, 64, 2, 512, conv_igemm64_kernel<256, 64, 4, 2, 1>, "k64w8s1:256x64"},       // 28
-    {64, 128, 2, 256, conv_igemm64_kernel<64, 128, 2, 2, 1>, "k64s1:64x128"},         // 29
     // narrow outputs (Cout <= 32: U-Net full-resolution layers): no MFMA work wasted on zero cout columns
     {128, 32, 1, 256, conv_igemm64_kernel<128, 32, 4, 1>, "k64:128x32"},              // 30
     {256, 32, 1, 256, conv_igemm64_kernel<256, 32, 4, 1>, "k64:256x32"},              // 31
     // DMA issue interleaved with the MFMAs (8-wave tiles)
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 3, 0, 1>, "k64w8s3i:128x128(64x32)"},  // 32
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 4, 2, 3, 0, 1>, "k64w8s3i:128x128(32x64)"},  // 33
-    {256, 128, 1, 512, conv_igemm64_kernel<256, 128, 4, 2, 2, 0, 1>, "k64w8i:256x128"},           // 34
     {256, 128, 1, 512, conv_igemm64_kernel<256, 128, 4, 2, 3, 0, 1>, "k64w8s3i:256x128"},         // 35
-    {256, 64, 1, 512, conv_igemm64_kernel<256, 64, 4, 2, 3, 0, 1>, "k64w8s3i:256x64"},            // 36
-    {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 4, 2, 3, 0, 1>, "k64w8s3i:128x64"},            // 37
     {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 4, 2, 0, 1>, "k64w8i:128x128(64x32)"},    // 38
-    // loader/consumer wave specialisation: WGM x WGN MFMA waves + 4 loader waves (one per SIMD) that issue all LDS-DMA
-    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 2, 3, 0, 0, 4>, "k64ws4+4s3:128x128"},        // 39
-    {128, 128, 1, 768, conv_igemm64_kernel<128, 128, 2, 4, 3, 0, 0, 4>, "k64ws8+4s3:128x128(64x32)"}, // 40
-    {128, 128, 1, 768, conv_igemm64_kernel<128, 128, 4, 2, 3, 0, 0, 4>, "k64ws8+4s3:128x128(32x64)"}, // 41
-    {256, 128, 1, 768, conv_igemm64_kernel<256, 128, 4, 2, 3, 0, 0, 4>, "k64ws8+4s3:256x128"},        // 42
-    {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 2, 2, 3, 0, 0, 4>, "k64ws4+4s3:128x64"},           // 43
-    {256, 64, 1, 768, conv_igemm64_kernel<256, 64, 4, 2, 3, 0, 0, 4>, "k64ws8+4s3:256x64"},           // 44
-    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 2, 4, 0, 0, 4>, "k64ws4+4s4:128x128"},        // 45
-    {64, 64, 1, 384, conv_igemm64_kernel<64, 64, 2, 2, 3, 0, 0, 2>, "k64ws4+2s3:64x64"},              // 46
-    {64, 128, 1, 512, conv_igemm64_kernel<64, 128, 2, 2, 3, 0, 0, 4>, "k64ws4+4s3:64x128"},           // 47
+    // (round 5: the loader/consumer wave-specialised, K-split-in-block, 4-stage and most single-stage / DMA-interleaved instantiations of rounds 1-2 are gone: no layer of the three BASELINE
+    //  models ever picked them in an autotune log — profiles/r04_layers_*.txt — and each cost ~40 KB of code object and ~25 test parametrisations; DESIGN_APPENDIX.md A4.2 keeps what they measured)
     // K split inside the block: 2 groups of 2x2 waves, group g multiplies K tile 2i+g of stage i (64x64 / 64x32 / 32x64 wave tiles)
-    {128, 128, 1, 512, conv_igemm64_kernel<128, 128, 2, 2, 2, 0, 0, 0, 2>, "k64ks2:128x128"},         // 48
-    {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 2, 2, 3, 0, 0, 0, 2>, "k64ks2s3:128x64"},          // 49
     {64, 128, 1, 512, conv_igemm64_kernel<64, 128, 2, 2, 3, 0, 0, 0, 2>, "k64ks2s3:64x128"},          // 50
-    {128, 64, 1, 512, conv_igemm64_kernel<128, 64, 2, 2, 2, 0, 0, 0, 2>, "k64ks2:128x64"},            // 51
     // kind 3 (conv3x3_strip.hpp): 3x3 / stride 1 / pad 1, one activation strip per kernel row serves its three taps
     {128, 128, 3, 512, conv3x3_strip_kernel<128, 128, 2, 4, 2>, "strip:128x128(64x32)"},              // 52
     {128, 128, 3, 512, conv3x3_strip_kernel<128, 128, 4, 2, 2>, "strip:128x128(32x64)"},              // 53
@@ -1010,7 +988,7 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         (p.y_ld % 8) == 0 && (!p.res || (p.res_ld % 8) == 0)) {
         long work = (long)p.M * (p.Cout / 8);
         const bool k3 = p.kH == 3 && p.kW == 3 && p.dH == 1 && p.dW == 1 && p.sH == p.sW && (((uintptr_t)p.w) & 15) == 0;
-        static const bool dw_strip = getenv("SMELTER_DW_STRIP") != nullptr;   // experiment switch, read once (launch() is on the per-launch path)
+        static const bool dw_strip = SM_ABL_ENV("SMELTER_DW_STRIP") != nullptr;   // experiment switch, read once (launch() is on the per-launch path)
         const bool lds_ok = k3 && (p.sH == 1 || p.sH == 2) && !dw_strip;
         if (lds_ok) {
             // Channel vectors per block: ALL of them when the patch of some tile fits ~52 KB of LDS; otherwise the largest divisor of
@@ -1131,7 +1109,7 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     // block -> tile order (see map_block): weight-stationary per XCD when the weights outweigh the input tensor
     const int combos = p.nt * p.splitk;
     const double a_bytes = 2.0 * p.N * p.H * p.W * p.Cin, b_bytes = 2.0 * p.Cout * p.K;
-    static const int forced_order = getenv("SM_CONV_ORDER") ? atoi(getenv("SM_CONV_ORDER")) : -1;
+    static const int forced_order = SM_ABL_ENV("SM_CONV_ORDER") ? atoi(SM_ABL_ENV("SM_CONV_ORDER")) : -1;
     p.order = (combos >= SM_NUM_XCD && b_bytes > a_bytes) ? 1 : 0;
     if (forced_order == 0 || (forced_order == 1 && combos >= SM_NUM_XCD)) p.order = forced_order;
     p.mt_per_xcd = sm_ceil_div(p.mt, SM_NUM_XCD); p.cpx = sm_ceil_div(combos, SM_NUM_XCD);
@@ -1239,7 +1217,7 @@ int sm_conv2d_xhead_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const
     if (!y) p.y = nullptr;
     p.w3 = (const half_t*)w3; p.b3 = b3; p.y3 = (half_t*)y3; p.n3 = n3; p.y3_ld = y3_ld ? y3_ld : n3; p.act3 = act3; p.sl3 = act3 == SM_ACT_RELU ? 0.f : act3 == SM_ACT_NONE ? 1.f : slope3;
     p.res3 = (const half_t*)res3; p.res3_ld = res3_ld ? res3_ld : n3;
-    { static const int dbg = getenv("SM_HX_DEBUG") ? atoi(getenv("SM_HX_DEBUG")) : 0; p.hx_dbg = dbg; }   // ablation switch, read once
+    { static const int dbg = SM_ABL_ENV("SM_HX_DEBUG") ? atoi(SM_ABL_ENV("SM_HX_DEBUG")) : 0; p.hx_dbg = dbg; }   // ablation switch, read once
     const bool small = n3 <= 32 && !res3;                            // (the narrow heads without residual run on the " head" instantiations)
     if (small || cfg < 0 || cfg >= kNumCfgs) {                       // default pick: the two-role kernel where it applies (the faster one), else the first that takes the shape
         cfg = -1;
@@ -1259,7 +1237,7 @@ int sm_conv2d_xhead_proj_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, 
     p.y = nullptr;
     p.w3 = (const half_t*)w3; p.b3 = b3; p.y3 = (half_t*)y3; p.n3 = n3; p.y3_ld = y3_ld ? y3_ld : n3; p.act3 = act3; p.sl3 = act3 == SM_ACT_RELU ? 0.f : act3 == SM_ACT_NONE ? 1.f : slope3;
     p.res3 = (const half_t*)xs; p.res3_ld = xs_ld ? xs_ld : 64; p.w3s = (const half_t*)ws;
-    { static const int dbg = getenv("SM_HX_DEBUG") ? atoi(getenv("SM_HX_DEBUG")) : 0; p.hx_dbg = dbg; }
+    { static const int dbg = SM_ABL_ENV("SM_HX_DEBUG") ? atoi(SM_ABL_ENV("SM_HX_DEBUG")) : 0; p.hx_dbg = dbg; }
     if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) cfg = i; }
     if (cfg < 0) { sm_set_error("sm_conv2d_xhead_proj_fwd_cfg: no kernel takes this shape (3x3 / s1 / p1, Cin = Cout = 64, n3 <= 256, n3 %% 32 == 0, 64-channel side input)"); return SM_ERR_INVALID_ARGUMENT; }
     return launch(d, p, cfg, nullptr, 0, sm_s(stream));
@@ -1331,7 +1309,7 @@ int sm_conv2d_stem_f32_pool_fwd(const sm_conv_desc* d, const float* x_nchw, int3
     ConvParams p; int rc = fill_params(d, x_nchw, w, bias, nullptr, y_pool, &p); if (rc) return rc;
     p.xf = x_nchw; p.in_C = C; p.in_H = H_in; p.in_W = W_in; p.in_pt = pt; p.in_pl = pl; p.y = nullptr;
     p.y2 = (half_t*)y_pool; p.y2_ld = pool_ld ? pool_ld : p.Cout;
-    { static const int dbg = getenv("SM_SP_DEBUG") ? atoi(getenv("SM_SP_DEBUG")) : 0; p.hx_dbg = dbg; }   // ablation switch (1 = no pooling, 2 = no k loop, 4 = no patch building, 8 = no hand-over), read once
+    { static const int dbg = SM_ABL_ENV("SM_SP_DEBUG") ? atoi(SM_ABL_ENV("SM_SP_DEBUG")) : 0; p.hx_dbg = dbg; }   // ablation switch (1 = no pooling, 2 = no k loop, 4 = no patch building, 8 = no hand-over), read once
     size_t lds = 0;
     if (!stem_pool_ok(d, p, C, H_in, W_in, pool_H, pool_W) || (p.y2_ld & 7) || (((uintptr_t)y_pool) & 15) || (long)p.N * pool_H * pool_W * p.y2_ld * 2 >= 0x7fff0000L ||
         !(lds = stem_pool_setup(p, pool_H, pool_W))) {
@@ -1409,7 +1387,7 @@ int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w,
     rc = launch(d, p, cfg, ws, ws_bytes, s); if (rc) return rc;
     hipEvent_t a, b; SM_HIP_CHECK(hipEventCreate(&a)); SM_HIP_CHECK(hipEventCreate(&b));
     float t = 0;
-    if (getenv("SM_TIME_COLD")) {
+    if (SM_ABL_ENV("SM_TIME_COLD")) {
         // cold-cache timing: in a network every layer finds its weights in HBM and its input in HBM / Infinity Cache,
         // not in a cache warmed by the previous launch of the same kernel -> evict (768 MB memset) before each launch
         static char* scratch = nullptr; const size_t sbytes = (size_t)768 << 20;
@@ -1433,7 +1411,7 @@ int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w,
         static unsigned long long h[8192 * 16];
         memset(h, 0, sizeof h);
         SM_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tl), h, sizeof h));
-        if (getenv("SM_TIME_COLD")) { static char* scratch2 = nullptr; if (!scratch2) SM_HIP_CHECK(hipMalloc((void**)&scratch2, (size_t)768 << 20)); SM_HIP_CHECK(hipMemsetAsync(scratch2, 1, (size_t)768 << 20, s)); }
+        if (SM_ABL_ENV("SM_TIME_COLD")) { static char* scratch2 = nullptr; if (!scratch2) SM_HIP_CHECK(hipMalloc((void**)&scratch2, (size_t)768 << 20)); SM_HIP_CHECK(hipMemsetAsync(scratch2, 1, (size_t)768 << 20, s)); }
         rc = launch(d, p, cfg, ws, ws_bytes, s); SM_HIP_CHECK(hipStreamSynchronize(s));
         SM_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_tl), sizeof h));
         static const char* names[8] = {"map_block", "rows", "brow+cursor", "prologue issue", "res+bias+init", "first tile", "main loop", "epilogue"};
@@ -1444,7 +1422,7 @@ int sm_conv2d_time(const sm_conv_desc* d, int cfg, const void* x, const void* w,
             nb++; for (int q = 0; q < 8; q++) if (e[2 + q] && e[1 + q]) ph[q] += (double)(e[2 + q] - e[1 + q]);
             wall += (double)(e[15] - e[0]); if (e[0] < w0) w0 = e[0]; if (e[15] > w1) w1 = e[15];
         }
-        if (const char* dp = getenv("SM_TL_DUMP")) {              // raw per-block stamps for offline analysis
+        if (const char* dp = SM_ABL_ENV("SM_TL_DUMP")) {              // raw per-block stamps for offline analysis
             char fn[512]; snprintf(fn, sizeof fn, "%s.cfg%d.bin", dp, cfg);
             if (FILE* f = fopen(fn, "wb")) { fwrite(h, 1, sizeof h, f); fclose(f); }
         }

@@ -1605,14 +1605,14 @@ static size_t mb_v5_lds_nw(const sm_mbconv_desc* d, int nw) {
     return (size_t)ChP * KP1 * 2 + (size_t)ChP * 24 * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)nw * 32 * 80;
 }
 static bool mb_v5_ok(const sm_mbconv_desc* d) {
-    static const int off = getenv("SMELTER_MBCONV_NO_V5") ? 1 : 0;          // experiment switch, read once
+    static const int off = SM_ABL_ENV("SMELTER_MBCONV_NO_V5") ? 1 : 0;          // experiment switch, read once
     return !off && d->expand && d->Cin <= 46 && d->Cout <= 64 && mb_v5_lds_nw(d, 16) <= 160 * 1024;
 }
 static bool mb_v3_wg(const sm_mbconv_desc* d) { return d->expand && mb_v3_lds_nw(d, 8) > 160 * 1024; }
 // waves per block: 16 (one block per CU; its 128-register budget holds) when the LDS takes it, else 8, else 4
 static int mb_v3_waves(const sm_mbconv_desc* d) {
     if (mb_v3_wg(d)) return 8;
-    const char* fe = getenv("SMELTER_MBCONV_WAVES"); const int force = fe ? atoi(fe) : 0;            // experiment switch: 4 | 8 | 16 where the LDS takes it
+    const char* fe = SM_ABL_ENV("SMELTER_MBCONV_WAVES"); const int force = fe ? atoi(fe) : 0;            // experiment switch: 4 | 8 | 16 where the LDS takes it
     if ((force == 4 || force == 8 || force == 16) && mb_v3_lds_nw(d, force) <= 160 * 1024) return force;
     if (mb_v3_lds_nw(d, 16) <= 160 * 1024) return 16;
     if (mb_v3_lds_nw(d, 8) <= 160 * 1024) return 8;
@@ -1656,8 +1656,7 @@ static bool mb_v4_ok(const sm_mbconv_desc* d) {
     if (mb_v4_nfw(d) > 3) return false;                               // (three accumulator sets per wave: cout <= 96 on 14 x 14 tiles, <= 384 on small ones)
     return mb_v4_lds(d) <= 160 * 1024;
 }
-static int mb_pick(const sm_mbconv_desc* d) {                         // 4, 3, 1 or 2; SMELTER_MBCONV_KERNEL=1|2|3|4 forces one where it applies
-    const char* fe = getenv("SMELTER_MBCONV_KERNEL"); const int force = fe ? atoi(fe) : 0;          // (read per call: the tests switch it)
+static int mb_pick(const sm_mbconv_desc* d, int force = 0) {          // 4, 3, 1 or 2; force = 1 | 2 | 3 | 4: that kernel where it applies (sm_mbconv_fwd_kind: tests, tuning)
     const bool ok1 = d && mb_v1_ok(d), ok2 = d && mb_v2_ok(d), ok3 = d && mb_v3_ok(d), ok4 = d && mb_v4_ok(d);
     if (force == 1 && ok1) return 1;
     if (force == 2 && ok2) return 2;
@@ -1679,9 +1678,9 @@ static int mb_pick(const sm_mbconv_desc* d) {                         // 4, 3, 1
 
 
 
-size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d) {
-    if (!d) return 0;
-    const int k = mb_pick(d);
+static size_t mb_lds_for(const sm_mbconv_desc* d, int k);
+size_t sm_mbconv_lds_bytes(const sm_mbconv_desc* d) { return d ? mb_lds_for(d, mb_pick(d)) : 0; }
+static size_t mb_lds_for(const sm_mbconv_desc* d, int k) {
     return k == 4 ? mb_v4_lds(d) : k == 3 ? (mb_v5_ok(d) ? mb_v5_lds_nw(d, 16) : mb_v3_lds(d)) : k == 1 ? mb_v1_lds(d) : mb_v2_lds(d);
 }
 
@@ -1690,6 +1689,11 @@ int sm_mbconv_kernel_kind(const sm_mbconv_desc* d) { return mb_pick(d); }
 
 int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const float* b1, const void* wd, const float* bd, const void* w2, const float* b2, void* y,
                   sm_stream_t stream) {
+    return sm_mbconv_fwd_kind(d, 0, x, w1, b1, wd, bd, w2, b2, y, stream);
+}
+int sm_mbconv_fwd_kind(const sm_mbconv_desc* d, int32_t kind, const void* x, const void* w1, const float* b1, const void* wd, const float* bd, const void* w2, const float* b2, void* y,
+                       sm_stream_t stream) {
+    SM_REQUIRE(kind >= 0 && kind <= 4, "sm_mbconv_fwd_kind: kernel %d", kind);
     SM_REQUIRE(sm_mbconv_supported(d) && x && wd && w2 && y && (!d->expand || w1), "sm_mbconv_fwd: unsupported block geometry");
     MbParams p{};
     p.x = (const half_t*)x; p.y = (half_t*)y; p.w1 = (const half_t*)w1; p.wd = (const half_t*)wd; p.w2 = (const half_t*)w2; p.b1 = b1; p.bd = bd; p.b2 = b2;
@@ -1708,8 +1712,8 @@ int sm_mbconv_fwd(const sm_mbconv_desc* d, const void* x, const void* w1, const 
     SM_REQUIRE(nt < (1L << 31), "sm_mbconv_fwd: too many tiles");
     p.ntiles = (int)nt;
     fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh); fastdiv_make((unsigned)PW, &p.pw_mul, &p.pw_sh);
-    const size_t lds = sm_mbconv_lds_bytes(d);
-    const int kernel = mb_pick(d);
+    const int kernel = mb_pick(d, kind);
+    const size_t lds = mb_lds_for(d, kernel);
     if (kernel == 4) {                                               // tile per block: persistent over the tiles, one 8-wave block per CU
         SM_REQUIRE(((((uintptr_t)w1) | ((uintptr_t)w2)) & 15) == 0, "sm_mbconv_fwd: weights must be 16-byte aligned");
         p.ChP = (d->Ch + 63) / 64 * 64;

@@ -123,10 +123,10 @@ __global__ __launch_bounds__(PWT_WAVES * 64) void pw_thin_kernel(ConvParams p, i
 // eligibility + launch (called from launch() before the tiled MFMA paths)
 static int pw_thin_ksn(int cin) { const int k = (cin + 15) >> 4; return k <= 1 ? 1 : k <= 2 ? 2 : k <= 4 ? 4 : k <= 6 ? 6 : k <= 9 ? 9 : 12; }   // instantiated k-step counts
 static bool pw_thin_eligible(const sm_conv_desc* d, const ConvParams& p) {
-    static const bool no_thin = getenv("SMELTER_NO_PW_THIN") != nullptr, thin_res = getenv("SMELTER_PW_THIN_RES") != nullptr;   // experiment switches, read once
+    static const bool no_thin = SM_ABL_ENV("SMELTER_NO_PW_THIN") != nullptr, thin_res = SM_ABL_ENV("SMELTER_PW_THIN_RES") != nullptr;   // experiment switches, read once
     if (no_thin) return false;
     if (d->groups != 1 || p.kH != 1 || p.kW != 1 || p.sH != 1 || p.sW != 1 || p.pt != 0 || p.pl != 0 || p.Ho != p.H || p.Wo != p.W) return false;
-    static const bool k64 = getenv("SMELTER_PW_THIN_K64") != nullptr;      // experiment: also take Cin == 64 (ResNet-50 layer-1 1x1 convs)
+    static const bool k64 = SM_ABL_ENV("SMELTER_PW_THIN_K64") != nullptr;      // experiment: also take Cin == 64 (ResNet-50 layer-1 1x1 convs)
     if (p.yplace || (p.Cin & 7) || ((p.Cin % 64) == 0 && !(k64 && p.Cin == 64)) || p.Cin > 16 * PWT_KSMAX || (p.Cout & 7)) return false;
     if ((p.x_ld & 7) || (p.y_ld & 7) || (((uintptr_t)p.x) & 15) || (((uintptr_t)p.y) & 15) || (((uintptr_t)p.w) & 15) || (((uintptr_t)p.bias) & 15)) return false;
     if (p.res && ((p.res_ld & 7) || (((uintptr_t)p.res) & 15))) return false;

@@ -290,7 +290,7 @@ def conv2d_xhead_proj(x, w_ohwi, bias, w3, b3sum, xs, ws, act=ACT_RELU, slope=0.
     return y3
 
 
-def mbconv(x, w1, b1, wd, bd, w2, b2, stride=1, residual=False, acts=(ACT_RELU, ACT_RELU, ACT_NONE), slopes=(0.0, 0.0, 0.0)):
+def mbconv(x, w1, b1, wd, bd, w2, b2, stride=1, residual=False, acts=(ACT_RELU, ACT_RELU, ACT_NONE), slopes=(0.0, 0.0, 0.0), kernel=0):
     """fused inverted-residual block (sm_mbconv_fwd): [1x1 expand w1 (None = absent)] -> depthwise 3x3 wd [Ch,3,3] -> 1x1 project w2 (+ x)"""
     from ._native import MbConvDesc
     n, h, w, cin, x_ld = _check_nhwc(x)
@@ -298,7 +298,8 @@ def mbconv(x, w1, b1, wd, bd, w2, b2, stride=1, residual=False, acts=(ACT_RELU, 
     ho, wo = (h + 2 - 3) // stride + 1, (w + 2 - 3) // stride + 1
     y = torch.empty((n, ho, wo, cout), dtype=torch.float16, device=x.device)
     d = MbConvDesc(n, h, w, ho, wo, stride, cin, ch, cout, 1 if w1 is not None else 0, 1 if residual else 0, acts[0], slopes[0], acts[1], slopes[1], acts[2], slopes[2], x_ld, _ld(y))
-    check(lib().sm_mbconv_fwd(C.byref(d), _ptr(x), _ptr(w1), _ptr(b1), _ptr(wd), _ptr(bd), _ptr(w2), _ptr(b2), _ptr(y), _stream()))
+    # kernel = 1 .. 4: that block kernel where its domain holds the block (sm_mbconv_fwd_kind), 0 = the launcher's choice
+    check(lib().sm_mbconv_fwd_kind(C.byref(d), kernel, _ptr(x), _ptr(w1), _ptr(b1), _ptr(wd), _ptr(bd), _ptr(w2), _ptr(b2), _ptr(y), _stream()))
     return y
 
 
