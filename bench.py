@@ -212,7 +212,8 @@ def main():
                 d, ms = ex.opDesc(i), times[1 + i]
                 per.append((ms, d))
                 if d.startswith(("Conv", "FC")) and " g=1" in d:
-                    conv_ms += ms; conv_n += 1
+                    conv_ms += ms
+                    conv_n += 0 if "[persistent run: launched with step" in d else 1      # (the members of a persistent run leave with its first step: one launch)
                 else:
                     other_ms += ms
             # Average duration of a conv launch INSIDE the timed region: the K timed steps replay one hipGraph whose kernels run

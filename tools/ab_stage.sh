@@ -6,5 +6,5 @@ for i in 1 2 3; do
   python tools/gpu_probe.py --model r50 2>&1 | grep " bs=" | sed 's/^/runs (default)   /'
   SMELTER_STAGE=wide python tools/gpu_probe.py --model r50 2>&1 | grep " bs=" | sed 's/^/runs + 14x14     /'
 done
-python tools/gpu_probe.py --model r50 --ops 2>&1 | grep -i "persistent run"
-SMELTER_STAGE=wide python tools/gpu_probe.py --model r50 --ops 2>&1 | grep -i "persistent run"
+# the compile's own in-situ measurement of every run (stderr note of the autotune pass)
+SMELTER_STAGE=wide SMELTER_DEBUG_PLAN=1 python tools/gpu_probe.py --model r50 2>&1 | grep "\[plan\] persistent run"

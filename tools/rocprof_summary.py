@@ -27,7 +27,7 @@ def load(path):
 
 
 def short(name):
-    m = re.search(r"(conv_igemm\w*|conv3x3_strip_kernel|conv3x3_wsx_kernel|conv3x3_ws_kernel|conv3x3_p9_kernel|conv1x1_ps_kernel|conv1x1_rwl?_kernel|conv_stem_pool_kernel|mbconv\w*|pw_thin_kernel)<[^>]*>", name)
+    m = re.search(r"(stage_kernel|conv_igemm\w*|conv3x3_strip_kernel|conv3x3_wsx_kernel|conv3x3_ws_kernel|conv3x3_p9_kernel|conv1x1_ps_kernel|conv1x1_rwl?_kernel|conv_stem_pool_kernel|mbconv\w*|pw_thin_kernel)<[^>]*>", name)
     if m:
         return m.group(0)
     m = re.search(r"N_1\d+(\w+?)E", name)
@@ -95,9 +95,9 @@ def main():
     print("%-46s %8s %12s %10s %7s" % ("kernel", "calls", "total_us", "avg_us", "%"))
     for k, (c, t) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         print("%-46s %8d %12.1f %10.2f %6.1f%%" % (k, c, t, t / c, 100 * t / total_us))
-    conv = [(c, t) for k, (c, t) in per.items() if k.startswith(("conv_igemm", "conv3x3_strip", "conv3x3_ws", "conv3x3_p9", "conv1x1_ps", "conv1x1_rw", "conv3x3_kq", "conv_stem_pool", "mbconv", "pw_thin")) or "splitk" in k]
+    conv = [(c, t) for k, (c, t) in per.items() if k.startswith(("stage_kernel", "conv_igemm", "conv3x3_strip", "conv3x3_ws", "conv3x3_p9", "conv1x1_ps", "conv1x1_rw", "conv3x3_kq", "conv_stem_pool", "mbconv", "pw_thin")) or "splitk" in k]
     cc, ct = sum(c for c, _ in conv), sum(t for _, t in conv)
-    print("# MFMA conv/FC family (conv_igemm*, conv3x3_strip/ws/wsx/p9, conv3x3_kq, conv1x1_ps / rw, split-K reduce): %d launches/step, avg %.2f us/launch, %.3f ms/step -> %.1f TFLOP/s (%.1f%% of 2500)" % (
+    print("# MFMA conv/FC family (stage_kernel = a persistent run of layers, conv_igemm*, conv3x3_strip/ws/wsx/p9, conv3x3_kq, conv1x1_ps / rw, split-K reduce): %d launches/step, avg %.2f us/launch, %.3f ms/step -> %.1f TFLOP/s (%.1f%% of 2500)" % (
         cc // a.steps, ct / cc, ct / 1e3 / a.steps, a.flops_per_step / (ct / a.steps * 1e-6) / 1e12, a.flops_per_step / (ct / a.steps * 1e-6) / 1e12 / 25))
 
 
