@@ -54,7 +54,9 @@ inline void fastdiv_make(unsigned d, unsigned* mul, unsigned* sh) { unsigned s =
 __device__ __forceinline__ unsigned fastdiv(unsigned n, unsigned mul, unsigned sh) { return (unsigned)(((unsigned long long)n * mul) >> sh); }
 // the activations a fused block takes: x >= 0 ? x : sl x (none: sl = 1, ReLU: sl = 0, leaky / PReLU), then min(., hi) — hi = +inf but for SM_ACT_CLIP (ONNX Clip(0, hi), ReLU6 = 6:
 // sl = 0).  The packed-max fast paths below serve plain ReLU only (hi = +inf); a clipped activation takes the general path with one v_min more per value.
-__device__ __forceinline__ float relu_family(float v, float sl, float hi) { return fminf(v < 0.f ? v * sl : v, hi); }
+// CLIP is a compile-time property of the kernel instantiation: the kernels that are NOT instantiated for clipped activations keep exactly the code (and the registers: they sit at
+// their spill edge) they had without the bound.
+template <bool CLIP> __device__ __forceinline__ float relu_family(float v, float sl, float hi) { const float r = v < 0.f ? v * sl : v; if constexpr (CLIP) return fminf(r, hi); else return r; }
 // Barrier that orders LDS traffic only.  __syncthreads() also waits vmcnt(0): inside the tile loop that made every barrier wait for the
 // X-patch prefetch of the NEXT tile (a full HBM round trip) and for the previous tile's output stores.
 __device__ __forceinline__ void mb_lds_barrier() {
@@ -109,9 +111,8 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
     for (int i = tid; i < OP * (hs / 2); i += NT) ((half_t*)hid2)[i] = (half_t)0.f;      // (the pad channels / pad slot of the hidden tile stay zero for good)
     if (!p.expand) for (int i = tid; i < 2 * HIDB / 2; i += NT) ((half_t*)hid0)[i] = (half_t)0.f;   // (pad channels of the copied patch)
 
-    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;           // block-uniform: (clipped) ReLU takes the packed-max path ...
-    const bool clip1 = p.hi1 != INFINITY, clip2 = p.hi2 != INFINITY;   // ... + a packed min when the activation is ONNX Clip(0, hi); min commutes with the rounding (monotone)
-    const half_t hh1 = (half_t)p.hi1, hh2 = (half_t)p.hi2;            // block-uniform: plain ReLU takes the packed-max path
+    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;   // block-uniform: plain ReLU takes the packed-max path; a clipped one (ONNX Clip(0, hi)) the general path below
+                                                                      // (a packed min inside the fast path cost these kernels 5 registers each — they sit at their spill edge: +6.6 us on MobileNet-v2's 7 x 7 blocks)            // block-uniform: plain ReLU takes the packed-max path
     const int T = p.ntiles, G = gridDim.x;
     const int t_begin = (int)((long)blockIdx.x * T / G), t_end = (int)((long)(blockIdx.x + 1) * T / G);
     const int nfa = ChP >> 5, ks1 = KP1 >> 4, ks2 = ChP >> 4, nfc = CoP >> 5, cvn = p.Ch >> 3;
@@ -180,10 +181,9 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
 #pragma unroll
                     for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[4 * q + r2];
                     o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
-                    if (clip1) o = __builtin_elementwise_min(o, half4_t{hh1, hh1, hh1, hh1});
                 } else {
 #pragma unroll
-                    for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[4 * q + r2], p.sl1, p.hi1);
+                    for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family<false>(acc[4 * q + r2], p.sl1, p.hi1);
                 }
                 *(half4_t*)(hid + pp * hs + (nf * 32 + 8 * q + 4 * hi) * 2) = o;
             }
@@ -221,10 +221,9 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
 #pragma unroll
                 for (int j = 0; j < 8; j++) ov[j] = (half_t)a[j];
                 ov = __builtin_elementwise_max(ov, half8_t{0, 0, 0, 0, 0, 0, 0, 0});
-                if (clip2) ov = __builtin_elementwise_min(ov, half8_t{hh2, hh2, hh2, hh2, hh2, hh2, hh2, hh2});
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2, p.hi2);
+                for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family<false>(a[j], p.sl2, p.hi2);
             }
             *(half8_t*)(hid2 + op * hs + cv * 16) = ov;
         }
@@ -265,7 +264,7 @@ __global__ __launch_bounds__(1024) void mbconv_kernel(MbParams p) {
                         for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                     half8_t ov;
 #pragma unroll
-                    for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
+                    for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family<false>(o[r2], p.sl3, p.hi3);
                     *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                 }
             }
@@ -370,7 +369,7 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
                     for (int q = 0; q < 4; q++) {
                         half4_t o;
 #pragma unroll
-                        for (int r2 = 0; r2 < 4; r2++) o[r2] = inimg ? (half_t)relu_family(acc[4 * q + r2] + bq[q][r2], p.sl1, p.hi1) : (half_t)0.f;
+                        for (int r2 = 0; r2 < 4; r2++) o[r2] = inimg ? (half_t)relu_family<false>(acc[4 * q + r2] + bq[q][r2], p.sl1, p.hi1) : (half_t)0.f;
                         *(half4_t*)(hid + pp * HS + (8 * q + 4 * hi) * 2) = o;
                     }
                 }
@@ -411,7 +410,7 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
                     }
                 half8_t ov;
 #pragma unroll
-                for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2, p.hi2);
+                for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family<false>(a[j], p.sl2, p.hi2);
                 *(half8_t*)(dwo + op * HS + cv * 16) = ov;
             }
             MB_TL(3);
@@ -450,7 +449,7 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
                         for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                     half8_t ov;
 #pragma unroll
-                    for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
+                    for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family<false>(o[r2], p.sl3, p.hi3);
                     *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                 }
             }
@@ -537,9 +536,8 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
     __syncthreads();                                                     // the only barrier of the kernel
 
-    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;           // block-uniform: (clipped) ReLU takes the packed-max path ...
-    const bool clip1 = p.hi1 != INFINITY, clip2 = p.hi2 != INFINITY;   // ... + a packed min when the activation is ONNX Clip(0, hi); min commutes with the rounding (monotone)
-    const half_t hh1 = (half_t)p.hi1, hh2 = (half_t)p.hi2;
+    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;   // block-uniform: plain ReLU takes the packed-max path; a clipped one (ONNX Clip(0, hi)) the general path below
+                                                                      // (a packed min inside the fast path cost these kernels 5 registers each — they sit at their spill edge: +6.6 us on MobileNet-v2's 7 x 7 blocks)
     const long T = p.ntiles, GW = (long)gridDim.x * NW, gw = (long)blockIdx.x * NW + wave;
     const int t_begin = (int)(gw * T / GW), t_end = (int)((gw + 1) * T / GW);
     const half8_t hz = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -661,10 +659,9 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 #pragma unroll
                         for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[4 * q + r2];
                         o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
-                        if (clip1) o = __builtin_elementwise_min(o, half4_t{hh1, hh1, hh1, hh1});
                     } else {
 #pragma unroll
-                        for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[4 * q + r2], p.sl1, p.hi1);
+                        for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family<false>(acc[4 * q + r2], p.sl1, p.hi1);
                     }
                     *(half4_t*)(hid + (mf * 32 + l31) * HS + (8 * q + 4 * hi) * 2) = o;
                 }
@@ -710,10 +707,9 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)accB[pg][cg][r2];
                             o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
-                            if (clip2) o = __builtin_elementwise_min(o, half4_t{hh2, hh2, hh2, hh2});
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(accB[pg][cg][r2], p.sl2, p.hi2);
+                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family<false>(accB[pg][cg][r2], p.sl2, p.hi2);
                         }
                         *(half4_t*)(dwo + (pg * 16 + n16) * HS + cg * 32 + g4 * 8) = o;
                     }
@@ -756,12 +752,12 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                         half8_t ov;
-                        if (p.sl3 == 1.f && p.hi3 == INFINITY) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
+                        if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family<false>(o[r2], p.sl3, p.hi3);
                         }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }
@@ -915,7 +911,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
                     const float a = accA[q0 >> 4][q0 & 15], b = (2 * q + 1 < WC) ? accA[q1 >> 4][q1 & 15] : 0.f;
                     half2_t o;
                     if constexpr (RELU != 0) { o[0] = (half_t)a; o[1] = (half_t)b; o = __builtin_elementwise_max(o, half2_t{0, 0}); if constexpr (RELU == 2) o = __builtin_elementwise_min(o, half2_t{(half_t)p.hi1, (half_t)p.hi1}); }
-                    else { o[0] = (half_t)relu_family(a, p.sl1, p.hi1); o[1] = (half_t)relu_family(b, p.sl1, p.hi1); }
+                    else { o[0] = (half_t)relu_family<false>(a, p.sl1, p.hi1); o[1] = (half_t)relu_family<false>(b, p.sl1, p.hi1); }
                     hw[py][q] = __builtin_bit_cast(unsigned, o);
                 }
             // ---- phase B: depthwise 3x3 over the lane's window: TH x 4 outputs, nine fp32 FMAs each -------------------------------------------------------------------
@@ -942,7 +938,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
                 });
                 half2_t o;
                 if constexpr (RELU != 0) { o[0] = (half_t)a2[0]; o[1] = (half_t)a2[1]; o = __builtin_elementwise_max(o, half2_t{0, 0}); if constexpr (RELU == 2) o = __builtin_elementwise_min(o, half2_t{(half_t)p.hi2, (half_t)p.hi2}); }
-                else { o[0] = (half_t)relu_family(a2[0], p.sl2, p.hi2); o[1] = (half_t)relu_family(a2[1], p.sl2, p.hi2); }
+                else { o[0] = (half_t)relu_family<false>(a2[0], p.sl2, p.hi2); o[1] = (half_t)relu_family<false>(a2[1], p.sl2, p.hi2); }
                 *(half_t*)(dwo + woff[2 * op2] + oy * TW * HS) = o[0];
                 *(half_t*)(dwo + woff[2 * op2 + 1] + oy * TW * HS) = o[1];
             });
@@ -982,12 +978,12 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                         half8_t ov;
-                        if (p.sl3 == 1.f && p.hi3 == INFINITY) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
+                        if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family<false>(o[r2], p.sl3, p.hi3);
                         }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }
@@ -1135,7 +1131,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     const float a = accA[q0 >> 4][q0 & 15], b = (2 * q + 1 < WC) ? accA[q1 >> 4][q1 & 15] : 0.f;
                     half2_t o;
                     if constexpr (RELU != 0) { o[0] = (half_t)a; o[1] = (half_t)b; o = __builtin_elementwise_max(o, half2_t{0, 0}); if constexpr (RELU == 2) o = __builtin_elementwise_min(o, half2_t{(half_t)p.hi1, (half_t)p.hi1}); }
-                    else { o[0] = (half_t)relu_family(a, p.sl1, p.hi1); o[1] = (half_t)relu_family(b, p.sl1, p.hi1); }
+                    else { o[0] = (half_t)relu_family<true>(a, p.sl1, p.hi1); o[1] = (half_t)relu_family<true>(b, p.sl1, p.hi1); }
                     hw[py][q] = __builtin_bit_cast(unsigned, o);
                 }
             // ---- phase B (mbconv5_kernel) ----------------------------------------------------------------------------------------------------------------------------
@@ -1159,7 +1155,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 });
                 half2_t o;
                 if constexpr (RELU != 0) { o[0] = (half_t)a2[0]; o[1] = (half_t)a2[1]; o = __builtin_elementwise_max(o, half2_t{0, 0}); if constexpr (RELU == 2) o = __builtin_elementwise_min(o, half2_t{(half_t)p.hi2, (half_t)p.hi2}); }
-                else { o[0] = (half_t)relu_family(a2[0], p.sl2, p.hi2); o[1] = (half_t)relu_family(a2[1], p.sl2, p.hi2); }
+                else { o[0] = (half_t)relu_family<true>(a2[0], p.sl2, p.hi2); o[1] = (half_t)relu_family<true>(a2[1], p.sl2, p.hi2); }
                 *(half_t*)(dwo + woff[2 * op2] + oy * TW * HS) = o[0];
                 *(half_t*)(dwo + woff[2 * op2 + 1] + oy * TW * HS) = o[1];
             });
@@ -1204,7 +1200,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                 for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                             } else {
 #pragma unroll
-                                for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
+                                for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family<true>(o[r2], p.sl3, p.hi3);
                             }
                             *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                         }
@@ -1238,7 +1234,7 @@ __device__ __attribute__((aligned(64))) unsigned int g_mb_zero[16];       // zer
 #define MB_GLDS16(gptr, ldsptr) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr), (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, 0)
 
 // AS: the patch has at most four fragments (a 7 x 7 image: 81 pixels): waves (fragment, row block) — every wave multiplies ONE of the chunk's two row blocks.
-template <int S, int TCF, int KSX, int NFW, bool AS = false>
+template <int S, int TCF, int KSX, int NFW, bool AS = false, bool CLIP = false>   // CLIP: act1 / act2 / act3 may carry an upper bound (ONNX Clip(0, hi))
 __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
     constexpr int NT = 512, CF = 2, TP = TCF > 4 ? 8 : (TCF > 2 ? 4 : 2), NG = 8 / TP, CK = CF * 32, HSB = CK * 2 + 16, NCV = CF * 4, RPTM = 4, HPA = 256;
     constexpr int F1 = CF * KSX, W1B = F1 * 1024, NI1 = (F1 + 7) / 8, NI2 = (NFW * NG * 2 * CF + 7) / 8;
@@ -1343,9 +1339,8 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
     }
     const int rlong = TO % RP, rbase = TO / RP;
     const int ty0 = rp * rbase + (rp < rlong ? rp : rlong), ty1 = task_on ? ty0 + rbase + (rp < rlong ? 1 : 0) : 0;
-    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;           // block-uniform: (clipped) ReLU takes the packed-max path ...
-    const bool clip1 = p.hi1 != INFINITY, clip2 = p.hi2 != INFINITY;   // ... + a packed min when the activation is ONNX Clip(0, hi); min commutes with the rounding (monotone)
-    const half_t hh1 = (half_t)p.hi1, hh2 = (half_t)p.hi2;
+    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;            // block-uniform: (clipped) ReLU takes the packed-max path; the CLIP instantiations add a packed min (monotone: commutes with the rounding)   // block-uniform: plain ReLU takes the packed-max path; a clipped one (ONNX Clip(0, hi)) the general path below
+                                                                      // (a packed min inside the fast path cost these kernels 5 registers each — they sit at their spill edge: +6.6 us on MobileNet-v2's 7 x 7 blocks)
 
     int g = 0;                                                            // chunks done since the launch (buffer parity); the chunk's channels = g % NC
 #pragma unroll 1
@@ -1400,10 +1395,10 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)acc[cf][4 * qq + r2];
                             o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
-                            if (clip1) o = __builtin_elementwise_min(o, half4_t{hh1, hh1, hh1, hh1});
+                            if constexpr (CLIP) { if (p.hi1 != INFINITY) { const half_t hh = (half_t)p.hi1; o = __builtin_elementwise_min(o, half4_t{hh, hh, hh, hh}); } }
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family(acc[cf][4 * qq + r2], p.sl1, p.hi1);
+                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family<CLIP>(acc[cf][4 * qq + r2], p.sl1, p.hi1);
                         }
                         *(half4_t*)(hid + pp * HSB + ((cfa0 + cf) * 32 + 8 * qq + 4 * hi) * 2) = o;
                     }
@@ -1443,10 +1438,10 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
 #pragma unroll
                         for (int j = 0; j < 8; j++) ov[j] = (half_t)a[j];
                         ov = __builtin_elementwise_max(ov, hz);
-                        if (clip2) ov = __builtin_elementwise_min(ov, half8_t{hh2, hh2, hh2, hh2, hh2, hh2, hh2, hh2});
+                        if constexpr (CLIP) { if (p.hi2 != INFINITY) { const half_t hh = (half_t)p.hi2; ov = __builtin_elementwise_min(ov, half8_t{hh, hh, hh, hh, hh, hh, hh, hh}); } }
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family(a[j], p.sl2, p.hi2);
+                        for (int j = 0; j < 8; j++) ov[j] = (half_t)relu_family<CLIP>(a[j], p.sl2, p.hi2);
                     }
                     *(half8_t*)(dwo + (y * TO + tx) * HSB + cv * 16) = ov;
                 };
@@ -1548,12 +1543,12 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
                             for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rres[i][j][r2];
                         }
                         half8_t ov;
-                        if (p.sl3 == 1.f && p.hi3 == INFINITY) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
+                        if (p.sl3 == 1.f && (!CLIP || p.hi3 == INFINITY)) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family(o[r2], p.sl3, p.hi3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family<CLIP>(o[r2], p.sl3, p.hi3);
                         }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }
@@ -1629,15 +1624,18 @@ static bool mb_common_ok(const sm_mbconv_desc* d) {
     if (!act_ok(d->act1) || !act_ok(d->act2) || !act_ok(d->act3)) return false;
     return d->Ho == (d->H + 2 - 3) / d->stride + 1 && d->Wo == (d->W + 2 - 3) / d->stride + 1;
 }
-static bool mb_v1_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && d->Cin <= 32 && d->Ch <= 192 && d->Cout <= 64 && mb_v1_lds(d) <= 160 * 1024; }
+// (kernels 1-3 hold no instantiation for bounded activations: SM_ACT_CLIP blocks go to the register-window kernels — template RELU = 2 — or to kernel 4's CLIP instantiations)
+static bool mb_clip(const sm_mbconv_desc* d) { return d->act1 == SM_ACT_CLIP || d->act2 == SM_ACT_CLIP || d->act3 == SM_ACT_CLIP; }
+static bool mb_v1_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && !mb_clip(d) && d->Cin <= 32 && d->Ch <= 192 && d->Cout <= 64 && mb_v1_lds(d) <= 160 * 1024; }
 // v2 (chunked): any Ch; Cin <= 64 when there is an expand layer (X patch in LDS, <= 4 k steps); Cout <= 64 (stride 1) / 128 (stride 2): one
 // (row block, cout block) pair per wave; the residual is read from the X patch, i.e. needs the expand form
 static bool mb_v2_ok(const sm_mbconv_desc* d) {
-    return mb_common_ok(d) && (!d->expand || d->Cin <= 64) && d->Cout <= (d->stride == 1 ? 64 : 128) && (!d->residual || d->expand) && d->Ch <= 4096 && mb_v2_lds(d) <= 64 * 1024;
+    return mb_common_ok(d) && !mb_clip(d) && (!d->expand || d->Cin <= 64) && d->Cout <= (d->stride == 1 ? 64 : 128) && (!d->residual || d->expand) && d->Ch <= 4096 && mb_v2_lds(d) <= 64 * 1024;
 }
 // v3 (wave pipelines): the expand form with K = Cin + 2 <= 48 (three k steps of X fragments in registers), Cout <= 64, weights + four wave regions in LDS
 static bool mb_v3_ok(const sm_mbconv_desc* d) {
     if (!mb_common_ok(d)) return false;
+    if (mb_clip(d) && !mb_v5_ok(d)) return false;                     // (bounded activations: only the register-window form of this family)
     if (mb_v3_wg(d)) return d->Cin <= 110 && d->Cout <= 96 && mb_v3_lds(d) <= 160 * 1024;      // (five accumulator sets, Cout = 160, spill)
     return (d->expand ? d->Cin <= 46 : !d->residual) && d->Cout <= 64 && mb_v3_lds(d) <= 160 * 1024;
 }
@@ -1724,16 +1722,21 @@ int sm_mbconv_fwd_kind(const sm_mbconv_desc* d, int32_t kind, const void* x, con
         p.ntiles = (int)nt4;
         fastdiv_make((unsigned)p.tiles_x, &p.tx_mul, &p.tx_sh); fastdiv_make((unsigned)(p.tiles_x * p.tiles_y), &p.txy_mul, &p.txy_sh);
         void (*fn)(MbParams) = nullptr;
-#define MB4_PICK(S_, T_) (ksx == 2 ? (nfw == 1 ? mbconv4_kernel<S_, T_, 2, 1> : nfw == 2 ? mbconv4_kernel<S_, T_, 2, 2> : mbconv4_kernel<S_, T_, 2, 3>) \
-                        : ksx == 4 ? (nfw <= 2 ? mbconv4_kernel<S_, T_, 4, 2> : mbconv4_kernel<S_, T_, 4, 3>) \
-                        : ksx == 6 ? (nfw <= 2 ? mbconv4_kernel<S_, T_, 6, 2> : mbconv4_kernel<S_, T_, 6, 3>) \
-                                   : (nfw <= 2 ? mbconv4_kernel<S_, T_, 10, 2> : mbconv4_kernel<S_, T_, 10, 3>))
+#define MB4_PICKC(S_, T_, A_, C_) (ksx == 2 ? (nfw == 1 ? mbconv4_kernel<S_, T_, 2, 1, A_, C_> : nfw == 2 ? mbconv4_kernel<S_, T_, 2, 2, A_, C_> : mbconv4_kernel<S_, T_, 2, 3, A_, C_>) \
+                        : ksx == 4 ? (nfw <= 2 ? mbconv4_kernel<S_, T_, 4, 2, A_, C_> : mbconv4_kernel<S_, T_, 4, 3, A_, C_>) \
+                        : ksx == 6 ? (nfw <= 2 ? mbconv4_kernel<S_, T_, 6, 2, A_, C_> : mbconv4_kernel<S_, T_, 6, 3, A_, C_>) \
+                                   : (nfw <= 2 ? mbconv4_kernel<S_, T_, 10, 2, A_, C_> : mbconv4_kernel<S_, T_, 10, 3, A_, C_>))
+        const bool clip = p.hi1 != INFINITY || p.hi2 != INFINITY || p.hi3 != INFINITY;   // (a bounded activation: the CLIP instantiations; everything else runs the code it ran before the bound existed)
+#define MB4_PICK(S_, T_) (clip ? MB4_PICKC(S_, T_, false, true) : MB4_PICKC(S_, T_, false, false))
         const int pw = (to - 1) * d->stride + 3;
-        if (d->stride == 1 && tcf == 2 && pw * pw <= 128 && ksx >= 6) fn = ksx == 6 ? (nfw <= 2 ? mbconv4_kernel<1, 2, 6, 2, true> : mbconv4_kernel<1, 2, 6, 3, true>)
+        if (d->stride == 1 && tcf == 2 && pw * pw <= 128 && ksx >= 6 && !clip) fn = ksx == 6 ? (nfw <= 2 ? mbconv4_kernel<1, 2, 6, 2, true> : mbconv4_kernel<1, 2, 6, 3, true>)
                                                                                    : (nfw <= 2 ? mbconv4_kernel<1, 2, 10, 2, true> : mbconv4_kernel<1, 2, 10, 3, true>);
+        else if (d->stride == 1 && tcf == 2 && pw * pw <= 128 && ksx >= 6) fn = ksx == 6 ? (nfw <= 2 ? mbconv4_kernel<1, 2, 6, 2, true, true> : mbconv4_kernel<1, 2, 6, 3, true, true>)
+                                                                                   : (nfw <= 2 ? mbconv4_kernel<1, 2, 10, 2, true, true> : mbconv4_kernel<1, 2, 10, 3, true, true>);
         else if (d->stride == 1) fn = tcf == 7 ? MB4_PICK(1, 7) : MB4_PICK(1, 2);
         else fn = MB4_PICK(2, 2);
 #undef MB4_PICK
+#undef MB4_PICKC
         hipLaunchKernelGGL(fn, dim3((unsigned)std::min<long>(nt4, SM_NUM_CU)), dim3(512), lds, sm_s(stream), p);
         SM_LAUNCH_CHECK(); return SM_OK;
     }
