@@ -302,3 +302,17 @@ def test_fused_pool_and_head_predicates_reject_grouped_convolutions():
         d = N.ConvDesc(2, 64, 64, 32, 32, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, groups, 64, 64, 1, 0.0, 32, 32, 0)
         assert L.sm_conv2d_head_supported(C.byref(d), 16) == want
         assert L.sm_conv2d_pool_supported(C.byref(d)) == want
+
+
+def test_docs_are_stamped_from_the_profile_files():
+    """every number block of DESIGN.md / README.md is generated from profiles/r05_* by tools/doc_numbers.py; a block edited by hand, or a profile replaced
+    without re-stamping, fails here"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "doc_numbers.py"), "--check"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    for doc in ("DESIGN.md", "README.md"):
+        text = open(os.path.join(root, doc)).read()
+        assert "<!-- numbers:state -->" in text and "<!-- numbers:parity -->" in text and "<!-- numbers:stage -->" in text
