@@ -213,7 +213,8 @@ int sm_stem3x3_f32_fwd(const float* x_nchw, int32_t N, int32_t C, int32_t in_H, 
  * padding 1, groups 1, Cin % 128 == 0, Cout % 8 == 0, images of at most 208 pixels, fp16 NHWC.  An operand of phase i that lies inside the output of an earlier
  * phase of the run is read from it once the producing tiles of the SAME image have published (the batch has no cross-sample dependency: BN uses stored
  * statistics, Converters.swift:760-773); everything else must be complete before the launch.  No phase may overwrite a tensor another phase of the run reads or
- * writes.  The blocks of one XCD form a team that keeps N/8 images for the whole run, so a phase's output is read back from that XCD's L2.
+ * writes.  The blocks of one XCD form a team that keeps N/8 images for the whole run, so a phase's output is read back from that XCD's L2; when the 256 blocks do not all become
+ * resident promptly with 32 per XCD the same launch completes in a slower mode that needs no co-residency (sm_stage_status).
  * `ctl`: sm_stage_ctl_bytes(ph, n) bytes of device memory, zeroed once by the caller; the kernel leaves it zeroed (but for the status words).
  * Same numerics per phase as a phase launched alone through this entry (bit-identical); fp32 accumulation, one rounding to fp16 per phase output. */
 #define SM_STAGE_MAX_PHASES 18
@@ -232,8 +233,10 @@ int sm_stage_fwd(const sm_stage_phase* ph, int32_t n, void* ctl, sm_stream_t str
 /* HOST side, once per model: phase i's OHWI weights (host memory) re-ordered for the tile form the planner gives the phase in THIS run (the phase list and the batch decide it) */
 size_t sm_stage_packed_weight_bytes(const sm_stage_phase* ph, int32_t n, int32_t i);
 int sm_stage_pack_weights(const sm_stage_phase* ph, int32_t n, int32_t i, const void* w_ohwi_host, void* dst_host);
-/* After a run (synchronises `stream`): error_bits 1 = the 256 blocks did not become co-resident within the spin bound, 2 = a hand-off wait ran out (results are
- * undefined in both cases); mode 1 = XCD-local hand-off (every XCD held 32 blocks), 2 = the fenced fallback (agent-scope release / acquire).  Clears both words. */
+/* After a run (synchronises `stream`): error_bits 2 = a hand-off wait ran out (results undefined; the graph level turns it into an error of smelter_exec_read_float); mode = the modes the
+ * launches since the last call ran in, OR-ed: 1 = static tile assignment, XCD-local hand-off (all 256 blocks arrived promptly, 32 per XCD), 2 = tiles claimed by whichever blocks run, hand-off
+ * through agent-scope release / acquire (no co-residency needed: another process on the GPU, a partitioned device).  Clears both words.
+ * Test hook: word 12 of `ctl` preset to 2 makes the next launch run in mode 2. */
 int sm_stage_status(void* ctl, sm_stream_t stream, int32_t* error_bits, int32_t* mode);
 
 /* MPSCNNConvolutionTransposeNode (Converters.swift:277) + ONNX_ConvolutionPadding(isTranspose) (:66-71, :97-103).

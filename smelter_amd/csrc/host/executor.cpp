@@ -1335,6 +1335,16 @@ int Executor::readFloat(hipStream_t s, float* dst, size_t cap, int layout) {
     if (rc) return rc;
     SM_HIP_CHECK(hipMemcpyAsync(dst, out_f32_, count * 4, hipMemcpyDeviceToHost, s));
     SM_HIP_CHECK(hipStreamSynchronize(s));
+    return checkRuns(s);
+}
+
+// A persistent run whose hand-off wait ran out left undefined tensors behind: say so where the host first looks at a result (the encode itself only enqueues)
+int Executor::checkRuns(hipStream_t s) const {
+    if (!stage_ctl_) return SM_OK;
+    int32_t err = 0, mode = 0;
+    const int rc = sm_stage_status(stage_ctl_, (sm_stream_t)s, &err, &mode);
+    if (rc) return rc;
+    if (err) { sm_set_error("a persistent run (sm_stage_fwd) reported a timed-out hand-off (bits %d, modes %d): the results of this encode are undefined", err, mode); return SM_ERR_INCONSISTENT_STATE; }
     return SM_OK;
 }
 
@@ -1344,6 +1354,7 @@ int Executor::materializedStored(int i) const {
     return 0;
 }
 int Executor::readValue(hipStream_t s, const char* name, float* dst, size_t cap, int* c, int* h, int* w) {
+    { const int rc0 = checkRuns(s); if (rc0) return rc0; }
     int v = -1; for (size_t i = 0; i < value_names_.size(); i++) if (value_names_[i] == name) v = (int)i;
     if (v < 0) { sm_set_error("no value named '%s' survives fusion", name); return SM_ERR_NO_SUCH_OUTPUT; }
     if (!stored_[v]) { sm_set_error("value '%s' has no storage: a fused launch keeps it in registers / LDS only", name); return SM_ERR_NO_SUCH_OUTPUT; }

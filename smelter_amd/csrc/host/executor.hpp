@@ -116,6 +116,7 @@ class Executor {
     std::vector<sm_stage_phase> runPhases(const StageRun& r, const char* arena, const char* act, bool packed) const;
     int numLaunchesNow() const;
     void annotateRuns();
+    int checkRuns(hipStream_t s) const;
     sm_conv_desc convDesc(const Step& st) const;
     int convertInput(hipStream_t s, const float* in) const;
     int launchAll(hipStream_t s, const float* in) const;

@@ -20,10 +20,11 @@
 // Numerics: fp32 accumulation over (channel block, tap, channel) ascending inside a wave's K slice, slices added in ascending order — the same as the wave-split
 // per-layer kernel (conv3x3_kq.hpp); a phase launched ALONE through this file is bit-identical to the same phase inside a run (tests/test_gpu_stage.py).
 //
-// Placement check: every block takes a ticket from its XCD's counter and all wait (bounded) until 256 tickets are out; if every XCD holds exactly 32 blocks the run is
-// XCD-local as above.  Otherwise (partitioned device, foreign work on some CUs) teams are formed in arrival order and every hand-off uses the architecturally sanctioned
-// agent-scope release / acquire (buffer_wbl2 sc1 / buffer_inv sc1, MI355X_MICROARCH.md §Workgroup dispatch) — slower, never wrong.  Every spin is bounded; a timeout sets
-// an error word the host reads with sm_stage_status.
+// Two modes, decided once per launch by the blocks themselves: every block takes a ticket from its XCD's counter; if all 256 arrive within a short bound and every XCD holds exactly 32, the
+// launch is STATIC and XCD-local as above.  Otherwise (blocks of another process on some CUs, a partitioned device, another placement) the tiles of a phase are CLAIMED from one counter by
+// whichever blocks are running, and every hand-off uses the architecturally sanctioned agent-scope release / acquire (buffer_wbl2 sc1 / buffer_inv sc1, MI355X_MICROARCH.md §Workgroup
+// dispatch) — slower, never wrong, and it needs no co-residency at all (a claimed tile belongs to a running block; a phase is claimed out before the next one opens).  Every spin is bounded;
+// sm_stage_status reports the modes seen and whether a hand-off wait ever ran out.
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
@@ -34,7 +35,9 @@ namespace {
 
 typedef unsigned st_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int ST_MAXPH = SM_STAGE_MAX_PHASES, ST_TEAM = 32, ST_NTEAM = 8, ST_GRID = ST_TEAM * ST_NTEAM;
-constexpr int ST_CTL_HDR = 16;                  // ctl words: [0..7] tickets per XCD, [8] arrived, [9] done, [10] error bits, [11] mode seen (1 = XCD-local, 2 = fenced), then cnt[phase][cnt_ld]
+constexpr int ST_CTL_HDR = 48;                  // ctl words: [0..7] tickets per XCD, [8] arrived, [9] done, [10] error bits, [11] modes seen (1 = XCD-local, 2 = claimed + fenced), [12] this launch's mode,
+                                                // [16 .. 16 + phases) next unclaimed tile per phase (mode 2), then cnt[phase][cnt_ld]
+constexpr int ST_MODE = 12, ST_CLAIM = 16;
 
 struct StPhase {
     const half_t* x; const half_t* x2; const half_t* w; const half_t* wp; const float* bias; const half_t* res; half_t* y;   // wp: the weights in fragment order (sm_stage_pack_weights) or nullptr
@@ -46,8 +49,8 @@ struct StPhase {
     unsigned x_bytes, x2_bytes, res_bytes, y_bytes;
     unsigned hw_mul, hw_sh, w_mul, w_sh, h1_mul, h1_sh, kpr_mul, kpr_sh;
 };
-struct StArgs { unsigned* ctl; int nphase, N, ipt, spin_limit, cnt_ld, lds_bytes; StPhase ph[ST_MAXPH]; };
-static_assert(sizeof(StArgs) <= 4096, "kernel argument block");
+struct StArgs { unsigned* ctl; int nphase, N, ipt, spin_limit, arrive_limit, cnt_ld, lds_bytes; StPhase ph[ST_MAXPH]; };
+static_assert(sizeof(StArgs) <= 4096 && ST_CLAIM + ST_MAXPH <= ST_CTL_HDR, "kernel argument block, control words");
 
 // KG x NG = 4 waves: KG = K groups (a wave multiplies channels [kg WCH, (kg + 1) WCH) of every super-block of KG WCH channels), NG = cout groups of NF 16-cout fragments;
 // NFR = 16-pixel fragments per tile; TAPS = 1 | 9; SBG = super-blocks per unrolled loop body; NB = patch buffers.
@@ -436,28 +439,58 @@ __global__ __launch_bounds__(256) void stage_kernel(const StArgs a) {
     unsigned* const ctl = a.ctl;
     unsigned* const cnt = ctl + ST_CTL_HDR;
     if (tid == 0) {
+        // Mode of this launch, decided ONCE, by the first block to arrive (a single writer: 256 compare-and-swaps on one word cost a 10 us start ramp): 1 = every one of the 256 blocks arrived within the bound and every XCD
+        // holds 32 of them -> static tile assignment per XCD team, XCD-local hand-off; 2 = anything else (blocks of another process on some CUs, a partitioned device, a placement
+        // that is not 32 per XCD) -> tiles are CLAIMED from a counter per phase by whichever blocks are running, every hand-off through agent-scope release / acquire.  Mode 2 needs no
+        // co-residency at all: a claimed tile belongs to a running block, every phase is claimed out before the next one opens, so the earliest unfinished tile always progresses; a block
+        // that becomes resident late adopts the mode it finds and claims what is left (nothing: it leaves).
         unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); xcc &= 7u;
         const unsigned slot = __hip_atomic_fetch_add(&ctl[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned gi = __hip_atomic_fetch_add(&ctl[8], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int spins = 0; bool to = false;
-        while (st_ld_sc1(&ctl[8]) < (unsigned)ST_GRID) { __builtin_amdgcn_s_sleep(1); if (++spins > a.spin_limit) { to = true; break; } }
-        bool local = !to;
-        for (int i = 0; i < ST_NTEAM; i++) local = local && st_ld_sc1(&ctl[i]) == (unsigned)ST_TEAM;
-        s_info[0] = local ? (int)xcc : (int)(gi / ST_TEAM); s_info[1] = local ? (int)slot : (int)(gi % ST_TEAM); s_info[2] = local ? 1 : 0;
-        if (to) __hip_atomic_fetch_or(&ctl[10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_or(&ctl[11], local ? 1u : 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned mode = 0u;
+        if (gi == 0u) {                                               // the FIRST block to arrive decides (it is running: nobody waits on a block that is not), everybody else reads the word
+            int spins = 0;
+            while (st_ld_sc1(&ctl[8]) < (unsigned)ST_GRID && spins < a.arrive_limit) { __builtin_amdgcn_s_sleep(1); spins++; }
+            bool local = st_ld_sc1(&ctl[8]) >= (unsigned)ST_GRID;
+            for (int i = 0; i < ST_NTEAM; i++) local = local && st_ld_sc1(&ctl[i]) == (unsigned)ST_TEAM;
+            mode = local ? 1u : 2u;
+            if (st_ld_sc1(&ctl[ST_MODE]) == 2u) mode = 2u;              // (test hook: the host preset the word — the claimed mode is forced)
+            __hip_atomic_store(&ctl[ST_MODE], mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int spins = 0;
+            while ((mode = st_ld_sc1(&ctl[ST_MODE])) == 0u) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > 8 * a.arrive_limit + 1000) { __hip_atomic_fetch_or(&ctl[10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); mode = 2u; break; }   // (cannot happen while block 0 runs; flagged, not hung)
+            }
+        }
+        s_info[0] = (int)xcc; s_info[1] = (int)slot; s_info[2] = (int)mode;
+        __hip_atomic_fetch_or(&ctl[11], mode, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    const int team = s_info[0], member = s_info[1]; const bool local = s_info[2] != 0;
-    const int i0 = team * a.ipt, i1 = min(a.N, i0 + a.ipt);
+    const bool local = s_info[2] == 1;
+    const int member = s_info[1];
     const unsigned smem_lds = ws_lds_addr(st_smem), lds0 = (smem_lds + 1023u) & ~1023u;
     int tl_slot = 0;                                                  // (tiles this block has run: index of the diagnostic build's stamps)
 #pragma unroll 1
     for (int ph = 0; ph < a.nphase; ph++) {
         const StPhase& p = a.ph[ph];
         const int ntiles = p.MT * p.NT, HW = p.HW;
+        // mode 1: tiles member, member + 32, ... of MY team; mode 2: the next unclaimed (team, tile) of the phase
+        int jj = local ? member : 0;
 #pragma unroll 1
-        for (int j = member; j < ntiles; j += ST_TEAM) {
+        for (;;) {
+            int team, j;
+            if (local) { team = s_info[0]; j = jj; jj += ST_TEAM; if (j >= ntiles) break; }
+            else {
+                __syncthreads();
+                if (tid == 0) s_info[3] = (int)__hip_atomic_fetch_add(&ctl[ST_CLAIM + ph], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                const int c = s_info[3];
+                if (c >= ntiles * ST_NTEAM) break;
+                team = c / ntiles; j = c - team * ntiles;
+            }
+            const int i0 = team * a.ipt, i1 = min(a.N, i0 + a.ipt);
+
             const int mt = (int)((unsigned)j / (unsigned)p.NT), nt = j - mt * p.NT;
             const int pix0 = i0 * HW + mt * p.TP, PTe = min(p.TP, i1 * HW - pix0);
             if (PTe <= 0) continue;
@@ -521,7 +554,7 @@ __global__ __launch_bounds__(256) void stage_kernel(const StArgs a) {
     __syncthreads();
     if (s_info[3]) {
         for (int i = tid; i < a.nphase * a.cnt_ld; i += 256) __hip_atomic_store(&cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < 10) __hip_atomic_store(&ctl[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (error bits [10] and the mode word [11] stay for sm_stage_status)
+        if (tid < 10 || tid == ST_MODE || (tid >= ST_CLAIM && tid < ST_CLAIM + ST_MAXPH)) __hip_atomic_store(&ctl[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (error bits [10] and the modes-seen word [11] stay for sm_stage_status)
     }
 }
 
@@ -546,7 +579,7 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
     memset(&a, 0, sizeof a);
     const int N = ph[0].d.N;
     ST_REQ(N >= 1 && N <= 4096, "sm_stage: batch %d", N);
-    a.nphase = n; a.N = N; a.ipt = sm_ceil_div(N, ST_NTEAM); a.spin_limit = 1000000; a.cnt_ld = (N + 15) / 16 * 16;
+    a.nphase = n; a.N = N; a.ipt = sm_ceil_div(N, ST_NTEAM); a.spin_limit = 1000000; a.arrive_limit = 200; a.cnt_ld = (N + 15) / 16 * 16;
     size_t lds = 0;
     struct Range { const void* p; size_t n; };
     std::vector<Range> ys(n);
@@ -704,8 +737,7 @@ extern "C" int sm_stage_fwd(const sm_stage_phase* ph, int32_t n, void* ctl, sm_s
     SM_LAUNCH_CHECK();
     return SM_OK;
 }
-// bit 0: the blocks did not all become resident in time; bit 1: a hand-off wait ran out.  mode: 1 = XCD-local hand-off, 2 = fenced (placement was not 32 blocks per XCD), 3 = both seen.
-// Synchronises the stream.  Clears the words.
+// error bit 1: a hand-off wait ran out.  mode: modes seen since the last call (1 = static + XCD-local, 2 = claimed + fenced, 3 = both).  Synchronises the stream.  Clears the words.
 extern "C" int sm_stage_status(void* ctl, sm_stream_t stream, int32_t* error_bits, int32_t* mode) {
     unsigned h[2] = {0, 0};
     SM_HIP_CHECK(hipMemcpyAsync(h, (char*)ctl + 10 * 4, 8, hipMemcpyDeviceToHost, sm_s(stream)));

@@ -38,6 +38,10 @@ def main():
         print("%-5d %-5d %9.2f %9.2f %9.2f | %8.2f %8.2f %8.2f %8.2f %8.2f" % (ph, len(rs), us(min(r[0] for r in rs)), us(max(r[0] for r in rs)), us(max(r[5] for r in rs)),
                                                                                seg(0, 1), seg(1, 2), seg(2, 3), seg(3, 4), seg(4, 5)))
     print("kernel: first stamp -> last stamp %.2f us" % us(max(r[4][5] for r in rows)))
+    if "starts" in sys.argv:                               # when does each block start its first tile (us after the earliest): the launch ramp + the mode decision
+        st0 = sorted((us(r[4][0]), r[3], r[1]) for r in rows if r[0] == 0)
+        print("first-tile starts, sorted:", " ".join("%.1f" % v[0] for v in st0[::8]))
+        print("latest 8 (us, block, team):", st0[-8:])
     # one team in detail: team 0's blocks, start and end of each tile
     if "detail" in sys.argv:
         for r in sorted((r for r in rows if r[1] == 0), key=lambda r: (r[3], r[4][0])):
