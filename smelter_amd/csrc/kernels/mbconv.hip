@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void mbconv2_kernel(MbParams p) {
 #ifndef MB3_BD
 #define MB3_BD 1
 #endif
-template <int S, int KS1, int NW, bool WREG, int TH = (S == 1 ? 4 : 2), bool WG = false, int NF = 2>
+template <int S, int KS1, int NW, bool WREG, int TH = (S == 1 ? 4 : 2), bool WG = false, int NF = 2, bool CLIP = false>   // CLIP: bounded activations (instantiated for the no-expand form only)
 __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     constexpr int TW = 8, OPX = TH * TW, PH = (TH - 1) * S + 3, PW = (TW - 1) * S + 3, HP = PH * PW, MFA = (HP + 31) / 32, HS = 80, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char mb_smem[];
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
     for (int i = tid; i < CoP; i += NT) b2l[i] = (p.b2 && i < p.Cout) ? p.b2[i] : 0.f;
     __syncthreads();                                                     // the only barrier of the kernel
 
-    const bool relu1 = p.sl1 == 0.f, relu2 = p.sl2 == 0.f;   // block-uniform: plain ReLU takes the packed-max path; a clipped one (ONNX Clip(0, hi)) the general path below
+    const bool relu1 = p.sl1 == 0.f && (!CLIP || p.hi1 == INFINITY), relu2 = p.sl2 == 0.f && (!CLIP || p.hi2 == INFINITY);   // block-uniform: plain ReLU takes the packed-max path; a clipped one (ONNX Clip(0, hi)) the general path below
                                                                       // (a packed min inside the fast path cost these kernels 5 registers each — they sit at their spill edge: +6.6 us on MobileNet-v2's 7 x 7 blocks)
     const long T = p.ntiles, GW = (long)gridDim.x * NW, gw = (long)blockIdx.x * NW + wave;
     const int t_begin = (int)(gw * T / GW), t_end = (int)((gw + 1) * T / GW);
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
                         o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
                     } else {
 #pragma unroll
-                        for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family<false>(acc[4 * q + r2], p.sl1, p.hi1);
+                        for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family<CLIP>(acc[4 * q + r2], p.sl1, p.hi1);
                     }
                     *(half4_t*)(hid + (mf * 32 + l31) * HS + (8 * q + 4 * hi) * 2) = o;
                 }
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
                             o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family<false>(accB[pg][cg][r2], p.sl2, p.hi2);
+                            for (int r2 = 0; r2 < 4; r2++) o[r2] = (half_t)relu_family<CLIP>(accB[pg][cg][r2], p.sl2, p.hi2);
                         }
                         *(half4_t*)(dwo + (pg * 16 + n16) * HS + cg * 32 + g4 * 8) = o;
                     }
@@ -752,12 +752,12 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) o[r2] += (float)rv[r2]; }
                         half8_t ov;
-                        if (p.sl3 == 1.f) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
+                        if (p.sl3 == 1.f && (!CLIP || p.hi3 == INFINITY)) {                                  // no activation behind the projection (the usual linear bottleneck): 4 conversions instead of 8 compare / multiply / select
 #pragma unroll
                             for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family<false>(o[r2], p.sl3, p.hi3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family<CLIP>(o[r2], p.sl3, p.hi3);
                         }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }
@@ -1635,7 +1635,7 @@ static bool mb_v2_ok(const sm_mbconv_desc* d) {
 // v3 (wave pipelines): the expand form with K = Cin + 2 <= 48 (three k steps of X fragments in registers), Cout <= 64, weights + four wave regions in LDS
 static bool mb_v3_ok(const sm_mbconv_desc* d) {
     if (!mb_common_ok(d)) return false;
-    if (mb_clip(d) && !mb_v5_ok(d)) return false;                     // (bounded activations: only the register-window form of this family)
+    if (mb_clip(d) && !mb_v5_ok(d) && d->expand) return false;        // (bounded activations: the register-window form and the no-expand form of this family)
     if (mb_v3_wg(d)) return d->Cin <= 110 && d->Cout <= 96 && mb_v3_lds(d) <= 160 * 1024;      // (five accumulator sets, Cout = 160, spill)
     return (d->expand ? d->Cin <= 46 : !d->residual) && d->Cout <= 64 && mb_v3_lds(d) <= 160 * 1024;
 }
@@ -1767,7 +1767,9 @@ int sm_mbconv_fwd_kind(const sm_mbconv_desc* d, int32_t kind, const void* x, con
             const int nf = (d->Cout + 31) / 32;
             if (d->stride == 1) fn = ks1 <= 5 ? (nf <= 2 ? mbconv3_kernel<1, 5, 8, false, 4, true, 2> : mbconv3_kernel<1, 5, 8, false, 4, true, 3>) : mbconv3_kernel<1, 7, 8, false, 4, true, 3>;
             else fn = ks1 <= 5 ? mbconv3_kernel<2, 5, 8, false, 2, true, 3> : mbconv3_kernel<2, 7, 8, false, 2, true, 3>;
-        } else if (ks1 == 0) fn = d->stride == 2 ? (nw == 16 ? mbconv3_kernel<2, 0, 16, false> : nw == 8 ? mbconv3_kernel<2, 0, 8, false> : mbconv3_kernel<2, 0, 4, false>)
+        } else if (ks1 == 0 && mb_clip(d)) fn = d->stride == 2 ? (nw == 16 ? mbconv3_kernel<2, 0, 16, false, 2, false, 2, true> : nw == 8 ? mbconv3_kernel<2, 0, 8, false, 2, false, 2, true> : mbconv3_kernel<2, 0, 4, false, 2, false, 2, true>)
+                                          : nw == 16 ? mbconv3_kernel<1, 0, 16, false, 4, false, 2, true> : nw == 8 ? mbconv3_kernel<1, 0, 8, true, 4, false, 2, true> : mbconv3_kernel<1, 0, 4, true, 4, false, 2, true>;
+        else if (ks1 == 0) fn = d->stride == 2 ? (nw == 16 ? mbconv3_kernel<2, 0, 16, false> : nw == 8 ? mbconv3_kernel<2, 0, 8, false> : mbconv3_kernel<2, 0, 4, false>)
                                           : nw == 16 ? mbconv3_kernel<1, 0, 16, false> : nw == 8 ? mbconv3_kernel<1, 0, 8, true> : mbconv3_kernel<1, 0, 4, true>;
         else if (d->stride == 2) fn = nw == 16 ? (ks1 <= 2 ? mbconv3_kernel<2, 2, 16, false> : mbconv3_kernel<2, 3, 16, false>)
                                     : nw == 8 ? (ks1 <= 2 ? mbconv3_kernel<2, 2, 8, false> : mbconv3_kernel<2, 3, 8, false>)

@@ -780,6 +780,8 @@ def test_mbconv_register_window_kernel_other_activations(hw, cin, ch, cout, stri
     ((14, 14), 96, 576, 160, 2, False),    # stride 2 into 7 x 7
     ((7, 7), 160, 960, 160, 1, True),      # 7 x 7
     ((20, 24), 16, 96, 24, 1, False),      # all-in-LDS / chunked domain
+    ((112, 112), 32, 32, 16, 1, False),    # MobileNet-v2's first block: NO expand layer (depthwise -> project), the wave-pipeline kernel's CLIP instantiations
+    ((40, 36), 32, 32, 24, 2, False),      # ... stride 2, ragged tiles
 ])
 def test_mbconv_relu6_clip(hw, cin, ch, cout, stride, res):
     """a torchvision MobileNet-v2 export holds ONNX Clip(0, 6) where the stand-in model has Relu.  The fused block kernels take SM_ACT_CLIP (upper bound in
@@ -787,20 +789,23 @@ def test_mbconv_relu6_clip(hw, cin, ch, cout, stride, res):
     import ctypes
     from smelter_amd._native import MbConvDesc
     so = lambda v: (v + 2 - 3) // stride + 1
-    dsc = MbConvDesc(2, hw[0], hw[1], so(hw[0]), so(hw[1]), stride, cin, ch, cout, 1, 1 if res else 0, 12, 6.0, 12, 6.0, 0, 0.0, cin, cout)
+    expand = ch != cin
+    dsc = MbConvDesc(2, hw[0], hw[1], so(hw[0]), so(hw[1]), stride, cin, ch, cout, 1 if expand else 0, 1 if res else 0, 12, 6.0, 12, 6.0, 0, 0.0, cin, cout)
     if not ops.lib().sm_mbconv_supported(ctypes.byref(dsc)):
         pytest.skip("no fused kernel takes this geometry (the executor keeps the three launches)")
     rng = np.random.default_rng(cin + ch + cout + stride)
     x = h(rng.standard_normal((2, cin, hw[0], hw[1])) * 3)
+    if not expand:
+        x = h(np.clip(x * 2, 0, 6))                      # (the block input IS the hidden tensor: what a clipped stem would hand over)
     w1 = h(rng.standard_normal((ch, 1, 1, cin)) * np.sqrt(2.0 / cin)); b1 = rng.standard_normal(ch).astype(np.float32)
     wd = h(rng.standard_normal((ch, 3, 3, 1)) * np.sqrt(2.0 / 9) * 2); bd = rng.standard_normal(ch).astype(np.float32)
     w2 = h(rng.standard_normal((cout, 1, 1, ch)) * np.sqrt(1.0 / ch)); b2 = rng.standard_normal(cout).astype(np.float32) * 0.1
-    hid = h(np.clip(O.conv2d(x, w1, b1), 0, 6))
+    hid = h(np.clip(O.conv2d(x, w1, b1), 0, 6)) if expand else x
     hid2 = h(np.clip(O.conv2d(hid, wd, bd, stride=(stride, stride), pads=(1, 1, 1, 1), groups=ch), 0, 6))
     assert (hid == 6).mean() > 0.02 and (hid2 == 6).mean() > 0.02, "the test data must reach the upper bound"
     ref = O.conv2d(hid2, w2, b2) + (x if res else 0)
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    got = to_host(ops.mbconv(to_dev(x), dev(w1).half(), dev(b1), dev(wd.reshape(ch, 3, 3)).half(), dev(bd), dev(w2).half(), dev(b2), stride=stride, residual=res,
+    got = to_host(ops.mbconv(to_dev(x), dev(w1).half() if expand else None, dev(b1) if expand else None, dev(wd.reshape(ch, 3, 3)).half(), dev(bd), dev(w2).half(), dev(b2), stride=stride, residual=res,
                              acts=(ops.ACT_CLIP, ops.ACT_CLIP, ops.ACT_NONE), slopes=(6.0, 6.0, 0.0)))
     ref16 = h(ref)
     assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
