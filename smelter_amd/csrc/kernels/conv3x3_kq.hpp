@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
 // (the fragment's pixel base goes into the VECTOR offset, the scalar offset stays the constant 0: with a 16-byte store whose soffset is an SGPR, hipcc
                     // lets the next VALU instruction overwrite the store's data registers at once — LLVM's hazard recogniser exempts that form — and on gfx950 a few lanes then
                     // stored the NEW contents of one data dword: wrong values in lanes 12..15 of every 16, found by tests/test_gpu_ops.py::test_conv3x3_wave_split)
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, ov), rs_y, (int)((t < PTe ? yoff[jp] : 0x80000000u) + (ybase + (unsigned)F * yfrag)), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4s, ov), rs_y, (int)((t < PTe && yoff[jp] != 0x80000000u) ? yoff[jp] + (ybase + (unsigned)F * yfrag) : 0x80000000u), 0, 0);   // (the select covers the WHOLE sum: a dead lane's marker plus a base near 2 GB would wrap into range — ADVICE r4)
                 }
             }
         });

@@ -79,6 +79,12 @@ typedef StKind<2, 2, 4, 7, 1, 128, ST_SBG1, 3, ST_RW1> StR14;   // 3: 1x1, K % 2
 typedef StKind<1, 4, 4, 13, 1, 128, 1, 3, 4> StE14;  // 4: 1x1 (+ second source), <= 208 px x 256 couts       (14x14: 256 -> 1024)
 typedef StKind<4, 1, 4, 13, 9, 64, 1, 1, 6> StT14;   // 5: 3x3, one image of <= 208 px x 64 couts, patch single-buffered (14x14 256 -> 256)
 constexpr int ST_NKINDS = 6;
+// Epilogue of the cout-split forms: 1 (default) = straight from the accumulator layout (16 x 4 lanes = 16 pixels x 64 bytes per instruction: half lines); 0 = through the LDS like the
+// K-split forms (a pixel's 64 couts leave as one 128-byte piece per 8 lanes: whole lines for stores and residual loads).  Measured (profiles/r05_stage_ablation.txt part 5): the LDS round
+// trip costs more than the whole lines save — 14 x 14 expand epilogue 8.2 -> 11.1 us, 7 x 7 3.6 -> 4.6 us, the 7 x 7 run 135 -> 143 us.
+#ifndef ST_EPI_DIRECT
+#define ST_EPI_DIRECT 1
+#endif
 
 #ifdef SM_STAGE_TL   // diagnostic build (tools/stage_tl.py): per block and tile, wall clock (100 MHz, the same on every XCD) at 8 points
 __device__ unsigned long long g_st_tl[ST_GRID * 64 * 8];
@@ -121,7 +127,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     unsigned boff[NF];
 #pragma unroll
     for (int j = 0; j < NF; j++) {
-        int co = KG == 1 ? co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) : co0 + j * 16 + l15;
+        int co = (KG == 1 && ST_EPI_DIRECT) ? co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) : co0 + j * 16 + l15;
         if (co >= Cout) co = Cout - 1;
         boff[j] = (unsigned)(co * K + g * 8) * 2u;
     }
@@ -357,7 +363,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
         return __builtin_bit_cast(u32x4s, ov);
     };
     const unsigned ybase = (unsigned)pix0 * (unsigned)p.y_ld * 2u, rbase = (unsigned)pix0 * (unsigned)p.res_ld * 2u;
-    if constexpr (KG == 1) {
+    if constexpr (KG == 1 && ST_EPI_DIRECT) {
         // registers -> memory: lane (l15, g) of fragments 2 jp, 2 jp + 1 holds couts co0 + 32 jp + 8 g .. + 7 of pixel 16 F + l15
         floatx4 bq[NF];
 #pragma unroll
@@ -409,19 +415,25 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
                 for (int j = 0; j < NF; j++) *(floatx4*)&red[(wave * RROWS + fi * 16 + l15) * RLD + j * 16 + g * 4] = acc[F0 + fi][j];
             st_lds_barrier();
             constexpr int ITS = (NFRR * 16 + KG * PPS - 1) / (KG * PPS);
+            half8_t rv[ITS];                                          // every residual piece of the round in flight before the first sum (the partial sums are on their way through the LDS meanwhile)
+#pragma unroll
+            for (int it = 0; it < ITS; it++) {
+                const int pp = kg * PPS + lane / OCT + it * KG * PPS, t = F0 * 16 + pp;
+                const bool ok = pp < NFRR * 16 && t < PTe && co < Cout;
+                rv[it] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.res) rv[it] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(ok ? rbase + (unsigned)t * (unsigned)p.res_ld * 2u + (unsigned)co * 2u : 0x80000000u), 0, 16));
+            }
 #pragma unroll
             for (int it = 0; it < ITS; it++) {
                 const int pp = kg * PPS + lane / OCT + it * KG * PPS, ppc = pp < NFRR * 16 ? pp : 0, t = F0 * 16 + pp;
                 const bool ok = pp < NFRR * 16 && t < PTe && co < Cout;
-                half8_t rv = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (p.res) rv = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(ok ? rbase + (unsigned)t * (unsigned)p.res_ld * 2u + (unsigned)co * 2u : 0x80000000u), 0, 16));
                 floatx4 a0 = *(const floatx4*)&red[((0 * NG + ng) * RROWS + ppc) * RLD + o * 8], a1 = *(const floatx4*)&red[((0 * NG + ng) * RROWS + ppc) * RLD + o * 8 + 4];
 #pragma unroll
                 for (int k = 1; k < KG; k++) {
                     a0 += *(const floatx4*)&red[((k * NG + ng) * RROWS + ppc) * RLD + o * 8];
                     a1 += *(const floatx4*)&red[((k * NG + ng) * RROWS + ppc) * RLD + o * 8 + 4];
                 }
-                const u32x4s ov = finish(a0 + bq0, a1 + bq1, rv);
+                const u32x4s ov = finish(a0 + bq0, a1 + bq1, rv[it]);
                 __builtin_amdgcn_raw_buffer_store_b128(ov, rs_y, (int)(ok ? ybase + (unsigned)t * (unsigned)p.y_ld * 2u + (unsigned)co * 2u : 0x80000000u), 0, 0);
             }
             if (RND + 1 < ROUNDS) st_lds_barrier();
@@ -618,7 +630,7 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
             } else { tp = tile_pixels(HW, ki.NFR * 16); if (!tp) continue; ni = (tp + 7) / 8; }
             if (ni > ki.NI_MAX) continue;
             const size_t need = (size_t)ki.NB * ki.KG * (ki.WCH / 64) * ni * 1024 + 1024 + 1024;
-            const size_t red = ki.KG > 1 ? (size_t)4 * std::min(ki.NFR, 7) * 16 * (ki.NF * 16 + 4) * 4 + 1024 : 0;
+            const size_t red = (ki.KG > 1 || !ST_EPI_DIRECT) ? (size_t)4 * std::min(ki.NFR, 7) * 16 * (ki.NF * 16 + 4) * 4 + 1024 : 0;
             if (std::max(need, red) > 160 * 1024 - 64) continue;
             const int mt = sm_ceil_div(team_px, tp), nt = sm_ceil_div(d.Cout, (4 / ki.KG) * ki.NF * 16);
             const double cost = (double)sm_ceil_div(mt * nt, ST_TEAM) * ((double)tp + (4 / ki.KG) * ki.NF * 16) * (K1 + K2) * (t3 ? 1.0 : 1.0) * 2 * (ki.KG > 1 ? 1.05 : 1.0);
@@ -639,7 +651,7 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
         sm_fastdiv_make((unsigned)(q.RS / 8), &q.kpr_mul, &q.kpr_sh);
         // arrivals per image: every cout tile of every pixel tile that overlaps the image
         q.expect = q.NT * (HW > best_tp ? HW / best_tp : 1);
-        lds = std::max(lds, std::max((size_t)ki.NB * ki.KG * (ki.WCH / 64) * q.NI * 1024 + 1024, ki.KG > 1 ? (size_t)4 * std::min(ki.NFR, 7) * 16 * (ki.NF * 16 + 4) * 4 : (size_t)0) + 1024);
+        lds = std::max(lds, std::max((size_t)ki.NB * ki.KG * (ki.WCH / 64) * q.NI * 1024 + 1024, (ki.KG > 1 || !ST_EPI_DIRECT) ? (size_t)4 * std::min(ki.NFR, 7) * 16 * (ki.NF * 16 + 4) * 4 : (size_t)0) + 1024);
         ys[i] = {ph[i].y, (size_t)yb};
         // ---- producers: the LATEST earlier phase whose output holds the operand ----
         q.dep0 = q.dep1 = q.dep2 = -1;
@@ -708,7 +720,7 @@ extern "C" int sm_stage_pack_weights(const sm_stage_phase* ph, int32_t n, int32_
                         for (int j = 0; j < NF; j++)
                             for (int lane = 0; lane < 64; lane++) {
                                 const int l15 = lane & 15, g = lane >> 4, co0 = nt * BN + ng * NF * 16;
-                                const int co = KG == 1 ? co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) : co0 + j * 16 + l15;
+                                const int co = (KG == 1 && ST_EPI_DIRECT) ? co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) : co0 + j * 16 + l15;
                                 const size_t k = (size_t)(ul / QPW) * q.K1 + (size_t)sb * SBCH + kg * WCH + (ul % QPW) * 32 + g * 8;
                                 if (co < q.Cout) memcpy(dst + o, w + (size_t)co * q.K + k, 16); else memset(dst + o, 0, 16);
                                 o += 8;
