@@ -227,6 +227,7 @@ typedef struct sm_stage_phase {
     int32_t form;                   /* 0 = the planner picks the tile form (fewest bytes through a CU's L1); k + 1 = tile form k if it takes the phase (tests, tuning) */
 } sm_stage_phase;
 int sm_stage_supported(const sm_stage_phase* ph, int32_t n);
+int sm_stage_device_fast(void);   /* 1: the current device has the 256 compute units the static XCD-local mode wants (a smaller / partitioned device still runs a launch correctly, in the slower claimed mode) */
 int sm_stage_phase_kind(const sm_stage_phase* ph, int32_t n, int32_t i);   /* tile form phase i runs on (0 .. 5; logs and tests), -1 = run not supported */
 size_t sm_stage_ctl_bytes(const sm_stage_phase* ph, int32_t n);
 int sm_stage_fwd(const sm_stage_phase* ph, int32_t n, void* ctl, sm_stream_t stream);

@@ -77,6 +77,7 @@ SYMBOLS = {
     "sm_conv2d_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sm_conv2d_dual_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sm_stage_supported": (_i32, [C.POINTER(StagePhase), _i32]),
+    "sm_stage_device_fast": (_i32, []),
     "sm_stage_phase_kind": (_i32, [C.POINTER(StagePhase), _i32, _i32]),
     "sm_stage_ctl_bytes": (_sz, [C.POINTER(StagePhase), _i32]),
     "sm_stage_fwd": (_i32, [C.POINTER(StagePhase), _i32, _vp, _vp]),

@@ -1073,6 +1073,7 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit();
                                  st.head.weight.clear(); st.head.weight.shrink_to_fit(); st.side.weight.clear(); st.side.weight.shrink_to_fit(); st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
     if (!e->runs_.empty()) {
+        if (!sm_stage_device_fast()) for (StageRun& r : e->runs_) r.on = false;   // fewer than 256 compute units: the runs would complete (claimed mode) but slower than their layers
         size_t ctl = 0;
         for (StageRun& r : e->runs_) {                                // the real address map: the kernel-level planner must take every run (pass 4 keeps a run's tensors apart)
             const std::vector<sm_stage_phase> ph = e->runPhases(r, e->arena_, e->act_, true);

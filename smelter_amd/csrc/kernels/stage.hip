@@ -689,6 +689,12 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
 
 }  // namespace
 
+// 1 if the current device runs a launch in its fast mode when nothing else occupies it: at least 256 compute units (one block each); the executor keeps its layers apart otherwise
+extern "C" int sm_stage_device_fast(void) {
+    int dev = 0; hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return prop.multiProcessorCount >= ST_GRID ? 1 : 0;
+}
 extern "C" int sm_stage_supported(const sm_stage_phase* ph, int32_t n) { StArgs a; return stage_plan(ph, n, a, true) == SM_OK ? 1 : 0; }
 extern "C" size_t sm_stage_ctl_bytes(const sm_stage_phase* ph, int32_t n) {
     if (!ph || n < 1) return 0;
@@ -733,14 +739,7 @@ extern "C" int sm_stage_fwd(const sm_stage_phase* ph, int32_t n, void* ctl, sm_s
     if (rc) return rc;
     SM_REQUIRE(ctl && !((uintptr_t)ctl & 15), "sm_stage_fwd: ctl = %p (sm_stage_ctl_bytes of zeroed device memory, 16-byte aligned)", ctl);
     a.ctl = (unsigned*)ctl;
-    static int cu_count = 0;
-    if (!cu_count) {
-        int dev = 0; hipDeviceProp_t prop;
-        SM_HIP_CHECK(hipGetDevice(&dev)); SM_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        cu_count = prop.multiProcessorCount;
-    }
-    // co-residency: one block per CU (the kernel's LDS and registers admit no second block), every block of the grid must be resident for the hand-offs to complete
-    SM_REQUIRE(cu_count >= ST_GRID, "sm_stage_fwd: %d compute units, the persistent grid needs %d resident blocks", cu_count, ST_GRID);
+    // (no co-residency requirement: a device that cannot hold the 256 blocks together — fewer CUs, a compute partition, other work — completes the launch in the claimed mode)
     int mask = 0;
     for (int i = 0; i < n; i++) mask |= 1 << a.ph[i].kind;
     if ((mask & ~0x7) == 0) hipLaunchKernelGGL(stage_kernel<0x7>, dim3(ST_GRID), dim3(256), (size_t)a.lds_bytes, sm_s(stream), a);
