@@ -228,7 +228,7 @@ typedef struct sm_stage_phase {
 } sm_stage_phase;
 int sm_stage_supported(const sm_stage_phase* ph, int32_t n);
 int sm_stage_device_fast(void);   /* 1: the current device has the 256 compute units the static XCD-local mode wants (a smaller / partitioned device still runs a launch correctly, in the slower claimed mode) */
-int sm_stage_phase_kind(const sm_stage_phase* ph, int32_t n, int32_t i);   /* tile form phase i runs on (0 .. 5; logs and tests), -1 = run not supported */
+int sm_stage_phase_kind(const sm_stage_phase* ph, int32_t n, int32_t i);   /* tile form phase i runs on (0 .. 8; logs and tests), -1 = run not supported */
 size_t sm_stage_ctl_bytes(const sm_stage_phase* ph, int32_t n);
 int sm_stage_fwd(const sm_stage_phase* ph, int32_t n, void* ctl, sm_stream_t stream);
 /* HOST side, once per model: phase i's OHWI weights (host memory) re-ordered for the tile form the planner gives the phase in THIS run (the phase list and the batch decide it) */

@@ -46,12 +46,15 @@ struct StPhase {
     int act; float slope;
     int TP, TI, MT, NT, nsb1, nsb, RS, NI;      // pixels / whole images per tile; tiles per team; super-blocks from x / in all; patch row slots; DMA instructions per 64-channel slice
     int dep0, dep1, dep2, expect;               // producing phase of x / x2 / res (-1: outside the run); arrivals per image that complete THIS phase's output
-    unsigned x_bytes, x2_bytes, res_bytes, y_bytes;
+    unsigned x_bytes, x2_bytes, res_bytes, y_bytes, wt_bytes;   // wt_bytes: packed weights of ONE cout tile (a wave reads a fourth of it, front to back)
     unsigned hw_mul, hw_sh, w_mul, w_sh, h1_mul, h1_sh, kpr_mul, kpr_sh;
 };
-struct StArgs { unsigned* ctl; int nphase, N, ipt, spin_limit, arrive_limit, cnt_ld, lds_bytes; StPhase ph[ST_MAXPH]; };
+struct StArgs { unsigned* ctl; int nphase, N, ipt, spin_limit, arrive_limit, cnt_ld, lds_bytes, touch; StPhase ph[ST_MAXPH]; };   // touch: bytes of a tile's weights a wave asks the L2 for ahead of its ring (0: none)
 static_assert(sizeof(StArgs) <= 4096 && ST_CLAIM + ST_MAXPH <= ST_CTL_HDR, "kernel argument block, control words");
 
+#ifndef ST_EPI_DIRECT
+#define ST_EPI_DIRECT 1
+#endif
 // KG x NG = 4 waves: KG = K groups (a wave multiplies channels [kg WCH, (kg + 1) WCH) of every super-block of KG WCH channels), NG = cout groups of NF 16-cout fragments;
 // NFR = 16-pixel fragments per tile; TAPS = 1 | 9; SBG = super-blocks per unrolled loop body; NB = patch buffers.
 template <int KG_, int NG_, int NF_, int NFR_, int TAPS_, int WCH_, int SBG_, int NB_, int RW_>
@@ -60,12 +63,17 @@ struct StKind {
     static constexpr int QPW = WCH / 32, UPS = TAPS * QPW, UB = SBG * UPS, NSL = WCH / 64, SBCH = KG * WCH, WN = NF * 16, BN = NG * WN, PD = NB - 1;
     static constexpr int RW = RW_, PA = RW - 2;                 // weight ring (units) and how many units ahead a PAIR of units is requested.  (Requesting unit U + PA fragment by
                                                                 // fragment between the MFMAs of unit U instead of as a burst at its top: 136 -> 155 us on the 7x7 stage, profiles/r05_stage_ablation.txt)
-    static constexpr int NI_MAX = TAPS == 1 ? NFR * 2 : (NFR <= 7 ? 18 : 37);  // DMA instructions per slice the kind can take
+    static constexpr int NI_LDS = 157 / (NB_ * KG_ * (WCH_ / 64));              // ... that fit the LDS (NB buffers of KG x WCH / 64 slices of NI KB)
+    static constexpr int NI_MAX = TAPS == 1 ? (NFR * 2 < NI_LDS ? NFR * 2 : NI_LDS) : (NFR <= 7 ? 18 : 37);  // DMA instructions per slice the kind can take
+    static constexpr bool FIXS = TAPS == 1;                     // 1x1 forms: a slice is NI_MAX KB whatever the tile holds — slice and channel half of a fragment read are an immediate offset and a
+                                                                // choice between two address registers, not arithmetic per fragment and unit
     static constexpr int NIW_MAX = (NSL * NI_MAX + NG - 1) / NG;               // ... per wave and super-block
     static constexpr int DPU = NB > 1 ? (NIW_MAX + UPS - 1) / UPS : 0, V = NF + DPU;   // DMA slots per unit; VMEM operations per unit
     static constexpr bool DUAL = TAPS == 1 && KG == 1, SHARED = NG > 1;
     static constexpr int TPMAX = NFR * 16;
-    static_assert(KG * NG == 4 && UB % RW == 0 && UB % 2 == 0 && QPW % 2 == 0 && (NB > 1 || DPU == 0), "shape of the loop body");
+    static constexpr bool XCH = ST_EPI_DIRECT && KG_ == 1;   // weight rows assigned so that an accumulator lane holds eight consecutive couts: the tile leaves from the registers
+    static constexpr int NW = KG * NG;                          // waves of the block: 4 (one per SIMD, up to 512 registers each) or 8 (two per SIMD, 256 each)
+    static_assert((NW == 4 || NW == 8) && UB % RW == 0 && UB % 2 == 0 && QPW % 2 == 0 && (NB > 1 || DPU == 0), "shape of the loop body");
 };
 #ifndef ST_RW1
 #define ST_RW1 4          // weight ring of the 1x1 forms, in units (a pair is requested ST_RW1 - 2 units ahead); 8 needs loop bodies of 8 units
@@ -78,12 +86,20 @@ typedef StKind<1, 4, 4, 7, 1, 128, ST_SBG1, 3, ST_RW1> StE7;    // 2: 1x1 (+ sec
 typedef StKind<2, 2, 4, 7, 1, 128, ST_SBG1, 3, ST_RW1> StR14;   // 3: 1x1, K % 256 == 0, <= 112 px x 128 couts          (14x14: 1024 -> 256)
 typedef StKind<1, 4, 4, 13, 1, 128, 1, 3, 4> StE14;  // 4: 1x1 (+ second source), <= 208 px x 256 couts       (14x14: 256 -> 1024)
 typedef StKind<4, 1, 4, 13, 9, 64, 1, 1, 6> StT14;   // 5: 3x3, one image of <= 208 px x 64 couts, patch single-buffered (14x14 256 -> 256)
-constexpr int ST_NKINDS = 6;
+// EIGHT-wave forms (two waves per SIMD, <= 256 registers each: one wave's memory issue and counter waits sit under its SIMD partner's MFMAs; a run is all-4 or all-8)
+typedef StKind<1, 8, 2, 7, 1, 128, 1, 3, 4> StE8;    // 6: form 2's tile (<= 112 px x 256 couts), couts split over eight waves of 32 (every wave reads every pixel fragment: twice form 2's LDS reads, no exchange of partial sums)
+typedef StKind<4, 2, 2, 7, 1, 64, 2, 3, 4> StR8;     // 7: form 0's tile (<= 104 px x 64 couts): K split 4 ways, two waves of 32 couts per K group
+typedef StKind<4, 2, 2, 7, 9, 64, 1, 2, 6> StT8;     // 8: form 1's tile (3x3, images of <= 56 px, 2+ per tile x 64 couts), K split 4 x 2 waves of 32 couts
+constexpr int ST_NKINDS = 9;
 // Epilogue of the cout-split forms: 1 (default) = straight from the accumulator layout (16 x 4 lanes = 16 pixels x 64 bytes per instruction: half lines); 0 = through the LDS like the
 // K-split forms (a pixel's 64 couts leave as one 128-byte piece per 8 lanes: whole lines for stores and residual loads).  Measured (profiles/r05_stage_ablation.txt part 5): the LDS round
 // trip costs more than the whole lines save — 14 x 14 expand epilogue 8.2 -> 11.1 us, 7 x 7 3.6 -> 4.6 us, the 7 x 7 run 135 -> 143 us.
-#ifndef ST_EPI_DIRECT
-#define ST_EPI_DIRECT 1
+// Weight touch (st_touch): 1 = each wave asks the L2 for its fourth of the tile's weight slice at tile start, in front of the wait for the producers; 0 = off.
+#ifndef ST_TOUCH
+#define ST_TOUCH 0
+#endif
+#ifndef ST_TOUCH_BYTES
+#define ST_TOUCH_BYTES (160 * 1024)     // per wave and tile (a 7 x 7 3x3 tile's fourth is 147 KB)
 #endif
 
 #ifdef SM_STAGE_TL   // diagnostic build (tools/stage_tl.py): per block and tile, wall clock (100 MHz, the same on every XCD) at 8 points
@@ -102,7 +118,25 @@ __device__ __forceinline__ void st_bdma16(unsigned voff, st_u32x4 rsrc, unsigned
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen" ST_DMA_AUX " lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
 }
+// One dword per 128-byte line of [base, base + bytes): 64 lines = 8 KB per instruction, into an LDS word nobody reads.  Nothing waits for the data: the point is that the XCD's L2 asks the
+// Infinity Cache / HBM for the lines NOW, so that the weight ring's requests (a few KB in flight per wave) find them at L2 latency instead of serialising on the far latency.
+__device__ __forceinline__ void st_touch(const void* base, unsigned bytes, unsigned sink_lds, unsigned lane128) {
+    const uintptr_t b = (uintptr_t)base;
+    const st_u32x4 rs = {(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(b >> 32) & 0xffffu)), (unsigned)__builtin_amdgcn_readfirstlane((int)bytes), 0x00020000u};
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)sink_lds);
+    for (unsigned o = 0; o < bytes; o += 8192u) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(lane128), "s"(rs), "s"(dst), "s"(o) : "memory");
+    }
+}
+__device__ __forceinline__ void st_bdma4_dead(st_u32x4 rsrc, unsigned lds_dst) {   // a DMA slot that can never be a real one (the counted waits see every slot): 4 bytes per lane, out of range, into the sink
+    unsigned keep; const unsigned voff = 0x80000000u;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst) : "memory");
+}
 template <int OFF> __device__ __forceinline__ void st_gload16(half8_t& d, unsigned voff, const half_t* sbase) { asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(d) : "v"(voff), "s"(sbase), "n"(OFF) : "memory"); }
+template <int OFF> __device__ __forceinline__ void st_dsread16(half8_t& d, unsigned addr) { asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF)); }
 __device__ __forceinline__ void st_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ unsigned st_ld_sc1(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <int N> __device__ __forceinline__ void st_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N > 63 ? 63 : N) : "memory"); }
@@ -117,7 +151,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4, c8 = lane & 7, l8 = lane >> 3;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), kg = wave / NG, ng = wave % NG;
     const int H = p.H, W = p.W, HW = p.HW, RS = p.RS, NI = p.NI, K1 = p.K1, K = p.K, Cout = p.Cout, nsb = p.nsb, nsb1 = p.nsb1;
-    const unsigned SLB = (unsigned)NI * 1024u, BUFB = (unsigned)(KG * NSL) * SLB, sink = lds0 + (unsigned)NB * BUFB;
+    const unsigned SLB = KD::FIXS ? (unsigned)KD::NI_MAX * 1024u : (unsigned)NI * 1024u, BUFB = (unsigned)(KG * NSL) * SLB, sink = lds0 + (unsigned)NB * BUFB;
     const unsigned myslices = lds0 + (unsigned)(kg * NSL) * SLB;       // this K group's slices inside buffer 0
     const int co0 = ntile * BN + ng * WN;
     const int n0 = (int)sm_fastdiv((unsigned)pix0, p.hw_mul, p.hw_sh), imgs = T3 ? (int)sm_fastdiv((unsigned)PTe, p.hw_mul, p.hw_sh) : 1;
@@ -127,7 +161,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     unsigned boff[NF];
 #pragma unroll
     for (int j = 0; j < NF; j++) {
-        int co = (KG == 1 && ST_EPI_DIRECT) ? co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) : co0 + j * 16 + l15;
+        int co = KD::XCH ? co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) : co0 + j * 16 + l15;
         if (co >= Cout) co = Cout - 1;
         boff[j] = (unsigned)(co * K + g * 8) * 2u;
     }
@@ -142,11 +176,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
 #ifndef ST_ABL_NOW
         if (packed) {
             const half_t* ub = wstream + (size_t)(sb * UPS + ul) * (size_t)(NF * 512);
-            static_assert(NF == 4, "four fragments per unit");
-            { half8_t& d = wb[SLOT][0]; asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d) : "v"(lane16), "s"(ub) : "memory"); }
-            { half8_t& d = wb[SLOT][1]; asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024" : "=&v"(d) : "v"(lane16), "s"(ub) : "memory"); }
-            { half8_t& d = wb[SLOT][2]; asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048" : "=&v"(d) : "v"(lane16), "s"(ub) : "memory"); }
-            { half8_t& d = wb[SLOT][3]; asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072" : "=&v"(d) : "v"(lane16), "s"(ub) : "memory"); }
+            sm_static_for<0, NF>([&](auto jc) { constexpr int J = decltype(jc)::value; st_gload16<J * 1024>(wb[SLOT][J], lane16, ub); });
             return;
         }
 #endif
@@ -186,6 +216,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
         if (++t3_k == (RS >> 3)) { t3_k = 0; t3_r++; if (++t3_y == H + 1) { t3_y = 0; t3_im++; } }
         return (rok && okc) ? v : 0x80000000u;
     };
+    auto t3_skip = [&]() { if (++t3_k == (RS >> 3)) { t3_k = 0; t3_r++; if (++t3_y == H + 1) { t3_y = 0; t3_im++; } } };   // (another wave's instruction: the counters only)
     auto dma_off2 = [&](int i) -> unsigned {                          // second source: output pixel (n, oy, ox) reads pixel (n, oy s, ox s) of x2
         const int s = 8 * i + l8;
         const unsigned chunk = (((unsigned)c8 ^ (unsigned)((s >> 1) & 7)) << 4);
@@ -199,16 +230,17 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     const int nidx = NSL * NI;
     auto issue_slot = [&](auto mc, int sbn, unsigned bufo) {           // one DMA slot: real if the super-block and the instruction exist, else zeros into the sink (the counted waits see every slot)
         constexpr int M = decltype(mc)::value;
+        if constexpr (M * NG >= NSL * KD::NI_MAX) { st_bdma4_dead(rs_x, (unsigned)__builtin_amdgcn_readfirstlane((int)sink)); return; }   // (slots per unit are a whole number: the last ones of a super-block never carry an instruction)
         const int idx = ng + M * NG;
 #ifdef ST_ABL_NODMA
         const bool real = false;
 #else
         const bool real = sbn < nsb && idx < nidx;
 #endif
-        const bool second = DUAL && sbn >= nsb1;
         const int sl = idx >= NI ? 1 : 0;
+        const bool second = DUAL && sbn >= nsb1;
         const unsigned chb = (unsigned)(((second ? sbn - nsb1 : sbn) * SBCH + kg * WCH + sl * 64) * 2);
-        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(real ? myslices + bufo + (unsigned)idx * 1024u : sink));
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(real ? myslices + bufo + (unsigned)idx * 1024u + (sl ? SLB - (unsigned)NI * 1024u : 0u) : sink));
         if constexpr (DUAL) {
             if (second) { st_bdma16(real ? dmo2[M] : 0x80000000u, rs_x2, dst, chb); return; }
         }
@@ -222,7 +254,15 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
         sm_static_for<0, NTAB>([&](auto mc) {
             constexpr int M = decltype(mc)::value;
             const int idx = ng + M * NG, sl = idx >= NI ? 1 : 0, i = idx - sl * NI;
-            if constexpr (T3) { static_assert(!T3 || (NG == 1 && NSL == 1), "3x3 forms: a wave issues its slice's instructions in order"); const unsigned v = t3_next(); dmo[M] = idx < nidx ? v : 0x80000000u; }
+            if constexpr (T3) {                                        // the running counters walk the slice's instructions in order: with NG waves per slice every NG-th is this wave's
+                static_assert(!T3 || NSL == 1, "3x3 forms: one 64-channel slice per K group");
+                unsigned v = 0x80000000u;
+                if constexpr (M * NG < NSL * KD::NI_MAX) {
+#pragma unroll
+                    for (int w = 0; w < NG; w++) { if (w == ng) v = t3_next(); else t3_skip(); }
+                }
+                dmo[M] = idx < nidx ? v : 0x80000000u;
+            }
             if constexpr (DUAL) { dmo2[M] = 0x80000000u; if (idx < nidx && nsb1 < nsb) dmo2[M] = dma_off2(i); }
             issue_slot(mc, 0, 0u);
         });
@@ -232,7 +272,10 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
         });
     }
     // (while they are in flight) pixel fragments: slice-relative LDS byte offset of this lane's slot — 1x1: swizzled, channel half 0; 3x3: slot of tap (0, 0), before the swizzle
-    unsigned pf[NFR];
+    constexpr bool FIXS = KD::FIXS;
+    unsigned pf[T3 ? NFR : 1];
+    constexpr bool AD1 = FIXS && KD::NW == 4;                          // (8-wave forms: 256 registers — the second address is an XOR at the read)
+    unsigned ad[NFR], ad1[AD1 ? NFR : 1];                             // 1x1: this lane's slot in slice 0 of the current buffer, channel half 0 / half 1 (the swizzle puts the half into bit 6: an XOR, not an offset)
     floatx4 acc[NFR][NF];
 #pragma unroll
     for (int f = 0; f < NFR; f++) {
@@ -240,13 +283,13 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
         if constexpr (T3) {
             const int im = (int)sm_fastdiv((unsigned)tc, p.hw_mul, p.hw_sh), rr = tc - im * HW, yy = (int)sm_fastdiv((unsigned)rr, p.w_mul, p.w_sh), xx = rr - yy * W;
             pf[f] = (unsigned)(((im * (H + 1) + yy) * RS + xx) << 7);
-        } else pf[f] = ((unsigned)tc << 7) + ((((unsigned)g) ^ (unsigned)((tc >> 1) & 7)) << 4);
+        } else { ad[f] = myslices + ((unsigned)tc << 7) + ((((unsigned)g) ^ (unsigned)((tc >> 1) & 7)) << 4); if constexpr (AD1) ad1[f] = ad[f] ^ 64u; }
 #pragma unroll
         for (int j = 0; j < NF; j++) acc[f][j] = floatx4{0.f, 0.f, 0.f, 0.f};
     }
     const unsigned G0 = (unsigned)g << 4;
     half8_t af[NFR];                                                   // ONE buffer: fragment F of the next unit is requested into slot F right behind the last MFMA that reads it (an MFMA takes its operands at issue)
-    unsigned ad[NFR];
+    unsigned bufo_at = 0u;                                             // (1x1) the buffer ad / ad1 point into
     // LDS address of fragment F under unit `ul` (tap ul / QPW, 32-channel piece ul % QPW) of the buffer at `bufo`
     auto frag_addr = [&](int F, int ul, unsigned bufo) -> unsigned {
         const int tap = ul / QPW, q = ul % QPW;
@@ -255,7 +298,15 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
             unsigned to = (unsigned)(((tap / 3) * RS + tap % 3) << 7); asm volatile("" : "+s"(to));
             const unsigned rel = pf[F] + to;
             return ((rel ^ G0 ^ ((rel >> 4) & 0x70u)) ^ (unsigned)((q & 1) << 6)) + base;
-        } else return (pf[F] ^ (unsigned)((q & 1) << 6)) + base;
+        } else return 0u;
+    };
+    // (1x1) fragment F of unit `ul` of the current buffer: half = ul % 2 picks the register, slice = ul / 2 is the immediate offset
+    auto read_frag = [&](auto fc, auto ulc) {
+        constexpr int F = decltype(fc)::value, Q = decltype(ulc)::value % QPW;
+        static_assert((Q >> 1) * KD::NI_MAX * 1024 < 65536, "ds_read offset field");
+        if constexpr ((Q & 1) && AD1) st_dsread16<(Q >> 1) * KD::NI_MAX * 1024>(af[F], ad1[F]);
+        else if constexpr (Q & 1) st_dsread16<(Q >> 1) * KD::NI_MAX * 1024>(af[F], ad[F] ^ 64u);
+        else st_dsread16<(Q >> 1) * KD::NI_MAX * 1024>(af[F], ad[F]);
     };
 
     // ---- main loop.  VMEM operations per unit, in program order: [even units: 2 NF weight loads of the pair PA units ahead] then DPU patch slots of super-block sb + PD ----
@@ -269,11 +320,12 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
             if constexpr (UL == 0) {                                   // ---- super-block boundary: its patch has landed, everybody has left the buffer the next patch goes to ----
                 if constexpr (NB == 1) {
                     if (sb > 0) { st_lds_barrier(); t3_k = 0; t3_y = -1; t3_im = 0; t3_r = 0; }
+                    if constexpr (T3 && NG > 1) { for (int w = 0; w < ng; w++) t3_skip(); }   // (the slice's instructions in order; every NG-th is this wave's)
 #pragma unroll 1
                     for (int idx = ng; idx < nidx; idx += NG) {
                         const int sl = idx >= NI ? 1 : 0;
                         unsigned vo;
-                        if constexpr (T3) vo = t3_next(); else vo = dma_off(idx - sl * NI);
+                        if constexpr (T3) { vo = t3_next(); if constexpr (NG > 1) { for (int w = 1; w < NG; w++) t3_skip(); } } else vo = dma_off(idx - sl * NI);
                         st_bdma16(vo, rs_x, (unsigned)__builtin_amdgcn_readfirstlane((int)(myslices + (unsigned)idx * 1024u)), (unsigned)((sb * SBCH + kg * WCH + sl * 64) * 2));
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -286,8 +338,13 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
                 }
                 if (sb0 == 0 && SBL == 0) ST_TL(2);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (FIXS) {
+                    const unsigned dlt = bufo - bufo_at; bufo_at = bufo;
+                    sm_static_for<0, NFR>([&](auto fc) { constexpr int F = decltype(fc)::value; ad[F] += dlt; if constexpr (AD1) ad1[F] += dlt; read_frag(fc, std::integral_constant<int, 0>()); });
+                } else {
 #pragma unroll
-                for (int f = 0; f < NFR; f++) { ad[f] = frag_addr(f, 0, bufo); half8_t& d = af[f]; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad[f])); }
+                    for (int f = 0; f < NFR; f++) { ad[f] = frag_addr(f, 0, bufo); half8_t& d = af[f]; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad[f])); }
+                }
             }
             if constexpr (U % 2 == 0) {                                // weights of the pair PA units ahead (beyond the last unit: a harmless reload keeps the counted waits exact)
                 constexpr int U2 = U + PA;
@@ -312,15 +369,17 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
 #endif
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (!LASTU) {
-                        if (j == 0) {
-                            constexpr int VL = UL + 1;
-                            if constexpr ((VL % QPW) % 2 == 1) ad[F] ^= 64u;       // same tap, same slice, other channel half
-                            else ad[F] = frag_addr(F, VL, bufo);
-                            __builtin_amdgcn_sched_barrier(0);
+                        constexpr int VL = UL + 1;
+                        if constexpr (!FIXS) {
+                            if (j == 0) {
+                                if constexpr ((VL % QPW) % 2 == 1) ad[F] ^= 64u;       // same tap, same slice, other channel half
+                                else ad[F] = frag_addr(F, VL, bufo);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                         }
                         if (j == NF - 1) {
-                            half8_t& d = af[F];
-                            asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad[F]));
+                            if constexpr (FIXS) read_frag(fc, std::integral_constant<int, VL>());
+                            else { half8_t& d = af[F]; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad[F])); }
                             __builtin_amdgcn_sched_barrier(0);
                         }
                     }
@@ -363,45 +422,49 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
         return __builtin_bit_cast(u32x4s, ov);
     };
     const unsigned ybase = (unsigned)pix0 * (unsigned)p.y_ld * 2u, rbase = (unsigned)pix0 * (unsigned)p.res_ld * 2u;
-    if constexpr (KG == 1 && ST_EPI_DIRECT) {
-        // registers -> memory: lane (l15, g) of fragments 2 jp, 2 jp + 1 holds couts co0 + 32 jp + 8 g .. + 7 of pixel 16 F + l15
-        floatx4 bq[NF];
+    // registers -> memory, fragments [F0, F1): lane (l15, g) of fragments 2 jp, 2 jp + 1 holds couts co0 + 32 jp + 8 g .. + 7 of pixel 16 F + l15.  Two steps, so that a form can do
+    // something else while the residual rows are on their way: every residual load of the range in flight (ONE memory latency per tile, not one per fragment: the weight ring and
+    // the pixel fragments are dead by now, the registers are there), then sums + stores
+    constexpr int RVF = KD::XCH ? NFR : 1;
+    half8_t rv[RVF][NF / 2];
+    floatx4 bq[NF];
+    auto direct_load = [&](auto f0c, auto f1c) {
+        constexpr int F0 = decltype(f0c)::value, F1 = decltype(f1c)::value;
 #pragma unroll
         for (int j = 0; j < NF; j++) {
             const int co = co0 + (j >> 1) * 32 + g * 8 + (j & 1) * 4;
             bq[j] = (p.bias && co + 3 < Cout) ? *(const floatx4*)(p.bias + co) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
-        // every residual load of the tile is in flight before the first sum: ONE memory latency per tile, not one per fragment (the weight ring and the pixel
-        // fragments are dead by now: NFR NF / 2 x 4 registers are there)
-        half8_t rv[NFR][NF / 2];
-        if (p.res) {
 #pragma unroll
-            for (int f = 0; f < NFR; f++)
+        for (int f = 0; f < F1 - F0; f++)
 #pragma unroll
-                for (int jp = 0; jp < NF / 2; jp++) {
-                    const int t = f * 16 + l15, co = co0 + jp * 32 + g * 8;
-                    rv[f][jp] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((t < PTe && co < Cout) ? rbase + (unsigned)t * (unsigned)p.res_ld * 2u + (unsigned)co * 2u : 0x80000000u), 0, 16));
-                }
-        } else {
-#pragma unroll
-            for (int f = 0; f < NFR; f++)
-#pragma unroll
-                for (int jp = 0; jp < NF / 2; jp++) rv[f][jp] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-        sm_static_for<0, NFR>([&](auto fc) {
+            for (int jp = 0; jp < NF / 2; jp++) {
+                const int t = (F0 + f) * 16 + l15, co = co0 + jp * 32 + g * 8;
+                rv[f][jp] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                if (p.res) rv[f][jp] = __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((t < PTe && co < Cout) ? rbase + (unsigned)t * (unsigned)p.res_ld * 2u + (unsigned)co * 2u : 0x80000000u), 0, 16));
+            }
+    };
+    auto direct_store = [&](auto f0c, auto f1c) {
+        constexpr int F0 = decltype(f0c)::value, F1 = decltype(f1c)::value;
+        sm_static_for<F0, F1>([&](auto fc) {
             constexpr int F = decltype(fc)::value;
             const int t = F * 16 + l15;
 #pragma unroll
             for (int jp = 0; jp < NF / 2; jp++) {
                 const int co = co0 + jp * 32 + g * 8;
                 const bool ok = t < PTe && co < Cout;
-                const u32x4s ov = finish(acc[F][2 * jp] + bq[2 * jp], acc[F][2 * jp + 1] + bq[2 * jp + 1], rv[F][jp]);
+                const u32x4s ov = finish(acc[F][2 * jp] + bq[2 * jp], acc[F][2 * jp + 1] + bq[2 * jp + 1], rv[F - F0][jp]);
                 __builtin_amdgcn_raw_buffer_store_b128(ov, rs_y, (int)(ok ? ybase + (unsigned)t * (unsigned)p.y_ld * 2u + (unsigned)co * 2u : 0x80000000u), 0, 0);
             }
         });
+    };
+    constexpr auto c0 = std::integral_constant<int, 0>(); constexpr auto cn = std::integral_constant<int, NFR>();
+    if constexpr (KD::XCH) {
+        direct_load(c0, cn);
+        direct_store(c0, cn);
     } else {
         // the KG partial sums meet in LDS (fp32 rows [pixel][WN + 4] per wave, in rounds of <= RFR fragments), are added in the order kg = 0 .. KG - 1, then as above
-        constexpr int RFR = NFR > 7 ? 7 : NFR, ROUNDS = (NFR + RFR - 1) / RFR, RLD = WN + 4, RROWS = RFR * 16, OCT = WN / 8, PPS = 64 / OCT;
+        constexpr int RFRW = (140 * 1024) / (KD::NW * 16 * (WN + 4) * 4) < 7 ? (140 * 1024) / (KD::NW * 16 * (WN + 4) * 4) : 7, RFR = NFR > RFRW ? RFRW : NFR, ROUNDS = (NFR + RFR - 1) / RFR, RLD = WN + 4, RROWS = RFR * 16, OCT = WN / 8, PPS = 64 / OCT;
         st_lds_barrier();                                             // everybody has left the patch: its LDS becomes the exchange area
         float* const red = (float*)(smem + (lds0 - smem_lds));
         const int o = lane % OCT, co = co0 + o * 8;
@@ -443,10 +506,11 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
 
 // MASK: the tile forms this instantiation holds (bit k = form k).  One kernel with all six pays for the union of their registers (the 208-accumulator forms push the
 // others' lane constants to scratch memory); a run of forms 0-2 or 3-5 only gets a kernel of its own.
-template <int MASK>
-__global__ __launch_bounds__(256) void stage_kernel(const StArgs a) {
+template <int MASK, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void stage_kernel(const StArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char st_smem[];
     __shared__ int s_info[4];
+    __shared__ unsigned s_sink[64];
     const int tid = threadIdx.x;
     unsigned* const ctl = a.ctl;
     unsigned* const cnt = ctl + ST_CTL_HDR;
@@ -508,6 +572,18 @@ __global__ __launch_bounds__(256) void stage_kernel(const StArgs a) {
             if (PTe <= 0) continue;
             const int ia = (int)sm_fastdiv((unsigned)pix0, p.hw_mul, p.hw_sh), ib = (int)sm_fastdiv((unsigned)(pix0 + PTe - 1), p.hw_mul, p.hw_sh);
             ST_TL(0);
+#if ST_TOUCH
+            if (p.wp && a.touch) {                                    // this wave's fourth of the tile's weights (ST_TOUCH 2: of the NEXT phase's tile with the same index, for whoever runs it)
+                const int php = ST_TOUCH == 2 ? ph + 1 : ph;
+                if (php < a.nphase && a.ph[php].wp) {
+                    const StPhase& pt = a.ph[php];
+                    const int ntp = ST_TOUCH == 2 ? j % pt.NT : nt;
+                    const unsigned q4 = pt.wt_bytes >> 2;
+                    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+                    st_touch((const char*)pt.wp + (size_t)ntp * pt.wt_bytes + (size_t)wv * q4, min(q4, (unsigned)a.touch), ws_lds_addr(s_sink), (unsigned)(tid & 63) * 128u);
+                }
+            }
+#endif
             // ---- wait for the tiles that produce this tile's inputs (wave 0, lane 0), called by the tile body behind its first weight requests ----
             auto sync = [&]() {
                 if (tid == 0) {
@@ -537,7 +613,10 @@ __global__ __launch_bounds__(256) void stage_kernel(const StArgs a) {
             case 2: ST_CASE(2) st_tile<StE7>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
             case 3: ST_CASE(3) st_tile<StR14>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
             case 4: ST_CASE(4) st_tile<StE14>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
-            default: ST_CASE(5) st_tile<StT14>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
+            case 5: ST_CASE(5) st_tile<StT14>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
+            case 6: ST_CASE(6) st_tile<StE8>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
+            case 7: ST_CASE(7) st_tile<StR8>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
+            default: ST_CASE(8) st_tile<StT8>(p, pix0, PTe, nt, lds0, st_smem, smem_lds, sync, tl_slot); break;
             }
             ST_TL(4);
             // ---- publish: every wave's stores are drained, then one arrival per covered image ----
@@ -565,15 +644,15 @@ __global__ __launch_bounds__(256) void stage_kernel(const StArgs a) {
     }
     __syncthreads();
     if (s_info[3]) {
-        for (int i = tid; i < a.nphase * a.cnt_ld; i += 256) __hip_atomic_store(&cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int i = tid; i < a.nphase * a.cnt_ld; i += NW * 64) __hip_atomic_store(&cnt[i], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < 10 || tid == ST_MODE || (tid >= ST_CLAIM && tid < ST_CLAIM + ST_MAXPH)) __hip_atomic_store(&ctl[tid], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (error bits [10] and the modes-seen word [11] stay for sm_stage_status)
     }
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-struct KindInfo { int KG, NG, NF, NFR, TAPS, WCH, SBG, NB, NI_MAX; };
-template <class KD> constexpr KindInfo kind_info() { return {KD::KG, KD::NG, KD::NF, KD::NFR, KD::TAPS, KD::WCH, KD::SBG, KD::NB, KD::NI_MAX}; }
-const KindInfo kKinds[ST_NKINDS] = {kind_info<StR7>(), kind_info<StT7>(), kind_info<StE7>(), kind_info<StR14>(), kind_info<StE14>(), kind_info<StT14>()};
+struct KindInfo { int KG, NG, NF, NFR, TAPS, WCH, SBG, NB, NI_MAX, NW; bool XCH; };
+template <class KD> constexpr KindInfo kind_info() { return {KD::KG, KD::NG, KD::NF, KD::NFR, KD::TAPS, KD::WCH, KD::SBG, KD::NB, KD::NI_MAX, KD::NW, KD::XCH}; }
+const KindInfo kKinds[ST_NKINDS] = {kind_info<StR7>(), kind_info<StT7>(), kind_info<StE7>(), kind_info<StR14>(), kind_info<StE14>(), kind_info<StT14>(), kind_info<StE8>(), kind_info<StR8>(), kind_info<StT8>()};
 
 bool overlap(const void* a, size_t an, const void* b, size_t bn) { return a && b && (const char*)a < (const char*)b + bn && (const char*)b < (const char*)a + an; }
 
@@ -584,6 +663,38 @@ int tile_pixels(int HW, int cap) {
     return 0;
 }
 
+// the tile form of one phase among the forms with `nw` waves (ph.form > 0: that form or nothing), and its tile's pixels; -1: none takes it
+int pick_kind(const sm_stage_phase& ph, int ipt, int nw, int* tp_out) {
+    const sm_conv_desc& d = ph.d;
+    const bool dual = ph.x2 != nullptr, t3 = d.kH == 3;
+    const int K2 = dual ? ph.K2 : 0, K1 = d.Cin - K2, HW = d.H * d.W;
+    if (HW <= 0 || K1 <= 0 || d.Cout <= 0) return -1;
+    const int team_px = ipt * HW;
+    int best = -1; double best_cost = 0;
+    for (int k = 0; k < ST_NKINDS; k++) {
+        const KindInfo& ki = kKinds[k];
+        if ((ki.TAPS == 9) != t3 || ki.NW != nw || (ph.form > 0 && ph.form != k + 1)) continue;
+        const int sbch = ki.KG * ki.WCH;
+        if (K1 % sbch || (dual && (K2 % sbch || !(ki.TAPS == 1 && ki.KG == 1))) || ((K1 + K2) / sbch) % ki.SBG) continue;
+        int tp, ni;
+        if (t3) {
+            if (HW > ki.NFR * 16) continue;
+            const int rs = (d.W + 1 + 7) / 8 * 8, extra = rs == d.W + 1 ? 1 : 0;
+            int ti = ki.NFR * 16 / HW;                               // whole images per tile: as many as the fragments and the patch instructions allow
+            while (ti > 1 && (ti * (d.H + 1) + 1) * (rs / 8) + extra > ki.NI_MAX) ti--;
+            tp = ti * HW; ni = (ti * (d.H + 1) + 1) * (rs / 8) + extra;
+        } else { tp = tile_pixels(HW, std::min(ki.NFR * 16, ki.NI_MAX * 8)); if (!tp) continue; ni = (tp + 7) / 8; }
+        if (ni > ki.NI_MAX) continue;
+        const size_t need = (size_t)ki.NB * ki.KG * (ki.WCH / 64) * (t3 ? ni : ki.NI_MAX) * 1024 + 1024 + 1024;
+        const size_t red = (ki.KG > 1 || !ST_EPI_DIRECT) ? (size_t)ki.NW * std::min(ki.NFR, std::min(7, (140 * 1024) / (ki.NW * 16 * (ki.NF * 16 + 4) * 4))) * 16 * (ki.NF * 16 + 4) * 4 + 1024 : 0;
+        if (std::max(need, red) > 160 * 1024 - 320) continue;
+        const int mt = sm_ceil_div(team_px, tp), nt = sm_ceil_div(d.Cout, ki.NG * ki.NF * 16);
+        const double cost = (double)sm_ceil_div(mt * nt, ST_TEAM) * ((double)tp + ki.NG * ki.NF * 16) * (K1 + K2) * 2 * (ki.KG > 1 ? 1.05 : 1.0);
+        if (best < 0 || cost < best_cost) { best = k; best_cost = cost; *tp_out = tp; }
+    }
+    return best;
+}
+
 // fills `a` from the caller's phase list; returns SM_OK or an error code with the reason in smelter_last_error_string
 int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
 #define ST_REQ(cond, ...) do { if (!(cond)) { if (!quiet) sm_set_error(__VA_ARGS__); return SM_ERR_INVALID_ARGUMENT; } } while (0)
@@ -591,8 +702,15 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
     memset(&a, 0, sizeof a);
     const int N = ph[0].d.N;
     ST_REQ(N >= 1 && N <= 4096, "sm_stage: batch %d", N);
-    a.nphase = n; a.N = N; a.ipt = sm_ceil_div(N, ST_NTEAM); a.spin_limit = 1000000; a.arrive_limit = 200; a.cnt_ld = (N + 15) / 16 * 16;
+    a.nphase = n; a.N = N; a.ipt = sm_ceil_div(N, ST_NTEAM); a.spin_limit = 1000000; a.arrive_limit = 200; a.touch = ST_TOUCH_BYTES; a.cnt_ld = (N + 15) / 16 * 16;
     size_t lds = 0;
+    // block size of the launch: the 8-wave forms (two waves per SIMD) when EVERY phase has one, else the 4-wave forms; a phase that names its form (form > 0) decides, form < 0 on any phase keeps the 4-wave forms
+    int nw_run = 8;
+    for (int i = 0; i < n; i++) {
+        int tp;
+        if (ph[i].form > 0 && ph[i].form <= ST_NKINDS) { nw_run = kKinds[ph[i].form - 1].NW; break; }
+        if (ph[i].form < 0 || pick_kind(ph[i], a.ipt, 8, &tp) < 0) nw_run = 4;
+    }
     struct Range { const void* p; size_t n; };
     std::vector<Range> ys(n);
     for (int i = 0; i < n; i++) {
@@ -612,46 +730,25 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
         const long x2b = dual ? (long)N * ph[i].x2_H * ph[i].x2_W * x2_ld * 2 : 0;
         ST_REQ(xb < 0x7fff0000L && yb < 0x7fff0000L && rb < 0x7fff0000L && wb < 0x7fff0000L && x2b < 0x7fff0000L, "sm_stage: phase %d: a tensor of 2 GB or more", i);
         if (dual) ST_REQ(ph[i].x2_stride >= 1 && (long)(d.H - 1) * ph[i].x2_stride < ph[i].x2_H && (long)(d.W - 1) * ph[i].x2_stride < ph[i].x2_W && K2 > 0, "sm_stage: phase %d: second source geometry", i);
-        // ---- kind: the cheapest by bytes a CU pulls through its L1 (tiles per CU x (pixels + couts) x K x 2) ----
-        const int team_px = a.ipt * HW;
-        int best = -1, best_tp = 0; double best_cost = 0;
-        for (int k = 0; k < ST_NKINDS; k++) {
-            const KindInfo& ki = kKinds[k];
-            if ((ki.TAPS == 9) != t3 || (ph[i].form > 0 && ph[i].form != k + 1)) continue;
-            const int sbch = ki.KG * ki.WCH;
-            if (K1 % sbch || (dual && (K2 % sbch || !(ki.TAPS == 1 && ki.KG == 1))) || ((K1 + K2) / sbch) % ki.SBG) continue;
-            int tp, ni;
-            if (t3) {
-                if (HW > ki.NFR * 16) continue;
-                const int rs = (d.W + 1 + 7) / 8 * 8, extra = rs == d.W + 1 ? 1 : 0;
-                int ti = ki.NFR * 16 / HW;                               // whole images per tile: as many as the fragments and the patch instructions allow
-                while (ti > 1 && (ti * (d.H + 1) + 1) * (rs / 8) + extra > ki.NI_MAX) ti--;
-                tp = ti * HW; ni = (ti * (d.H + 1) + 1) * (rs / 8) + extra;
-            } else { tp = tile_pixels(HW, ki.NFR * 16); if (!tp) continue; ni = (tp + 7) / 8; }
-            if (ni > ki.NI_MAX) continue;
-            const size_t need = (size_t)ki.NB * ki.KG * (ki.WCH / 64) * ni * 1024 + 1024 + 1024;
-            const size_t red = (ki.KG > 1 || !ST_EPI_DIRECT) ? (size_t)4 * std::min(ki.NFR, 7) * 16 * (ki.NF * 16 + 4) * 4 + 1024 : 0;
-            if (std::max(need, red) > 160 * 1024 - 64) continue;
-            const int mt = sm_ceil_div(team_px, tp), nt = sm_ceil_div(d.Cout, (4 / ki.KG) * ki.NF * 16);
-            const double cost = (double)sm_ceil_div(mt * nt, ST_TEAM) * ((double)tp + (4 / ki.KG) * ki.NF * 16) * (K1 + K2) * (t3 ? 1.0 : 1.0) * 2 * (ki.KG > 1 ? 1.05 : 1.0);
-            if (best < 0 || cost < best_cost) { best = k; best_cost = cost; best_tp = tp; }
-        }
+        // ---- kind: the cheapest by bytes a CU pulls through its L1 (tiles per CU x (pixels + couts) x K x 2), among the forms of the run's block size ----
+        int best_tp = 0;
+        const int team_px = a.ipt * HW, best = pick_kind(ph[i], a.ipt, nw_run, &best_tp);
         ST_REQ(best >= 0, "sm_stage: phase %d (%dx%d, %d -> %d channels, %dx%d kernel): no tile form takes it", i, d.H, d.W, d.Cin, d.Cout, d.kH, d.kW);
         const KindInfo& ki = kKinds[best];
         q.x = (const half_t*)ph[i].x; q.x2 = (const half_t*)ph[i].x2; q.w = (const half_t*)ph[i].w_ohwi; q.wp = (const half_t*)ph[i].w_packed; q.bias = ph[i].bias; q.res = (const half_t*)ph[i].residual; q.y = (half_t*)ph[i].y;
         q.kind = best; q.H = d.H; q.W = d.W; q.HW = HW; q.K1 = K1; q.K = d.kH * d.kW * K1 + K2; q.Cout = d.Cout;
         q.x_ld = x_ld; q.x2_ld = x2_ld; q.res_ld = res_ld; q.y_ld = y_ld; q.x2_W = dual ? ph[i].x2_W : 0; q.x2_HW = dual ? ph[i].x2_H * ph[i].x2_W : 0; q.x2_s = dual ? ph[i].x2_stride : 1;
         q.act = d.act; q.slope = d.act == SM_ACT_RELU ? 0.f : d.slope;
-        q.TP = best_tp; q.TI = t3 ? best_tp / HW : 0; q.MT = sm_ceil_div(team_px, best_tp); q.NT = sm_ceil_div(d.Cout, (4 / ki.KG) * ki.NF * 16);
+        q.TP = best_tp; q.TI = t3 ? best_tp / HW : 0; q.MT = sm_ceil_div(team_px, best_tp); q.NT = sm_ceil_div(d.Cout, ki.NG * ki.NF * 16);
         const int sbch = ki.KG * ki.WCH;
         q.nsb1 = K1 / sbch; q.nsb = (K1 + K2) / sbch;
         q.RS = t3 ? (d.W + 1 + 7) / 8 * 8 : 8; q.NI = t3 ? (q.TI * (d.H + 1) + 1) * (q.RS / 8) + (q.RS == d.W + 1 ? 1 : 0) : (best_tp + 7) / 8;
-        q.x_bytes = (unsigned)xb; q.x2_bytes = (unsigned)x2b; q.res_bytes = (unsigned)rb; q.y_bytes = (unsigned)yb;
+        q.x_bytes = (unsigned)xb; q.x2_bytes = (unsigned)x2b; q.res_bytes = (unsigned)rb; q.y_bytes = (unsigned)yb; q.wt_bytes = (unsigned)(ki.NG * ki.NF * 16 * q.K * 2);
         sm_fastdiv_make((unsigned)HW, &q.hw_mul, &q.hw_sh); sm_fastdiv_make((unsigned)d.W, &q.w_mul, &q.w_sh); sm_fastdiv_make((unsigned)(d.H + 1), &q.h1_mul, &q.h1_sh);
         sm_fastdiv_make((unsigned)(q.RS / 8), &q.kpr_mul, &q.kpr_sh);
         // arrivals per image: every cout tile of every pixel tile that overlaps the image
         q.expect = q.NT * (HW > best_tp ? HW / best_tp : 1);
-        lds = std::max(lds, std::max((size_t)ki.NB * ki.KG * (ki.WCH / 64) * q.NI * 1024 + 1024, (ki.KG > 1 || !ST_EPI_DIRECT) ? (size_t)4 * std::min(ki.NFR, 7) * 16 * (ki.NF * 16 + 4) * 4 : (size_t)0) + 1024);
+        lds = std::max(lds, std::max((size_t)ki.NB * ki.KG * (ki.WCH / 64) * (t3 ? q.NI : ki.NI_MAX) * 1024 + 1024, (ki.KG > 1 || !ST_EPI_DIRECT) ? (size_t)ki.NW * std::min(ki.NFR, std::min(7, (140 * 1024) / (ki.NW * 16 * (ki.NF * 16 + 4) * 4))) * 16 * (ki.NF * 16 + 4) * 4 : (size_t)0) + 1024);
         ys[i] = {ph[i].y, (size_t)yb};
         // ---- producers: the LATEST earlier phase whose output holds the operand ----
         q.dep0 = q.dep1 = q.dep2 = -1;
@@ -681,8 +778,9 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
             ST_REQ(!(reads && e > i && a.ph[e].dep0 != i && a.ph[e].dep1 != i && a.ph[e].dep2 != i), "sm_stage: phase %d's output is overwritten before phase %d reads it", i, e);
             ST_REQ(!overlap(ys[i].p, ys[i].n, ys[e].p, ys[e].n), "sm_stage: phases %d and %d write overlapping tensors", i, e);
         }
+    for (int i = 1; i < n; i++) ST_REQ(kKinds[a.ph[i].kind].NW == kKinds[a.ph[0].kind].NW, "sm_stage: phase %d's tile form has %d waves, phase 0's %d (one block size per launch)", i, kKinds[a.ph[i].kind].NW, kKinds[a.ph[0].kind].NW);
     a.lds_bytes = (int)lds;
-    ST_REQ(lds <= 160 * 1024 - 64, "sm_stage: %zu bytes of LDS", lds);   // (+ 16 bytes of static LDS)
+    ST_REQ(lds <= 160 * 1024 - 320, "sm_stage: %zu bytes of LDS", lds);   // (+ 272 bytes of static LDS)
     return SM_OK;
 #undef ST_REQ
 }
@@ -707,7 +805,7 @@ extern "C" size_t sm_stage_packed_weight_bytes(const sm_stage_phase* ph, int32_t
     StArgs a;
     if (stage_plan(ph, n, a, true) != SM_OK || i < 0 || i >= n) return 0;
     const KindInfo& ki = kKinds[a.ph[i].kind];
-    return (size_t)a.ph[i].NT * (4 / ki.KG) * ki.NF * 16 * (size_t)a.ph[i].K * 2;
+    return (size_t)a.ph[i].NT * ki.NG * ki.NF * 16 * (size_t)a.ph[i].K * 2;
 }
 extern "C" int sm_stage_pack_weights(const sm_stage_phase* ph, int32_t n, int32_t i, const void* w_ohwi_host, void* dst_host) {
     StArgs a;
@@ -715,7 +813,7 @@ extern "C" int sm_stage_pack_weights(const sm_stage_phase* ph, int32_t n, int32_
     if (rc) return rc;
     SM_REQUIRE(i >= 0 && i < n && w_ohwi_host && dst_host, "sm_stage_pack_weights: phase %d of %d", i, n);
     const StPhase& q = a.ph[i]; const KindInfo& ki = kKinds[q.kind];
-    const int KG = ki.KG, NG = 4 / ki.KG, NF = ki.NF, WCH = ki.WCH, QPW = WCH / 32, UPS = ki.TAPS * QPW, SBCH = KG * WCH, BN = NG * NF * 16;
+    const int KG = ki.KG, NG = ki.NG, NF = ki.NF, WCH = ki.WCH, QPW = WCH / 32, UPS = ki.TAPS * QPW, SBCH = KG * WCH, BN = NG * NF * 16;
     const uint16_t* w = (const uint16_t*)w_ohwi_host; uint16_t* dst = (uint16_t*)dst_host;
     size_t o = 0;
     for (int nt = 0; nt < q.NT; nt++)
@@ -726,7 +824,7 @@ extern "C" int sm_stage_pack_weights(const sm_stage_phase* ph, int32_t n, int32_
                         for (int j = 0; j < NF; j++)
                             for (int lane = 0; lane < 64; lane++) {
                                 const int l15 = lane & 15, g = lane >> 4, co0 = nt * BN + ng * NF * 16;
-                                const int co = (KG == 1 && ST_EPI_DIRECT) ? co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) : co0 + j * 16 + l15;
+                                const int co = ki.XCH ? co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) : co0 + j * 16 + l15;
                                 const size_t k = (size_t)(ul / QPW) * q.K1 + (size_t)sb * SBCH + kg * WCH + (ul % QPW) * 32 + g * 8;
                                 if (co < q.Cout) memcpy(dst + o, w + (size_t)co * q.K + k, 16); else memset(dst + o, 0, 16);
                                 o += 8;
@@ -742,7 +840,10 @@ extern "C" int sm_stage_fwd(const sm_stage_phase* ph, int32_t n, void* ctl, sm_s
     // (no co-residency requirement: a device that cannot hold the 256 blocks together — fewer CUs, a compute partition, other work — completes the launch in the claimed mode)
     int mask = 0;
     for (int i = 0; i < n; i++) mask |= 1 << a.ph[i].kind;
-    if ((mask & ~0x7) == 0) hipLaunchKernelGGL(stage_kernel<0x7>, dim3(ST_GRID), dim3(256), (size_t)a.lds_bytes, sm_s(stream), a);
+    if (kKinds[a.ph[0].kind].NW == 8) {
+        hipLaunchKernelGGL((stage_kernel<0x1c0, 8>), dim3(ST_GRID), dim3(512), (size_t)a.lds_bytes, sm_s(stream), a);   // forms 6, 7, 8
+    }
+    else if ((mask & ~0x7) == 0) hipLaunchKernelGGL(stage_kernel<0x7>, dim3(ST_GRID), dim3(256), (size_t)a.lds_bytes, sm_s(stream), a);
     else if ((mask & ~0x38) == 0) hipLaunchKernelGGL(stage_kernel<0x38>, dim3(ST_GRID), dim3(256), (size_t)a.lds_bytes, sm_s(stream), a);
     else hipLaunchKernelGGL(stage_kernel<0x3f>, dim3(ST_GRID), dim3(256), (size_t)a.lds_bytes, sm_s(stream), a);
     SM_LAUNCH_CHECK();

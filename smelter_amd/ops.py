@@ -112,8 +112,9 @@ class Stage:
     """A run of convolutions as ONE persistent launch (sm_stage_fwd).  `add(...)` appends a phase with the operands of `conv2d` / `conv2d_dual`;
     tensors are kept alive by the object.  `run()` enqueues the launch, `status()` reads (error_bits, mode) after synchronising."""
 
-    def __init__(self):
-        self.phases, self.keep, self.ctl = [], [], None
+    def __init__(self, four_waves=False):
+        """four_waves: keep the planner to the 4-wave tile forms (default: the 8-wave forms when every phase has one)"""
+        self.phases, self.keep, self.ctl, self.four_waves = [], [], None, four_waves
 
     def add(self, x, w_ohwi, bias=None, residual=None, act=ACT_NONE, slope=0.0, out=None, x2=None, stride2=1, kind=None):
         n, h, w, k1, x_ld = _check_nhwc(x)
@@ -133,7 +134,7 @@ class Stage:
             residual.data_ptr() if residual is not None else None, out.data_ptr()
         if x2 is not None:
             ph.x2, ph.K2, ph.x2_ld, ph.x2_H, ph.x2_W, ph.x2_stride = x2.data_ptr(), k2, x2_ld, h2, w2, stride2
-        ph.form = 0 if kind is None else kind + 1
+        ph.form = (-1 if self.four_waves else 0) if kind is None else kind + 1
         self.phases.append(ph)
         self.keep += [x, w_ohwi, bias, residual, out, x2]
         return out

@@ -51,9 +51,9 @@ def weights(rng, cout, k, cin):
 class Net:
     """a run under construction: device tensors for sm_stage_fwd + what the oracle needs to redo each phase"""
 
-    def __init__(self, seed):
+    def __init__(self, seed, four_waves=False):
         self.rng = np.random.default_rng(seed)
-        self.st = ops.Stage()
+        self.st = ops.Stage(four_waves=four_waves)
         self.recs = []
 
     def phase(self, x, cout, k=1, res=None, act=1, slope=0.0, x2=None, stride2=1, bias=True, out=None, kind=None):
@@ -81,10 +81,10 @@ class Net:
         return act_ref(ref, r["act"], r["slope"]), x.shape[1] * r["k"] ** 2
 
 
-def bottleneck_run(n, hw, cin, mid, blocks, seed, head_src=None):
+def bottleneck_run(n, hw, cin, mid, blocks, seed, head_src=None, four_waves=False):
     """ResNet bottleneck blocks at one resolution: [1x1 cin -> mid, 3x3 mid -> mid, 1x1 mid -> cin + residual] x blocks; with `head_src` (the previous stage's output at twice
     the resolution, cin / 2 channels) the run starts with the K-concatenated expand + projection shortcut of a stage's first block (executor pass 3h)"""
-    net = Net(seed)
+    net = Net(seed, four_waves)
     rng = np.random.default_rng(seed + 1000)
     if head_src:
         t0 = dev(h(np.abs(rng.standard_normal((n, mid, hw, hw)))))
@@ -130,6 +130,53 @@ SINGLE = [
 ]
 
 
+# the 8-wave tile forms (two waves per SIMD; packed weights only): (n, hw, cin, cout, k, dual, res, act, tile form)
+SINGLE8 = [
+    (16, 7, 512, 2048, 1, False, True, 1, 6),      # E8   form 2's tile, couts split over eight waves, residual
+    (16, 7, 512, 2048, 1, True, False, 1, 6),      # E8   second source (stride 2)
+    (13, 7, 512, 200, 1, False, True, 0, 6),       # ragged batch, Cout % 256 != 0, no activation
+    (8, 14, 256, 1024, 1, False, True, 1, 6),      # half-image tiles
+    (9, 10, 768, 256, 1, False, False, 2, 6),      # 100-pixel images, six super-blocks, PReLU
+    (16, 7, 2048, 512, 1, False, False, 1, 7),     # R8   form 0's tile: K split 4 ways x two waves of 32 couts
+    (13, 7, 512, 200, 1, False, True, 0, 7),       # ragged batch and couts, residual through the exchange rounds
+    (8, 14, 1024, 256, 1, False, False, 1, 7),     # half-image tiles
+    (16, 7, 512, 512, 3, False, False, 1, 8),      # T8   3x3, two images per tile, two waves per patch slice
+    (3, 5, 256, 64, 3, False, False, 1, 8),        # 5 x 5 images: four per tile
+    (5, 7, 256, 72, 3, False, True, 2, 8),         # ragged couts, residual, PReLU
+]
+
+
+@pytest.mark.parametrize("case", SINGLE8)
+def test_single_phase_eight_waves_vs_oracle(case):
+    n, hw, cin, cout, k, dual, res, act, kind = case
+    rng = np.random.default_rng(hash(case) & 0xffff)
+    net = Net(11)
+    x = dev(h(rng.standard_normal((n, cin, hw, hw))))
+    x2 = dev(h(rng.standard_normal((n, 2 * cin, 2 * hw, 2 * hw)))) if dual else None
+    r = dev(h(rng.standard_normal((n, cout, hw, hw)))) if res else None
+    y = net.phase(x, cout, k, res=r, act=act, slope=0.25, x2=x2, stride2=2, kind=kind)
+    assert net.st.supported() and net.st.kinds() == [kind]
+    net.st.run()
+    ref, kk = net.oracle_phase(0)
+    assert_close(host(y), ref, kk)
+    first = y.clone()
+    err, _ = net.st.status()                        # (the first launch of a kernel in a process may find its blocks arriving apart and take the claimed mode: same bits, checked here)
+    assert err == 0
+    net.st.pack()
+    for _ in range(3):
+        y.zero_(); net.st.run(); torch.cuda.synchronize()
+        assert torch.equal(y, first), "packed weights / repeat: %d elements differ from the OHWI run" % int((y != first).sum())
+    check_status(net)
+
+
+def test_four_and_eight_wave_forms_do_not_share_a_launch():
+    net = Net(3)
+    x = dev(h(np.random.default_rng(1).standard_normal((8, 512, 7, 7))))
+    a = net.phase(x, 512, 1, kind=0)
+    net.phase(a, 2048, 1, kind=6)
+    assert not net.st.supported()
+
+
 @pytest.mark.parametrize("case", SINGLE)
 def test_single_phase_vs_oracle(case):
     n, hw, cin, cout, k, dual, res, act, kind = case
@@ -167,11 +214,14 @@ def test_pixel_strides_and_channel_slices():
     check_status(net)
 
 
-@pytest.mark.parametrize("shape", [(16, 7, 2048, 512, True), (8, 14, 1024, 256, True), (16, 7, 2048, 512, False), (11, 14, 1024, 256, False)])
+# (n, hw, cin, mid, head, four-wave forms only): at 7 x 7 the planner takes the 8-wave forms (two waves per SIMD) unless told otherwise; 14 x 14 has no 8-wave 3x3 form
+@pytest.mark.parametrize("shape", [(16, 7, 2048, 512, True, False), (16, 7, 2048, 512, True, True), (8, 14, 1024, 256, True, False), (16, 7, 2048, 512, False, True), (13, 7, 2048, 512, False, False),
+                                   (11, 14, 1024, 256, False, False)])
 def test_run_phase_by_phase_vs_oracle_and_bit_identical_to_single_launches(shape):
-    n, hw, cin, mid, head = shape
-    net = bottleneck_run(n, hw, cin, mid, 2, seed=hw + n, head_src=head)
+    n, hw, cin, mid, head, four = shape
+    net = bottleneck_run(n, hw, cin, mid, 2, seed=hw + n, head_src=head, four_waves=four)
     assert net.st.supported()
+    assert all((k >= 6) == (hw == 7 and not four) for k in net.st.kinds()), net.st.kinds()
     fused = run_and_snapshot(net)
     check_status(net)
     for i in range(len(net.recs)):                       # each phase against the oracle on the run's own inputs
@@ -179,7 +229,9 @@ def test_run_phase_by_phase_vs_oracle_and_bit_identical_to_single_launches(shape
         assert_close(host(fused[i]), ref, kk)
     for r in net.recs:
         r["y"].zero_()
-    for i in range(len(net.recs)):                       # the same phases, one launch each
+    for i, k in enumerate(net.st.kinds()):               # the same phases ON THE SAME TILE FORMS (a phase alone would get the planner's choice for a run of one), one launch each
+        net.st.phases[i].form = k + 1
+    for i in range(len(net.recs)):
         net.st.run([i])
     torch.cuda.synchronize()
     for i, r in enumerate(net.recs):
@@ -195,14 +247,14 @@ def test_run_phase_by_phase_vs_oracle_and_bit_identical_to_single_launches(shape
     check_status(net)
 
 
-@pytest.mark.parametrize("stage", ["stage4", "stage3"])
+@pytest.mark.parametrize("stage", ["stage4", "stage4-4w", "stage3"])
 def test_real_shape_run(stage):
     """ResNet-50 bs 64: stage 4 = 64 x 7^2 x 2048 (mid 512, head + 2 blocks: 7 phases), stage 3 = 64 x 14^2 x 1024 (mid 256, head + 5 blocks: 16 phases)"""
     n = 64
-    hw, cin, mid, blocks = (7, 2048, 512, 2) if stage == "stage4" else (14, 1024, 256, 5)
-    net = bottleneck_run(n, hw, cin, mid, blocks, seed=11, head_src=True)
+    hw, cin, mid, blocks = (7, 2048, 512, 2) if stage.startswith("stage4") else (14, 1024, 256, 5)
+    net = bottleneck_run(n, hw, cin, mid, blocks, seed=11, head_src=True, four_waves=stage.endswith("-4w"))
     assert net.st.supported()
-    want = {"stage4": [2] + [0, 1, 2] * 2, "stage3": [4] + [3, 5, 4] * 5}[stage]
+    want = {"stage4": [6] + [7, 8, 6] * 2, "stage4-4w": [2] + [0, 1, 2] * 2, "stage3": [4] + [3, 5, 4] * 5}[stage]
     assert net.st.kinds() == want
     fused = run_and_snapshot(net)
     check_status(net)
@@ -225,6 +277,8 @@ def test_real_shape_run(stage):
             assert_close(got[ni, :, oy, ox].T, act_ref(ref, r["act"], r["slope"]), x.shape[1])
     for r in net.recs:
         r["y"].zero_()
+    for i, k in enumerate(net.st.kinds()):               # (the run's tile forms, also for the phases launched alone)
+        net.st.phases[i].form = k + 1
     for i in range(len(net.recs)):
         net.st.run([i])
     torch.cuda.synchronize()

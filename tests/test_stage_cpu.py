@@ -10,7 +10,9 @@ from smelter_amd._native import ConvDesc, StagePhase, lib
 
 ACT_RELU = 1
 #            KG NG NF  NFR TAPS WCH   (stage.hip: StR7, StT7, StE7, StR14, StE14, StT14)
-KINDS = {0: (4, 1, 4, 7, 1, 64), 1: (4, 1, 4, 7, 9, 64), 2: (1, 4, 4, 7, 1, 128), 3: (2, 2, 4, 7, 1, 128), 4: (1, 4, 4, 13, 1, 128), 5: (4, 1, 4, 13, 9, 64)}
+KINDS = {0: (4, 1, 4, 7, 1, 64), 1: (4, 1, 4, 7, 9, 64), 2: (1, 4, 4, 7, 1, 128), 3: (2, 2, 4, 7, 1, 128), 4: (1, 4, 4, 13, 1, 128), 5: (4, 1, 4, 13, 9, 64),
+         6: (1, 8, 2, 7, 1, 128), 7: (4, 2, 2, 7, 1, 64), 8: (4, 2, 2, 7, 9, 64)}     # 6 .. 8: eight waves (two per SIMD)
+XCH = {2, 4, 6}                       # forms whose tile leaves from the registers: weight rows assigned so that a lane holds eight consecutive couts
 
 
 class Run:
@@ -55,21 +57,23 @@ class Run:
         return [lib().sm_stage_phase_kind(a, n, i) for i in range(n)]
 
 
-def resnet_stage(n, hw, cin, mid, blocks):
+def resnet_stage(n, hw, cin, mid, blocks, form=0):
     r = Run(n)
     t0, xin = r.tensor(hw, hw, mid), r.tensor(2 * hw, 2 * hw, cin // 2)
-    cur = r.add(t0, cin, 1, x2=xin, stride2=2)             # expand + projection shortcut, concatenated along K (executor pass 3h)
+    cur = r.add(t0, cin, 1, x2=xin, stride2=2, form=form)             # expand + projection shortcut, concatenated along K (executor pass 3h)
     for _ in range(blocks):
-        a = r.add(cur, mid, 1)
-        b = r.add(a, mid, 3)
-        cur = r.add(b, cin, 1, res=cur)
+        a = r.add(cur, mid, 1, form=form)
+        b = r.add(a, mid, 3, form=form)
+        cur = r.add(b, cin, 1, res=cur, form=form)
     return r
 
 
 def test_resnet50_stage_shapes_get_their_tile_forms():
     s4, s3 = resnet_stage(64, 7, 2048, 512, 2), resnet_stage(64, 14, 1024, 256, 5)
-    assert s4.supported() and s4.kinds() == [2] + [0, 1, 2] * 2
-    assert s3.supported() and s3.kinds() == [4] + [3, 5, 4] * 5
+    assert s4.supported() and s4.kinds() == [6] + [7, 8, 6] * 2          # every phase has an 8-wave form (two waves per SIMD): the run takes them
+    s4f = resnet_stage(64, 7, 2048, 512, 2, form=-1)
+    assert s4f.supported() and s4f.kinds() == [2] + [0, 1, 2] * 2         # form < 0: the 4-wave forms
+    assert s3.supported() and s3.kinds() == [4] + [3, 5, 4] * 5          # 14 x 14: no 8-wave 3x3 form, so the 4-wave forms for the whole run
     a, n = s4.arr()
     # control block: 48 header words + 18 phases x (batch rounded up to 16) counters
     assert lib().sm_stage_ctl_bytes(a, n) == (48 + 18 * 64) * 4
@@ -134,14 +138,14 @@ def pack_reference(w, kind, cout, k1, k2, nt):
                             for lane in range(64):
                                 l15, g = lane & 15, lane >> 4
                                 co0 = nti * BN + ng * NF * 16
-                                co = co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) if KG == 1 else co0 + j * 16 + l15
+                                co = co0 + (j >> 1) * 32 + (l15 >> 2) * 8 + (j & 1) * 4 + (l15 & 3) if kind in XCH else co0 + j * 16 + l15
                                 k = (ul // QPW) * k1 + sb * SBCH + kg * WCH + (ul % QPW) * 32 + g * 8
                                 if co < cout:
                                     out[nti, ng, kg, sb, ul, j, lane] = w2[co, k:k + 8]
     return out.reshape(-1)
 
 
-@pytest.mark.parametrize("kind,hw,cin,cout,k", [(0, 7, 512, 72, 1), (1, 7, 256, 64, 3), (2, 7, 128, 264, 1), (3, 14, 256, 136, 1), (4, 14, 128, 256, 1), (5, 14, 256, 40, 3)])
+@pytest.mark.parametrize("kind,hw,cin,cout,k", [(0, 7, 512, 72, 1), (1, 7, 256, 64, 3), (2, 7, 128, 264, 1), (3, 14, 256, 136, 1), (4, 14, 128, 256, 1), (5, 14, 256, 40, 3), (6, 7, 512, 264, 1), (7, 7, 512, 72, 1), (8, 7, 256, 64, 3)])
 def test_packed_weights_are_the_documented_fragment_order(kind, hw, cin, cout, k):
     r = Run(8)
     x = r.tensor(hw, hw, cin)
@@ -166,7 +170,7 @@ def test_packed_weights_are_the_documented_fragment_order(kind, hw, cin, cout, k
 def test_packed_weights_of_a_two_source_phase_keep_the_concatenated_k_order():
     r = Run(8)
     t0, xin = r.tensor(7, 7, 128), r.tensor(14, 14, 256)
-    r.add(t0, 256, 1, x2=xin, stride2=2)
+    r.add(t0, 256, 1, x2=xin, stride2=2, form=3)
     assert r.kinds() == [2]
     a, n = r.arr()
     w = np.arange(256 * 384, dtype=np.uint32).astype(np.uint16).reshape(256, 1, 1, 384) | 1

@@ -7,10 +7,10 @@ sys.path.insert(0, ".")
 from smelter_amd import ops
 
 
-def build(n, hw, cin, mid, blocks, seed=0, pack=True):
+def build(n, hw, cin, mid, blocks, seed=0, pack=True, four_waves=False):
     g = torch.Generator(device="cuda"); g.manual_seed(seed)
     rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
-    st = ops.Stage(); layers = []
+    st = ops.Stage(four_waves=four_waves); layers = []
     def phase(x, cout, k=1, res=None, x2=None):
         kk = x.shape[3] + (x2.shape[3] if x2 is not None else 0)
         w = (rn(cout, k, k, kk) * (2.0 / (k * k * kk)) ** 0.5).half(); b = (rn(cout) * 0.1).float()
@@ -39,7 +39,7 @@ def timeit(fn, iters):
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "stage4"; iters = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 50
     hw, cin, mid, blocks = (7, 2048, 512, 2) if which == "stage4" else (14, 1024, 256, 5)
-    st, layers = build(64, hw, cin, mid, blocks, pack="nopack" not in sys.argv)
+    st, layers = build(64, hw, cin, mid, blocks, pack="nopack" not in sys.argv, four_waves="4w" in sys.argv)
     print(which, "packed weights:", "nopack" not in sys.argv, "kinds", st.kinds(), flush=True)
     st.run(); torch.cuda.synchronize(); print("status (error bits, mode)", st.status(), flush=True)
     fused = [l[5].clone() for l in layers]

@@ -15,8 +15,21 @@ from stage_bench import build
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "stage4"
-    hw, cin, mid, blocks = (7, 2048, 512, 2) if which == "stage4" else (14, 1024, 256, 5)
-    st, layers = build(64, hw, cin, mid, blocks, pack="nopack" not in sys.argv)
+    if which.startswith("form"):
+        # formK:SHAPE — four INDEPENDENT phases of one shape on tile form K (no hand-off between them: the columns are the tile body alone): expand7 | reduce7 | conv7 | expand14 | reduce14 | conv14
+        kind, shape = int(which[4:].split(":")[0]), which.split(":")[1]
+        hw, cin, cout, k, res = {"expand7": (7, 512, 2048, 1, True), "reduce7": (7, 2048, 512, 1, False), "conv7": (7, 512, 512, 3, False),
+                                 "expand14": (14, 256, 1024, 1, True), "reduce14": (14, 1024, 256, 1, False), "conv14": (14, 256, 256, 3, False)}[shape]
+        g = torch.Generator(device="cuda"); g.manual_seed(0)
+        rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
+        st = ops.Stage()
+        x = rn(64, hw, hw, cin).abs().half(); r = rn(64, hw, hw, cout).abs().half() if res else None
+        for _ in range(4):
+            st.add(x, (rn(cout, k, k, cin) * (2.0 / (k * k * cin)) ** 0.5).half(), (rn(cout) * 0.1).float(), residual=r, act=1, kind=kind)
+        st.pack()
+    else:
+        hw, cin, mid, blocks = (7, 2048, 512, 2) if which == "stage4" else (14, 1024, 256, 5)
+        st, layers = build(64, hw, cin, mid, blocks, pack="nopack" not in sys.argv, four_waves="4w" in sys.argv)
     L = lib()
     L.sm_stage_timeline_read.argtypes = [C.c_void_p, C.c_void_p]; L.sm_stage_timeline_read.restype = C.c_int
     for _ in range(5):
