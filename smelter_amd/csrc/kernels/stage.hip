@@ -343,7 +343,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
                     sm_static_for<0, NFR>([&](auto fc) { constexpr int F = decltype(fc)::value; ad[F] += dlt; if constexpr (AD1) ad1[F] += dlt; read_frag(fc, std::integral_constant<int, 0>()); });
                 } else {
 #pragma unroll
-                    for (int f = 0; f < NFR; f++) { ad[f] = frag_addr(f, 0, bufo); half8_t& d = af[f]; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad[f])); }
+                    for (int f = 0; f < NFR; f++) { const unsigned a0 = frag_addr(f, 0, bufo); if constexpr (!(T3 && KD::NW == 8)) ad[f] = a0; st_dsread16<0>(af[f], a0); }
                 }
             }
             if constexpr (U % 2 == 0) {                                // weights of the pair PA units ahead (beyond the last unit: a harmless reload keeps the counted waits exact)
@@ -370,7 +370,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
                     __builtin_amdgcn_sched_barrier(0);
                     if constexpr (!LASTU) {
                         constexpr int VL = UL + 1;
-                        if constexpr (!FIXS) {
+                        if constexpr (!FIXS && !(T3 && KD::NW == 8)) {
                             if (j == 0) {
                                 if constexpr ((VL % QPW) % 2 == 1) ad[F] ^= 64u;       // same tap, same slice, other channel half
                                 else ad[F] = frag_addr(F, VL, bufo);
@@ -379,6 +379,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
                         }
                         if (j == NF - 1) {
                             if constexpr (FIXS) read_frag(fc, std::integral_constant<int, VL>());
+                            else if constexpr (T3 && KD::NW == 8) st_dsread16<0>(af[F], frag_addr(F, VL, bufo));   // (256 registers: the address is made where it is used, not kept per fragment)
                             else { half8_t& d = af[F]; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad[F])); }
                             __builtin_amdgcn_sched_barrier(0);
                         }
