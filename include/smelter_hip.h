@@ -224,7 +224,8 @@ typedef struct sm_stage_phase {
     const void* w_packed;           /* optional (NULL: none): the same weights in the run's fragment order (sm_stage_pack_weights), device memory — the kernel then streams them
                                      * as contiguous 1 KB requests instead of 64-byte row pieces (about twice the weight bandwidth per compute unit) */
     const void* x2; int32_t K2, x2_ld, x2_H, x2_W, x2_stride;   /* second source, as in sm_conv2d_dual_fwd_cfg (x2 = NULL: none) */
-    int32_t form;                   /* 0 = the planner picks the tile form (fewest bytes through a CU's L1); k + 1 = tile form k if it takes the phase (tests, tuning) */
+    int32_t form;                   /* 0 = the planner picks the tile form (fewest bytes through a CU's L1; the 8-wave forms, two waves per SIMD, when every phase of the run has one);
+                                       k + 1 = tile form k if it takes the phase (tests, tuning; a run is all 4-wave or all 8-wave forms); < 0 on any phase = the planner keeps to the 4-wave forms */
 } sm_stage_phase;
 int sm_stage_supported(const sm_stage_phase* ph, int32_t n);
 int sm_stage_device_fast(void);   /* 1: the current device has the 256 compute units the static XCD-local mode wants (a smaller / partitioned device still runs a launch correctly, in the slower claimed mode) */

@@ -14,6 +14,9 @@
 //   * a phase's tile = TP output pixels (whole images or an aligned part of one) x BN couts, K reduction in "units" of 32 channels:
 //       kinds R (1x1, many input channels, few couts) and T (3x3): K split over the four waves (each wave owns the whole tile, partial sums meet in LDS);
 //       kinds E (1x1, few input channels, many couts; optionally a second source = projection shortcut concatenated along K): couts split over the four waves;
+//       the same three with EIGHT waves (forms 6-8: two waves per SIMD, <= 256 registers each, 32 couts per wave): with one wave per SIMD every cycle the wave spends issuing its
+//       memory instructions or waiting on a counter is a cycle its matrix unit idles (profiles/r05_stage_ablation.txt part 8); with two, one's issue and waits sit under the
+//       other's MFMAs.  The planner takes the 8-wave forms when every phase of the run has one (a launch has one block size);
 //     the input patch goes HBM/L2 -> LDS by buffer LDS-DMA (out-of-range lanes = zeros without a memory access: padding, halo, dead pixels), 64-channel slices
 //     [slot][128 B] XOR-swizzled by slot/2, NB buffers deep; weights go global -> registers in fragment layout (never through the LDS), two units per request so that
 //     both halves of a 128-byte line are asked for together; v_mfma_f32_16x16x32_f16, fp32 accumulators; bias + residual + activation + one rounding in the epilogue.
