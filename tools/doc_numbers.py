@@ -140,7 +140,8 @@ def block_stage(tag):
                 tables[cur]["total"] = float(l.split()[-2])
         for kinds, t in tables.items():
             k = [int(x) for x in kinds.split(",")]
-            name = "7 × 7 × 2048 (dual head + 2 bottleneck blocks)" if max(k) <= 2 else "14 × 14 × 1024 (dual head + 5 bottleneck blocks)"
+            name = "7 × 7 × 2048 (dual head + 2 bottleneck blocks)" if set(k) <= {0, 1, 2, 6, 7, 8} else "14 × 14 × 1024 (dual head + 5 bottleneck blocks)"
+            name += ", 8-wave tile forms (two waves per SIMD)" if min(k) >= 6 else ", 4-wave tile forms"
             out.append("ResNet-50 bs 64, %s, %d phases, ONE launch: **%.1f µs** first stamp → last stamp (`profiles/%s_stage_timeline.txt`; hand-off mode %s = XCD-local).  Per phase, µs, averages over 256 tiles:\n" % (
                 name, len(k), t["total"], tag, t["mode"]))
             out.append("| phase | tile form | wait for producers | first patch fill | main loop | epilogue | store drain + publish |\n|---|---|---|---|---|---|---|")

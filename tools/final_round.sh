@@ -9,7 +9,7 @@ done
 python tools/fixed_cost_fit.py --out $OUT/${TAG}_fixed_cost_fit.json --head $HEAD > $OUT/${TAG}_fit.log 2>&1
 [ -d build/${PREV:-r04tree} ] && bash tools/ab_round.sh > $OUT/${TAG}_ab_same_box.txt 2>&1
 bash tools/ab_stage.sh > $OUT/${TAG}_ab_stage_same_box.txt 2>&1
-[ -f build/libsmelter_hip_stagetl.so ] && for s in stage4 stage3; do SMELTER_LIB_PATH=build/libsmelter_hip_stagetl.so python tools/stage_tl.py $s 2>&1 | grep -v amdgpu.ids; done > $OUT/${TAG}_stage_timeline.txt
+[ -f build/libsmelter_hip_stagetl.so ] && for s in "stage4" "stage4 4w" "stage3"; do SMELTER_LIB_PATH=build/libsmelter_hip_stagetl.so python tools/stage_tl.py $s 2>&1 | grep -v amdgpu.ids; done > $OUT/${TAG}_stage_timeline.txt
 for m in r50 mbv2 unet; do bash tools/profile.sh $TAG $HEAD $m > $OUT/${TAG}_profile_$m.log 2>&1; done
 SMELTER_ROCTX=1 python tools/gpu_probe.py --model r50 2>&1 | grep "bs=64" > $OUT/${TAG}_roctx_smoke.txt
 # where a launch's time goes: instruction mix of every launch of the ResNet-50 step, SQ / TCP / TCC counters of the persistent runs alone, what the memory system delivers to 256 streaming CUs
