@@ -157,7 +157,11 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     const unsigned SLB = KD::FIXS ? (unsigned)KD::NI_MAX * 1024u : (unsigned)NI * 1024u, BUFB = (unsigned)(KG * NSL) * SLB, sink = lds0 + (unsigned)NB * BUFB;
     const unsigned myslices = lds0 + (unsigned)(kg * NSL) * SLB;       // this K group's slices inside buffer 0
     const int co0 = ntile * BN + ng * WN;
-    const int n0 = (int)sm_fastdiv((unsigned)pix0, p.hw_mul, p.hw_sh), imgs = T3 ? (int)sm_fastdiv((unsigned)PTe, p.hw_mul, p.hw_sh) : 1;
+    const int n0 = (int)sm_fastdiv((unsigned)pix0, p.hw_mul, p.hw_sh);
+    // 3x3: a tile is whole images, or (TP < HW) a BAND of whole rows of one image — its patch is then rows y0 - 1 .. y0 + TP / W of that image
+    const bool band = T3 && p.TP < HW;
+    const int imgs = !T3 ? 1 : band ? 1 : (int)sm_fastdiv((unsigned)PTe, p.hw_mul, p.hw_sh);
+    const int t3_y0 = band ? (int)sm_fastdiv((unsigned)(pix0 - n0 * HW), p.w_mul, p.w_sh) - 1 : -1;   // image row of patch row 0
 
     // ---- weight fragments: lane (l15, g) of fragment j holds one cout row, channels 8 g .. 8 g + 7 of the unit's 32.  KG == 1 (register epilogue): row l15 of fragment j is
     // cout (j/2) 32 + (l15/4) 8 + (j%2) 4 + l15%4, so that an accumulator lane holds eight CONSECUTIVE couts across fragments 2 jp, 2 jp + 1 (one 16-byte store) ----
@@ -209,7 +213,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     // 3x3: the instructions of a slice in order — patch row r = 0 .. (row 0 = halo above the first image; images H + 1 rows apart: the row between two images is zero), 8-slot group k
     // of the row.  Which image row a patch row is, whether it exists, its byte offset: wave-uniform running counters (no division); per lane only the column test and the add.
     // Swizzle key of slot r RS + 8 k + l8 = ((r RS / 2 + 4 k) & 4) | l8 / 2 (RS % 8 == 0): the two lane constants of the 1x1 case.
-    int t3_k = 0, t3_y = -1, t3_im = 0, t3_r = 0;
+    int t3_k = 0, t3_y = t3_y0, t3_im = 0, t3_r = 0;
     auto t3_next = [&]() -> unsigned {
         const bool rok = t3_y >= 0 && t3_y < H && t3_im < imgs;
         const int cc0 = 8 * t3_k;
@@ -322,7 +326,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
             const unsigned bufo = (unsigned)bcur * BUFB;
             if constexpr (UL == 0) {                                   // ---- super-block boundary: its patch has landed, everybody has left the buffer the next patch goes to ----
                 if constexpr (NB == 1) {
-                    if (sb > 0) { st_lds_barrier(); t3_k = 0; t3_y = -1; t3_im = 0; t3_r = 0; }
+                    if (sb > 0) { st_lds_barrier(); t3_k = 0; t3_y = t3_y0; t3_im = 0; t3_r = 0; }
                     if constexpr (T3 && NG > 1) { for (int w = 0; w < ng; w++) t3_skip(); }   // (the slice's instructions in order; every NG-th is this wave's)
 #pragma unroll 1
                     for (int idx = ng; idx < nidx; idx += NG) {
@@ -682,11 +686,17 @@ int pick_kind(const sm_stage_phase& ph, int ipt, int nw, int* tp_out) {
         if (K1 % sbch || (dual && (K2 % sbch || !(ki.TAPS == 1 && ki.KG == 1))) || ((K1 + K2) / sbch) % ki.SBG) continue;
         int tp, ni;
         if (t3) {
-            if (HW > ki.NFR * 16) continue;
             const int rs = (d.W + 1 + 7) / 8 * 8, extra = rs == d.W + 1 ? 1 : 0;
-            int ti = ki.NFR * 16 / HW;                               // whole images per tile: as many as the fragments and the patch instructions allow
-            while (ti > 1 && (ti * (d.H + 1) + 1) * (rs / 8) + extra > ki.NI_MAX) ti--;
-            tp = ti * HW; ni = (ti * (d.H + 1) + 1) * (rs / 8) + extra;
+            if (HW > ki.NFR * 16) {                                   // a band of TR whole rows of one image (TR | H): patch = TR + 2 rows
+                int tr = ki.NFR * 16 / d.W;
+                while (tr > 0 && (d.H % tr || (tr + 2) * (rs / 8) + extra > ki.NI_MAX)) tr--;
+                if (tr < 1) continue;
+                tp = tr * d.W; ni = (tr + 2) * (rs / 8) + extra;
+            } else {
+                int ti = ki.NFR * 16 / HW;                           // whole images per tile: as many as the fragments and the patch instructions allow
+                while (ti > 1 && (ti * (d.H + 1) + 1) * (rs / 8) + extra > ki.NI_MAX) ti--;
+                tp = ti * HW; ni = (ti * (d.H + 1) + 1) * (rs / 8) + extra;
+            }
         } else { tp = tile_pixels(HW, std::min(ki.NFR * 16, ki.NI_MAX * 8)); if (!tp) continue; ni = (tp + 7) / 8; }
         if (ni > ki.NI_MAX) continue;
         const size_t need = (size_t)ki.NB * ki.KG * (ki.WCH / 64) * (t3 ? ni : ki.NI_MAX) * 1024 + 1024 + 1024;
@@ -708,12 +718,15 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
     ST_REQ(N >= 1 && N <= 4096, "sm_stage: batch %d", N);
     a.nphase = n; a.N = N; a.ipt = sm_ceil_div(N, ST_NTEAM); a.spin_limit = 1000000; a.arrive_limit = 200; a.touch = ST_TOUCH_BYTES; a.cnt_ld = (N + 15) / 16 * 16;
     size_t lds = 0;
-    // block size of the launch: the 8-wave forms (two waves per SIMD) when EVERY phase has one, else the 4-wave forms; a phase that names its form (form > 0) decides, form < 0 on any phase keeps the 4-wave forms
+    // block size of the launch: the 8-wave forms (two waves per SIMD) when EVERY phase has one whose tile is no smaller than its 4-wave form's — same tile, the waves' stalls overlapped:
+    // the 7 x 7 stage; at 14 x 14 the 8-wave forms hold half an image where forms 4 / 5 hold a whole one, and two tiles per CU pay the per-tile chain twice (365 against 352 us).
+    // A phase that names its form (form > 0) decides; form < 0 on any phase keeps the 4-wave forms
     int nw_run = 8;
     for (int i = 0; i < n; i++) {
-        int tp;
+        int tp8 = 0, tp4 = 0;
         if (ph[i].form > 0 && ph[i].form <= ST_NKINDS) { nw_run = kKinds[ph[i].form - 1].NW; break; }
-        if (ph[i].form < 0 || pick_kind(ph[i], a.ipt, 8, &tp) < 0) nw_run = 4;
+        const int k8 = ph[i].form < 0 ? -1 : pick_kind(ph[i], a.ipt, 8, &tp8), k4 = pick_kind(ph[i], a.ipt, 4, &tp4);
+        if (k8 < 0 || (k4 >= 0 && (long)tp8 * kKinds[k8].NG * kKinds[k8].NF < (long)tp4 * kKinds[k4].NG * kKinds[k4].NF)) nw_run = 4;
     }
     struct Range { const void* p; size_t n; };
     std::vector<Range> ys(n);
@@ -746,7 +759,8 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
         q.TP = best_tp; q.TI = t3 ? best_tp / HW : 0; q.MT = sm_ceil_div(team_px, best_tp); q.NT = sm_ceil_div(d.Cout, ki.NG * ki.NF * 16);
         const int sbch = ki.KG * ki.WCH;
         q.nsb1 = K1 / sbch; q.nsb = (K1 + K2) / sbch;
-        q.RS = t3 ? (d.W + 1 + 7) / 8 * 8 : 8; q.NI = t3 ? (q.TI * (d.H + 1) + 1) * (q.RS / 8) + (q.RS == d.W + 1 ? 1 : 0) : (best_tp + 7) / 8;
+        q.RS = t3 ? (d.W + 1 + 7) / 8 * 8 : 8;
+        q.NI = !t3 ? (best_tp + 7) / 8 : ((best_tp < HW ? best_tp / d.W + 2 : q.TI * (d.H + 1) + 1) * (q.RS / 8) + (q.RS == d.W + 1 ? 1 : 0));   // (3x3: patch rows x 8-slot groups; a band of rows has one halo row above and one below)
         q.x_bytes = (unsigned)xb; q.x2_bytes = (unsigned)x2b; q.res_bytes = (unsigned)rb; q.y_bytes = (unsigned)yb; q.wt_bytes = (unsigned)(ki.NG * ki.NF * 16 * q.K * 2);
         sm_fastdiv_make((unsigned)HW, &q.hw_mul, &q.hw_sh); sm_fastdiv_make((unsigned)d.W, &q.w_mul, &q.w_sh); sm_fastdiv_make((unsigned)(d.H + 1), &q.h1_mul, &q.h1_sh);
         sm_fastdiv_make((unsigned)(q.RS / 8), &q.kpr_mul, &q.kpr_sh);

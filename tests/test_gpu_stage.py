@@ -81,21 +81,22 @@ class Net:
         return act_ref(ref, r["act"], r["slope"]), x.shape[1] * r["k"] ** 2
 
 
-def bottleneck_run(n, hw, cin, mid, blocks, seed, head_src=None, four_waves=False):
+def bottleneck_run(n, hw, cin, mid, blocks, seed, head_src=None, four_waves=False, eight=False):
     """ResNet bottleneck blocks at one resolution: [1x1 cin -> mid, 3x3 mid -> mid, 1x1 mid -> cin + residual] x blocks; with `head_src` (the previous stage's output at twice
     the resolution, cin / 2 channels) the run starts with the K-concatenated expand + projection shortcut of a stage's first block (executor pass 3h)"""
     net = Net(seed, four_waves)
+    ke, kr, kt = (6, 7, 8) if eight else (None, None, None)     # eight: the 8-wave tile forms by name (the planner takes them by itself only where their tiles are as large as the 4-wave forms')
     rng = np.random.default_rng(seed + 1000)
     if head_src:
         t0 = dev(h(np.abs(rng.standard_normal((n, mid, hw, hw)))))
         xin = dev(h(np.abs(rng.standard_normal((n, cin // 2, 2 * hw, 2 * hw)))))
-        cur = net.phase(t0, cin, 1, x2=xin, stride2=2)
+        cur = net.phase(t0, cin, 1, x2=xin, stride2=2, kind=ke)
     else:
         cur = dev(h(np.abs(rng.standard_normal((n, cin, hw, hw)))))
     for _ in range(blocks):
-        r = net.phase(cur, mid, 1)
-        t = net.phase(r, mid, 3)
-        cur = net.phase(t, cin, 1, res=cur)
+        r = net.phase(cur, mid, 1, kind=kr)
+        t = net.phase(r, mid, 3, kind=kt)
+        cur = net.phase(t, cin, 1, res=cur, kind=ke)
     return net
 
 
@@ -143,6 +144,11 @@ SINGLE8 = [
     (16, 7, 512, 512, 3, False, False, 1, 8),      # T8   3x3, two images per tile, two waves per patch slice
     (3, 5, 256, 64, 3, False, False, 1, 8),        # 5 x 5 images: four per tile
     (5, 7, 256, 72, 3, False, True, 2, 8),         # ragged couts, residual, PReLU
+    (8, 14, 256, 256, 3, False, False, 1, 8),      # 14 x 14 images: a tile is a BAND of seven rows (patch = nine rows of one image)
+    (5, 14, 256, 72, 3, False, True, 2, 8),        # bands, ragged batch and couts, residual
+    (3, 12, 256, 64, 3, False, False, 1, 8),       # 12 x 12 images: bands of six rows
+    (8, 14, 256, 256, 3, False, False, 1, 1),      # the 4-wave 3x3 form on bands
+    (4, 28, 256, 64, 3, False, True, 1, 8),        # 28 x 28 images: bands of two rows (four-row patches)
 ]
 
 
@@ -214,14 +220,14 @@ def test_pixel_strides_and_channel_slices():
     check_status(net)
 
 
-# (n, hw, cin, mid, head, four-wave forms only): at 7 x 7 the planner takes the 8-wave forms (two waves per SIMD) unless told otherwise; 14 x 14 has no 8-wave 3x3 form
-@pytest.mark.parametrize("shape", [(16, 7, 2048, 512, True, False), (16, 7, 2048, 512, True, True), (8, 14, 1024, 256, True, False), (16, 7, 2048, 512, False, True), (13, 7, 2048, 512, False, False),
-                                   (11, 14, 1024, 256, False, False)])
+# (n, hw, cin, mid, head, wave count of the tile forms: 4 = the 4-wave forms only, 8 = the 8-wave forms by name, 0 = the planner's choice)
+@pytest.mark.parametrize("shape", [(16, 7, 2048, 512, True, 0), (16, 7, 2048, 512, True, 4), (8, 14, 1024, 256, True, 8), (8, 14, 1024, 256, True, 4), (16, 7, 2048, 512, False, 4),
+                                   (13, 7, 2048, 512, False, 8), (11, 14, 1024, 256, False, 0), (11, 14, 1024, 256, False, 8)])
 def test_run_phase_by_phase_vs_oracle_and_bit_identical_to_single_launches(shape):
-    n, hw, cin, mid, head, four = shape
-    net = bottleneck_run(n, hw, cin, mid, 2, seed=hw + n, head_src=head, four_waves=four)
+    n, hw, cin, mid, head, waves = shape
+    net = bottleneck_run(n, hw, cin, mid, 2, seed=hw + n, head_src=head, four_waves=waves == 4, eight=waves == 8)
     assert net.st.supported()
-    assert all((k >= 6) == (hw == 7 and not four) for k in net.st.kinds()), net.st.kinds()
+    assert waves == 0 or all((k >= 6) == (waves == 8) for k in net.st.kinds()), net.st.kinds()
     fused = run_and_snapshot(net)
     check_status(net)
     for i in range(len(net.recs)):                       # each phase against the oracle on the run's own inputs
@@ -247,14 +253,14 @@ def test_run_phase_by_phase_vs_oracle_and_bit_identical_to_single_launches(shape
     check_status(net)
 
 
-@pytest.mark.parametrize("stage", ["stage4", "stage4-4w", "stage3"])
+@pytest.mark.parametrize("stage", ["stage4", "stage4-4w", "stage3", "stage3-8w"])
 def test_real_shape_run(stage):
     """ResNet-50 bs 64: stage 4 = 64 x 7^2 x 2048 (mid 512, head + 2 blocks: 7 phases), stage 3 = 64 x 14^2 x 1024 (mid 256, head + 5 blocks: 16 phases)"""
     n = 64
     hw, cin, mid, blocks = (7, 2048, 512, 2) if stage.startswith("stage4") else (14, 1024, 256, 5)
-    net = bottleneck_run(n, hw, cin, mid, blocks, seed=11, head_src=True, four_waves=stage.endswith("-4w"))
+    net = bottleneck_run(n, hw, cin, mid, blocks, seed=11, head_src=True, four_waves=stage.endswith("-4w"), eight=stage.endswith("-8w"))
     assert net.st.supported()
-    want = {"stage4": [6] + [7, 8, 6] * 2, "stage4-4w": [2] + [0, 1, 2] * 2, "stage3": [4] + [3, 5, 4] * 5}[stage]
+    want = {"stage4": [6] + [7, 8, 6] * 2, "stage4-4w": [2] + [0, 1, 2] * 2, "stage3": [4] + [3, 5, 4] * 5, "stage3-8w": [6] + [7, 8, 6] * 5}[stage]
     assert net.st.kinds() == want
     fused = run_and_snapshot(net)
     check_status(net)
@@ -304,7 +310,7 @@ def test_rejected_runs():
     w5 = torch.zeros((512, 5, 5, 512), dtype=torch.float16, device="cuda")
     st = ops.Stage(); st.add(x, w5)
     assert not st.supported()
-    big = torch.zeros((8, 28, 28, 512), dtype=torch.float16, device="cuda")   # 784-pixel images: no tile form yet
+    big = torch.zeros((2, 120, 120, 512), dtype=torch.float16, device="cuda")   # rows of 120 pixels: no 3x3 tile form holds even one row
     w3 = torch.zeros((512, 3, 3, 512), dtype=torch.float16, device="cuda")
     st = ops.Stage(); st.add(big, w3)
     assert not st.supported()

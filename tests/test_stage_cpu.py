@@ -73,7 +73,13 @@ def test_resnet50_stage_shapes_get_their_tile_forms():
     assert s4.supported() and s4.kinds() == [6] + [7, 8, 6] * 2          # every phase has an 8-wave form (two waves per SIMD): the run takes them
     s4f = resnet_stage(64, 7, 2048, 512, 2, form=-1)
     assert s4f.supported() and s4f.kinds() == [2] + [0, 1, 2] * 2         # form < 0: the 4-wave forms
-    assert s3.supported() and s3.kinds() == [4] + [3, 5, 4] * 5          # 14 x 14: no 8-wave 3x3 form, so the 4-wave forms for the whole run
+    assert s3.supported() and s3.kinds() == [4] + [3, 5, 4] * 5          # 14 x 14: the 8-wave forms would hold half an image where forms 4 / 5 hold a whole one: the planner stays on four waves
+    s38 = Run(64)                                                         # ... but they take the stage when named: half-image tiles (1x1), bands of seven rows (3x3)
+    t0, xin = s38.tensor(14, 14, 256), s38.tensor(28, 28, 512)
+    cur = s38.add(t0, 1024, 1, x2=xin, stride2=2, form=7)
+    for _ in range(2):
+        cur = s38.add(s38.add(s38.add(cur, 256, 1, form=8), 256, 3, form=9), 1024, 1, res=cur, form=7)
+    assert s38.supported() and s38.kinds() == [6] + [7, 8, 6] * 2
     a, n = s4.arr()
     # control block: 48 header words + 18 phases x (batch rounded up to 16) counters
     assert lib().sm_stage_ctl_bytes(a, n) == (48 + 18 * 64) * 4
@@ -109,9 +115,11 @@ def test_what_the_planner_refuses():
     # channel counts the tile forms do not divide
     r = Run(8); x = r.tensor(7, 7, 96); r.add(x, 512, 1)
     assert not r.supported()
-    # a 3x3 image larger than a tile (28 x 28)
-    r = Run(8); x = r.tensor(28, 28, 256); r.add(x, 256, 3)
+    # a 3x3 image whose rows are longer than a tile (a tile is whole images or a band of whole rows)
+    r = Run(2); x = r.tensor(120, 120, 256); r.add(x, 256, 3)
     assert not r.supported()
+    r = Run(8); x = r.tensor(28, 28, 256); r.add(x, 256, 3)          # bands of two rows
+    assert r.supported()
     # a 5 x 5 kernel
     r = Run(8); x = r.tensor(7, 7, 256); r.add(x, 256, 5)
     assert not r.supported()
