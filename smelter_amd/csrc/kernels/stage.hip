@@ -512,7 +512,7 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     }
 }
 
-// MASK: the tile forms this instantiation holds (bit k = form k).  One kernel with all six pays for the union of their registers (the 208-accumulator forms push the
+// MASK: the tile forms this instantiation holds (bit k = form k); NW: waves of a block (4 or 8: a launch has ONE block size).  One kernel with all six 4-wave forms pays for the union of their registers (the 208-accumulator forms push the
 // others' lane constants to scratch memory); a run of forms 0-2 or 3-5 only gets a kernel of its own.
 template <int MASK, int NW = 4>
 __global__ __launch_bounds__(NW * 64) void stage_kernel(const StArgs a) {
