@@ -1469,9 +1469,10 @@ int Executor::autotune(hipStream_t s) {
         st.desc += " cfg=" + std::to_string(best_cfg);
     }
     // Persistent runs (pass 3k): ONE launch against its layers launched one by one with the configurations just chosen, both behind the two real predecessor launches;
-    // median of 7.  The faster form is kept; a run whose kernel reports a timeout or fell back to the fenced hand-off is turned down.
+    // median of 7 after one untimed launch.  The faster form is kept; a run whose kernel reports a timeout or fell back to the fenced hand-off in a timed launch is turned down.
     for (size_t ri = 0; ri < runs_.size() && !rc; ri++) {
         StageRun& r = runs_[ri];
+        bool first_err = false;
         auto timeForm = [&](bool as_run) -> float {
             std::vector<float> smp;
             for (int it = 0; it < 8 && !rc; it++) {
@@ -1482,6 +1483,7 @@ int Executor::autotune(hipStream_t s) {
                 float t = 0;
                 if (rc || hipEventRecord(b, s) != hipSuccess || hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&t, a, b) != hipSuccess) { rc = rc ? rc : SM_ERR_HIP; return 0.f; }
                 if (it > 0) smp.push_back(t);
+                else if (as_run) { int32_t e0 = 0, m0 = 0; rc = sm_stage_status(stage_ctl_, (sm_stream_t)s, &e0, &m0); if (!rc && e0) first_err = true; }   // (the untimed first launch may be the kernel's first in the process — blocks arriving apart, claimed mode: its mode is not the run's)
             }
             std::sort(smp.begin(), smp.end());
             return smp.empty() ? 0.f : smp[smp.size() / 2];
@@ -1490,7 +1492,7 @@ int Executor::autotune(hipStream_t s) {
         if (rc) break;
         int32_t err = 0, mode = 0;
         rc = sm_stage_status(stage_ctl_, (sm_stream_t)s, &err, &mode); if (rc) break;
-        r.on = err == 0 && mode == 1 && t_run < t_layers;
+        r.on = err == 0 && !first_err && mode == 1 && t_run < t_layers;
         if (getenv("SMELTER_DEBUG_PLAN")) fprintf(stderr, "[plan] persistent run at step %d (%d layers): %.1f us as one launch, %.1f us layer by layer -> %s\n", r.first, r.count, t_run * 1e3f, t_layers * 1e3f, r.on ? "run" : "layers");
     }
     annotateRuns();
