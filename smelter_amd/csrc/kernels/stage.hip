@@ -97,6 +97,10 @@ constexpr int ST_NKINDS = 9;
 // Epilogue of the cout-split forms: 1 (default) = straight from the accumulator layout (16 x 4 lanes = 16 pixels x 64 bytes per instruction: half lines); 0 = through the LDS like the
 // K-split forms (a pixel's 64 couts leave as one 128-byte piece per 8 lanes: whole lines for stores and residual loads).  Measured (profiles/r05_stage_ablation.txt part 5): the LDS round
 // trip costs more than the whole lines save — 14 x 14 expand epilogue 8.2 -> 11.1 us, 7 x 7 3.6 -> 4.6 us, the 7 x 7 run 135 -> 143 us.
+// Plain ReLU in the epilogues as round + packed max instead of compare / multiply / select per value (the 7 x 7 run 125.2 -> 124.4 us; the same values).
+#ifndef ST_RELU_MAX
+#define ST_RELU_MAX 1
+#endif
 // Weight touch (st_touch): 1 = each wave asks the L2 for its fourth of the tile's weight slice at tile start, in front of the wait for the producers; 0 = off.
 #ifndef ST_TOUCH
 #define ST_TOUCH 0
@@ -421,10 +425,19 @@ __device__ __forceinline__ void st_tile(const StPhase& p, const int pix0, const 
     const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.y), 0, (int)(p.res ? p.res_bytes : 0u), 0x00020000);
     typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+    const bool relu0 = p.act != SM_ACT_NONE && sl == 0.f; (void)relu0;
     auto finish = [&](floatx4 a0, floatx4 a1, half8_t rv) -> u32x4s {   // 8 consecutive couts of one pixel: + residual, activation, one rounding
         half8_t ov;
 #pragma unroll
         for (int e = 0; e < 4; e++) { a0[e] += (float)rv[e]; a1[e] += (float)rv[4 + e]; }
+#if ST_RELU_MAX
+        if (relu0) {                                                  // plain ReLU: round, then four packed maxima (rounding is monotone: the same values as max-then-round)
+#pragma unroll
+            for (int e = 0; e < 4; e++) { ov[e] = (half_t)a0[e]; ov[4 + e] = (half_t)a1[e]; }
+            ov = __builtin_elementwise_max(ov, half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+            return __builtin_bit_cast(u32x4s, ov);
+        }
+#endif
 #pragma unroll
         for (int e = 0; e < 4; e++) { ov[e] = (half_t)(a0[e] < 0.f ? a0[e] * sl : a0[e]); ov[4 + e] = (half_t)(a1[e] < 0.f ? a1[e] * sl : a1[e]); }
         return __builtin_bit_cast(u32x4s, ov);
