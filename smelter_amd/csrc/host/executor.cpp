@@ -352,7 +352,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         steps_.push_back(std::move(st));
     }
 
-    // ---- 3a. Conv 3x3 -> MaxPool 2x2 / 2: the pooled tensor is a second output of the weight-stationary convolution kernel (the
+    // ---- 3a. Conv 3x3 -> MaxPool 2x2 / 2: the pooled tensor is a second output of the weight-stationary convolution kernel or of the pooling form of the nine-tap patch kernel (the
     // window is the two fragments of a lane and its neighbour lane); the full-resolution tensor is still written (skip connection).
     // (not with branchConcurrency: the side-branch selection below knows nothing of a step's second output)
     if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency) {

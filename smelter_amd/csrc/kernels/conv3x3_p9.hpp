@@ -19,7 +19,9 @@
 //    upsampled image never exists (MPSCNNUpsamplingNearestNode in front of a convolution, Converters.swift:524).
 #pragma once
 
-template <int BM, int BN, int WGM, int WGN, int NSB = 3>
+// POOL: the 2x2 / stride-2 max-pool of the output is a second output (p.y2) of the same launch — a wave's two fragments are image rows 2k, 2k + 1 of one 32-column band (TW = 32, tiles
+// of 8 whole rows: the launcher checks), neighbouring columns are neighbouring lanes: two packed maxima per 32-bit word, the even lanes store.
+template <int BM, int BN, int WGM, int WGN, int NSB = 3, bool POOL = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p) {
     constexpr int NW = WGM * WGN, NT = NW * 64, TM = BM / (WGM * 32), TN = BN / (WGN * 32);
     constexpr int B_IT = BN * 8 / NT, B_BYTES = BN * 128;
@@ -94,6 +96,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
     // (TM = 4: 144 precomputed fragment addresses do not fit next to 128 accumulator registers — the big tile derives them per tap)
     constexpr bool A_RT = TM > 2;
     unsigned aoff[A_RT ? 1 : TM][A_RT ? 1 : 9][4]; int slotq[TM]; long opix[TM]; bool ovalid[TM];
+    long ppix = 0;                                                    // (POOL) the pooled pixel this lane's column pair / this wave's row pair lands on
 #pragma unroll
     for (int b = 0; b < TM; b++) {
         const long f = f0 + (wm * TM + b) * 32 + l31;
@@ -104,6 +107,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
         const int ox = x0 + xx;
         ovalid[b] = in && ox < W;
         opix[b] = (long)R * W + ox;
+        if constexpr (POOL) { if (b == 0) { const int n = R / H, row = R - n * H; ppix = ((long)n * (H >> 1) + (row >> 1)) * (W >> 1) + (ox >> 1); } }
         slotq[b] = prow0 * PW + xx;
         if constexpr (!A_RT) {
 #pragma unroll
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
             const int co = co0 + 8 * q + 4 * hi;
             bq[q] = (p.bias && co + 3 < p.Cout) ? *(const floatx4*)(p.bias + co) : floatx4{0.f, 0.f, 0.f, 0.f};
         }
+        unsigned pm[4][2];                                            // (POOL) row-pair maximum of this lane's column, packed halves
 #pragma unroll
         for (int b = 0; b < TM; b++) {
             unsigned d[4][2];
@@ -199,6 +204,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
                     v0 = v0 < 0.f ? v0 * sl : v0; v1 = v1 < 0.f ? v1 * sl : v1;
                     const half2_t hv = {(half_t)v0, (half_t)v1};
                     d[q][h2] = __builtin_bit_cast(unsigned, hv);
+                    if constexpr (POOL) {
+                        if (b == 0) pm[q][h2] = d[q][h2];
+                        else pm[q][h2] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(half2_t, pm[q][h2]), hv));
+                    }
                 }
 #pragma unroll
             for (int j = 0; j < 2; j++) {
@@ -206,6 +215,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
                 sm_permlane32_swap(d[2 * j][1], d[2 * j + 1][1]);
                 const int co = co0 + 16 * j + 8 * hi;                 // this lane's 8 consecutive couts
                 if (ovalid[b] && co < p.Cout) *(u32x4*)(p.y + opix[b] * p.y_ld + co) = u32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]};
+            }
+        }
+        if constexpr (POOL) {
+            static_assert(!POOL || TM == 2, "a wave's two fragments are the two rows of a pooling window");
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {                      // the neighbouring column = the neighbouring lane (quad_perm 1, 0, 3, 2)
+                    const unsigned nb = (unsigned)__builtin_amdgcn_update_dpp((int)pm[q][h2], (int)pm[q][h2], 0xB1, 0xf, 0xf, false);
+                    pm[q][h2] = __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(half2_t, pm[q][h2]), __builtin_bit_cast(half2_t, nb)));
+                }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                sm_permlane32_swap(pm[2 * j][0], pm[2 * j + 1][0]);
+                sm_permlane32_swap(pm[2 * j][1], pm[2 * j + 1][1]);
+                const int co = co0 + 16 * j + 8 * hi;
+                if (ovalid[0] && ovalid[1] && !(l31 & 1) && co < p.Cout) *(u32x4*)(p.y2 + ppix * p.y2_ld + co) = u32x4{pm[2 * j][0], pm[2 * j][1], pm[2 * j + 1][0], pm[2 * j + 1][1]};
             }
         }
     }

@@ -570,7 +570,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_lds_kernel(ConvParams p, int cb
 //   kind 9: flags = patch buffers (1 | 2), p0 = KG, p1 = NG, p2 = NF
 //   kind 8: BM = pixels per step (32 FS), BN = channels per block, p0 = Cin of the instantiation; CF_RES = the instantiation that stages a residual tile;
 //           ring form: p1 = stages, p2 = parts the weight slice passes the LDS in (0 = 1); CF_DUAL = takes (only) launches with a second source
-enum { CF_HEAD = 1, CF_XHEAD = 2, CF_W44 = 4, CF_SIDE = 8, CF_RES = 16, CF_DUAL = 32 };
+enum { CF_HEAD = 1, CF_XHEAD = 2, CF_W44 = 4, CF_SIDE = 8, CF_RES = 16, CF_DUAL = 32, CF_POOL = 64 };
 struct TileCfg { int BM, BN, kind, threads; void (*fn)(ConvParams); const char* name; int flags = 0, p0 = 0, p1 = 0, p2 = 0; };
 const TileCfg kCfgs[] = {
     {128, 128, 0, 256, conv_igemm_kernel<128, 128, 2, 2>, "128x128"},
@@ -707,6 +707,8 @@ const TileCfg kCfgs[] = {
     // kind 10 (conv3x3_kqp.hpp): persistent wave-split 3x3 with the whole weight tensor in registers, 16 x 14-pixel tiles; p0 = KG (Cin = 64 KG), p1 = NG (Cout = 32 NG)
     {224, 64, 10, 256, nullptr, "kqp:k2n2 128->64", 0, 2, 2},
     {224, 128, 10, 256, nullptr, "kqp:k1n4 64->128", 0, 1, 4},
+    // kind 5 with the 2x2 / stride-2 max-pool of the output as a second output of the launch (conv3x3_p9.hpp POOL: the U-Net's 128-channel level; the weight-stationary kernel has it for Cin, Cout <= 64)
+    {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 3, true>, "p9:256x128 s3 pool", CF_POOL, 3},
     // ---- build-conditional entries stay BEHIND the product pool so that product indices do not depend on the build ----
 #ifdef SM_ABLATION   // the single-role expand head (conv3x3_ws.hpp HX): 16 of 55 us added to the 3x3; the two-role kernel replaced it
     {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead", CF_XHEAD, 64},
@@ -886,7 +888,7 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
         if (ok && p.y2) return c.BM / (c.threads / 64) == 64 && q.ws_TW == 32 && (q.ws_TH & 1) == 0 && (p.H & 1) == 0 && (p.W & 1) == 0 && (p.y2_ld & 7) == 0 && ((((uintptr_t)p.y2) & 15) == 0);
         return ok;
     }
-    if (p.y2 || p.y3) return false;                                  // only the weight-stationary kernel writes the pooled second output / applies a head
+    if (p.y3 || (p.y2 && !(c.kind == 5 && (c.flags & CF_POOL)))) return false;   // only the weight-stationary kernel applies a head; it and the pooling form of the patch kernel write the pooled second output
     if (c.kind == 8)     // weights in registers: 1x1 / stride 1 / no padding, Cin = the instantiation's, Cout a multiple of the block's slice, dense 16-byte rows, ReLU family
         return p.kH == 1 && p.kW == 1 && p.pt == 0 && p.pl == 0 && p.sH == 1 && p.sW == 1 && p.Ho == p.H && p.Wo == p.W && p.Cin == c.p0 && (p.Cout % c.BN) == 0 && p.Cout / c.BN <= 32 &&
                !p.ups && !p.yplace && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 && ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.x) & 15) == 0) &&
@@ -919,8 +921,12 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
     }
     if (c.kind == 5) {   // nine-tap patch kernel: no residual, dense 16-byte rows, ReLU family
         ConvParams q = p;
-        return same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 &&
+        if (((c.flags & CF_POOL) != 0) != (p.y2 != nullptr)) return false;
+        const bool ok = same3x3 && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 &&
                ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) && p9_setup(q, c) > 0;
+        // pooling form: 32-column bands, tiles of BM / 32 whole rows that never straddle two images, even sizes, a stored full-resolution output
+        if (ok && p.y2) return !p.ups && p.y && q.p9_TW == 32 && (p.W % 32) == 0 && (p.H % (c.BM / 32)) == 0 && (p.y2_ld & 7) == 0 && ((((uintptr_t)p.y2) & 15) == 0);
+        return ok;
     }
     if ((p.Cin % 64) != 0 || p.kH * p.kW > 32) return false;
     if (c.kind == 1) return true;
@@ -1170,7 +1176,7 @@ int sm_conv2d_pool_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const 
     SM_REQUIRE(d && d->groups == 1, "sm_conv2d_pool_fwd_cfg: grouped convolutions have no fused max-pool");
     ConvParams p; int rc = fill_params(d, x, w, bias, nullptr, y, &p); if (rc) return rc;
     p.y2 = (half_t*)y_pool; p.y2_ld = pool_ld ? pool_ld : d->Cout;
-    if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) cfg = i; }
+    if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if ((kCfgs[i].kind == 4 || (kCfgs[i].kind == 5 && (kCfgs[i].flags & CF_POOL))) && cfg_eligible(kCfgs[i], p)) cfg = i; }
     if (cfg < 0) { sm_set_error("sm_conv2d_pool_fwd_cfg: no kernel takes this shape with a fused max-pool (3x3 / s1 / p1, Cin, Cout in {32, 64}, W %% 32 == 0, even H)"); return SM_ERR_INVALID_ARGUMENT; }
     return launch(d, p, cfg, nullptr, 0, sm_s(stream));
 }
@@ -1179,7 +1185,7 @@ int sm_conv2d_pool_supported(const sm_conv_desc* d) {
     alignas(16) static char dummy[16];
     ConvParams p; if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
     p.y2 = (half_t*)dummy; p.y2_ld = d->Cout;
-    for (int i = 0; i < kNumCfgs; i++) if (kCfgs[i].kind == 4 && cfg_eligible(kCfgs[i], p)) return 1;
+    for (int i = 0; i < kNumCfgs; i++) if ((kCfgs[i].kind == 4 || (kCfgs[i].kind == 5 && (kCfgs[i].flags & CF_POOL))) && cfg_eligible(kCfgs[i], p)) return 1;
     return 0;
 }
 

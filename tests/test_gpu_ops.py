@@ -883,6 +883,31 @@ def test_conv3x3_with_fused_maxpool(n, hw, cin, cout, act, cfg):
     assert np.array_equal(to_host(yp), O.maxpool(to_host(y), (2, 2), (2, 2), (0, 0)))
 
 
+@pytest.mark.parametrize("n,hw,cin,cout,act", [(2, (64, 64), 64, 128, 1), (1, (16, 96), 128, 128, 2), (3, (8, 32), 64, 72, 1), (1, (128, 128), 64, 128, 1)])
+def test_conv3x3_patch_kernel_with_fused_maxpool(n, hw, cin, cout, act):
+    """the pooling form of conv3x3_p9.hpp (wider layers than the weight-stationary kernel takes: the U-Net's 128-channel level): y bit-identical to the plain launch of
+    the same tile shape, pooled == max-pool of y (exact); shapes it cannot take (W % 32, H % 8) are refused, not mis-pooled"""
+    cfg = [c for c in ALL_CFGS if ops.config_name(c) == "p9:256x128 s3 pool"][0]
+    plain = [c for c in ALL_CFGS if ops.config_name(c) == "p9:256x128 s3"][0]
+    rng = np.random.default_rng(cin + cout + hw[1])
+    x = h(rng.standard_normal((n, cin, hw[0], hw[1])))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * np.sqrt(2.0 / (cin * 9))); b = rng.standard_normal(cout).astype(np.float32)
+    slope = 0.25 if act == 2 else 0.0
+    wd, bd = torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda()
+    y, yp = ops.conv2d_pool(to_dev(x), wd, bd, act=act, slope=slope, cfg=cfg)
+    ref = O.conv2d(x, w, b, stride=(1, 1), pads=(1, 1, 1, 1))
+    ref = np.where(ref >= 0, ref, ref * slope)
+    assert_close(to_host(y), ref, cin * 9)
+    assert np.array_equal(to_host(yp), O.maxpool(to_host(y), (2, 2), (2, 2), (0, 0)))
+    y0 = ops.conv2d(to_dev(x), wd, bd, pads=(1, 1, 1, 1), act=act, slope=slope, cfg=plain)
+    assert torch.equal(y0, y)
+    from smelter_amd._native import SmelterError
+    for bad in ((12, 32), (16, 48)):                                  # H % 8 != 0; W % 32 != 0
+        xb = to_dev(h(rng.standard_normal((1, cin, bad[0], bad[1]))))
+        with pytest.raises(SmelterError):
+            ops.conv2d_pool(xb, wd, bd, act=act, slope=slope, cfg=cfg)
+
+
 @pytest.mark.parametrize("shape", [
     # n, C, H, W, cout, k, stride, pads
     (2, 3, 64, 64, 64, 7, 2, (3, 3, 3, 3)),      # ResNet-50 class
