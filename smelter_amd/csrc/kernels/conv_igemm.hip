@@ -1177,7 +1177,7 @@ int sm_conv2d_pool_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const 
     ConvParams p; int rc = fill_params(d, x, w, bias, nullptr, y, &p); if (rc) return rc;
     p.y2 = (half_t*)y_pool; p.y2_ld = pool_ld ? pool_ld : d->Cout;
     if (cfg < 0 || cfg >= kNumCfgs) { cfg = -1; for (int i = 0; i < kNumCfgs && cfg < 0; i++) if ((kCfgs[i].kind == 4 || (kCfgs[i].kind == 5 && (kCfgs[i].flags & CF_POOL))) && cfg_eligible(kCfgs[i], p)) cfg = i; }
-    if (cfg < 0) { sm_set_error("sm_conv2d_pool_fwd_cfg: no kernel takes this shape with a fused max-pool (3x3 / s1 / p1, Cin, Cout in {32, 64}, W %% 32 == 0, even H)"); return SM_ERR_INVALID_ARGUMENT; }
+    if (cfg < 0) { sm_set_error("sm_conv2d_pool_fwd_cfg: no kernel takes this shape with a fused max-pool (3x3 / s1 / p1; Cin, Cout in {32, 64}, W %% 32 == 0, even H — or Cin %% 64 == 0, W %% 32 == 0, H %% 8 == 0)"); return SM_ERR_INVALID_ARGUMENT; }
     return launch(d, p, cfg, nullptr, 0, sm_s(stream));
 }
 int sm_conv2d_pool_supported(const sm_conv_desc* d) {
