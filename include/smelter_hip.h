@@ -120,7 +120,7 @@ int sm_conv2d_dual_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const 
 
 /* MPSCNNConvolutionNode (3x3 / stride 1 / pad 1, Cin, Cout in {32, 64}) + the MPSCNNPoolingMaxNode (2x2 / stride 2, Converters.swift:662)
  * that consumes it, in ONE launch; both the full-resolution tensor `y` (the U-Net's skip connection) and the pooled one are written.
- * W % 32 == 0, H even.  cfg < 0 picks a configuration. */
+ * W % 32 == 0, H even.  Wider layers (Cin % 64 == 0, any Cout; W % 32 == 0, H % 8 == 0) go to the pooling form of the nine-tap patch kernel.  cfg < 0 picks a configuration. */
 int sm_conv2d_pool_supported(const sm_conv_desc* d);
 int sm_conv2d_pool_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, const void* w_ohwi, const float* bias, void* y,
                            void* y_pool, int32_t pool_ld, sm_stream_t stream);
