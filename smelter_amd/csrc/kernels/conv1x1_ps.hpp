@@ -131,6 +131,7 @@ __global__ __launch_bounds__((WGM * WGN + 4) * 64) void conv1x1_ps_kernel(ConvPa
         for (int ks = 0; ks < 4; ks++) voff[ks] = l31 * 128 + (((ks * 2 + hi) ^ sw) << 4);
     }
     const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;              // f(v) = v < 0 ? v*sl : v  (ReLU family only: launcher)
+    const bool relu0 = p.act != SM_ACT_NONE && sl == 0.f;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     floatx16 acc[TN][TM];
     u32x4 outv[TN][TM][2];                                              // finished tile waiting for its stores: [a][b][j] = couts a*32 + 16j + 8hi .. +7 of pixel b
@@ -244,7 +245,8 @@ __global__ __launch_bounds__((WGM * WGN + 4) * 64) void conv1x1_ps_kernel(ConvPa
                         }
                         half8_t o;
 #pragma unroll
-                        for (int k = 0; k < 8; k++) o[k] = (half_t)(v[k] < 0.f ? v[k] * sl : v[k]);
+                        for (int k = 0; k < 8; k++) o[k] = relu0 ? (half_t)v[k] : (half_t)(v[k] < 0.f ? v[k] * sl : v[k]);
+                        if (relu0) o = __builtin_elementwise_max(o, half8_t{0, 0, 0, 0, 0, 0, 0, 0});   // plain ReLU: round, then four packed maxima (the same values)
                         outv[a][b][j] = __builtin_bit_cast(u32x4, o);
                         if (!DEFER) { pm0 = m0; pn0 = n0; store_one(a, b, j); }
                     }

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
 
     // ---- epilogue in registers: register 4q+r of acc[a][b] <-> cout (wn*TN+a)*32 + 8q + 4*hi + r of pixel (wm*TM+b)*32 + (lane & 31) ----
     const float sl = p.act == SM_ACT_NONE ? 1.f : p.slope;
+    const bool relu0 = p.act != SM_ACT_NONE && sl == 0.f;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int a = 0; a < TN; a++) {
@@ -201,8 +202,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv3x3_p9_kernel(ConvParams p
 #pragma unroll
                 for (int h2 = 0; h2 < 2; h2++) {
                     float v0 = acc[a][b][4 * q + 2 * h2] + bq[q][2 * h2], v1 = acc[a][b][4 * q + 2 * h2 + 1] + bq[q][2 * h2 + 1];
-                    v0 = v0 < 0.f ? v0 * sl : v0; v1 = v1 < 0.f ? v1 * sl : v1;
-                    const half2_t hv = {(half_t)v0, (half_t)v1};
+                    if (!relu0) { v0 = v0 < 0.f ? v0 * sl : v0; v1 = v1 < 0.f ? v1 * sl : v1; }
+                    half2_t hv = {(half_t)v0, (half_t)v1};
+                    if (relu0) hv = __builtin_elementwise_max(hv, half2_t{0, 0});   // plain ReLU: round, then one packed maximum (the same values: rounding is monotone)
                     d[q][h2] = __builtin_bit_cast(unsigned, hv);
                     if constexpr (POOL) {
                         if (b == 0) pm[q][h2] = d[q][h2];
