@@ -1469,7 +1469,7 @@ int Executor::autotune(hipStream_t s) {
         st.desc += " cfg=" + std::to_string(best_cfg);
     }
     // Persistent runs (pass 3k): ONE launch against its layers launched one by one with the configurations just chosen, both behind the two real predecessor launches;
-    // median of 7 after one untimed launch.  The faster form is kept; a run whose kernel reports a timeout or fell back to the fenced hand-off in a timed launch is turned down.
+    // median of 7 after one untimed launch.  The faster form is kept; a run whose kernel reports a timeout or never ran in the XCD-local mode is turned down.
     for (size_t ri = 0; ri < runs_.size() && !rc; ri++) {
         StageRun& r = runs_[ri];
         bool first_err = false;
@@ -1492,7 +1492,7 @@ int Executor::autotune(hipStream_t s) {
         if (rc) break;
         int32_t err = 0, mode = 0;
         rc = sm_stage_status(stage_ctl_, (sm_stream_t)s, &err, &mode); if (rc) break;
-        r.on = err == 0 && !first_err && mode == 1 && t_run < t_layers;
+        r.on = err == 0 && !first_err && (mode & 1) && t_run < t_layers;   // (a timed launch that fell back to the claimed mode is in the median it lost time in: the clock decides)
         if (getenv("SMELTER_DEBUG_PLAN")) fprintf(stderr, "[plan] persistent run at step %d (%d layers): %.1f us as one launch, %.1f us layer by layer -> %s\n", r.first, r.count, t_run * 1e3f, t_layers * 1e3f, r.on ? "run" : "layers");
     }
     annotateRuns();

@@ -729,7 +729,7 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
     memset(&a, 0, sizeof a);
     const int N = ph[0].d.N;
     ST_REQ(N >= 1 && N <= 4096, "sm_stage: batch %d", N);
-    a.nphase = n; a.N = N; a.ipt = sm_ceil_div(N, ST_NTEAM); a.spin_limit = 1000000; a.arrive_limit = 200; a.touch = ST_TOUCH_BYTES; a.cnt_ld = (N + 15) / 16 * 16;
+    a.nphase = n; a.N = N; a.ipt = sm_ceil_div(N, ST_NTEAM); a.spin_limit = 1000000; a.arrive_limit = 800;   /* polls of 64 clk: ~20 us for the last block of the previous launch to make room before the launch gives up on the static mode */ a.touch = ST_TOUCH_BYTES; a.cnt_ld = (N + 15) / 16 * 16;
     size_t lds = 0;
     // block size of the launch: the 8-wave forms (two waves per SIMD) when EVERY phase has one whose tile is no smaller than its 4-wave form's — same tile, the waves' stalls overlapped:
     // the 7 x 7 stage; at 14 x 14 the 8-wave forms hold half an image where forms 4 / 5 hold a whole one, and two tiles per CU pay the per-tile chain twice (365 against 352 us).
