@@ -1,7 +1,8 @@
 """Per-phase timeline of ONE sm_stage_fwd run (diagnostic build: tools/stage_tl.sh, SMELTER_LIB_PATH=build/libsmelter_hip_stagetl.so).
 Every block stamps the 100 MHz wall clock (the same counter on every XCD) per tile: 0 tile start (weights requested), 1 producers published + block synchronised,
 2 first patch landed, 3 main loop done, 4 epilogue done (stores issued), 5 stores drained + published.  Printed per phase: when the first / last tile of the phase starts and
-ends (us after the first stamp of the kernel), and the average length of each segment.  Usage: python tools/stage_tl.py [stage4|stage3] [reps]"""
+ends (us after the first stamp of the kernel), and the average length of each segment.  Usage: python tools/stage_tl.py [stage4|stage3] [4w] [nopack]   (4w: the 4-wave tile forms only)
+       python tools/stage_tl.py formK:SHAPE   four independent phases of one shape on tile form K (expand7 | reduce7 | conv7 | expand14 | reduce14 | conv14)"""
 import ctypes as C
 import sys
 import numpy as np
