@@ -87,7 +87,7 @@ def measure_secondary(key, a, local, stream, **model_kw):
         roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                 "byte_model": "post-fusion compulsory bytes (smelter_exec_launch_bytes)", "basis": "bytes the launches must move / whole-step time"}
     res = {"metric": metric, "value": round(batch * 1e3 / wall_ms, 1), "unit": "images/s", "ms_per_step": round(wall_ms, 4), "ms_per_step_hip_events": round(ev_ms, 4),
-           "steps": a.steps, "warmup": a.warmup, "launches_per_step": ex.numLaunches, "config": {"workload": workload % batch}, "roofline": roof}
+           "steps": a.steps, "warmup": a.warmup, "launches_per_step": ex.numLaunches, "config": {"workload": workload % batch, "persistent_runs": ex.persistentRuns}, "roofline": roof}
     del ex, x
     torch.cuda.empty_cache()
     return res
@@ -197,7 +197,9 @@ def main():
                "data": "synthetic", "mfma_peak_frac": round(flops_step / (ms_per_step * 1e-3) / (MFMA_PEAK_TFLOPS * 1e12), 4),
                "config": {"workload": workload % batch,
                           "global_batch": batch * world, "parallelism": "batch-shard x%d (RCCL weight broadcast, no data-path collective)" % world,
-                          "launches_per_step": ex.numLaunches, "hip_graph": True, "compile_s": round(compile_s, 2)},
+                          "launches_per_step": ex.numLaunches, "hip_graph": True, "compile_s": round(compile_s, 2),
+                          # which persistent runs the timed path really launched as one kernel, and the two medians the compile's A/B decided on
+                          "persistent_runs": ex.persistentRuns},
                "timing": {"regions": len(regions), "steps_per_region": a.steps, "ms_per_step_median": round(regions[len(regions) // 2], 4),
                           "ms_per_step_min": round(regions[0], 4), "ms_per_step_max": round(regions[-1], 4), "clock": "HIP events on the launch stream"}}
         if shard_check is not None:

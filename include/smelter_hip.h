@@ -465,6 +465,26 @@ const void* smelter_exec_output_device(const smelter_exec* e);
 /* introspection used by tests / bench */
 int smelter_exec_num_launches(const smelter_exec* e);       /* kernels per encode after fusion */
 int smelter_exec_num_ops(const smelter_exec* e);            /* op records after fusion */
+/* Persistent runs of this executor (executor pass 3k; the reference's MPSNNGraph has no counterpart, ONNXGraph.swift:185-190 hands every node to MPS) and what the compile's in-situ
+ * A/B measured for each: a host reads here which layers leave in one launch, which form the clock picked and why a run was turned down (bench.py prints it as config.persistent_runs). */
+enum { SM_RUN_ON = 0,            /* the run is launched as one kernel */
+       SM_RUN_OFF_SLOWER = 1,    /* the A/B measured the run more than 3 % slower than its layers */
+       SM_RUN_OFF_TIMEOUT = 2,   /* a hand-off wait ran out during the A/B (results undefined: never kept) */
+       SM_RUN_OFF_CLAIMED = 4,   /* no timed launch ran in the static XCD-local mode (the 256 blocks were never co-resident in time) */
+       SM_RUN_OFF_DEVICE = 8,    /* the device has fewer than 256 compute units / is partitioned (sm_stage_device_fast) */
+       SM_RUN_OFF_PLAN = 16 };   /* an imported plan (smelter_graph_compile_with_plan) carried it turned down */
+typedef struct smelter_run_info {
+    int32_t first_step, layers;  /* steps [first_step, first_step + layers) of the op list */
+    int32_t on;                  /* 1: launched as ONE sm_stage_fwd */
+    int32_t timed;               /* 1: the fields below were measured by this compile (autotune on); 0: default / imported decision */
+    int32_t samples;             /* timed launches per form (interleaved, medians) */
+    int32_t mode_bits;           /* hand-off modes of the timed launches, OR-ed (sm_stage_status: 1 = static XCD-local, 2 = claimed) */
+    int32_t err_bits;            /* sm_stage_status error bits seen during the A/B */
+    int32_t why_off;             /* SM_RUN_OFF_* bits, 0 when on */
+    float t_run_us, t_layers_us; /* median time of the run as one launch / of its layers launched one by one, behind the two real predecessor launches */
+} smelter_run_info;
+int smelter_exec_num_runs(const smelter_exec* e);
+int smelter_exec_run_info(const smelter_exec* e, int32_t idx, smelter_run_info* out);
 size_t smelter_exec_weight_bytes(const smelter_exec* e);
 void* smelter_exec_weight_arena(const smelter_exec* e);
 size_t smelter_exec_activation_bytes(const smelter_exec* e);

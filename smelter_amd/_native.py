@@ -64,6 +64,12 @@ class Shape(C.Structure):
 # every symbol include/smelter_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _f, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _pi32 = C.POINTER(C.c_int32)
+class RunInfo(C.Structure):
+    """smelter_run_info (include/smelter_hip.h): one persistent run of an executor and what the compile's in-situ A/B measured for it"""
+    _fields_ = [("first_step", C.c_int32), ("layers", C.c_int32), ("on", C.c_int32), ("timed", C.c_int32), ("samples", C.c_int32), ("mode_bits", C.c_int32),
+                ("err_bits", C.c_int32), ("why_off", C.c_int32), ("t_run_us", C.c_float), ("t_layers_us", C.c_float)]
+
+
 SYMBOLS = {
     "smelter_last_error_string": (C.c_char_p, []),
     "smelter_version": (C.c_char_p, []),
@@ -170,6 +176,8 @@ SYMBOLS = {
     "smelter_exec_output_device": (_vp, [_vp]),
     "smelter_exec_num_launches": (_i32, [_vp]),
     "smelter_exec_num_ops": (_i32, [_vp]),
+    "smelter_exec_num_runs": (_i32, [_vp]),
+    "smelter_exec_run_info": (_i32, [_vp, _i32, C.POINTER(RunInfo)]),
     "smelter_exec_weight_bytes": (_sz, [_vp]),
     "smelter_exec_weight_arena": (_vp, [_vp]),
     "smelter_exec_activation_bytes": (_sz, [_vp]),

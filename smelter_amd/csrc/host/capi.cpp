@@ -125,6 +125,14 @@ int smelter_exec_read_float(smelter_exec* e, sm_stream_t s, float* dst, size_t c
 const void* smelter_exec_output_device(const smelter_exec* e) { return e ? e->e->outputDevice() : nullptr; }
 int smelter_exec_num_launches(const smelter_exec* e) { return e ? e->e->numLaunches() : 0; }
 int smelter_exec_num_ops(const smelter_exec* e) { return e ? e->e->numOps() : 0; }
+int smelter_exec_num_runs(const smelter_exec* e) { return e ? e->e->numRuns() : 0; }
+int smelter_exec_run_info(const smelter_exec* e, int32_t idx, smelter_run_info* out) {
+    SM_REQUIRE(e && out, "smelter_exec_run_info: null argument");
+    const StageRun* r = e->e->run(idx);
+    SM_REQUIRE(r, "smelter_exec_run_info: this executor has %d persistent runs, index %d", e->e->numRuns(), idx);
+    *out = smelter_run_info{r->first, r->count, r->on ? 1 : 0, r->timed ? 1 : 0, r->samples, r->mode_bits, r->err_bits, r->why_off, r->t_run_us, r->t_layers_us};
+    return SM_OK;
+}
 size_t smelter_exec_weight_bytes(const smelter_exec* e) { return e ? e->e->weightBytesUsed() : 0; }
 void* smelter_exec_weight_arena(const smelter_exec* e) { return e ? e->e->weightArena() : nullptr; }
 size_t smelter_exec_activation_bytes(const smelter_exec* e) { return e ? e->e->activationBytes() : 0; }

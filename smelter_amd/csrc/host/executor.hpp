@@ -64,7 +64,12 @@ struct Step {                // one op after fusion, with everything resolved
 };
 
 // pass 3k: steps [first, first + count) — plain 1x1 / 3x3 stride-1 convolutions at one resolution — run as ONE persistent launch (sm_stage_fwd) when `on`
-struct StageRun { int first = 0, count = 0; bool on = true, wide = false; };
+struct StageRun {
+    int first = 0, count = 0; bool on = true, wide = false;
+    // what the compile's in-situ A/B measured (autotune): medians over `samples` interleaved launches of each form, the hand-off modes the timed
+    // launches ran in, whether a hand-off wait ever ran out, and why the run was turned down (SM_RUN_* of smelter_hip.h; 0 = not turned down)
+    bool timed = false; float t_run_us = 0.f, t_layers_us = 0.f; int samples = 0, mode_bits = 0, err_bits = 0, why_off = 0;
+};
 
 class Executor {
    public:
@@ -94,6 +99,8 @@ class Executor {
     const void* outputDevice() const;
     int numLaunches() const { return numLaunchesNow(); }
     int numOps() const { return (int)steps_.size(); }
+    int numRuns() const { return (int)runs_.size(); }
+    const StageRun* run(int i) const { return i >= 0 && i < (int)runs_.size() ? &runs_[i] : nullptr; }
     size_t weightBytesUsed() const { return arena_bytes_; }
     void* weightArena() const { return arena_; }
     size_t activationBytes() const { return act_bytes_; }

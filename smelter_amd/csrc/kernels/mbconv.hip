@@ -911,7 +911,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
                     const float a = accA[q0 >> 4][q0 & 15], b = (2 * q + 1 < WC) ? accA[q1 >> 4][q1 & 15] : 0.f;
                     half2_t o;
                     if constexpr (RELU != 0) { o[0] = (half_t)a; o[1] = (half_t)b; o = __builtin_elementwise_max(o, half2_t{0, 0}); if constexpr (RELU == 2) o = __builtin_elementwise_min(o, half2_t{(half_t)p.hi1, (half_t)p.hi1}); }
-                    else { o[0] = (half_t)relu_family<false>(a, p.sl1, p.hi1); o[1] = (half_t)relu_family<false>(b, p.sl1, p.hi1); }
+                    else { o[0] = (half_t)relu_family<true>(a, p.sl1, p.hi1); o[1] = (half_t)relu_family<true>(b, p.sl1, p.hi1); }   // (<true> — act1 = Clip next to a non-ReLU act2 lands here; a bound of +inf is a no-op min)
                     hw[py][q] = __builtin_bit_cast(unsigned, o);
                 }
             // ---- phase B: depthwise 3x3 over the lane's window: TH x 4 outputs, nine fp32 FMAs each -------------------------------------------------------------------
@@ -938,7 +938,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
                 });
                 half2_t o;
                 if constexpr (RELU != 0) { o[0] = (half_t)a2[0]; o[1] = (half_t)a2[1]; o = __builtin_elementwise_max(o, half2_t{0, 0}); if constexpr (RELU == 2) o = __builtin_elementwise_min(o, half2_t{(half_t)p.hi2, (half_t)p.hi2}); }
-                else { o[0] = (half_t)relu_family<false>(a2[0], p.sl2, p.hi2); o[1] = (half_t)relu_family<false>(a2[1], p.sl2, p.hi2); }
+                else { o[0] = (half_t)relu_family<true>(a2[0], p.sl2, p.hi2); o[1] = (half_t)relu_family<true>(a2[1], p.sl2, p.hi2); }
                 *(half_t*)(dwo + woff[2 * op2] + oy * TW * HS) = o[0];
                 *(half_t*)(dwo + woff[2 * op2 + 1] + oy * TW * HS) = o[1];
             });
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
                             for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)o[r2];
                         } else {
 #pragma unroll
-                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family<false>(o[r2], p.sl3, p.hi3);
+                            for (int r2 = 0; r2 < 8; r2++) ov[r2] = (half_t)relu_family<true>(o[r2], p.sl3, p.hi3);
                         }
                         *(half8_t*)(p.y + opix * p.y_ld + co) = ov;
                     }

@@ -243,6 +243,19 @@ class Executor:
         L = N.lib()
         return [L.smelter_exec_value_name(self._h, i).decode() for i in range(L.smelter_exec_num_values(self._h)) if L.smelter_exec_value_stored(self._h, i)]
 
+    @property
+    def persistentRuns(self):
+        """the persistent runs of this executor (executor pass 3k) with what the compile's A/B measured: a list of dicts, one per run (smelter_exec_run_info)"""
+        L = N.lib()
+        out = []
+        for i in range(L.smelter_exec_num_runs(self._h)):
+            r = N.RunInfo()
+            N.check(L.smelter_exec_run_info(self._h, i, C.byref(r)))
+            why = [name for bit, name in ((1, "slower"), (2, "timeout"), (4, "claimed_mode_only"), (8, "device"), (16, "imported_plan")) if r.why_off & bit]
+            out.append({"first_step": r.first_step, "layers": r.layers, "on": bool(r.on), "timed": bool(r.timed), "samples": r.samples,
+                        "t_run_us": round(r.t_run_us, 1), "t_layers_us": round(r.t_layers_us, 1), "mode_bits": r.mode_bits, "first_err": r.err_bits, "why_off": why})
+        return out
+
     def opDesc(self, idx: int) -> str:
         return N.lib().smelter_exec_op_desc(self._h, idx).decode()
 

@@ -811,6 +811,46 @@ def test_mbconv_relu6_clip(hw, cin, ch, cout, stride, res):
     assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
 
 
+@pytest.mark.parametrize("acts,slopes", [
+    ((12, 12, 12), (6.0, 6.0, 2.0)),      # Clip behind all three layers: the bound on the PROJECT layer was dropped by the register-window kernel
+    ((12, 0, 0), (6.0, 0.0, 0.0)),        # Clip next to a linear depthwise layer: the kernel's general-activation branch (RELU == 0) must keep the bound
+    ((12, 2, 12), (6.0, 0.1, 1.5)),       # Clip, leaky ReLU, Clip
+    ((1, 12, 12), (0.0, 4.0, 3.0)),       # plain ReLU, then two different bounds
+])
+@pytest.mark.parametrize("hw,cin,ch,cout,stride,res", [
+    ((56, 56), 24, 144, 24, 1, True),      # register-window kernel (kind 5)
+    ((56, 56), 24, 144, 32, 2, False),     # ... stride 2
+    ((14, 14), 64, 384, 64, 1, True),      # one image per block (kind 4)
+    ((20, 24), 16, 96, 24, 1, False),      # all-in-LDS / chunked domain
+])
+def test_mbconv_clip_every_layer(hw, cin, ch, cout, stride, res, acts, slopes):
+    """SM_ACT_CLIP on any of the three layers of a fused inverted-residual block, mixed with the other members of the ReLU family — every block kernel the
+    descriptor can land on must apply each layer's own bound (12 = SM_ACT_CLIP with the bound in `slope`, 1 = ReLU, 2 = leaky ReLU, 0 = none)"""
+    import ctypes
+    from smelter_amd._native import MbConvDesc
+    so = lambda v: (v + 2 - 3) // stride + 1
+    dsc = MbConvDesc(2, hw[0], hw[1], so(hw[0]), so(hw[1]), stride, cin, ch, cout, 1, 1 if res else 0, acts[0], slopes[0], acts[1], slopes[1], acts[2], slopes[2], cin, cout)
+    if not ops.lib().sm_mbconv_supported(ctypes.byref(dsc)):
+        pytest.skip("no fused kernel takes this geometry / activation triple (the executor keeps the three launches)")
+    def act(v, a, sl):
+        return np.clip(v, 0, sl) if a == 12 else np.maximum(v, 0) if a == 1 else np.where(v < 0, v * sl, v) if a == 2 else v
+    rng = np.random.default_rng(cin + ch + cout + stride + sum(acts))
+    x = h(rng.standard_normal((2, cin, hw[0], hw[1])) * 3)
+    w1 = h(rng.standard_normal((ch, 1, 1, cin)) * np.sqrt(2.0 / cin)); b1 = rng.standard_normal(ch).astype(np.float32)
+    wd = h(rng.standard_normal((ch, 3, 3, 1)) * np.sqrt(2.0 / 9) * 2); bd = rng.standard_normal(ch).astype(np.float32)
+    w2 = h(rng.standard_normal((cout, 1, 1, ch)) * np.sqrt(4.0 / ch)); b2 = rng.standard_normal(cout).astype(np.float32)
+    hid = h(act(O.conv2d(x, w1, b1), acts[0], slopes[0]))
+    hid2 = h(act(O.conv2d(hid, wd, bd, stride=(stride, stride), pads=(1, 1, 1, 1), groups=ch), acts[1], slopes[1]))
+    pre = O.conv2d(hid2, w2, b2) + (x if res else 0)
+    ref = act(pre, acts[2], slopes[2])
+    if acts[2] == 12:
+        assert (pre > slopes[2]).mean() > 0.02, "the test data must reach the project layer's bound"
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    got = to_host(ops.mbconv(to_dev(x), dev(w1).half(), dev(b1), dev(wd.reshape(ch, 3, 3)).half(), dev(bd), dev(w2).half(), dev(b2), stride=stride, residual=res, acts=acts, slopes=slopes))
+    ref16 = h(ref)
+    assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
+
+
 @pytest.mark.parametrize("n,c,hw,cout,stride,pad,act,slope", [
     (2, 3, (64, 64), 32, 2, 1, 12, 6.0),               # ReLU6 behind the stem (SM_ACT_CLIP), as MobileNet-v2's first layer holds it
     (2, 1, (70, 45), 32, 1, 1, ops.ACT_RELU, 0.0),     # U-Net's first layer (one plane), ragged block tiles
