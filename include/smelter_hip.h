@@ -150,6 +150,24 @@ int sm_conv2d_xhead_proj_fwd_cfg(const sm_conv_desc* d, int cfg, const void* x, 
                                  int32_t n3, int32_t act3, float slope3, const void* xs, int32_t xs_ld, const void* ws, void* y3, int32_t y3_ld,
                                  sm_stream_t stream);
 
+/* A whole bottleneck block as ONE tile pass (csrc/kernels/bneck.hip): three ConvolutionConverter nodes (Converters.swift:187-338) — 1x1 reduce C0 -> Cm, 3x3 / stride 1 /
+ * pad 1 Cm -> Cm, 1x1 expand Cm -> C3 — each with its ReluConverter (:342-359), and the AddConverter (:430-451) of the identity shortcut:
+ *     y = act3(w3 . act2(conv3x3(act1(w1 . x + b1)) + b2) + b3 + res)
+ * The two hidden tensors exist in the LDS only, rounded to fp16 there exactly as the layer-by-layer launches round them on their way to memory; x is read once per tile
+ * (+ a one-pixel halo) and `res` (NULL: none; normally x itself) once.  Taken: Cm = 64, C0 in {64, 128, 256}, C3 = 32 .. 256 (% 32 == 0), activations of the ReLU family
+ * (none / ReLU / leaky with one slope), every tensor below 2 GB.  Weights: w1 [Cm][C0], w2 [Cm][3][3][Cm] (OHWI), w3 [C3][Cm], fp16; biases fp32 or NULL. */
+typedef struct sm_bneck_desc {
+    int32_t N, H, W;                /* batch, spatial size (the block keeps it) */
+    int32_t C0, Cm, C3;             /* channels: block input, hidden (both hidden tensors), block output */
+    int32_t x_ld, y_ld, res_ld;     /* pixel strides in elements (res_ld ignored when res == NULL) */
+    int32_t act1; float slope1;     /* SM_ACT_* behind the reduce layer */
+    int32_t act2; float slope2;     /* ... the 3x3 layer */
+    int32_t act3; float slope3;     /* ... the Add */
+} sm_bneck_desc;
+int sm_bottleneck_supported(const sm_bneck_desc* d);
+int sm_bottleneck_fwd(const sm_bneck_desc* d, const void* x, const void* w1, const float* b1, const void* w2_ohwi, const float* b2, const void* w3, const float* b3,
+                      const void* res, void* y, sm_stream_t stream);
+
 /* The image stem (first ConvolutionConverter of a network, Cin <= 4) with the texture -> MPSImage conversion INSIDE the launch: loader waves build
  * the stem kernel's row-pair patches from the fp32 NCHW batch (`x_nchw`: [N, C, H_in, W_in]; zero outside the image = the padding (pt, pl)).
  * `d` is the stem-form descriptor sm_conv2d_fwd takes for the same layer (row-pair geometry: Cin = 64, kW = 1, dH = 2, x_ld = 8), `w` the weights

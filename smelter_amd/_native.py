@@ -64,6 +64,13 @@ class Shape(C.Structure):
 # every symbol include/smelter_hip.h declares: name -> (restype, argtypes)
 _vp, _i32, _i64, _f, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
 _pi32 = C.POINTER(C.c_int32)
+class BneckDesc(C.Structure):
+    """sm_bneck_desc (include/smelter_hip.h): a bottleneck block launched as one tile pass (sm_bottleneck_fwd)"""
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C0", C.c_int32), ("Cm", C.c_int32), ("C3", C.c_int32),
+                ("x_ld", C.c_int32), ("y_ld", C.c_int32), ("res_ld", C.c_int32),
+                ("act1", C.c_int32), ("slope1", C.c_float), ("act2", C.c_int32), ("slope2", C.c_float), ("act3", C.c_int32), ("slope3", C.c_float)]
+
+
 class RunInfo(C.Structure):
     """smelter_run_info (include/smelter_hip.h): one persistent run of an executor and what the compile's in-situ A/B measured for it"""
     _fields_ = [("first_step", C.c_int32), ("layers", C.c_int32), ("on", C.c_int32), ("timed", C.c_int32), ("samples", C.c_int32), ("mode_bits", C.c_int32),
@@ -99,6 +106,8 @@ SYMBOLS = {
     "sm_conv2d_stem_f32_pool_fwd": (_i32, [C.POINTER(ConvDesc), _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "sm_conv2d_stem_f32_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "sm_conv2d_xhead_supported": (_i32, [C.POINTER(ConvDesc), _i32, _i32]),
+    "sm_bottleneck_supported": (_i32, [C.POINTER(BneckDesc)]),
+    "sm_bottleneck_fwd": (_i32, [C.POINTER(BneckDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sm_conv2d_xhead_proj_supported": (_i32, [C.POINTER(ConvDesc), _i32]),
     "sm_conv2d_xhead_proj_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sm_conv2d_xhead_fwd_cfg": (_i32, [C.POINTER(ConvDesc), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _f, _vp, _i32, _vp, _i32, _vp]),

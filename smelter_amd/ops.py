@@ -291,6 +291,19 @@ def conv2d_xhead_proj(x, w_ohwi, bias, w3, b3sum, xs, ws, act=ACT_RELU, slope=0.
     return y3
 
 
+def bottleneck(x, w1, b1, w2_ohwi, b2, w3, b3, residual=None, acts=(ACT_RELU, ACT_RELU, ACT_RELU), slopes=(0.0, 0.0, 0.0), out=None):
+    """a whole bottleneck block in one launch (sm_bottleneck_fwd): 1x1 reduce w1 [64][C0] -> 3x3 / s1 / p1 w2 [64][3][3][64] -> 1x1 expand w3 [C3][64] (+ residual), the two
+    hidden tensors in LDS only"""
+    from ._native import BneckDesc
+    n, h, w, c0, x_ld = _check_nhwc(x)
+    cm, c3 = w1.shape[0], w3.shape[0]
+    y = out if out is not None else torch.empty((n, h, w, c3), dtype=torch.float16, device=x.device)
+    res_ld = _check_nhwc(residual)[4] if residual is not None else 0
+    d = BneckDesc(n, h, w, c0, cm, c3, x_ld, _ld(y), res_ld, acts[0], slopes[0], acts[1], slopes[1], acts[2], slopes[2])
+    check(lib().sm_bottleneck_fwd(C.byref(d), _ptr(x), _ptr(w1), _ptr(b1), _ptr(w2_ohwi), _ptr(b2), _ptr(w3), _ptr(b3), _ptr(residual), _ptr(y), _stream()))
+    return y
+
+
 def mbconv(x, w1, b1, wd, bd, w2, b2, stride=1, residual=False, acts=(ACT_RELU, ACT_RELU, ACT_NONE), slopes=(0.0, 0.0, 0.0), kernel=0):
     """fused inverted-residual block (sm_mbconv_fwd): [1x1 expand w1 (None = absent)] -> depthwise 3x3 wd [Ch,3,3] -> 1x1 project w2 (+ x)"""
     from ._native import MbConvDesc

@@ -1,0 +1,163 @@
+"""sm_bottleneck_fwd (csrc/kernels/bneck.hip) on a real MI355X against the CPU oracle: a whole bottleneck block — 1x1 reduce, 3x3 / stride 1 / pad 1, 1x1 expand + residual,
+each with its activation (Converters.swift:187-338, :430-451, :342-359) — as ONE launch, the two hidden tensors in LDS only.
+
+The oracle runs the three layers one after the other and rounds both hidden tensors to fp16 (the executor's rounding list: what the layer-by-layer launches store), so the
+comparison is the kernel-level tolerance of test_gpu_ops.py: one fp16 ulp of the value plus an accumulation-order floor.  Besides the oracle the fused launch is compared
+bit for bit with the two launches it replaces (reduce, then 3x3 + expand head) where those exist (C3 <= 256 with a residual)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+import oracle as O
+from smelter_amd import ops
+from smelter_amd._native import BneckDesc
+
+pytestmark = pytest.mark.gpu
+
+
+def h(a):
+    return O.round_to_half(np.asarray(a, np.float32))
+
+
+def to_dev(a_nchw):
+    return torch.from_numpy(np.ascontiguousarray(a_nchw.transpose(0, 2, 3, 1))).cuda().half()
+
+
+def to_host(t_nhwc):
+    torch.cuda.synchronize()
+    return t_nhwc.float().cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def act(v, a, sl):
+    return np.maximum(v, 0) if a == ops.ACT_RELU else np.where(v < 0, v * sl, v) if a == ops.ACT_PRELU else v
+
+
+def make_block(rng, n, hh, ww, c0, c3):
+    x = h(rng.standard_normal((n, c0, hh, ww)))
+    w1 = h(rng.standard_normal((64, 1, 1, c0)) * np.sqrt(2.0 / c0)); b1 = rng.standard_normal(64).astype(np.float32) * 0.2
+    w2 = h(rng.standard_normal((64, 3, 3, 64)) * np.sqrt(2.0 / 576)); b2 = rng.standard_normal(64).astype(np.float32) * 0.2
+    w3 = h(rng.standard_normal((c3, 1, 1, 64)) * np.sqrt(2.0 / 64)); b3 = rng.standard_normal(c3).astype(np.float32) * 0.2
+    return x, w1, b1, w2, b2, w3, b3
+
+
+def oracle_block(x, w1, b1, w2, b2, w3, b3, res, acts, slopes):
+    t1 = h(act(O.conv2d(x, w1, b1), acts[0], slopes[0]))
+    t2 = h(act(O.conv2d(t1, w2, b2, pads=(1, 1, 1, 1)), acts[1], slopes[1]))
+    y = O.conv2d(t2, w3, b3)
+    if res is not None:
+        y = y + res
+    return act(y, acts[2], slopes[2]), t1, t2
+
+
+def assert_close(got, ref, k):
+    ref16 = h(ref)
+    tol = np.abs(ref16) * 2.0 ** -10 + np.abs(ref).max() * 2.0 ** -11 * max(1.0, np.sqrt(k)) * 1e-2 + 1e-7
+    bad = np.abs(got - ref16) > tol
+    assert not bad.any(), "max err %g at %d of %d elements" % (np.abs(got - ref16).max(), bad.sum(), bad.size)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+CASES = [
+    # n, h, w, c0, c3, residual, acts, slopes                      -- what is exercised
+    (2, 56, 56, 256, 256, True, (1, 1, 1), (0, 0, 0)),             # ResNet-50 stage 1, blocks 2 / 3: 4 column bands x 7 row bands, whole tiles
+    (3, 28, 28, 256, 256, True, (1, 1, 1), (0, 0, 0)),             # TH = 7 (4 bands of 7 rows): the fifth patch fragment is half empty
+    (2, 14, 14, 128, 128, True, (1, 1, 1), (0, 0, 0)),             # C0 = 128 instantiation, one column band
+    (2, 20, 17, 64, 96, False, (1, 1, 0), (0, 0, 0)),              # C0 = 64, no residual, ragged in both directions, C3 = 96 (the fourth consumer wave has no channels)
+    (1, 9, 30, 256, 32, False, (2, 2, 2), (0.1, 0.2, 0.3)),        # leaky activations on all three layers, C3 = 32, three column bands (the last holds 2 columns)
+    (5, 7, 7, 64, 64, True, (0, 1, 1), (0, 0, 0)),                 # tiny images: one tile each; no activation behind the reduce (the padding must still be ZERO, not b1)
+    (1, 3, 3, 128, 256, False, (1, 0, 1), (0, 0, 0)),              # 3 x 3 image: every tap but the centre crosses a border; linear 3x3
+    (300, 8, 14, 64, 32, False, (1, 1, 1), (0, 0, 0)),             # 300 tiles on 256 blocks: ranges of one and of two tiles
+]
+
+
+@pytest.mark.parametrize("n,hh,ww,c0,c3,use_res,acts,slopes", CASES)
+def test_bottleneck_against_oracle(n, hh, ww, c0, c3, use_res, acts, slopes):
+    rng = np.random.default_rng(n * 1000 + hh * 31 + ww + c0 + c3)
+    x, w1, b1, w2, b2, w3, b3 = make_block(rng, n, hh, ww, c0, c3)
+    res = x if (use_res and c0 == c3) else (h(rng.standard_normal((n, c3, hh, ww))) if use_res else None)
+    d = BneckDesc(n, hh, ww, c0, 64, c3, c0, c3, c3 if res is not None else 0, acts[0], slopes[0], acts[1], slopes[1], acts[2], slopes[2])
+    assert ops.lib().sm_bottleneck_supported(ctypes.byref(d))
+    ref, _, _ = oracle_block(x, w1, b1, w2, b2, w3, b3, res, acts, slopes)
+    xd = to_dev(x)
+    resd = xd if (res is x) else (to_dev(res) if res is not None else None)
+    got = to_host(ops.bottleneck(xd, dev(w1.reshape(64, c0)).half(), dev(b1), dev(w2).half(), dev(b2), dev(w3.reshape(c3, 64)).half(), dev(b3), residual=resd, acts=acts, slopes=slopes))
+    assert_close(got, ref, 576)
+
+
+def test_bottleneck_padding_is_zero_not_bias():
+    """Outside the image T1 is the 3x3's zero padding (ONNXConvolutionPadding.swift:73-79) — not act1(b1), which is what the reduce GEMM leaves on a zero pixel.  A large positive
+    b1 makes the difference visible at every border pixel."""
+    rng = np.random.default_rng(7)
+    n, hh, ww, c0, c3 = 2, 10, 16, 64, 64
+    x, w1, b1, w2, b2, w3, b3 = make_block(rng, n, hh, ww, c0, c3)
+    b1 = np.full(64, 3.0, np.float32)
+    ref, _, _ = oracle_block(x, w1, b1, w2, b2, w3, b3, None, (1, 1, 1), (0, 0, 0))
+    got = to_host(ops.bottleneck(to_dev(x), dev(w1.reshape(64, c0)).half(), dev(b1), dev(w2).half(), dev(b2), dev(w3.reshape(c3, 64)).half(), dev(b3)))
+    assert_close(got, ref, 576)
+
+
+@pytest.mark.parametrize("n,hh,ww,c0", [(2, 56, 56, 256), (3, 21, 33, 256), (2, 28, 28, 128), (4, 14, 14, 64)])
+def test_bottleneck_bit_identical_to_the_two_launches(n, hh, ww, c0):
+    """The fused launch = the 1x1 reduce launch + the 3x3 -> expand-head launch it replaces, bit for bit: same MFMA steps of 16 in the same order from zero, the same
+    fp32 bias / activation / single rounding of both hidden tensors (what lets the executor's flip test of SM_FUSE_BNECK compare with torch.equal)."""
+    c3 = c0
+    d = ops.ConvDesc(n, hh, ww, 64, 64, 3, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, hh, ww, 1, 0.0, 64, 64, 0)
+    if not ops.lib().sm_conv2d_xhead_supported(ctypes.byref(d), c3, 1):
+        pytest.skip("no expand-head kernel for this shape")
+    rng = np.random.default_rng(n + hh + ww + c0)
+    x, w1, b1, w2, b2, w3, b3 = make_block(rng, n, hh, ww, c0, c3)
+    xd = to_dev(x)
+    w1d, w2d, w3d = dev(w1).half(), dev(w2).half(), dev(w3.reshape(c3, 64)).half()
+    b1d, b2d, b3d = dev(b1), dev(b2), dev(b3)
+    t1 = ops.conv2d(xd, w1d, b1d, act=ops.ACT_RELU)
+    _, two = ops.conv2d_xhead(t1, w2d, b2d, w3d, b3d, residual=xd, act3=ops.ACT_RELU)
+    one = ops.bottleneck(xd, w1d.reshape(64, c0), b1d, w2d, b2d, w3d, b3d, residual=xd)
+    torch.cuda.synchronize()
+    assert torch.equal(one, two), "differs at %d elements, max %g" % ((one != two).sum().item(), (one.float() - two.float()).abs().max().item())
+
+
+def test_bottleneck_full_size_properties():
+    """BASELINE.json's full size (ResNet-50 stage 1 at bs 64: 64 x 56 x 56 x 256) — too large for the CPU oracle in seconds, so size-independent properties instead:
+    (a) the batch is 64 independent images: image i of the full launch = a launch of image i alone (first, middle, last), bit for bit;
+    (b) those three images meet the oracle;
+    (c) permuting the batch permutes the output."""
+    rng = np.random.default_rng(11)
+    n, hh, ww, c0 = 64, 56, 56, 256
+    x1, w1, b1, w2, b2, w3, b3 = make_block(rng, 3, hh, ww, c0, c0)
+    xd = torch.randn((n, hh, ww, c0), device="cuda").half()
+    pick = [0, 31, 63]
+    xd[pick] = to_dev(x1)
+    w1d, w2d, w3d = dev(w1.reshape(64, c0)).half(), dev(w2).half(), dev(w3.reshape(c0, 64)).half()
+    b1d, b2d, b3d = dev(b1), dev(b2), dev(b3)
+    full = ops.bottleneck(xd, w1d, b1d, w2d, b2d, w3d, b3d, residual=xd)
+    for k, i in enumerate(pick):
+        xi = xd[i:i + 1].contiguous()
+        alone = ops.bottleneck(xi, w1d, b1d, w2d, b2d, w3d, b3d, residual=xi)
+        assert torch.equal(alone[0], full[i]), "image %d depends on its neighbours" % i
+    ref, _, _ = oracle_block(x1, w1, b1, w2, b2, w3, b3, x1, (1, 1, 1), (0, 0, 0))
+    assert_close(to_host(full[pick]), ref, 576)
+    perm = torch.randperm(n, device="cuda")
+    xp = xd[perm].contiguous()
+    assert torch.equal(ops.bottleneck(xp, w1d, b1d, w2d, b2d, w3d, b3d, residual=xp), full[perm])
+
+
+def test_bottleneck_refusals():
+    """shapes the kernel does not take are refused by sm_bottleneck_supported and sm_bottleneck_fwd answers SM_ERR_INVALID_ARGUMENT (no silent other path)"""
+    L = ops.lib()
+    ok = BneckDesc(1, 8, 8, 256, 64, 256, 256, 256, 256, 1, 0.0, 1, 0.0, 1, 0.0)
+    assert L.sm_bottleneck_supported(ctypes.byref(ok))
+    for field, val in (("Cm", 128), ("C0", 512), ("C0", 96), ("C3", 288), ("C3", 40), ("act2", 3), ("x_ld", 128), ("y_ld", 250)):
+        bad = BneckDesc(1, 8, 8, 256, 64, 256, 256, 256, 256, 1, 0.0, 1, 0.0, 1, 0.0)
+        setattr(bad, field, val)
+        assert not L.sm_bottleneck_supported(ctypes.byref(bad)), field
+    x = torch.zeros((1, 8, 8, 512), device="cuda").half()
+    bad = BneckDesc(1, 8, 8, 512, 64, 256, 512, 256, 0, 1, 0.0, 1, 0.0, 1, 0.0)
+    w = torch.zeros((64 * 576,), device="cuda").half()
+    y = torch.zeros((1, 8, 8, 256), device="cuda").half()
+    rc = L.sm_bottleneck_fwd(ctypes.byref(bad), x.data_ptr(), w.data_ptr(), None, w.data_ptr(), None, w.data_ptr(), None, None, y.data_ptr(), None)
+    assert rc != 0
