@@ -52,10 +52,14 @@ def oracle_block(x, w1, b1, w2, b2, w3, b3, res, acts, slopes):
 
 
 def assert_close(got, ref, k):
+    """Three chained layers with two hidden fp16 roundings: where the kernel's accumulation order flips the rounding of a hidden element the output moves by a few 1e-4,
+    which in turn may flip ITS rounding — two fp16 ulps of the value plus an absolute floor (the tolerance of the fused inverted-residual block tests), and the mismatches
+    must stay rare.  The sharp statement is test_bottleneck_bit_identical_to_the_two_launches: each of those launches meets the oracle at the one-ulp kernel tolerance."""
     ref16 = h(ref)
-    tol = np.abs(ref16) * 2.0 ** -10 + np.abs(ref).max() * 2.0 ** -11 * max(1.0, np.sqrt(k)) * 1e-2 + 1e-7
+    tol = np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10
     bad = np.abs(got - ref16) > tol
     assert not bad.any(), "max err %g at %d of %d elements" % (np.abs(got - ref16).max(), bad.sum(), bad.size)
+    assert np.mean(got != ref16) < 0.05, "too many elements differ from the oracle's rounding: %g" % np.mean(got != ref16)
 
 
 def dev(a):

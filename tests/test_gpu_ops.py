@@ -848,7 +848,8 @@ def test_mbconv_clip_every_layer(hw, cin, ch, cout, stride, res, acts, slopes):
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     got = to_host(ops.mbconv(to_dev(x), dev(w1).half(), dev(b1), dev(wd.reshape(ch, 3, 3)).half(), dev(bd), dev(w2).half(), dev(b2), stride=stride, residual=res, acts=acts, slopes=slopes))
     ref16 = h(ref)
-    assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(ref16).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
+    # (the floor follows the UNCLIPPED project output: a bound on the last layer shrinks max|ref| but not the noise the hidden tensors' roundings carry into it)
+    assert (np.abs(got - ref16) <= np.abs(ref16) * 2.0 ** -9 + np.abs(pre).max() * 2.0 ** -10).all(), np.abs(got - ref16).max()
 
 
 @pytest.mark.parametrize("n,c,hw,cout,stride,pad,act,slope", [

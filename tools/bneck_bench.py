@@ -7,7 +7,7 @@ import torch
 from smelter_amd import ops
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--n", type=int, default=64); ap.add_argument("--hw", type=int, default=56); ap.add_argument("--c0", type=int, default=256); ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--n", type=int, default=64); ap.add_argument("--hw", type=int, default=56); ap.add_argument("--c0", type=int, default=256); ap.add_argument("--iters", type=int, default=50); ap.add_argument("--only", default="", help="one | two: launch only that form (PMC passes)")
 a = ap.parse_args()
 n, hw, c0 = a.n, a.hw, a.c0
 torch.manual_seed(0)
@@ -38,6 +38,11 @@ def timeit(fn, chain):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / a.iters * 1e3
 
+if a.only:
+    fn = one if a.only == "one" else two
+    bufs = [x.clone(), torch.empty_like(x)]
+    for i in range(a.iters): fn(bufs[i & 1], bufs[(i + 1) & 1])
+    torch.cuda.synchronize(); sys.exit(0)
 ya, yb = two(x, None), one(x, out)
 torch.cuda.synchronize()
 print("bit-identical:", bool(torch.equal(ya, yb)), " differing:", int((ya != yb).sum()))
