@@ -405,7 +405,7 @@ typedef struct smelter_config {
 } smelter_config;
 /* Executor behaviour is decided by THIS struct, read once at smelter_graph_create / _compile — no environment variable is consulted after that.
  * smelter_config_default() is where the bench / A/B tools' environment overrides enter (each read there, once): SMELTER_MBCONV=0, SMELTER_XHEAD=0,
- * SMELTER_XHEAD_PROJ=0, SMELTER_KCAT=0|copy, SMELTER_MBCONV_STEM=0, SMELTER_STEM_F32=0, SMELTER_STEM_POOL=0, SMELTER_STEM3=0, SMELTER_STAGE=0|wide clear / set the matching SM_FUSE_* bit;
+ * SMELTER_XHEAD_PROJ=0, SMELTER_KCAT=0|copy, SMELTER_MBCONV_STEM=0, SMELTER_STEM_F32=0, SMELTER_STEM_POOL=0, SMELTER_STEM3=0, SMELTER_STAGE=0|wide, SMELTER_BNECK=0 clear / set the matching SM_FUSE_* bit;
  * SMELTER_AUTOTUNE=cold, SMELTER_AUTOTUNE_MAXCFG=n, SMELTER_MBCONV_DOMAIN="cin,hidden,cout" fill the fields above.  A host that fills the struct itself
  * (the Swift shim of INTEGRATION.md) is not affected by the environment at all.
  * The kernel-level `sm_*` launchers consult NO environment variable (round 5): which kernel runs is a pure function of the descriptor and the explicit arguments
@@ -423,7 +423,8 @@ enum { SM_FUSE_MBCONV = 1,        /* expand -> depthwise -> project in one launc
        SM_FUSE_STEM3 = 256,       /* a 3x3 stem on <= 3 planes as the staged kernel of stem3.hip (needs SM_FUSE_STEM_F32: it reads the fp32 batch) */
        SM_FUSE_STAGE = 512,       /* runs of consecutive 1x1 / 3x3 stride-1 convolutions at one resolution as ONE persistent launch (sm_stage_fwd, stage.hip) — images of <= 112 pixels */
        SM_FUSE_STAGE_WIDE = 1024, /* ... also at images of 113 .. 208 pixels (the tile forms with 208 accumulator registers: behind the per-layer kernels on ResNet-50's 14 x 14 stage, off by default) */
-       SM_FUSE_DEFAULT = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 256 | 512 };
+       SM_FUSE_BNECK = 2048,      /* 1x1 reduce -> 3x3 -> 1x1 expand (+ residual) of a bottleneck block as ONE tile pass, hidden tensors on chip (sm_bottleneck_fwd, bneck.hip; needs SM_FUSE_XHEAD) */
+       SM_FUSE_DEFAULT = 1 | 2 | 4 | 8 | 32 | 64 | 128 | 256 | 512 | 2048 };
 enum { SM_TUNE_IN_SITU = 0, SM_TUNE_COLD = 1 };
 void smelter_config_default(smelter_config* c);
 

@@ -26,7 +26,7 @@ void smelter_config_default(smelter_config* c) {
     // The ONLY place the executor's environment switches are read (bench / A-B tools; documented in smelter_hip.h): they edit the defaults, once.
     auto off = [&](const char* name, int bit) { const char* e = getenv(name); if (e && e[0] == '0') c->fusions &= ~bit; };
     off("SMELTER_MBCONV", SM_FUSE_MBCONV); off("SMELTER_XHEAD", SM_FUSE_XHEAD); off("SMELTER_XHEAD_PROJ", SM_FUSE_XHEAD_PROJ); off("SMELTER_KCAT", SM_FUSE_KCAT);
-    off("SMELTER_MBCONV_STEM", SM_FUSE_MBCONV_STEM); off("SMELTER_STEM_F32", SM_FUSE_STEM_F32); off("SMELTER_STEM_POOL", SM_FUSE_STEM_POOL); off("SMELTER_STEM3", SM_FUSE_STEM3); off("SMELTER_STAGE", SM_FUSE_STAGE);
+    off("SMELTER_BNECK", SM_FUSE_BNECK); off("SMELTER_MBCONV_STEM", SM_FUSE_MBCONV_STEM); off("SMELTER_STEM_F32", SM_FUSE_STEM_F32); off("SMELTER_STEM_POOL", SM_FUSE_STEM_POOL); off("SMELTER_STEM3", SM_FUSE_STEM3); off("SMELTER_STAGE", SM_FUSE_STAGE);
     if (const char* e = getenv("SMELTER_STAGE")) if (!strcmp(e, "wide")) c->fusions |= SM_FUSE_STAGE_WIDE;
     if (const char* e = getenv("SMELTER_KCAT")) if (!strcmp(e, "copy")) c->fusions |= SM_FUSE_KCAT_COPY;
     if (const char* e = getenv("SMELTER_AUTOTUNE")) if (!strcmp(e, "cold")) c->autotune_mode = SM_TUNE_COLD;

@@ -515,6 +515,47 @@ int Executor::plan(ONNXGraph& g, int batch) {
         }
     }
 
+    // ---- 3l. whole bottleneck block (round 6): an expand-head step (3x3 64 -> 64 + 1x1 expand + residual, pass 3d') whose input comes from a plain 1x1
+    // convolution to 64 channels that nobody else reads — the block's REDUCE layer — takes that layer in as well: sm_bottleneck_fwd computes reduce -> 3x3 -> expand (+ block
+    // input) per output tile with both hidden tensors on chip (csrc/kernels/bneck.hip).  Layer by layer a 56 x 56 x 256 block at bs 64 moves 360 MB (x twice, T1 out and back,
+    // the output); as one pass x once (+ halo) + the residual + the output.  The hidden tensors keep their places in the rounding list.  SMELTER_BNECK=0 keeps the two launches.
+    if (cfg_.fuse && !cfg_.keepIntermediates && !cfg_.branchConcurrency && cfg_.allows(SM_FUSE_BNECK)) {
+        auto readers = [&](int v) {
+            int n = v == output_value_ ? 2 : 0;
+            for (const Step& q : steps_) {
+                for (int u : q.op.inputs) if (u == v) n++;
+                if (q.op.residual == v) n++;
+                if (q.has_head && q.head.residual == v) n++;
+                if (q.has_side) for (int u : q.side.inputs) if (u == v) n++;
+                if (q.dual_src == v) n++;
+            }
+            return n;
+        };
+        for (size_t t = 0; t < steps_.size(); t++) {
+            Step& c = steps_[t];
+            if (!c.has_head || c.has_side || c.has_reduce || c.pool_out >= 0 || c.op.x_ups || c.op.grid_h || c.op.kind != OpKind::Conv || c.op.kh != 3 || c.op.kw != 3 || c.op.cin != 64 || c.op.cout != 64) continue;
+            if (c.op.act > SM_ACT_PRELU || c.head.act > SM_ACT_PRELU) continue;
+            const int v = c.op.inputs[0];
+            long a = -1;
+            for (size_t q = 0; q < t; q++) if (steps_[q].op.output == v) a = (long)q;
+            if (a < 0 || readers(v) != 1) continue;
+            Step& r = steps_[a];
+            const Op& o = r.op;
+            if (o.kind != OpKind::Conv || o.kh != 1 || o.kw != 1 || o.sh != 1 || o.sw != 1 || o.pt || o.pl || o.pb || o.pr || o.groups != 1 || o.act > SM_ACT_PRELU || o.grid_h || o.x_ups ||
+                o.residual >= 0 || r.stem || r.stem3 || r.has_mb || r.has_head || r.has_side || r.pool_out >= 0 || r.pool3_out >= 0 || r.dual_src >= 0 || r.gather || r.kcat || r.join >= 0 || r.waits_side ||
+                o.cout != 64 || o.inputs.empty() || !vecOk(o.inputs[0]) || place_[v].root != v || place_[v].c_off != 0) continue;
+            const Value& iv = values_[o.inputs[0]]; const Value& ov = values_[c.head.output];
+            if (iv.h != ov.h || iv.w != ov.w) continue;
+            sm_bneck_desc bd{}; bd.N = batch; bd.H = ov.h; bd.W = ov.w; bd.C0 = o.cin; bd.Cm = 64; bd.C3 = c.head.cout;
+            bd.x_ld = std::max(place_[o.inputs[0]].ld, o.cin); bd.y_ld = std::max(place_[c.head.output].ld, c.head.cout); bd.res_ld = c.head.residual >= 0 ? std::max(place_[c.head.residual].ld, c.head.cout) : 0;
+            bd.act1 = o.act; bd.slope1 = o.slope; bd.act2 = c.op.act; bd.slope2 = c.op.slope; bd.act3 = c.head.act; bd.slope3 = c.head.slope;
+            if (!sm_bottleneck_supported(&bd)) continue;
+            c.has_reduce = true; c.reduce = std::move(r.op);
+            steps_.erase(steps_.begin() + a);
+            t--;                                                       // (the step list moved down by one: `c` now sits at t - 1, the next candidate at t)
+        }
+    }
+
     // ---- 3h. projection shortcut concatenated along K: in the first block of a later stage (ResNet stages 2-4) the expand layer E (1x1, K1 -> N, no
     // activation) is read only as the residual operand of the shortcut convolution S (1x1 / stride s on the block input, K2 -> N, + Add + ReLU).  The two
     // are ONE GEMM over K1 + K2: y = act([W_E | W_S] . [h ; x_s] + (b_E + b_S)).  The producer of h writes its rows with pixel stride K1 + K2, a
@@ -744,11 +785,12 @@ int Executor::plan(ONNXGraph& g, int batch) {
     for (int t = 0; t < ns; t++) {
         const Op& op = steps_[t].op;
         const int until = steps_[t].join >= 0 ? steps_[t].join : t;   // a side step may still be reading its operands at the join
-        for (int u : op.inputs) { touch(u, t); touch(u, until); }
+        if (!steps_[t].has_reduce) for (int u : op.inputs) { touch(u, t); touch(u, until); }   // (a whole-block step reads the REDUCE layer's input — touched below; its own input tensor exists in LDS only)
         if (op.residual >= 0) { touch(op.residual, t); touch(op.residual, until); }
         if (steps_[t].pool3_out >= 0) { touch(steps_[t].pool3_out, t); continue; }             // (the stem's own output exists in LDS only)
         if (steps_[t].has_mb) { touch(steps_[t].mb_proj.output, t); continue; }
         if (steps_[t].has_side) { touch(steps_[t].side.output, t); touch(steps_[t].side.inputs[0], t); continue; }                    // (neither the 3x3 nor the expand output exists)
+        if (steps_[t].has_reduce) touch(steps_[t].reduce.inputs[0], t);                      // (the block input is what the launch reads; the reduce output exists in LDS only)
         if (steps_[t].has_head) { touch(steps_[t].head.output, t); if (steps_[t].head.residual >= 0) touch(steps_[t].head.residual, t); continue; }             // (the 3x3 output exists in registers only)      // (the hidden tensors exist in LDS only; the residual is the step's own input)
         touch(op.output, t);
         if (steps_[t].pool_out >= 0) touch(steps_[t].pool_out, t);
@@ -821,6 +863,13 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 flops_ += 2.0 * st.M * st.side.cout * (double)st.side.cin;
                 alg_bytes_ += 2.0 * ((double)st.M * st.side.cin + (double)st.M * st.side.cout * 2 + (double)st.side.cout * st.side.cin);      // (the shortcut layer of the graph: input, residual, output, weights)
             }
+            if (st.has_reduce) {
+                st.w0_off = off; off = alignUp(off + st.reduce.weight.size() * 2);
+                st.has_bias0 = !st.reduce.bias.empty();
+                if (st.has_bias0) { st.b0_off = off; off = alignUp(off + (size_t)st.reduce.cout * 4); }
+                flops_ += 2.0 * st.M * st.reduce.cout * (double)st.reduce.cin;
+                alg_bytes_ += 2.0 * ((double)st.M * st.reduce.cin + (double)st.M * st.reduce.cout + (double)st.reduce.cout * st.reduce.cin);      // (accounted as the layer the graph holds)
+            }
             if (st.has_head) {
                 st.w2_off = off; off = alignUp(off + st.head.weight.size() * 2);
                 st.has_bias2 = !st.head.bias.empty() || (st.has_side && !st.side.bias.empty());
@@ -856,6 +905,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         if (st.pool3_out >= 0) { const Value& pv = values_[st.pool3_out]; st.desc += " >> MaxPool 3x3/2 (same launch)";
                                  alg_bytes_ += 2.0 * ((double)st.M * pv.c + (double)batch * pv.h * pv.w * pv.c); }       // (the pooling layer of the graph: input read, output written)
         if (st.pool_out >= 0) { st.desc += " >> MaxPool 2x2/2 (same launch)"; alg_bytes_ += 2.0 * (double)(st.M / 4) * values_[st.pool_out].c; }
+        if (st.has_reduce) { snprintf(buf, sizeof buf, "Conv %s N=%d K=%d k=1x1%s (same launch: whole bottleneck block) >> ", st.reduce.name.c_str(), st.reduce.cout, st.reduce.cin, st.reduce.act ? " +act" : ""); st.desc = buf + st.desc; }
         if (st.has_head) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s%s (same launch)", st.head.name.c_str(), st.head.cout, st.head.cin, st.head.residual >= 0 ? " +res" : "", st.head.act ? " +act" : ""); st.desc += buf; }
         if (st.has_side) { snprintf(buf, sizeof buf, " + Conv %s N=%d K=%d k=1x1 projection%s (same launch)", st.side.name.c_str(), st.side.cout, st.side.cin, st.side.act ? " +act" : ""); st.desc += buf; }
         if (st.has_mb && st.mb_noexp) { snprintf(buf, sizeof buf, " >> Conv %s N=%d K=%d k=1x1%s (same launch)", st.mb_proj.name.c_str(), st.mb_proj.cout, st.mb_proj.cin, st.mb_proj.act ? " +act" : ""); st.desc += buf; }
@@ -878,7 +928,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             const Op& op = st.op;
             std::vector<int> rd, wr;
             auto add = [](std::vector<int>& a, int v) { if (v >= 0 && std::find(a.begin(), a.end(), v) == a.end()) a.push_back(v); };
-            for (int u : op.inputs) add(rd, u);
+            if (st.has_reduce) add(rd, st.reduce.inputs[0]); else for (int u : op.inputs) add(rd, u);
             add(rd, op.residual);
             if (st.has_head) add(rd, st.head.residual);
             if (st.has_side) for (int u : st.side.inputs) add(rd, u);
@@ -894,6 +944,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
             if (op.x_ups) b -= 0.0;                                                                                   // (the half-resolution tensor is op.inputs[0]: already its true size)
             double wb = 2.0 * (double)op.weight.size() + 4.0 * (double)op.bias.size();
             if (st.has_head) wb += 2.0 * (double)st.head.weight.size();
+            if (st.has_reduce) wb += 2.0 * (double)st.reduce.weight.size() + 4.0 * (double)st.reduce.bias.size();
             if (st.has_side) wb += 2.0 * (double)st.side.weight.size();
             if (st.has_mb) wb += 2.0 * ((double)st.mb_dw.weight.size() + (double)st.mb_proj.weight.size()) + (st.mb_stem ? 2.0 * (double)st.stem_w.size() : 0.0);
             launch_bytes_ += b + wb;
@@ -903,6 +954,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
     materialized_.clear(); materialized_.push_back(values_[input_value_].name);
     for (auto& st : steps_) {
         if (st.has_side) { materialized_.push_back(values_[st.op.output].name); materialized_.push_back(values_[st.side.output].name); continue; }   // (the expand output is summed in fp32, never rounded)
+        if (st.has_reduce) materialized_.push_back(values_[st.reduce.output].name);                                                          // (rounded to fp16 on its way into the LDS patch)
         if (st.has_head) { materialized_.push_back(values_[st.op.output].name); materialized_.push_back(values_[st.head.output].name); continue; }   // (rounded to fp16 in registers)
         if (st.has_mb) {   // (the two hidden tensors live in LDS only, but are rounded to fp16 there exactly as a stored tensor would be: listed for the parity oracle)
             if (!st.mb_noexp) materialized_.push_back(values_[st.op.output].name);
@@ -943,6 +995,10 @@ int Executor::packWeights(std::vector<uint8_t>* host) const {
                 if (st.has_biasd) memcpy(host->data() + st.bd_off, st.mb_dw.bias.data(), st.mb_dw.bias.size() * 4);
                 sm_float_to_half(st.mb_proj.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.mb_proj.weight.size());
                 if (st.has_bias2) memcpy(host->data() + st.b2_off, st.mb_proj.bias.data(), st.mb_proj.bias.size() * 4);
+            }
+            if (st.has_reduce) {
+                sm_float_to_half(st.reduce.weight.data(), (uint16_t*)(host->data() + st.w0_off), st.reduce.weight.size());
+                if (st.has_bias0) memcpy(host->data() + st.b0_off, st.reduce.bias.data(), st.reduce.bias.size() * 4);
             }
             if (st.has_head) {
                 sm_float_to_half(st.head.weight.data(), (uint16_t*)(host->data() + st.w2_off), st.head.weight.size());
@@ -994,7 +1050,7 @@ static int32_t stepsFingerprint(const std::vector<Step>& steps) {
     auto mix = [&](uint32_t v) { h = (h ^ v) * 16777619u; };
     for (const Step& st : steps) {
         mix((uint32_t)st.op.kind); mix((uint32_t)st.M); mix((uint32_t)st.op.cout); mix((uint32_t)st.op.cin); mix((uint32_t)(st.op.kh * 16 + st.op.kw)); mix((uint32_t)(st.op.sh * 16 + st.op.groups));
-        mix((uint32_t)((st.has_mb ? 1 : 0) | (st.has_head ? 2 : 0) | (st.has_side ? 4 : 0) | (st.stem ? 8 : 0) | (st.stem3 ? 16 : 0) | (st.dual_src >= 0 ? 32 : 0) | (st.pool_out >= 0 ? 64 : 0) | (st.pool3_out >= 0 ? 128 : 0) | (st.op.residual >= 0 ? 256 : 0)));
+        mix((uint32_t)((st.has_reduce ? 0x10000 : 0) | (st.has_mb ? 1 : 0) | (st.has_head ? 2 : 0) | (st.has_side ? 4 : 0) | (st.stem ? 8 : 0) | (st.stem3 ? 16 : 0) | (st.dual_src >= 0 ? 32 : 0) | (st.pool_out >= 0 ? 64 : 0) | (st.pool3_out >= 0 ? 128 : 0) | (st.op.residual >= 0 ? 256 : 0)));
     }
     return (int32_t)h;
 }
@@ -1082,7 +1138,7 @@ int Executor::create(ONNXGraph& g, int device, int batch, void* ext_arena, bool 
     e->out_f32_count_ = std::max(sm_float_array_count(batch, ov.c, ov.h, ov.w), (size_t)batch * ov.c * ov.h * ov.w);
     SM_HIP_CHECK(hipMalloc((void**)&e->out_f32_, e->out_f32_count_ * 4));
     for (auto& st : e->steps_) { st.op.weight.clear(); st.op.weight.shrink_to_fit();
-                                 st.head.weight.clear(); st.head.weight.shrink_to_fit(); st.side.weight.clear(); st.side.weight.shrink_to_fit(); st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
+                                 st.head.weight.clear(); st.head.weight.shrink_to_fit(); st.reduce.weight.clear(); st.reduce.weight.shrink_to_fit(); st.side.weight.clear(); st.side.weight.shrink_to_fit(); st.mb_dw.weight.clear(); st.mb_dw.weight.shrink_to_fit(); st.mb_proj.weight.clear(); st.mb_proj.weight.shrink_to_fit(); }   // host masters no longer needed
     if (!e->runs_.empty()) {
         if (!sm_stage_device_fast()) for (StageRun& r : e->runs_) { r.on = false; r.why_off = SM_RUN_OFF_DEVICE; }   // fewer than 256 compute units: the runs would complete (claimed mode) but slower than their layers
         size_t ctl = 0;
@@ -1175,6 +1231,15 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
             return sm_conv2d_xhead_proj_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, arena_ + st.w2_off,
                                                 st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr, st.head.cout, st.side.act, st.side.slope, valuePtr(st.side.inputs[0]),
                                                 valueLd(st.side.inputs[0]), arena_ + st.wd_off, valuePtr(st.side.output), valueLd(st.side.output), ss);
+        if (st.has_reduce) {
+            const int xin = st.reduce.inputs[0];
+            sm_bneck_desc bd{}; bd.N = batch_; bd.H = values_[st.head.output].h; bd.W = values_[st.head.output].w; bd.C0 = st.reduce.cin; bd.Cm = 64; bd.C3 = st.head.cout;
+            bd.x_ld = valueLd(xin); bd.y_ld = valueLd(st.head.output); bd.res_ld = st.head.residual >= 0 ? valueLd(st.head.residual) : 0;
+            bd.act1 = st.reduce.act; bd.slope1 = st.reduce.slope; bd.act2 = op.act; bd.slope2 = op.slope; bd.act3 = st.head.act; bd.slope3 = st.head.slope;
+            return sm_bottleneck_fwd(&bd, valuePtr(xin), arena_ + st.w0_off, st.has_bias0 ? (const float*)(arena_ + st.b0_off) : nullptr, arena_ + st.w_off,
+                                     st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, arena_ + st.w2_off, st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr,
+                                     st.head.residual >= 0 ? valuePtr(st.head.residual) : nullptr, valuePtr(st.head.output), ss);
+        }
         if (st.has_head && (st.head.residual >= 0 || st.head.cout > 32))
             return sm_conv2d_xhead_fwd_cfg(&d, st.conv_cfg, valuePtr(op.inputs[0]), arena_ + st.w_off, st.has_bias ? (const float*)(arena_ + st.b_off) : nullptr, nullptr, arena_ + st.w2_off,
                                            st.has_bias2 ? (const float*)(arena_ + st.b2_off) : nullptr, st.head.cout, st.head.act, st.head.slope,
@@ -1444,7 +1509,7 @@ int Executor::autotune(hipStream_t s) {
     }
     for (size_t i = 0; i < steps_.size() && !rc; i++) {
         Step& st = steps_[i];
-        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8) || st.has_mb || st.pool3_out >= 0 || st.stem3) continue;
+        if (!isConvLike(st.op.kind) || st.op.groups != 1 || (st.op.cin % 8) || st.has_mb || st.has_reduce || st.pool3_out >= 0 || st.stem3) continue;   // (whole-block steps run one dedicated kernel)
         if (st.op.kind != OpKind::ConvTranspose) { const sm_conv_desc cd = convDesc(st); if (!sm_conv2d_uses_tile_config(&cd)) continue; }   // dedicated kernel, nothing to tune
         // one config: `reps` timed launches after an untimed first one (code fetch); returns false if the config does not apply
         auto timeCfg = [&](int c, int reps, std::vector<float>& samples) -> bool {

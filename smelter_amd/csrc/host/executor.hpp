@@ -49,6 +49,9 @@ struct Step {                // one op after fusion, with everything resolved
     // is the head's output; it becomes the head's second GEMM (sm_conv2d_xhead_proj_fwd_cfg; weights at wd_off, the two biases summed at b2_off) and the
     // head's own output is never materialised
     bool has_side = false; Op side;
+    // ... and the 1x1 REDUCE layer in front of the 3x3 (executor.cpp pass 3l): `reduce` is the pointwise convolution whose only reader is this step; the whole bottleneck block —
+    // reduce, 3x3, expand head (+ residual) — is one launch (sm_bottleneck_fwd; reduce weights at w0_off / b0_off) and neither hidden tensor is stored (both stay in the rounding list)
+    bool has_reduce = false; Op reduce; size_t w0_off = 0, b0_off = 0; bool has_bias0 = false;
     // ... behind an image stem (executor.cpp pass 3g): the stem convolution is the block kernel's "expand" layer, gathered from the fp32 batch
     // (sm_mbconv_stem_fwd): `stem_w` = the stem's weights [Ch][3][3][C] before the row-pair packing (kept for every stem step), at ws_off / bs_off
     bool mb_stem = false; std::vector<float> stem_w, stem_b; size_t ws_off = 0, bs_off = 0; int stem_oh = 0, stem_ow = 0, stem_s = 1, stem_p = 0, stem_act = 0; float stem_slope = 0.f;

@@ -130,6 +130,7 @@ def test_resnet50_runs_its_first_stage_bottleneck_tails_as_one_launch_each(monke
     """executor pass 3d, expand head: 3x3 64->64 -> 1x1 64->256 (+ block input + ReLU) = one sm_conv2d_xhead_fwd_cfg step; pass 3e: in the first
     block the projection shortcut (1x1 on the block input, + Add + ReLU) is the head's second GEMM (sm_conv2d_xhead_proj_fwd_cfg).  Same function as
     the separate launches, and as the oracle"""
+    monkeypatch.setenv("SMELTER_BNECK", "0")                                      # (pass 3l would take the reduce layers of blocks 2 and 3 in as well: its own test below)
     model = zoo.resnet50(hw=(64, 64))
     x = zoo.synthetic_images(3, 3, (64, 64))
     ex, got = run_hip(model, x)
@@ -149,6 +150,7 @@ def test_resnet50_expand_head_with_the_shortcut_listed_elsewhere(order, monkeypa
     """the same blocks with the projection shortcut listed between the 3x3 and the expand layer ("mid": pass 3d moves it in front of the 3x3, because
     the head runs where the 3x3 runs and needs its residual operand by then) or in front of the block ("first"): the expand layer carries the Add and
     every first-stage tail is an expand head WITH a residual"""
+    monkeypatch.setenv("SMELTER_BNECK", "0")
     model = zoo.resnet50(hw=(64, 64), shortcut_order=order)
     x = zoo.synthetic_images(2, 3, (64, 64))
     ex, got = run_hip(model, x)
@@ -157,6 +159,29 @@ def test_resnet50_expand_head_with_the_shortcut_listed_elsewhere(order, monkeypa
     monkeypatch.setenv("SMELTER_XHEAD", "0")
     ex0, plain = run_hip(model, x)
     assert ex0.numOps == ex.numOps + 3
+    assert nerr(got, plain) <= 1e-3
+    assert nerr(got, O.Graph(model).run(x)) <= 5e-3
+
+
+@pytest.mark.parametrize("hw,batch", [((64, 64), 3), ((224, 224), 2), ((96, 72), 2)])
+def test_resnet50_runs_whole_bottleneck_blocks_as_one_launch(hw, batch, monkeypatch):
+    """executor pass 3l (round 6): blocks 2 and 3 of the first stage — 1x1 reduce 256 -> 64, 3x3 64 -> 64, 1x1 expand 64 -> 256 + block input + ReLU — are ONE sm_bottleneck_fwd
+    step each (csrc/kernels/bneck.hip: both hidden tensors on chip).  Flip-and-compare: with SMELTER_BNECK=0 the reduce layers are launches of their own again (+2); the two
+    forms agree within the parity bar (bit for bit where the reduce layer's own kernel multiplies in the same MFMA steps: tests/test_gpu_bneck.py), both meet the oracle,
+    and the hidden tensors stay in the rounding list without storage."""
+    model = zoo.resnet50(hw=hw)
+    x = zoo.synthetic_images(batch, 3, hw)
+    ex, got = run_hip(model, x)
+    whole = [ex.opDesc(i) for i in range(ex.numOps) if "whole bottleneck block" in ex.opDesc(i)]
+    assert len(whole) == 2 and all("N=64 K=256 k=1x1 +act" in d.split(">>")[0] and "k=3x3" in d.split(">>")[1] and "N=256 K=64 k=1x1 +res +act" in d.split(">>")[2] for d in whole)
+    hidden = set(ex.valueNames) - set(ex.storedValueNames)
+    monkeypatch.setenv("SMELTER_BNECK", "0")
+    ex0, plain = run_hip(model, x)
+    assert ex0.numOps == ex.numOps + 2 and ex0.numLaunches == ex.numLaunches + 2 and not any("whole bottleneck block" in ex0.opDesc(i) for i in range(ex0.numOps))
+    assert abs(ex0.flops - ex.flops) <= 1e-9 * ex.flops and abs(ex0.algorithmicBytes - ex.algorithmicBytes) <= 1e-6 * ex.algorithmicBytes      # accounted as the layers the graph holds
+    assert ex.launchBytes < ex0.launchBytes                              # two hidden tensors fewer to move
+    assert set(ex.valueNames) == set(ex0.valueNames)                     # the rounding list is the same ...
+    assert len(hidden - (set(ex0.valueNames) - set(ex0.storedValueNames))) == 2      # ... two more of its tensors have no storage
     assert nerr(got, plain) <= 1e-3
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3
 
@@ -581,6 +606,7 @@ def test_resnet50_projection_shortcuts_are_concatenated_along_k(form, monkeypatc
 
 
 @pytest.mark.parametrize("env,make,shape,fewer_launches", [
+    ("SMELTER_BNECK", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 2),             # pass 3l: blocks 2 and 3 of the first stage as one launch each
     ("SMELTER_XHEAD_PROJ", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 1),        # pass 3e: the first block's shortcut as the head's second GEMM
     ("SMELTER_STEM_F32", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 2),          # pass 3f: no input-conversion launch (and no pool fusion, which needs it)
     ("SMELTER_STEM_F32", lambda: zoo.unet(hw=(64, 48)), (2, 3, 64, 48), 1),
