@@ -51,6 +51,18 @@ __device__ unsigned long long g_bn_tl[256 * 2 * 64];
 #else
 #define BN_STAMP(slot) do { } while (0)
 #endif
+// cache policy of the output stores / of the x and residual loads (aux operand of the raw buffer builtins: 0 default, 2 = nt, 16 = sc1, 17 = sc0 sc1) — build-time knobs for the A/B
+// (stores: sc1 = write through, the line is not kept — the output is never re-read through this launch's L2; same box, two repetitions: 58.3 / 58.7 -> 57.3 / 55.9 us.
+//  nt on the stores or on either load stream measured 14 .. 28 us WORSE: profiles/r06_bneck_policy.txt)
+#ifndef BN_ST_AUX
+#define BN_ST_AUX 16
+#endif
+#ifndef BN_LDX_AUX
+#define BN_LDX_AUX 0
+#endif
+#ifndef BN_LDR_AUX
+#define BN_LDR_AUX 0
+#endif
 constexpr int BN_TW = 14, BN_PW = 16, BN_THMAX = 8, BN_NPX = (BN_THMAX + 2) * BN_PW;       // 160 patch pixels = 5 fragments
 constexpr int BN_PLANE = BN_NPX * 16, BN_PATCH = 8 * BN_PLANE;                              // 2560-byte channel planes, 20 KB per patch
 constexpr int BN_W3 = 9 * 64 * 128, BN_B1 = BN_W3 + 256 * 128, BN_B2 = BN_B1 + 256, BN_B3 = BN_B2 + 256, BN_PAT = BN_B3 + 1024, BN_LDS = BN_PAT + 2 * BN_PATCH;
@@ -58,6 +70,25 @@ static_assert(BN_LDS <= 160 * 1024, "LDS budget");
 constexpr unsigned BN_DEAD = 0x80000000u;   // buffer offset beyond every descriptor: loads return 0, stores are dropped
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// LDS base pointers the optimiser cannot see through.  The kernel's LDS image is > 64 KB: written as `bn_smem + BN_B3 + ...` an address is "0 + a constant beyond the 16-bit
+// offset field of ds_read", and hipcc then keeps EVERY such address in a register of its own (32 bias addresses, 32 fragment addresses: the first pipelined expand spilled
+// over them).  A laundered per-lane base in one register + small compile-time offsets is what the hardware wants.
+typedef const __attribute__((address_space(3))) unsigned char* bn_lds_cptr;
+__device__ __forceinline__ bn_lds_cptr bn_lds_base(unsigned addr) { asm volatile("" : "+v"(addr)); return reinterpret_cast<bn_lds_cptr>(addr); }
+template <class T> __device__ __forceinline__ T bn_lds_read(bn_lds_cptr base, int off) { return *(const __attribute__((address_space(3))) T*)(base + off); }
+
+// ROW-PAIR TRANSPOSE of two MFMA-layout registers.  In the B / store layout of the 32x32x16 MFMA lane (p = lane & 31, hi = lane >> 5) holds 16 bytes of pixel p: per memory
+// instruction a pixel contributes 2 x 16 bytes, i.e. a wave touches 32 cache lines for 32 bytes each — the CU's vector-memory pipe spends a tag look-up and a 64-byte sector
+// on every one of them (measured: ~60 clk per instruction, the bottleneck of the first forms of this kernel).  Two registers a, b that hold the neighbouring 16-byte pieces
+// (j = 0, 1: bytes +0 and +32 of a 64-byte group) of 32 pixels are exchanged by v_permlane16_swap (odd 16-lane rows of a <-> even rows of b) into
+//     a' = all four pieces of pixels 0..15,  b' = all four pieces of pixels 16..31      lane L: pixel (L & 15) [+ 16], piece at byte ((L >> 4) & 1) * 32 + (L >> 5) * 16
+// so that ONE instruction moves 16 pixels x 64 contiguous bytes (16 lines, whole sectors).  The exchange is its own inverse: loads fetch a', b' and swap into a, b;
+// stores swap a, b into a', b'.  Pure data movement: the values, and every rounding, are what they were.
+__device__ __forceinline__ void bn_swap16(u32x4& a, u32x4& b) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) { unsigned x = a[e], y = b[e]; asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x), "+v"(y)); a[e] = x; b[e] = y; }
+}
 
 // KR = C0 / 16 k steps of the reduce (C0 in {64, 128, 256})
 template <int KR>
@@ -108,7 +139,8 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
         const int slot0 = in_tile ? ty * BN_PW + tx : 0;
         const unsigned a_base = lds0 + BN_PAT + (unsigned)(hi * BN_PLANE + slot0 * 16);
         const unsigned w_base0 = lds0 + (unsigned)(hi * 1024 + l31 * 16), w_base1 = w_base0 + 5 * 8192;
-        const unsigned char* const w3f = bn_smem + BN_W3 + hi * 512 + l31 * 16;     // A fragment of (chunk c, k step ks) = w3f + c * 4096 + ks * 1024
+        const bn_lds_cptr w3f = bn_lds_base(lds0 + BN_W3 + (unsigned)(hi * 512 + l31 * 16));     // A fragment of (chunk c, k step ks) = w3f + c * 4096 + ks * 1024
+        const bn_lds_cptr b2f = bn_lds_base(lds0 + BN_B2 + (unsigned)(hi * 16)), b3f = bn_lds_base(lds0 + BN_B3 + (unsigned)(hi * 16));   // bias rows 8 q + 4 hi .. +3 of chunk c at + c * 128 + q * 32
         const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)(pix_all * (unsigned)p.y_ld * 2u), 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res ? (int)(pix_all * (unsigned)p.res_ld * 2u) : 0, 0x00020000);
         half8_t onehot[2];                                                 // E_j[r][k] = (r == 16j + k): mfma(E_j, R_j, acc) adds residual rows that arrive in the B layout
@@ -117,28 +149,39 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
 #pragma unroll
             for (int e = 0; e < 8; e++) onehot[j][e] = (half_t)((l31 == 16 * j + 8 * hi + e) ? 1.f : 0.f);
         const int nch = p.n3 >> 5;                                         // 32-channel chunks of the output
-        auto pixel_off = [&](int t, int ld, bool on) -> unsigned {        // byte offset of (tile t, this lane's pixel) + 8 hi channels, or DEAD
+        // memory-side lane map (bn_swap16): instruction 0 of a pair moves pixels 0..15 of the fragment, instruction 1 pixels 16..31; lane L -> pixel (L & 15), 16-byte piece
+        // ((L >> 4) & 1) * 32 + (L >> 5) * 16 of each 64-byte channel group
+        const int mi0 = wave * 32 + (lane & 15), mty0 = mi0 / BN_TW, mtx0 = mi0 - mty0 * BN_TW, mi1 = mi0 + 16, mty1 = mi1 / BN_TW, mtx1 = mi1 - mty1 * BN_TW;
+        const bool min0 = mi0 < TH * BN_TW, min1 = mi1 < TH * BN_TW;
+        const unsigned piece = (unsigned)(((lane >> 4) & 1) * 32 + (lane >> 5) * 16);
+        auto pixel_off = [&](int t, int ld, bool on, int which) -> unsigned {   // byte offset of (tile t, this lane's pixel of instruction `which`) + its piece, or DEAD
             int n, y0, x0; tile_origin(t < t_end ? t : t_begin, n, y0, x0);
-            const int oy = y0 + ty, ox = x0 + tx;
-            const bool live = on && t < t_end && in_tile && oy < p.H && ox < p.W;
-            return live ? (unsigned)(((n * p.H + oy) * p.W + ox) * ld + 8 * hi) * 2u : BN_DEAD;
+            const int oy = y0 + (which ? mty1 : mty0), ox = x0 + (which ? mtx1 : mtx0);
+            const bool live = on && t < t_end && (which ? min1 : min0) && oy < p.H && ox < p.W;
+            return live ? (unsigned)(((n * p.H + oy) * p.W + ox) * ld) * 2u + piece : BN_DEAD;
         };
         const bool res_on = p.res != nullptr && !(BN_DBG(p) & 2);
-        u32x4 rres[8][2];                                                  // residual rows [chunk][j] (channels 32 c + 16 j + 8 hi .. +7) of the tile whose expand runs next
-        {
-            const unsigned off = pixel_off(t_begin, p.res_ld, res_on);
-#pragma unroll
-            for (int c = 0; c < 8; c++)
-#pragma unroll
-                for (int j = 0; j < 2; j++) rres[c][j] = c < nch ? __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(off + (unsigned)(c * 64 + 32 * j)), 0, 0) : u32x4{0, 0, 0, 0};
-        }
+        // residual rows of the tile being computed, as loaded (bn_swap16 turns [instruction] into [j]): three PAIR slots [pair % 3][chunk of pair][instruction] — pairs 0 and 1 are
+        // requested when the tile starts (the 3x3 loop is their flight time), pair 2 when pair 0's adds have issued, pair 3 one stage later into pair 0's slot
+        u32x4 rres[3][2][2];
         constexpr int NS = 36, PF = 4, RD = 3;
         static_assert(PF * RD <= 15, "lgkmcnt field");
         auto do_tile = [&](auto bufc, auto relu2c, auto relu3c, int t) {
             constexpr int BUF = decltype(bufc)::value;
+            constexpr bool RELU2 = decltype(relu2c)::value, RELU3 = decltype(relu3c)::value;
             const int tlb = (t - t_begin + 1) * 5; (void)tlb;
             BN_STAMP(tlb);
-            constexpr bool RELU2 = decltype(relu2c)::value, RELU3 = decltype(relu3c)::value;
+            const unsigned offr0 = pixel_off(t, p.res_ld, res_on, 0), offr1 = pixel_off(t, p.res_ld, res_on, 1);
+            auto load_res = [&](auto kc) __attribute__((always_inline)) {       // pair K of this tile -> slot K % 3 (chunks beyond n3: dead offset, zeros)
+                constexpr int K = decltype(kc)::value;
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++) {
+                    const bool on = 2 * K + cc < nch;
+                    rres[K % 3][cc][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((on ? offr0 : BN_DEAD) + (unsigned)((2 * K + cc) * 64)), 0, BN_LDR_AUX);
+                    rres[K % 3][cc][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((on ? offr1 : BN_DEAD) + (unsigned)((2 * K + cc) * 64)), 0, BN_LDR_AUX);
+                }
+            };
+            load_res(std::integral_constant<int, 0>()); load_res(std::integral_constant<int, 1>());
             floatx16 acc[2];
             {
                 half8_t fx[PF + 1], fw[PF + 1][2];
@@ -176,7 +219,7 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
                 unsigned d[4][2];
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const floatx4 bq = *(const floatx4*)(b2l + a * 32 + 8 * q + 4 * hi);
+                    const floatx4 bq = bn_lds_read<floatx4>(b2f, a * 128 + q * 32);
 #pragma unroll
                     for (int h2 = 0; h2 < 2; h2++) {
                         float v0 = acc[a][4 * q + 2 * h2] + bq[2 * h2], v1 = acc[a][4 * q + 2 * h2 + 1] + bq[2 * h2 + 1];
@@ -194,60 +237,81 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
                 }
             }
             BN_STAMP(tlb + 2);
-            // expand: four 32-channel chunks at a time — their MFMA chains are independent, so the matrix pipe never waits for its own result and the VALU work of one
-            // chunk runs under the MFMAs of the others
-            const unsigned offy = pixel_off(t, p.y_ld, !(BN_DBG(p) & 1)), offr = pixel_off(t + 1, p.res_ld, res_on);
-#pragma unroll
-            for (int g = 0; g < 2; g++) {
-                if (g * 4 < nch) {                                         // wave-uniform
-                    floatx16 a3[4];
-#pragma unroll
-                    for (int cc = 0; cc < 4; cc++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) a3[cc][r] = 0.f;
-                    if (!(BN_DBG(p) & 16)) {
-#pragma unroll
-                        for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-                            for (int cc = 0; cc < 4; cc++) {
-                                const half8_t wf = *(const half8_t*)(w3f + (g * 4 + cc) * 4096 + ks * 1024);
-                                a3[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, __builtin_bit_cast(half8_t, outv[ks >> 1][ks & 1]), a3[cc], 0, 0, 0);
-                            }
-                        // (no residual: the rows were loaded through an empty descriptor and are 0 — adding them is exact, and cheaper than a branch here)
-#pragma unroll
-                        for (int j = 0; j < 2; j++)
-#pragma unroll
-                            for (int cc = 0; cc < 4; cc++) a3[cc] = __builtin_amdgcn_mfma_f32_32x32x16_f16(onehot[j], __builtin_bit_cast(half8_t, rres[g * 4 + cc][j]), a3[cc], 0, 0, 0);
-                    }
-#pragma unroll
-                    for (int cc = 0; cc < 4; cc++) {
-                        const int c = g * 4 + cc;
-                        // these registers are free again: the NEXT tile's rows of the same chunk — a whole tile of flight time
-#pragma unroll
-                        for (int j = 0; j < 2; j++) rres[c][j] = c < nch ? __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(offr + (unsigned)(c * 64 + 32 * j)), 0, 0) : u32x4{0, 0, 0, 0};
-                        unsigned d[4][2];
-#pragma unroll
-                        for (int qq = 0; qq < 4; qq++) {
-                            const floatx4 bq = *(const floatx4*)(b3l + c * 32 + 8 * qq + 4 * hi);
-#pragma unroll
-                            for (int h = 0; h < 2; h++) {
-                                float v0 = a3[cc][4 * qq + 2 * h] + bq[2 * h], v1 = a3[cc][4 * qq + 2 * h + 1] + bq[2 * h + 1];
-                                if constexpr (!RELU3) { v0 = v0 < 0.f ? v0 * p.sl3 : v0; v1 = v1 < 0.f ? v1 * p.sl3 : v1; }
-                                half2_t hv = {(half_t)v0, (half_t)v1};
-                                if constexpr (RELU3) hv = __builtin_elementwise_max(hv, half2_t{0, 0});
-                                d[qq][h] = __builtin_bit_cast(unsigned, hv);
-                            }
-                        }
-                        const unsigned offc = c < nch ? offy : BN_DEAD;       // (a group's chunks beyond n3 are computed on whatever the LDS holds and dropped)
-#pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            sm_permlane32_swap(d[2 * j][0], d[2 * j + 1][0]);
-                            sm_permlane32_swap(d[2 * j][1], d[2 * j + 1][1]);
-                            __builtin_amdgcn_raw_buffer_store_b128(u32x4{d[2 * j][0], d[2 * j][1], d[2 * j + 1][0], d[2 * j + 1][1]}, rs_y, (int)(offc + (unsigned)(c * 64 + 32 * j)), 0, SM_ST_AUX);
-                        }
-                    }
+            // ---- expand, SOFTWARE-PIPELINED over PAIRS of 32-channel chunks.  A wave issues in order: a burst of MFMAs followed by a burst of epilogue VALU work leaves the
+            // matrix pipe idle during the second and the wave stalled during the first (the first form of this loop: 7 k clk per tile, more than the 3x3 itself).  Here the twelve
+            // MFMAs of pair k+1 (eight w3 . T2 steps, four one-hot residual adds; the two chunks' chains ALTERNATE — a dependent MFMA waits ~100 clk for its predecessor, an
+            // independent one 32: one chain at a time measured 115 clk per MFMA) are dealt ONE per slice between the twelve slices of pair k's epilogue (~7 VALU instructions
+            // each), the order pinned by sched_barrier; w3 fragments ride a four-deep ring of LDS reads, the bias rows of the next pair are fetched as soon as this pair's are
+            // consumed.  Everything is branch-free: chunks beyond n3 compute on whatever the LDS holds and store to a dead offset.
+            const unsigned offy0 = pixel_off(t, p.y_ld, !(BN_DBG(p) & 1), 0), offy1 = pixel_off(t, p.y_ld, !(BN_DBG(p) & 1), 1);
+            half8_t w3r[4];                                                // ring: w3 fragment F = 8 * pair + slice (chunk of pair = F & 1, k step = (F >> 1) & 3) in slot F & 3
+            floatx16 a3[2][2];                                             // [pair & 1][chunk of pair]
+            floatx4 bqr[4];                                                // ring: bias rows G = 4 * chunk + q in slot G & 3 (row q of the NEXT chunk is requested when this chunk's is consumed)
+            unsigned dd[4][2];                                             // the chunk being converted
+            u32x4 o2[2];
+            // MFMA number S (0..11) of pair K: S < 8 the w3 . T2 step (chunk S & 1, k step S >> 1), then the residual rows through the two one-hot matrices
+            auto mfma_slice = [&](auto kc, auto sc) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value, S = decltype(sc)::value, B = K & 1;
+                if constexpr (S < 8) {
+                    constexpr int CC = S & 1, KS = S >> 1, F = K * 8 + S, F4 = F + 4;
+                    if constexpr (KS == 0) a3[B][CC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3r[F & 3], __builtin_bit_cast(half8_t, outv[0][0]), (floatx16){0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                    else a3[B][CC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w3r[F & 3], __builtin_bit_cast(half8_t, outv[KS >> 1][KS & 1]), a3[B][CC], 0, 0, 0);
+                    if constexpr (F4 < 32) w3r[F & 3] = bn_lds_read<half8_t>(w3f, ((F4 >> 3) * 2 + (F4 & 1)) * 4096 + ((F4 >> 1) & 3) * 1024);   // (the slot is free: four fragments ahead)
+                } else {
+                    constexpr int CC = (S - 8) & 1, J = (S - 8) >> 1, C = 2 * K + CC;
+                    if constexpr (J == 0) bn_swap16(rres[K % 3][CC][0], rres[K % 3][CC][1]);          // as loaded -> [j] (the B layout)
+                    a3[B][CC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(onehot[J], __builtin_bit_cast(half8_t, rres[K % 3][CC][J]), a3[B][CC], 0, 0, 0);
                 }
-                BN_STAMP(tlb + 3 + g);
+            };
+            // slice S (0..11) of pair K's epilogue: per chunk four conversion slices (8 accumulators each: + b3, activation, one rounding), the half-wave swaps, then the
+            // row-pair transpose + the two stores
+            auto epi_slice = [&](auto kc, auto sc) __attribute__((always_inline)) {
+                constexpr int K = decltype(kc)::value, S = decltype(sc)::value, B = K & 1, CC = S / 6, PART = S % 6, C = 2 * K + CC;
+                if constexpr (PART < 4) {
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        float v0 = a3[B][CC][4 * PART + 2 * h] + bqr[PART][2 * h], v1 = a3[B][CC][4 * PART + 2 * h + 1] + bqr[PART][2 * h + 1];
+                        if constexpr (!RELU3) { v0 = v0 < 0.f ? v0 * p.sl3 : v0; v1 = v1 < 0.f ? v1 * p.sl3 : v1; }
+                        half2_t hv = {(half_t)v0, (half_t)v1};
+                        if constexpr (RELU3) hv = __builtin_elementwise_max(hv, half2_t{0, 0});
+                        dd[PART][h] = __builtin_bit_cast(unsigned, hv);
+                    }
+                    if constexpr (C + 1 < 8) bqr[PART] = bn_lds_read<floatx4>(b3f, (C + 1) * 128 + PART * 32);   // (consumed: the same row of the next chunk, six slices of flight)
+                } else if constexpr (PART == 4) {
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        sm_permlane32_swap(dd[2 * j][0], dd[2 * j + 1][0]);
+                        sm_permlane32_swap(dd[2 * j][1], dd[2 * j + 1][1]);
+                        o2[j] = u32x4{dd[2 * j][0], dd[2 * j][1], dd[2 * j + 1][0], dd[2 * j + 1][1]};
+                    }
+                } else {
+                    bn_swap16(o2[0], o2[1]);                                   // [j] -> 16 pixels x 64 contiguous bytes per store
+                    const bool on = C < nch;                                   // wave-uniform; folded into the offsets: no branch
+                    __builtin_amdgcn_raw_buffer_store_b128(o2[0], rs_y, (int)((on ? offy0 : BN_DEAD) + (unsigned)(C * 64)), 0, BN_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(o2[1], rs_y, (int)((on ? offy1 : BN_DEAD) + (unsigned)(C * 64)), 0, BN_ST_AUX);
+                }
+            };
+            if (!(BN_DBG(p) & 16)) {
+                // prologue: the ring, the first pair's bias rows, the first pair's MFMAs
+#pragma unroll
+                for (int F = 0; F < 4; F++) w3r[F] = bn_lds_read<half8_t>(w3f, (F & 1) * 4096 + (F >> 1) * 1024);
+#pragma unroll
+                for (int qq = 0; qq < 4; qq++) bqr[qq] = bn_lds_read<floatx4>(b3f, qq * 32);
+                sm_static_for<0, 12>([&](auto sc) { mfma_slice(std::integral_constant<int, 0>(), sc); });
+                load_res(std::integral_constant<int, 2>());                    // (slot 2 is free; pair 3 follows into pair 0's slot, whose adds have issued)
+                __builtin_amdgcn_sched_barrier(0);
+                // (all four pairs are walked whatever n3 is — the weights' LDS image and the bias image hold eight chunks, dead chunks store nowhere; narrow heads are not what
+                //  this kernel is for: wasted MFMAs at n3 = 64 cost less than a branchy loop costs the 256-channel case)
+                sm_static_for<0, 4>([&](auto kc) {
+                    constexpr int K = decltype(kc)::value;
+                    if constexpr (K == 0) load_res(std::integral_constant<int, 3>());
+                    sm_static_for<0, 12>([&](auto sc) {
+                        if constexpr (K + 1 < 4) mfma_slice(std::integral_constant<int, K + 1>(), sc);
+                        epi_slice(kc, sc);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    if constexpr (K == 1 || K == 3) BN_STAMP(tlb + 3 + (K >> 1));
+                });
             }
         };
         auto prun = [&](auto relu2c, auto relu3c) __attribute__((always_inline)) {
@@ -282,6 +346,7 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
             for (int ks = 0; ks < KR; ks++) w1r[c][ks] = *(const half8_t*)(p.w1 + (long)(c * 32 + l31) * p.C0 + ks * 16 + hi * 8);
         // b1 is read in period 0, BEFORE the first barrier: every reducer wave writes all of it itself (four waves store identical values; a wave sees its own LDS writes in order)
         b1l[lane] = p.b1 ? p.b1[lane] : 0.f;
+        const bn_lds_cptr b1f = bn_lds_base(lds0 + BN_B1 + (unsigned)(hi * 16));
         const int pr_l = l31 >> 4, pc_l = l31 & 15;
         // period q computes the patch of tile t_begin + q.  slide(q): the tile is directly below the previous one -> rows 0, 1 are copied, fragments 1 .. 4 computed (one per
         // reducer); else fragments 0 .. NF-1: reducer r takes r and r + 4.  unit (q, j) = my j-th fragment of period q (-1: none)
@@ -297,20 +362,30 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
             const int fp = j == 0 ? rw : rw + 4;
             return fp < NF ? fp : -1;
         };
-        auto unit_off = [&](int q, int fp, bool& valid) -> unsigned {      // byte offset of this lane's pixel row of fragment fp of period q's patch (+ 16 hi), DEAD outside the image
+        // compute-side validity of this lane's patch pixel (fragment fp, pixel lane & 31): inside the image?
+        auto unit_valid = [&](int q, int fp) -> bool {
             int n, y0, x0; tile_origin(t_begin + (q < nt ? q : 0), n, y0, x0);
             const int iy = y0 - 1 + 2 * fp + pr_l, ix = x0 - 1 + pc_l;
-            valid = fp >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-            return valid ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.x_ld + 8 * hi) * 2u : BN_DEAD;
+            return fp >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         };
-        // the ring of x loads: KR deep = the whole next unit in flight, where the registers allow it (w1 takes 8 KR of them); C0 = 256: eight k steps — the second half of a
-        // unit is requested while its first half is multiplied (a reducer has one unit per tile in the steady state: the wait this leaves is inside its slack)
+        // memory-side offsets (bn_swap16): instruction `which` of a pair reads patch row 2 fp + which, lane L its pixel (L & 15) and 16-byte piece; DEAD outside the image
+        const unsigned piece = (unsigned)(((lane >> 4) & 1) * 32 + (lane >> 5) * 16);
+        auto unit_off = [&](int q, int fp, int which) -> unsigned {
+            int n, y0, x0; tile_origin(t_begin + (q < nt ? q : 0), n, y0, x0);
+            const int iy = y0 - 1 + 2 * fp + which, ix = x0 - 1 + (lane & 15);
+            const bool valid = fp >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            return valid ? (unsigned)(((n * p.H + iy) * p.W + ix) * p.x_ld) * 2u + piece : BN_DEAD;
+        };
+        // the ring of x loads, in PAIRS (k steps 2m, 2m + 1 = one 64-byte channel group, rows 2 fp and 2 fp + 1 of the patch): KR deep = the whole next unit in flight, where the
+        // registers allow it (w1 takes 8 KR of them); C0 = 256: eight k steps — the second half of a unit is requested while its first half is multiplied (a reducer has one
+        // unit per tile in the steady state: the wait this leaves is inside its slack)
         constexpr int RDP = KR > 8 ? 8 : KR;
+        static_assert((RDP & 1) == 0 && (KR % RDP) == 0, "whole pairs");
         u32x4 xa[RDP];
         int fp_cur = unit_frag(0, 0);
-        bool v_cur; unsigned off_cur = unit_off(0, fp_cur, v_cur);
+        bool v_cur = unit_valid(0, fp_cur); unsigned off_cur0 = unit_off(0, fp_cur, 0), off_cur1 = unit_off(0, fp_cur, 1);
 #pragma unroll
-        for (int ks = 0; ks < RDP; ks++) xa[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off_cur + (unsigned)(ks * 32)), 0, 0);
+        for (int ks = 0; ks < RDP; ks++) xa[ks] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(((ks & 1) ? off_cur1 : off_cur0) + (unsigned)((ks >> 1) * 64)), 0, BN_LDX_AUX);
         auto rrun = [&](auto relu0c) __attribute__((always_inline)) {
             constexpr bool RELU0 = decltype(relu0c)::value;
 #pragma unroll 1
@@ -328,7 +403,7 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
                 for (int j = 0; j < nu; j++) {
                     // the unit after this one: my second fragment of this period, else my first of the next
                     const int q_next = j + 1 < nu ? q : q + 1, fp_next = j + 1 < nu ? unit_frag(q, j + 1) : unit_frag(q + 1, 0);
-                    bool v_next; const unsigned off_next = unit_off(q_next, fp_next, v_next);
+                    const bool v_next = unit_valid(q_next, fp_next); const unsigned off_next0 = unit_off(q_next, fp_next, 0), off_next1 = unit_off(q_next, fp_next, 1);
                     floatx16 acc[2];
 #pragma unroll
                     for (int c = 0; c < 2; c++)
@@ -336,10 +411,19 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
                         for (int r = 0; r < 16; r++) acc[c][r] = 0.f;
                     sm_static_for<0, KR>([&](auto kc) {
                         constexpr int KS = decltype(kc)::value;
+                        if constexpr ((KS & 1) == 0) bn_swap16(xa[KS % RDP], xa[(KS + 1) % RDP]);      // the pair as loaded -> k steps KS, KS + 1 in the B layout
 #pragma unroll
                         for (int c = 0; c < 2; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1r[c][KS], __builtin_bit_cast(half8_t, xa[KS % RDP]), acc[c], 0, 0, 0);
-                        if constexpr (KS + RDP < KR) xa[KS % RDP] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off_cur + (unsigned)((KS + RDP) * 32)), 0, 0);
-                        else xa[KS % RDP] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off_next + (unsigned)((KS + RDP - KR) * 32)), 0, 0);
+                        if constexpr ((KS & 1) == 1) {                         // both registers of the pair are free: the pair RDP k steps on (this unit's, or the next unit's)
+                            constexpr int K0 = KS - 1 + RDP;
+                            if constexpr (K0 < KR) {
+                                xa[(KS - 1) % RDP] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off_cur0 + (unsigned)((K0 >> 1) * 64)), 0, BN_LDX_AUX);
+                                xa[KS % RDP] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off_cur1 + (unsigned)((K0 >> 1) * 64)), 0, BN_LDX_AUX);
+                            } else {
+                                xa[(KS - 1) % RDP] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off_next0 + (unsigned)(((K0 - KR) >> 1) * 64)), 0, BN_LDX_AUX);
+                                xa[KS % RDP] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(off_next1 + (unsigned)(((K0 - KR) >> 1) * 64)), 0, BN_LDX_AUX);
+                            }
+                        }
                     });
                     BN_STAMP(q * 5 + 1 + 2 * j);
                     // bias, activation, ONE rounding; zeros outside the image (the 3x3's padding); lane swaps -> 8 consecutive channels per lane -> channel planes
@@ -349,7 +433,7 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
                         unsigned d[4][2];
 #pragma unroll
                         for (int qq = 0; qq < 4; qq++) {
-                            const floatx4 bq = *(const floatx4*)(b1l + c * 32 + 8 * qq + 4 * hi);
+                            const floatx4 bq = bn_lds_read<floatx4>(b1f, c * 128 + qq * 32);
 #pragma unroll
                             for (int h = 0; h < 2; h++) {
                                 float v0 = acc[c][4 * qq + 2 * h] + bq[2 * h], v1 = acc[c][4 * qq + 2 * h + 1] + bq[2 * h + 1];
@@ -367,7 +451,7 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
                         }
                     }
                     BN_STAMP(q * 5 + 2 + 2 * j);
-                    off_cur = off_next; v_cur = v_next; fp_cur = fp_next;
+                    off_cur0 = off_next0; off_cur1 = off_next1; v_cur = v_next; fp_cur = fp_next;
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // my patch writes (the x loads stay in flight across the barrier)
                 __builtin_amdgcn_s_barrier();                              // after period q
