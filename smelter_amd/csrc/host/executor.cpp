@@ -741,7 +741,8 @@ int Executor::plan(ONNXGraph& g, int batch) {
                 std::vector<size_t> save(root_offset_); root_offset_.assign(nv, 0);
                 size_t o = 0; for (int v = 0; v < nv; v++) { root_offset_[v] = o; o += alignUp((size_t)batch * values_[v].h * values_[v].w * std::max(place_[v].ld, 8) * 2 + 64); }
                 size_t wo = 0; for (size_t q = t; q < e; q++) { steps_[q].w_off = wo; wo += alignUp(steps_[q].op.weight.size() * 2); steps_[q].b_off = wo; wo += alignUp(steps_[q].op.bias.size() * 4 + 64); steps_[q].has_bias = !steps_[q].op.bias.empty(); }
-                for (size_t e2 = e; e2 >= t + 2 && !ok; e2--) {
+                // (a PREFIX must hold at least three layers: a two-layer run saves one launch gap and pays the run's arrival + hand-off protocol for it; the whole window may be two)
+                for (size_t e2 = e; e2 >= t + 2 && (e2 == e || e2 >= t + 3) && !ok; e2--) {
                     r = StageRun(); r.first = (int)t; r.count = (int)(e2 - t); r.wide = wide;
                     const std::vector<sm_stage_phase> ph = runPhases(r, (const char*)(uintptr_t)0x100000000ull, (const char*)(uintptr_t)0x4000000000ull, false);
                     ok = sm_stage_supported(ph.data(), (int)ph.size()) != 0;

@@ -459,6 +459,7 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(ConvParams p) {
 #include "pw_thin.hpp"
 #include "conv3x3_ws.hpp"
 #include "conv3x3_wsx.hpp"
+#include "fc_small.hpp"
 #include "conv3x3_p9.hpp"
 #include "conv1x1_ps.hpp"
 #include "conv1x1_rw.hpp"
@@ -1033,6 +1034,10 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
         }
         SM_LAUNCH_CHECK(); return SM_OK;
     }
+    if (fc_small_eligible(d, p)) {                                             // a classifier on few rows: 16 x 16 blocks, K over the block's waves (fc_small.hpp), no tile config
+        fc_small_launch(p, s);
+        SM_LAUNCH_CHECK(); return SM_OK;
+    }
     if (!p.ups && pw_thin_eligible(d, p)) {                                    // thin pointwise layers: untiled streaming kernel (pw_thin.hpp), no tile config
         pw_thin_launch(p, s);
         SM_LAUNCH_CHECK(); return SM_OK;
@@ -1380,6 +1385,7 @@ int sm_conv2d_uses_tile_config(const sm_conv_desc* d) {
     ConvParams p; alignas(16) static char dummy[16];
     if (fill_params(d, dummy, dummy, nullptr, nullptr, dummy, &p)) return 0;
     if (d->groups > 1 && d->groups == d->Cin && d->groups == d->Cout) return 0;
+    if (fc_small_eligible(d, p)) return 0;
     if (pw_thin_eligible(d, p)) return 0;
     return mfma_eligible(d, p) ? 1 : 0;
 }

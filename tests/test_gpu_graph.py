@@ -96,9 +96,10 @@ def test_fusion_counts_resnet50():
     # (8 x 8, 4 x 4, 2 x 2) are persistent runs (pass 3k): the eight bottleneck tails of stage 1 stay launches (fused heads are not run members), 3 + 3 stride-2 / reduce
     # layers in front of the runs, 3 runs, stem, pool + FC
     from smelter_amd.graph import FUSE_STAGE, default_fusions
-    assert ex.numOps == 48 and ex.numLaunches == 25, ex.numLaunches
+    # (round 6, pass 3l: blocks 2 and 3 of stage 1 are whole-block launches — their reduce layers are no steps of their own: 48 -> 46 ops, 25 -> 23 launches)
+    assert ex.numOps == 46 and ex.numLaunches == 23, ex.numLaunches
     ex0, _ = run_hip(zoo.resnet50(hw=(64, 64)), zoo.synthetic_images(1, 3, (64, 64)), fusions=default_fusions() & ~FUSE_STAGE)
-    assert ex0.numOps == 48 and ex0.numLaunches in (48, 49)
+    assert ex0.numOps == 46 and ex0.numLaunches in (46, 47)
     assert abs(ex.flops - 2 * 4089184256 * (64 * 64) / (224 * 224)) / ex.flops < 0.2      # scaled MAC count, FC unscaled
 
 
@@ -607,7 +608,7 @@ def test_resnet50_projection_shortcuts_are_concatenated_along_k(form, monkeypatc
 
 @pytest.mark.parametrize("env,make,shape,fewer_launches", [
     ("SMELTER_BNECK", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 2),             # pass 3l: blocks 2 and 3 of the first stage as one launch each
-    ("SMELTER_XHEAD_PROJ", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 1),        # pass 3e: the first block's shortcut as the head's second GEMM
+    ("SMELTER_XHEAD_PROJ", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 0),        # pass 3e (round 6: without it the first block's reduce layer joins its 3x3 + expand launch, pass 3l, and the shortcut is a launch of its own: the same count): the first block's shortcut as the head's second GEMM
     ("SMELTER_STEM_F32", lambda: zoo.resnet50(hw=(64, 64)), (2, 3, 64, 64), 2),          # pass 3f: no input-conversion launch (and no pool fusion, which needs it)
     ("SMELTER_STEM_F32", lambda: zoo.unet(hw=(64, 48)), (2, 3, 64, 48), 1),
     ("SMELTER_STEM3", lambda: zoo.unet(hw=(64, 48)), (2, 3, 64, 48), 0),                 # pass 3j: the staged 3x3 stem instead of the loader-wave form (same launch count)

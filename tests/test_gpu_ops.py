@@ -5,6 +5,8 @@ computes in fp32 and its result is rounded to fp16 once, as the kernel's store d
 Tolerance (fp16 output, fp32 accumulate): |got - ref| <= 1 fp16 ulp of the value (2^-10 relative) plus an absolute
 floor of 2^-11 * max|ref| * sqrt(K)*1e-2 covering accumulation-order differences that flip a rounding.  Byte-exact
 for the pure data-movement kernels (copy, nearest upsample, max-pool, layout)."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -92,6 +94,39 @@ CONV_CASES = [
     (1, 8, 8, 3, 8, 3, 1, 1, False, 1),                # Cin = 3 -> direct kernel
     (1, 6, 7, 12, 6, 3, 1, 1, True, 1),                # Cin % 8 != 0, odd Cout -> direct kernel, scalar stores
 ]
+
+
+FC_CASES = [
+    # rows, K, N, act       -- fc_small.hpp: 16 outputs x 16 rows per block, K over the block's four waves
+    (64, 2048, 1000, 0),    # ResNet-50's classifier at bs 64: 63 x 4 blocks, the last output tile holds 8 outputs
+    (70, 2048, 1000, 1),    # ragged rows (five row tiles, the last holds 6), ReLU
+    (1, 2048, 1000, 0),     # one row
+    (256, 1280, 1000, 0),   # MobileNet-v2's classifier at bs 256 (40 k steps)
+    (17, 288, 36, 2),       # 9 k steps over four waves (2 + 2 + 2 + 3), N % 16 != 0, leaky
+    (33, 256, 8, 0),        # the smallest K the kernel takes, one output tile of 8
+]
+
+
+@pytest.mark.parametrize("m,k,n,act", FC_CASES)
+def test_fully_connected_on_few_rows(m, k, n, act):
+    """MPSCNNFullyConnectedNode (Converters.swift:297) on a batch of vectors: the dedicated kernel behind sm_conv2d_fwd for 1 x 1 maps with M <= 256 (no tile configuration, no
+    split-K reduce launch), against the oracle's fp32 dot products"""
+    d = ops.ConvDesc(m, 1, 1, k, n, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 1, 1, 1, act, 0.25, k, n, 0)
+    assert not ops.lib().sm_conv2d_uses_tile_config(ctypes.byref(d))          # a dedicated kernel takes the shape
+    rng = np.random.default_rng(m * 7 + k + n)
+    x = h(rng.standard_normal((m, k, 1, 1)))
+    w = h(rng.standard_normal((n, 1, 1, k)) * np.sqrt(2.0 / k))
+    b = rng.standard_normal(n).astype(np.float32)
+    ref = O.conv2d(x, w, b)
+    slope = 0.25 if act == 2 else 0.0
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), act=act, slope=slope)
+    assert_close(to_host(y), ref, k)
+    # the same bits on every launch (the four K partials are added in a fixed order)
+    y2 = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), act=act, slope=slope)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
