@@ -161,9 +161,24 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
             return live ? (unsigned)(((n * p.H + oy) * p.W + ox) * ld) * 2u + piece : BN_DEAD;
         };
         const bool res_on = p.res != nullptr && !(BN_DBG(p) & 2);
-        // residual rows of the tile being computed, as loaded (bn_swap16 turns [instruction] into [j]): three PAIR slots [pair % 3][chunk of pair][instruction] — pairs 0 and 1 are
-        // requested when the tile starts (the 3x3 loop is their flight time), pair 2 when pair 0's adds have issued, pair 3 one stage later into pair 0's slot
+        // residual rows, as loaded (bn_swap16 turns [instruction] into [j]): three PAIR slots [slot][chunk of pair][instruction].  Pairs 0, 1, 2 of a tile are requested ONE TILE
+        // AHEAD, each as soon as its slot's previous tenant has been added (during the previous tile's expand: stages 3, 1, 2) — that is the half period in which the reducers
+        // read the same rows for the patch, so the XCD's L2 (4 MB against ~2.5 MB of traffic in between) still holds them and the fabric carries them once; pair 3 rides in
+        // pair 0's slot inside the tile (64 registers would hold a whole tile ahead; the expand's pipeline leaves 48).
         u32x4 rres[3][2][2];
+        auto load_res = [&](int t, auto kc, auto slotc) __attribute__((always_inline)) {       // pair K of tile t -> slot (chunks beyond n3 / tiles beyond the range: dead offset, zeros)
+            constexpr int K = decltype(kc)::value, SL = decltype(slotc)::value;
+            const unsigned o0 = pixel_off(t, p.res_ld, res_on, 0), o1 = pixel_off(t, p.res_ld, res_on, 1);
+#pragma unroll
+            for (int cc = 0; cc < 2; cc++) {
+                const bool on = 2 * K + cc < nch;
+                rres[SL][cc][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((on ? o0 : BN_DEAD) + (unsigned)((2 * K + cc) * 64)), 0, BN_LDR_AUX);
+                rres[SL][cc][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((on ? o1 : BN_DEAD) + (unsigned)((2 * K + cc) * 64)), 0, BN_LDR_AUX);
+            }
+        };
+        load_res(t_begin, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
+        load_res(t_begin, std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+        load_res(t_begin, std::integral_constant<int, 2>(), std::integral_constant<int, 2>());
         constexpr int NS = 36, PF = 4, RD = 3;
         static_assert(PF * RD <= 15, "lgkmcnt field");
         auto do_tile = [&](auto bufc, auto relu2c, auto relu3c, int t) {
@@ -171,17 +186,6 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
             constexpr bool RELU2 = decltype(relu2c)::value, RELU3 = decltype(relu3c)::value;
             const int tlb = (t - t_begin + 1) * 5; (void)tlb;
             BN_STAMP(tlb);
-            const unsigned offr0 = pixel_off(t, p.res_ld, res_on, 0), offr1 = pixel_off(t, p.res_ld, res_on, 1);
-            auto load_res = [&](auto kc) __attribute__((always_inline)) {       // pair K of this tile -> slot K % 3 (chunks beyond n3: dead offset, zeros)
-                constexpr int K = decltype(kc)::value;
-#pragma unroll
-                for (int cc = 0; cc < 2; cc++) {
-                    const bool on = 2 * K + cc < nch;
-                    rres[K % 3][cc][0] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((on ? offr0 : BN_DEAD) + (unsigned)((2 * K + cc) * 64)), 0, BN_LDR_AUX);
-                    rres[K % 3][cc][1] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((on ? offr1 : BN_DEAD) + (unsigned)((2 * K + cc) * 64)), 0, BN_LDR_AUX);
-                }
-            };
-            load_res(std::integral_constant<int, 0>()); load_res(std::integral_constant<int, 1>());
             floatx16 acc[2];
             {
                 half8_t fx[PF + 1], fw[PF + 1][2];
@@ -259,7 +263,7 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
                     if constexpr (F4 < 32) w3r[F & 3] = bn_lds_read<half8_t>(w3f, ((F4 >> 3) * 2 + (F4 & 1)) * 4096 + ((F4 >> 1) & 3) * 1024);   // (the slot is free: four fragments ahead)
                 } else {
                     constexpr int CC = (S - 8) & 1, J = (S - 8) >> 1, C = 2 * K + CC;
-                    if constexpr (J == 0) bn_swap16(rres[K % 3][CC][0], rres[K % 3][CC][1]);          // as loaded -> [j] (the B layout)
+                    if constexpr (J == 0) bn_swap16(rres[K % 3][CC][0], rres[K % 3][CC][1]);          // as loaded -> [j] (the B layout); pair 3 sits in slot 0
                     a3[B][CC] = __builtin_amdgcn_mfma_f32_32x32x16_f16(onehot[J], __builtin_bit_cast(half8_t, rres[K % 3][CC][J]), a3[B][CC], 0, 0, 0);
                 }
             };
@@ -298,13 +302,16 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
 #pragma unroll
                 for (int qq = 0; qq < 4; qq++) bqr[qq] = bn_lds_read<floatx4>(b3f, qq * 32);
                 sm_static_for<0, 12>([&](auto sc) { mfma_slice(std::integral_constant<int, 0>(), sc); });
-                load_res(std::integral_constant<int, 2>());                    // (slot 2 is free; pair 3 follows into pair 0's slot, whose adds have issued)
+                load_res(t, std::integral_constant<int, 3>(), std::integral_constant<int, 0>());      // (pair 0's adds have issued: this tile's pair 3 into its slot)
                 __builtin_amdgcn_sched_barrier(0);
                 // (all four pairs are walked whatever n3 is — the weights' LDS image and the bias image hold eight chunks, dead chunks store nowhere; narrow heads are not what
                 //  this kernel is for: wasted MFMAs at n3 = 64 cost less than a branchy loop costs the 256-channel case)
                 sm_static_for<0, 4>([&](auto kc) {
                     constexpr int K = decltype(kc)::value;
-                    if constexpr (K == 0) load_res(std::integral_constant<int, 3>());
+                    // the NEXT tile's pairs, each into the slot whose tenant was added in the stage before
+                    if constexpr (K == 1) load_res(t + 1, std::integral_constant<int, 1>(), std::integral_constant<int, 1>());
+                    if constexpr (K == 2) load_res(t + 1, std::integral_constant<int, 2>(), std::integral_constant<int, 2>());
+                    if constexpr (K == 3) load_res(t + 1, std::integral_constant<int, 0>(), std::integral_constant<int, 0>());
                     sm_static_for<0, 12>([&](auto sc) {
                         if constexpr (K + 1 < 4) mfma_slice(std::integral_constant<int, K + 1>(), sc);
                         epi_slice(kc, sc);
