@@ -25,6 +25,7 @@
 // (bit-identical to the 1x1 launch + the 3x3 -> expand-head launch it replaces: tests/test_gpu_bneck.py).
 #include <stdlib.h>
 #include <math.h>
+#include <algorithm>
 #include "conv_shared.hpp"
 
 namespace {
@@ -468,6 +469,8 @@ __global__ __launch_bounds__(512) void bneck_kernel(BnParams p) {
     }
 }
 
+#include "bneck128.hpp"
+
 }  // namespace
 
 static BnParams bn_params(const sm_bneck_desc* d) {
@@ -488,6 +491,14 @@ extern "C" int sm_bneck_timeline_clear(void) { static unsigned long long z[256 *
 #endif
 extern "C" int sm_bottleneck_supported(const sm_bneck_desc* d) {
     if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    if (d->Cm == BN2_CM) {                                             // the 128-channel middle: one band tile per block, three phases (bneck128.hpp)
+        if (d->act1 > SM_ACT_PRELU || d->act2 > SM_ACT_PRELU || d->act3 > SM_ACT_PRELU) return 0;
+        if (d->x_ld < d->C0 || d->y_ld < d->C3 || (d->x_ld & 7) || (d->y_ld & 7) || (d->res_ld & 7)) return 0;
+        const long px2 = (long)d->N * d->H * d->W;
+        if (px2 * d->x_ld * 2 >= 0x7fff0000L || px2 * d->y_ld * 2 >= 0x7fff0000L || px2 * (d->res_ld > 0 ? d->res_ld : 1) * 2 >= 0x7fff0000L) return 0;
+        if (!bn2_geometry(d, nullptr)) return 0;
+        return (long)d->N * sm_ceil_div(d->H, 1) < (1L << 30) ? 1 : 0;
+    }
     if (d->Cm != 64 || (d->C0 != 64 && d->C0 != 128 && d->C0 != 256) || d->C3 < 32 || d->C3 > 256 || (d->C3 % 32) != 0) return 0;
     if (d->act1 > SM_ACT_PRELU || d->act2 > SM_ACT_PRELU || d->act3 > SM_ACT_PRELU) return 0;
     if (d->x_ld < d->C0 || d->y_ld < d->C3 || (d->x_ld & 7) || (d->y_ld & 7) || (d->res_ld & 7)) return 0;
@@ -503,6 +514,22 @@ extern "C" int sm_bottleneck_fwd(const sm_bneck_desc* d, const void* x, const vo
     SM_REQUIRE(sm_bottleneck_supported(d), "sm_bottleneck_fwd: no kernel takes this block (1x1 C0 in {64, 128, 256} -> 64, 3x3 / s1 / p1 64 -> 64, 1x1 64 -> C3 <= 256, C3 %% 32 == 0, ReLU-family activations, tensors < 2 GB)");
     SM_REQUIRE(!res || d->res_ld >= d->C3, "sm_bottleneck_fwd: residual pixel stride %d < C3 %d", d->res_ld, d->C3);
     SM_REQUIRE(((((uintptr_t)x) | ((uintptr_t)w1) | ((uintptr_t)w2) | ((uintptr_t)w3) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) == 0, "sm_bottleneck_fwd: operands must be 16-byte aligned");
+    if (d->Cm == BN2_CM) {
+        SM_REQUIRE(!b1 || (((uintptr_t)b1) & 15) == 0, "sm_bottleneck_fwd: biases must be 16-byte aligned");
+        SM_REQUIRE((!b2 || (((uintptr_t)b2) & 15) == 0) && (!b3 || (((uintptr_t)b3) & 15) == 0), "sm_bottleneck_fwd: biases must be 16-byte aligned");
+        Bn2Params q{};
+        q.x = (const half_t*)x; q.w1 = (const half_t*)w1; q.b1 = b1; q.w2 = (const half_t*)w2; q.b2 = b2; q.w3 = (const half_t*)w3; q.b3 = b3; q.res = (const half_t*)res; q.y = (half_t*)y;
+        q.N = d->N; q.H = d->H; q.W = d->W; q.C0 = d->C0; q.n3 = d->C3; q.x_ld = d->x_ld; q.y_ld = d->y_ld; q.res_ld = d->res_ld;
+        auto sl2 = [](int act, float s) { return act == SM_ACT_NONE ? 1.f : act == SM_ACT_RELU ? 0.f : s; };
+        q.sl1 = sl2(d->act1, d->slope1); q.sl2 = sl2(d->act2, d->slope2); q.sl3 = sl2(d->act3, d->slope3);
+        bn2_geometry(d, &q);
+        const size_t lds = bn2_lds_bytes(q);
+        static size_t attr_lds = 0;
+        if (lds > attr_lds) { SM_HIP_CHECK(hipFuncSetAttribute((const void*)bneck128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_lds = lds; }
+        hipLaunchKernelGGL(bneck128_kernel, dim3((unsigned)(d->N * q.bands)), dim3(256), lds, sm_s(stream), q);
+        SM_LAUNCH_CHECK();
+        return SM_OK;
+    }
     BnParams p = bn_params(d);
     p.x = (const half_t*)x; p.w1 = (const half_t*)w1; p.b1 = b1; p.w2 = (const half_t*)w2; p.b2 = b2; p.w3 = (const half_t*)w3; p.b3 = b3; p.res = (const half_t*)res; p.y = (half_t*)y;
     { static const int dbg = SM_ABL_ENV("SM_BN_DEBUG") ? atoi(SM_ABL_ENV("SM_BN_DEBUG")) : 0; p.dbg = dbg; }   // ablation switch (diagnostic builds only), read once

@@ -1,0 +1,335 @@
+// bneck128.hpp — the bottleneck block with a 128-channel middle (ResNet-50's 28 x 28 stage: 512 -> 128 -> 128 -> 512) as ONE launch; included by bneck.hip.
+//
+//     T1 = act1(w1 . x  + b1)            1x1 "reduce",  C0 -> 128           (MPSCNNConvolutionNode, /root/reference/Sources/Smelter/Converters.swift:187-338)
+//     T2 = act2(w2 * T1 + b2)            3x3 / stride 1 / pad 1, 128 -> 128 (padding rule ONNXConvolutionPadding.swift:73-79: zeros outside the image)
+//     y  = act3(w3 . T2 + b3 + res)      1x1 "expand",  128 -> n3, + residual (MPSNNAdditionNode, Converters.swift:430-451), ReLU family (:342-359)
+//
+// Layer by layer such a block moves 205 MB at bs 64 (x in, T1 out and back, T2 out and back, x again as residual, y out) in three launches of 15 + 23 + 22 us, each at its
+// own memory or fill roofline; as one pass: x once (+ two halo rows per tile), the residual, y.  The weights (128 + 288 + 128 KB) cannot live in the LDS as the 64-channel
+// block's do (bneck_kernel above) — so the tile is as large as the chip allows, ONE per CU (a band of TH rows x the whole width: 7 x 28 = 196 pixels; 64 images x 4 bands =
+// 256 blocks), every weight is read exactly once per block, straight from global memory into MFMA A fragments (v_mfma_f32_16x16x32_f16: four lanes x 16 bytes = 64
+// contiguous bytes of a weight row per instruction), and the three layers are three PHASES of the block's four waves (one per SIMD: 512 registers each):
+//   1. reduce: x passes the LDS in 64-channel stages of (TH + 2) x W pixels (LDS-DMA, two stages: the copy of the next runs under the MFMAs of this one — every wave needs
+//      every pixel, so it is staged once instead of loaded four times); wave w owns couts [32 w, 32 w + 32) of all <= 256 patch pixels (128 accumulator registers).  The
+//      result — + b1, activation, one rounding — is written into the patch of the 3x3 in conv3x3_kq.hpp's slot format (rows RS = W + 1 .. slots apart: the zero columns
+//      between rows are the left / right halo; rows outside the image stay the zeros the patch was cleared to: the 3x3's padding, not act1(b1)).
+//   2. 3x3: conv3x3_kq.hpp's main loop without its DMA: wave w owns couts [32 w, 32 w + 32) of the tile's 13 pixel fragments, weights two units ahead in a register ring,
+//      pixel fragments one unit ahead from the LDS; no barrier.
+//   3. expand: T2 (+ b2, activation, one rounding) goes to LDS [pixel][128 channels] (over the dead x stages); wave w owns couts [n3 / 4 * w, ..) in passes of 32: the
+//      weight rows are dealt to the two fragments so that a lane ends up with EIGHT consecutive couts of its pixel (conv3x3_kq.hpp's XCH order) — residual loads and stores
+//      are 16 bytes per lane, 64 contiguous bytes per pixel and instruction.
+// Numerics: every layer accumulates in fp32 over k ascending (MFMA steps of 32) from zero, + bias in fp32, activation, ONE rounding to fp16 of both hidden tensors (they stay
+// in the parity oracle's rounding list).
+#pragma once
+
+struct Bn2Params {
+    const half_t* x; const half_t* w1; const float* b1; const half_t* w2; const float* b2; const half_t* w3; const float* b3; const half_t* res; half_t* y;
+    int N, H, W, C0, n3, x_ld, y_ld, res_ld;
+    float sl1, sl2, sl3;             // f(v) = v < 0 ? v * sl : v   (1 = no activation, 0 = ReLU)
+    int TH, bands, RS, PR, NP1;      // tile rows, bands per image, slots per patch row, patch rows (TH + 2), patch pixels inside image columns (PR * W)
+    int slice_bytes, xc_bytes;       // one T1 slice (64 channels of the patch, 2 KB aligned), one x stage (NP1 rounded up to 16 pixels x 128 bytes)
+    int ka, kb;                      // swizzle of the T1 patch: chunk c of slot (row r, column cc) at position c ^ ((ka (cc / 2) + kb r) & 7)   (conv3x3_kq.hpp)
+    unsigned w_mul, w_sh, bands_mul, bands_sh;
+};
+constexpr int BN2_XRING = 4 * 16384;                                  // the x ring of phase 1: four stages of 256 pixels x 64 bytes
+constexpr int BN2_CM = 128, BN2_NF1 = 16, BN2_NF2 = 13;                // middle channels; pixel fragments (16 pixels each) of the patch / of the tile
+
+__device__ __forceinline__ void bn2_bdma16(unsigned voff, u32x4 rsrc, unsigned lds_dst, unsigned soff) {   // LDS-DMA through a buffer descriptor (conv3x3_kq.hpp kq_bdma16): dead lanes -> zeros
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
+}
+
+#ifdef SM_BN_TL
+#define BN2_STAMP(slot) do { if (lane == 0 && blockIdx.x < 256 && (slot) < 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); g_bn_tl[(blockIdx.x * 2 + (wave & 1)) * 64 + (slot) + (wave >> 1) * 32] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define BN2_STAMP(slot) do { } while (0)
+#endif
+__global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char bn2_smem[];
+    const unsigned lds0 = (ws_lds_addr(bn2_smem) + 2047u) & ~2047u;    // slices start 2 KB aligned (the launcher adds the slack)
+    const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = p.H, W = p.W, RS = p.RS, TH = p.TH;
+    const int n0 = (int)sm_fastdiv((unsigned)blockIdx.x, p.bands_mul, p.bands_sh), y0 = ((int)blockIdx.x - n0 * p.bands) * TH;
+    const int PTe = min(TH, H - y0) * W;                              // output pixels of this tile
+    const long pix0 = ((long)n0 * H + y0) * W;
+    const unsigned t1_0 = lds0, xr_0 = lds0 + 2u * (unsigned)p.slice_bytes;
+    const bn_lds_cptr ldsb = bn_lds_base(0u);                           // (addresses below are absolute LDS byte addresses)
+    auto key = [&](int r, int cc) -> unsigned { return (unsigned)((p.ka * (cc >> 1) + p.kb * r) & 7); };
+
+    BN2_STAMP(0);
+    // ---- phase 0: the patch is cleared (halo columns, rows outside the image) -------------------------------------------------------------------------------------
+    {
+        const u32x4 z = {0, 0, 0, 0};
+        for (unsigned o = (unsigned)tid * 16u; o < 2u * (unsigned)p.slice_bytes; o += 256u * 16u) *(__attribute__((address_space(3))) u32x4*)(size_t)(t1_0 + o) = z;
+    }
+
+    // ---- phase 1: T1 = act1(w1 . x + b1) on the patch's image pixels i = r W + xx (r < PR, xx < W) -------------------------------------------------------------------
+    // x passes the LDS in stages of 32 channels (64 bytes per pixel, <= 256 pixels: 16 KB), a ring of FOUR with THREE in flight: the phase is bound by the fabric (every CU
+    // pulls its 270 KB at once), and what a CU gets is (bytes in flight) / latency — with one 32 KB stage in flight the first form of this loop took 53 k clk for 16 k of
+    // traffic.  Per stage a wave issues exactly SIX vector-memory operations (four LDS-DMA pieces, padded with dead ones; the two A fragments of w1 for that k step), all as
+    // asm statements, so the wait in front of a stage is a plain count: 6 (D - 1) younger operations may still be in flight.
+    constexpr int XS = 4, XD = 3;                                      // ring stages, stages in flight ahead
+    const int nst = p.C0 >> 5;                                         // 32-channel stages of x = k steps of the reduce
+    const unsigned ld2 = (unsigned)p.x_ld * 2u;
+    const u32x4 rs_x = {(unsigned)(uintptr_t)p.x, (unsigned)((uintptr_t)p.x >> 32) & 0xffffu, (unsigned)p.N * (unsigned)(H * W) * ld2, 0x00020000u};
+    // DMA: piece q = 4 i + j (j = 16-byte piece of pixel i's 64 bytes) lands lane-linear; instruction I = q / 64 covers 16 pixels, wave w issues I = w, w + 4, w + 8, w + 12.
+    // The source piece is j ^ swz(i), swz(i) = (i / 4) & 3 (the fragment reads below undo it: 16 consecutive pixels x one piece = 16 distinct 16-byte slots).
+    // Offsets without the channel base; pixels outside the image / beyond the patch: dead (zeros, no memory access).
+    unsigned dmo[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int q = (wave + 4 * k) * 64 + lane, i = q >> 2, j = q & 3;
+        const int r = (int)sm_fastdiv((unsigned)i, p.w_mul, p.w_sh), xx = i - r * W, iy = y0 - 1 + r;
+        const bool ok = i < p.NP1 && (unsigned)iy < (unsigned)H;
+        dmo[k] = ok ? (unsigned)(((n0 * H + iy) * W + xx)) * ld2 + (unsigned)((j ^ ((i >> 2) & 3)) << 4) : 0x80000000u;
+    }
+    // A fragments of w1: fragment j = couts 32 wave + 16 j + l15, channels 32 s + 8 g .. (asm loads: counted with the DMA pieces)
+    const unsigned w1o0 = (unsigned)(((32 * wave + l15) * p.C0 + 8 * g) * 2), w1o1 = w1o0 + (unsigned)(16 * p.C0 * 2);
+    half8_t wa[XS][2];
+    auto issue_stage = [&](auto slotc, int s) __attribute__((always_inline)) {   // stage s -> ring slot; beyond the last stage: six dead operations (the counts stay exact)
+        constexpr int SL = decltype(slotc)::value;
+        const bool real = s < nst;
+        const unsigned dst = xr_0 + (unsigned)SL * 16384u;
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            bn2_bdma16(real ? dmo[k] : 0x80000000u, rs_x, (unsigned)__builtin_amdgcn_readfirstlane((int)(dst + (unsigned)(wave + 4 * k) * 1024u)), (unsigned)(real ? s : 0) * 64u);
+        const half_t* wbse = p.w1 + (real ? s : 0) * 32;
+        // (asm operands are copied to locals first: inside generic lambdas hipcc does not capture a variable that only an asm operand names)
+        { half8_t& d0 = wa[SL][0]; const unsigned o0 = w1o0; asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d0) : "v"(o0), "s"(wbse) : "memory"); }
+        { half8_t& d1 = wa[SL][1]; const unsigned o1 = w1o1; asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(d1) : "v"(o1), "s"(wbse) : "memory"); }
+    };
+    // B fragment (16 pixels x 32 channels) f of a stage: lane (pixel l15, quarter g) reads piece g of pixel 16 f + l15
+    unsigned xba[BN2_NF1];
+#pragma unroll
+    for (int f = 0; f < BN2_NF1; f++) { const int i = f * 16 + l15; xba[f] = xr_0 + (unsigned)(i * 64 + ((g ^ ((i >> 2) & 3)) << 4)); }
+    floatx4 acc1[BN2_NF1][2];
+#pragma unroll
+    for (int f = 0; f < BN2_NF1; f++) { acc1[f][0] = floatx4{0.f, 0.f, 0.f, 0.f}; acc1[f][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+    BN2_STAMP(1);
+    issue_stage(std::integral_constant<int, 0>(), 0); issue_stage(std::integral_constant<int, 1>(), 1); issue_stage(std::integral_constant<int, 2>(), 2);
+    const int nf1 = (p.NP1 + 15) >> 4;                                 // fragments that hold patch pixels (wave-uniform)
+    auto stage = [&](auto slotc, int s) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slotc)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (XD - 1)) : "memory");    // my six operations of stage s (the younger ones: stages s + 1, s + 2)
+        __builtin_amdgcn_s_barrier();                                 // everybody's; everybody has left the slot stage s + 3 goes to (it held stage s - 1)
+        __builtin_amdgcn_sched_barrier(0);
+        issue_stage(std::integral_constant<int, (SL + XD) % XS>(), s + XD);
+#pragma unroll
+        for (int f = 0; f < BN2_NF1; f++) {
+            if (f < nf1) {
+                const half8_t bf = bn_lds_read<half8_t>(ldsb, (int)(xba[f] + (unsigned)SL * 16384u));
+                acc1[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[SL][0], bf, acc1[f][0], 0, 0, 0);
+                acc1[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[SL][1], bf, acc1[f][1], 0, 0, 0);
+            }
+        }
+    };
+#pragma unroll 1
+    for (int s0 = 0; s0 < nst; s0 += 4) {                             // (C0 % 64 == 0: stages come in pairs; the ring position is the stage number mod 4)
+        stage(std::integral_constant<int, 0>(), s0);
+        stage(std::integral_constant<int, 1>(), s0 + 1);
+        if (s0 + 2 < nst) { stage(std::integral_constant<int, 2>(), s0 + 2); stage(std::integral_constant<int, 3>(), s0 + 3); }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the dead operations behind the last stage
+    // (to the register allocator an asm output is written when the statement executes: keep the ring allocated up to here, behind the wait)
+#pragma unroll
+    for (int q = 0; q < XS; q++) { asm volatile("" ::"v"(wa[q][0])); asm volatile("" ::"v"(wa[q][1])); }
+    BN2_STAMP(2);
+    // epilogue 1: lane (pixel l15 of fragment f, g) holds couts 32 wave + 16 j + 4 g .. + 3 -> 8 bytes of the pixel's slot in slice (couts / 64), chunk (couts % 64) / 8
+    {
+        const unsigned t1s = t1_0 + (unsigned)(wave >> 1) * (unsigned)p.slice_bytes;
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const floatx4 bq = p.b1 ? *(const floatx4*)(p.b1 + 32 * wave + 16 * j + 4 * g) : floatx4{0.f, 0.f, 0.f, 0.f};
+            const int chunk = (wave & 1) * 4 + 2 * j + (g >> 1);
+#pragma unroll
+            for (int f = 0; f < BN2_NF1; f++) {
+                const int i = f * 16 + l15, r = (int)sm_fastdiv((unsigned)i, p.w_mul, p.w_sh), xx = i - r * W, iy = y0 - 1 + r;
+                if (i < p.NP1 && (unsigned)iy < (unsigned)H) {
+                    half4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { const float v = acc1[f][j][e] + bq[e]; o[e] = (half_t)(v < 0.f ? v * p.sl1 : v); }
+                    const int cc = xx + 1;
+                    *(__attribute__((address_space(3))) half4_t*)(size_t)(t1s + (unsigned)((r * RS + cc) * 128) + (((unsigned)chunk ^ key(r, cc)) << 4) + (unsigned)((g & 1) * 8)) = o;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    BN2_STAMP(3);
+    __builtin_amdgcn_s_barrier();                                     // the patch is complete
+    __builtin_amdgcn_sched_barrier(0);
+    BN2_STAMP(4);
+
+    // ---- phase 2: the 3x3 over the patch.  Unit U = (tap U / 2, 32-channel half U % 2) of super-block sb (64 channels = one slice): 13 x 2 MFMAs ------------------------
+    const int kflip = (p.kb >> 2) & 1;                                // (kb = 4: one patch row down flips bit 2 of the key, i.e. swaps the slot's two 64-byte planes)
+    unsigned atab[BN2_NF2][3];                                        // address of fragment f's slot under tap (0, kw), channel quarter g, half 0, in slice 0
+#pragma unroll
+    for (int f = 0; f < BN2_NF2; f++) {
+        const int t = f * 16 + l15, tc = t < PTe ? t : 0, vrow = (int)sm_fastdiv((unsigned)tc, p.w_mul, p.w_sh), xx = tc - vrow * W;
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) atab[f][kw] = t1_0 + (unsigned)((vrow * RS + xx + kw) * 128) + (((unsigned)g ^ key(vrow, xx + kw)) << 4);
+    }
+    const half_t* w2p[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) w2p[j] = p.w2 + (long)(32 * wave + 16 * j + l15) * (9 * BN2_CM) + 8 * g;      // + tap * 128 + sb * 64 + hh * 32
+    floatx4 acc2[BN2_NF2][2];
+#pragma unroll
+    for (int f = 0; f < BN2_NF2; f++) { acc2[f][0] = floatx4{0.f, 0.f, 0.f, 0.f}; acc2[f][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+    constexpr int LA = 2;                                              // weight units in flight ahead (ring of 3; 18 % 3 == 0)
+    half8_t wb[LA + 1][2];
+    half8_t af[2][BN2_NF2];
+    auto load_w2 = [&](auto slotc, int sb, int u) __attribute__((always_inline)) {     // unit u (tap u / 2, half u % 2) of super-block sb
+        constexpr int SL = decltype(slotc)::value;
+        const int off = (u >> 1) * BN2_CM + sb * 64 + (u & 1) * 32;
+        wb[SL][0] = *(const half8_t*)(w2p[0] + off); wb[SL][1] = *(const half8_t*)(w2p[1] + off);
+    };
+    // fragment f under unit u of super-block sb = (atab[f][kw] + T) ^ X with two per-unit scalars, opaque to the optimiser (18 x 13 addresses are NOT loop invariants to keep
+    // in registers: the first build spilled over them)
+    auto unit_TX = [&](int sb, int u, unsigned& T, unsigned& X) {
+        const int tap = u >> 1, kh = tap / 3, hh = (u & 1) ^ (kflip & kh & 1);
+        T = (unsigned)(sb * p.slice_bytes + kh * RS * 128); X = (unsigned)(hh * 64);
+        asm volatile("" : "+s"(T), "+s"(X));
+    };
+    load_w2(std::integral_constant<int, 0>(), 0, 0); load_w2(std::integral_constant<int, 1>(), 0, 1);
+    {
+        unsigned T, X; unit_TX(0, 0, T, X);
+#pragma unroll
+        for (int f = 0; f < BN2_NF2; f++) af[0][f] = bn_lds_read<half8_t>(ldsb, (int)((atab[f][0] + T) ^ X));
+    }
+#pragma unroll 1
+    for (int sb = 0; sb < 2; sb++) {
+        sm_static_for<0, 18>([&](auto uc) {
+            constexpr int U = decltype(uc)::value;
+            {   // weights LA units ahead (beyond the last unit: a harmless reload)
+                constexpr int U2 = (U + LA) % 18;
+                const int sb2 = U + LA >= 18 ? (sb + 1 < 2 ? sb + 1 : sb) : sb;
+                load_w2(std::integral_constant<int, (U + LA) % (LA + 1)>(), sb2, U2);
+            }
+            {   // pixel fragments one unit ahead
+                constexpr int U1 = (U + 1) % 18;
+                const int sb1 = U + 1 >= 18 ? (sb + 1 < 2 ? sb + 1 : sb) : sb;
+                unsigned T, X; unit_TX(sb1, U1, T, X);
+#pragma unroll
+                for (int f = 0; f < BN2_NF2; f++) af[(U + 1) & 1][f] = bn_lds_read<half8_t>(ldsb, (int)((atab[f][(U1 >> 1) % 3] + T) ^ X));
+            }
+#pragma unroll
+            for (int f = 0; f < BN2_NF2; f++) {
+                acc2[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[U % (LA + 1)][0], af[U & 1][f], acc2[f][0], 0, 0, 0);
+                acc2[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[U % (LA + 1)][1], af[U & 1][f], acc2[f][1], 0, 0, 0);
+            }
+        });
+    }
+
+    BN2_STAMP(5);
+    // ---- phase 3: T2 = act2(acc2 + b2), rounded, -> LDS [pixel t][128 channels] (256-byte rows; chunk c16 of pixel t at position c16 ^ (t & 15)); then the expand --------
+    const unsigned t2_0 = xr_0;                                        // (over the x stages: dead since the barrier that closed phase 1)
+    {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const floatx4 bq = p.b2 ? *(const floatx4*)(p.b2 + 32 * wave + 16 * j + 4 * g) : floatx4{0.f, 0.f, 0.f, 0.f};
+            const int c16 = 4 * wave + 2 * j + (g >> 1);
+#pragma unroll
+            for (int f = 0; f < BN2_NF2; f++) {
+                const int t = f * 16 + l15;
+                half4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const float v = acc2[f][j][e] + bq[e]; o[e] = (half_t)(v < 0.f ? v * p.sl2 : v); }
+                *(__attribute__((address_space(3))) half4_t*)(size_t)(t2_0 + (unsigned)(t * 256) + (unsigned)((c16 ^ (t & 15)) << 4) + (unsigned)((g & 1) * 8)) = o;
+            }
+        }
+    }
+    BN2_STAMP(6);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    BN2_STAMP(7);
+    {
+        const int cpw = p.n3 >> 2, npass = cpw >> 5;                  // couts per wave, passes of 32
+        const unsigned pix_all = (unsigned)p.N * (unsigned)(H * W);
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)(pix_all * (unsigned)p.y_ld * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.res ? (int)(pix_all * (unsigned)p.res_ld * 2u) : 0, 0x00020000);
+        unsigned t2a[BN2_NF2];                                        // B fragment of k step ks: chunk 4 ks + g of pixel t = 16 f + l15
+#pragma unroll
+        for (int f = 0; f < BN2_NF2; f++) t2a[f] = t2_0 + (unsigned)((f * 16 + l15) * 256);
+        const int tsw = l15;                                           // (t & 15 = l15)
+        // weight row l15 of fragment j is cout (l15 / 4) 8 + 4 j + l15 % 4 of the pass: an accumulator lane (rows 4 g .. 4 g + 3) then holds couts 8 g .. 8 g + 3 in fragment 0
+        // and 8 g + 4 .. 8 g + 7 in fragment 1 — eight consecutive couts
+        const int wrow = (l15 >> 2) * 8 + (l15 & 3);
+        // a pass's weight fragments and residual rows are requested during the pass before it, each INTO THE REGISTERS IT REPLACES as soon as they are consumed (a k step's two
+        // fragments behind that k step's MFMAs, a pixel fragment's residual row behind its conversion): one pass of flight time, no second register set
+        half8_t w3a[4][2];
+        u32x4 rr[BN2_NF2];                                            // residual: couts cb + 8 g .. + 7 of pixel t
+        auto w3_ptr = [&](int ps, int ks, int j) -> const half8_t* { return (const half8_t*)(p.w3 + (long)(cpw * wave + 32 * (ps < npass ? ps : 0) + wrow + 4 * j) * BN2_CM + ks * 32 + 8 * g); };
+        // per-fragment byte offsets of this lane's pixel (+ its 8 g couts) in the residual and in the output, without the pass's cout base (a dead lane stays beyond num_records
+        // whatever is added)
+        unsigned rb[BN2_NF2], yb[BN2_NF2];
+#pragma unroll
+        for (int f = 0; f < BN2_NF2; f++) {
+            const int t = f * 16 + l15;
+            rb[f] = t < PTe ? (unsigned)(pix0 + t) * (unsigned)p.res_ld * 2u + (unsigned)(cpw * wave + 8 * g) * 2u : BN_DEAD;
+            yb[f] = t < PTe ? (unsigned)(pix0 + t) * (unsigned)p.y_ld * 2u + (unsigned)(cpw * wave + 8 * g) * 2u : BN_DEAD;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) { w3a[ks][0] = *w3_ptr(0, ks, 0); w3a[ks][1] = *w3_ptr(0, ks, 1); }
+#pragma unroll
+        for (int f = 0; f < BN2_NF2; f++) rr[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)rb[f], 0, 0);
+#pragma unroll 1
+        for (int ps = 0; ps < npass; ps++) {
+            const int cb = cpw * wave + 32 * ps;                       // first cout of the pass
+            const unsigned pso = (unsigned)(64 * ps), psn = ps + 1 < npass ? (unsigned)(64 * (ps + 1)) : 0x80000000u;      // byte offset of this / the next pass's couts
+            const floatx4 bq0 = p.b3 ? *(const floatx4*)(p.b3 + cb + 8 * g) : floatx4{0.f, 0.f, 0.f, 0.f}, bq1 = p.b3 ? *(const floatx4*)(p.b3 + cb + 8 * g + 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+            // the 13 fragments in two halves (7 + 6): 56 accumulator registers live instead of 104 — the epilogue's conversions want them in the vector file
+            sm_static_for<0, 2>([&](auto hc) {
+                constexpr int HF = decltype(hc)::value, F0 = HF ? 7 : 0, F1 = HF ? BN2_NF2 : 7;
+                floatx4 acc3[7][2];
+#pragma unroll
+                for (int f = F0; f < F1; f++) { acc3[f - F0][0] = floatx4{0.f, 0.f, 0.f, 0.f}; acc3[f - F0][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int ks = 0; ks < 4; ks++) {
+#pragma unroll
+                    for (int f = F0; f < F1; f++) {
+                        const half8_t bf = bn_lds_read<half8_t>(ldsb, (int)(t2a[f] + (unsigned)(((4 * ks + g) ^ tsw) << 4)));
+                        acc3[f - F0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3a[ks][0], bf, acc3[f - F0][0], 0, 0, 0);
+                        acc3[f - F0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3a[ks][1], bf, acc3[f - F0][1], 0, 0, 0);
+                    }
+                    if constexpr (HF == 1) { w3a[ks][0] = *w3_ptr(ps + 1, ks, 0); w3a[ks][1] = *w3_ptr(ps + 1, ks, 1); }     // (consumed by both halves: the next pass's)
+                }
+#pragma unroll
+                for (int f = F0; f < F1; f++) {
+                    const half8_t rh = __builtin_bit_cast(half8_t, rr[f]);
+                    half8_t ov;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const float v0 = acc3[f - F0][0][e] + bq0[e] + (float)rh[e], v1 = acc3[f - F0][1][e] + bq1[e] + (float)rh[4 + e];
+                        ov[e] = (half_t)(v0 < 0.f ? v0 * p.sl3 : v0); ov[4 + e] = (half_t)(v1 < 0.f ? v1 * p.sl3 : v1);
+                    }
+                    rr[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(rb[f] + psn), 0, 0);              // the next pass's row of this fragment
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs_y, (int)(yb[f] + pso), 0, BN_ST_AUX);
+                }
+            });
+            BN2_STAMP(8 + ps);
+        }
+    }
+}
+
+static bool bn2_geometry(const sm_bneck_desc* d, Bn2Params* p) {
+    if (d->Cm != BN2_CM || (d->C0 & 63) || d->C0 < 64 || d->C0 > 2048 || (d->C3 & 127) || d->C3 < 128 || d->C3 > 2048) return false;
+    const int W = d->W, H = d->H;
+    if (W < 4 || W > 62) return false;
+    int TH = std::min(H, std::min(208 / W, 256 / W - 2));
+    if (TH < 1) return false;
+    const int RS = (W + 1 + 7) / 8 * 8, PR = TH + 2;
+    const int slice = (PR * RS * 128 + 2047) / 2048 * 2048, np1 = PR * W, xc = ((np1 + 15) & ~15) * 128;
+    const int t2 = 13 * 16 * 256;
+    if ((size_t)2 * slice + (size_t)std::max(BN2_XRING, t2) + 2048 > 160 * 1024) return false;
+    if (p) {
+        p->TH = TH; p->bands = sm_ceil_div(H, TH); p->RS = RS; p->PR = PR; p->NP1 = np1; p->slice_bytes = slice; p->xc_bytes = xc;
+        p->ka = 1; p->kb = (RS / 2) & 7;
+        if (RS == 32 && W == 28) { p->ka = 2; p->kb = 4; }             // conflict-free pair for 28-pixel rows in 32-slot patch rows (tools/lds_swizzle_search.py, as conv_kq.hip)
+        sm_fastdiv_make((unsigned)W, &p->w_mul, &p->w_sh); sm_fastdiv_make((unsigned)p->bands, &p->bands_mul, &p->bands_sh);
+    }
+    return true;
+}
+static size_t bn2_lds_bytes(const Bn2Params& p) { return (size_t)2 * p.slice_bytes + (size_t)std::max(BN2_XRING, 13 * 16 * 256) + 2048; }

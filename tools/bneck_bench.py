@@ -7,23 +7,26 @@ import torch
 from smelter_amd import ops
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--n", type=int, default=64); ap.add_argument("--hw", type=int, default=56); ap.add_argument("--c0", type=int, default=256); ap.add_argument("--iters", type=int, default=50); ap.add_argument("--only", default="", help="one | two: launch only that form (PMC passes)")
+ap.add_argument("--n", type=int, default=64); ap.add_argument("--hw", type=int, default=56); ap.add_argument("--c0", type=int, default=256); ap.add_argument("--cm", type=int, default=64); ap.add_argument("--iters", type=int, default=50); ap.add_argument("--only", default="", help="one | two: launch only that form (PMC passes)")
 a = ap.parse_args()
-n, hw, c0 = a.n, a.hw, a.c0
+n, hw, c0, cm = a.n, a.hw, a.c0, a.cm
 torch.manual_seed(0)
 x = torch.randn((n, hw, hw, c0), device="cuda").half()
 x2 = torch.randn((n, hw, hw, c0), device="cuda").half()
-w1 = (torch.randn((64, 1, 1, c0), device="cuda") * (2.0 / c0) ** 0.5).half(); b1 = torch.randn(64, device="cuda") * 0.1
-w2 = (torch.randn((64, 3, 3, 64), device="cuda") * (2.0 / 576) ** 0.5).half(); b2 = torch.randn(64, device="cuda") * 0.1
-w3 = (torch.randn((c0, 64), device="cuda") * (2.0 / 64) ** 0.5).half(); b3 = torch.randn(c0, device="cuda") * 0.1
+w1 = (torch.randn((cm, 1, 1, c0), device="cuda") * (2.0 / c0) ** 0.5).half(); b1 = torch.randn(cm, device="cuda") * 0.1
+w2 = (torch.randn((cm, 3, 3, cm), device="cuda") * (2.0 / (9 * cm)) ** 0.5).half(); b2 = torch.randn(cm, device="cuda") * 0.1
+w3 = (torch.randn((c0, cm), device="cuda") * (2.0 / cm) ** 0.5).half(); b3 = torch.randn(c0, device="cuda") * 0.1
 out = torch.empty_like(x)
 
 def two(src, dst):
     t1 = ops.conv2d(src, w1, b1, act=ops.ACT_RELU)
-    _, y = ops.conv2d_xhead(t1, w2, b2, w3, b3, residual=src, act3=ops.ACT_RELU)
-    return y
+    if cm == 64:
+        _, y = ops.conv2d_xhead(t1, w2, b2, w3, b3, residual=src, act3=ops.ACT_RELU)
+        return y
+    t2 = ops.conv2d(t1, w2, b2, pads=(1, 1, 1, 1), act=ops.ACT_RELU)       # (the 128-channel middle: three launches, as the graph runs them)
+    return ops.conv2d(t2, w3.reshape(c0, 1, 1, cm), b3, residual=src, act=ops.ACT_RELU)
 def one(src, dst):
-    return ops.bottleneck(src, w1.reshape(64, c0), b1, w2, b2, w3, b3, residual=src, out=dst)
+    return ops.bottleneck(src, w1.reshape(cm, c0), b1, w2, b2, w3, b3, residual=src, out=dst)
 
 def timeit(fn, chain):
     # chain: the block's output feeds the next launch (as two identical blocks in a row do in the network: the input was written by the previous launch).
@@ -50,9 +53,9 @@ def timeit(fn, chain):
 ya, yb = two(x, None), one(x, out)
 torch.cuda.synchronize()
 print("bit-identical:", bool(torch.equal(ya, yb)), " differing:", int((ya != yb).sum()))
-flops = 2.0 * n * hw * hw * (c0 * 64 + 576 * 64 + 64 * c0)
+flops = 2.0 * n * hw * hw * (c0 * cm + 9 * cm * cm + cm * c0)
 for chain in (False, True):
     t2, t1 = timeit(two, chain), timeit(one, chain)
-    mb2 = n * hw * hw * (c0 * 2 + 64 * 2 * 2 + c0 * 2 * 2) / 1e6; mb1 = n * hw * hw * (c0 * 2 * 2) / 1e6
+    mb2 = n * hw * hw * (c0 * 2 + cm * 2 * 2 * (1 if cm == 64 else 2) + c0 * 2 * 2) / 1e6; mb1 = n * hw * hw * (c0 * 2 * 2) / 1e6
     print("%s: two launches %.1f us (%.0f MB, %.2f TB/s)   one launch %.1f us (%.0f MB compulsory, %.2f TB/s, %.0f TFLOP/s)" % (
         "chained" if chain else "same buffers", t2, mb2, mb2 / t2, t1, mb1, mb1 / t1, flops / t1 / 1e6))
