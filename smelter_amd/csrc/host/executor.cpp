@@ -531,9 +531,47 @@ int Executor::plan(ONNXGraph& g, int batch) {
             }
             return n;
         };
+        // (a) the 128-channel middle (ResNet-50's 28 x 28 stage; bneck128.hpp): no expand-head step exists for it — a plain 3x3 128 -> 128 whose only reader is a 1x1 expand
+        // (+ residual, ReLU family) first takes that layer as its head; the reduce layer then joins below as it does for the 64-channel blocks
         for (size_t t = 0; t < steps_.size(); t++) {
             Step& c = steps_[t];
-            if (!c.has_head || c.has_side || c.has_reduce || c.pool_out >= 0 || c.op.x_ups || c.op.grid_h || c.op.kind != OpKind::Conv || c.op.kh != 3 || c.op.kw != 3 || c.op.cin != 64 || c.op.cout != 64) continue;
+            const Op& o3 = c.op;
+            if (o3.kind != OpKind::Conv || c.has_head || c.has_side || c.has_mb || c.stem || c.stem3 || c.pool_out >= 0 || c.pool3_out >= 0 || c.dual_src >= 0 || c.gather || c.kcat || c.join >= 0 || c.waits_side ||
+                o3.x_ups || o3.grid_h || o3.kh != 3 || o3.kw != 3 || o3.sh != 1 || o3.sw != 1 || o3.dh != 1 || o3.dw != 1 || o3.pt != 1 || o3.pl != 1 || o3.pb != 1 || o3.pr != 1 || o3.groups != 1 ||
+                o3.cin != 128 || o3.cout != 128 || o3.residual >= 0 || o3.act > SM_ACT_PRELU || readers(o3.output) != 1 || o3.inputs.empty()) continue;
+            const int v = o3.inputs[0];
+            long a = -1;
+            for (size_t q = 0; q < t; q++) if (steps_[q].op.output == v) a = (long)q;
+            if (a < 0 || readers(v) != 1 || place_[v].root != v || place_[v].c_off != 0) continue;
+            const Op& o1 = steps_[a].op;
+            const Step& r1 = steps_[a];
+            if (o1.kind != OpKind::Conv || o1.kh != 1 || o1.kw != 1 || o1.sh != 1 || o1.sw != 1 || o1.pt || o1.pl || o1.pb || o1.pr || o1.groups != 1 || o1.act > SM_ACT_PRELU || o1.grid_h || o1.x_ups ||
+                o1.residual >= 0 || r1.stem || r1.stem3 || r1.has_mb || r1.has_head || r1.has_side || r1.pool_out >= 0 || r1.pool3_out >= 0 || r1.dual_src >= 0 || r1.gather || r1.kcat || r1.join >= 0 || r1.waits_side ||
+                o1.cout != 128 || o1.inputs.empty() || !vecOk(o1.inputs[0])) continue;      // (everything the second loop asks of a reduce layer: the head is only taken where the whole block follows)
+            long u = -1;
+            for (size_t q = t + 1; q < steps_.size(); q++) if (!steps_[q].op.inputs.empty() && steps_[q].op.inputs[0] == o3.output) { u = (long)q; break; }
+            if (u < 0) continue;
+            Step& h = steps_[u];
+            const Op& oh = h.op;
+            if (oh.kind != OpKind::Conv || oh.kh != 1 || oh.kw != 1 || oh.sh != 1 || oh.sw != 1 || oh.pt || oh.pl || oh.pb || oh.pr || oh.groups != 1 || oh.act > SM_ACT_PRELU || oh.grid_h || oh.x_ups ||
+                h.stem || h.stem3 || h.has_mb || h.has_head || h.has_side || h.pool_out >= 0 || h.pool3_out >= 0 || h.dual_src >= 0 || h.gather || h.kcat || h.join >= 0 || h.waits_side ||
+                oh.cin != 128 || !vecOk(oh.output) || (oh.residual >= 0 && !vecOk(oh.residual))) continue;
+            if (oh.residual >= 0) {                                    // the launch runs where the 3x3 runs: the residual operand must exist by then
+                bool late = false;
+                for (size_t q = t; q < steps_.size(); q++) if (steps_[q].op.output == oh.residual || (steps_[q].has_head && steps_[q].head.output == oh.residual)) late = true;
+                if (late) continue;
+            }
+            const Value& iv = values_[o1.inputs[0]]; const Value& ov = values_[oh.output];
+            sm_bneck_desc bd{}; bd.N = batch; bd.H = ov.h; bd.W = ov.w; bd.C0 = o1.cin; bd.Cm = 128; bd.C3 = oh.cout;
+            bd.x_ld = std::max(place_[o1.inputs[0]].ld, o1.cin); bd.y_ld = std::max(place_[oh.output].ld, oh.cout); bd.res_ld = oh.residual >= 0 ? std::max(place_[oh.residual].ld, oh.cout) : 0;
+            bd.act1 = o1.act; bd.slope1 = o1.slope; bd.act2 = o3.act; bd.slope2 = o3.slope; bd.act3 = oh.act; bd.slope3 = oh.slope;
+            if (iv.h != ov.h || iv.w != ov.w || !sm_bottleneck_supported(&bd)) continue;
+            c.has_head = true; c.head = std::move(h.op);
+            steps_.erase(steps_.begin() + u);
+        }
+        for (size_t t = 0; t < steps_.size(); t++) {
+            Step& c = steps_[t];
+            if (!c.has_head || c.has_side || c.has_reduce || c.pool_out >= 0 || c.op.x_ups || c.op.grid_h || c.op.kind != OpKind::Conv || c.op.kh != 3 || c.op.kw != 3 || c.op.cin != c.op.cout || (c.op.cout != 64 && c.op.cout != 128)) continue;
             if (c.op.act > SM_ACT_PRELU || c.head.act > SM_ACT_PRELU) continue;
             const int v = c.op.inputs[0];
             long a = -1;
@@ -543,13 +581,17 @@ int Executor::plan(ONNXGraph& g, int batch) {
             const Op& o = r.op;
             if (o.kind != OpKind::Conv || o.kh != 1 || o.kw != 1 || o.sh != 1 || o.sw != 1 || o.pt || o.pl || o.pb || o.pr || o.groups != 1 || o.act > SM_ACT_PRELU || o.grid_h || o.x_ups ||
                 o.residual >= 0 || r.stem || r.stem3 || r.has_mb || r.has_head || r.has_side || r.pool_out >= 0 || r.pool3_out >= 0 || r.dual_src >= 0 || r.gather || r.kcat || r.join >= 0 || r.waits_side ||
-                o.cout != 64 || o.inputs.empty() || !vecOk(o.inputs[0]) || place_[v].root != v || place_[v].c_off != 0) continue;
+                o.cout != c.op.cout || o.inputs.empty() || !vecOk(o.inputs[0]) || place_[v].root != v || place_[v].c_off != 0) continue;
             const Value& iv = values_[o.inputs[0]]; const Value& ov = values_[c.head.output];
             if (iv.h != ov.h || iv.w != ov.w) continue;
-            sm_bneck_desc bd{}; bd.N = batch; bd.H = ov.h; bd.W = ov.w; bd.C0 = o.cin; bd.Cm = 64; bd.C3 = c.head.cout;
+            sm_bneck_desc bd{}; bd.N = batch; bd.H = ov.h; bd.W = ov.w; bd.C0 = o.cin; bd.Cm = c.op.cout; bd.C3 = c.head.cout;
             bd.x_ld = std::max(place_[o.inputs[0]].ld, o.cin); bd.y_ld = std::max(place_[c.head.output].ld, c.head.cout); bd.res_ld = c.head.residual >= 0 ? std::max(place_[c.head.residual].ld, c.head.cout) : 0;
             bd.act1 = o.act; bd.slope1 = o.slope; bd.act2 = c.op.act; bd.slope2 = c.op.slope; bd.act3 = c.head.act; bd.slope3 = c.head.slope;
-            if (!sm_bottleneck_supported(&bd)) continue;
+            if (!sm_bottleneck_supported(&bd)) {
+                // (a 128-channel 3x3 that took its expand layer as head above cannot run without the reduce layer: no two-layer kernel exists for it)
+                if (c.op.cout == 128) { sm_set_error("executor pass 3l: a 128-channel bottleneck tail without its reduce layer (internal)"); return SM_ERR_INCONSISTENT_STATE; }
+                continue;
+            }
             c.has_reduce = true; c.reduce = std::move(r.op);
             steps_.erase(steps_.begin() + a);
             t--;                                                       // (the step list moved down by one: `c` now sits at t - 1, the next candidate at t)
@@ -1234,7 +1276,7 @@ int Executor::launchStep(const Step& st, hipStream_t s) const {
                                                 valueLd(st.side.inputs[0]), arena_ + st.wd_off, valuePtr(st.side.output), valueLd(st.side.output), ss);
         if (st.has_reduce) {
             const int xin = st.reduce.inputs[0];
-            sm_bneck_desc bd{}; bd.N = batch_; bd.H = values_[st.head.output].h; bd.W = values_[st.head.output].w; bd.C0 = st.reduce.cin; bd.Cm = 64; bd.C3 = st.head.cout;
+            sm_bneck_desc bd{}; bd.N = batch_; bd.H = values_[st.head.output].h; bd.W = values_[st.head.output].w; bd.C0 = st.reduce.cin; bd.Cm = op.cout; bd.C3 = st.head.cout;
             bd.x_ld = valueLd(xin); bd.y_ld = valueLd(st.head.output); bd.res_ld = st.head.residual >= 0 ? valueLd(st.head.residual) : 0;
             bd.act1 = st.reduce.act; bd.slope1 = st.reduce.slope; bd.act2 = op.act; bd.slope2 = op.slope; bd.act3 = st.head.act; bd.slope3 = st.head.slope;
             return sm_bottleneck_fwd(&bd, valuePtr(xin), arena_ + st.w0_off, st.has_bias0 ? (const float*)(arena_ + st.b0_off) : nullptr, arena_ + st.w_off,

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
     floatx4 acc2[BN2_NF2][2];
 #pragma unroll
     for (int f = 0; f < BN2_NF2; f++) { acc2[f][0] = floatx4{0.f, 0.f, 0.f, 0.f}; acc2[f][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
-    constexpr int LA = 2;                                              // weight units in flight ahead (ring of 3; 18 % 3 == 0)
+    constexpr int LA = 5;                                              // weight units in flight ahead (ring of 6; 18 % 6 == 0): every CU asks the L2 for the same rows at the same time — two units
+                                                                       // ahead measured 600 clk per unit of waiting for them (with neither MFMAs nor fragment reads in the loop), as conv3x3_kq.hpp found
     half8_t wb[LA + 1][2];
     half8_t af[2][BN2_NF2];
     auto load_w2 = [&](auto slotc, int sb, int u) __attribute__((always_inline)) {     // unit u (tap u / 2, half u % 2) of super-block sb
@@ -192,14 +193,19 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
         T = (unsigned)(sb * p.slice_bytes + kh * RS * 128); X = (unsigned)(hh * 64);
         asm volatile("" : "+s"(T), "+s"(X));
     };
-    load_w2(std::integral_constant<int, 0>(), 0, 0); load_w2(std::integral_constant<int, 1>(), 0, 1);
+    sm_static_for<0, LA>([&](auto uc) { load_w2(uc, 0, decltype(uc)::value); });
+    // Fragment reads are asm statements with a HAND-COUNTED wait (conv3x3_kq.hpp's order): written as plain loads "one unit ahead", hipcc sank every read next to its MFMAs and
+    // waited for it there — one exposed LDS latency per fragment, 32 k clk for 15 k of MFMAs.  Pinned by sched_barriers: fragment F of unit U + 1 is requested right behind the
+    // MFMAs of fragment F of unit U; in front of those MFMAs the younger reads are the 12 - F left of this unit and the F already requested for the next: lgkmcnt(12) throughout
+    // (the last unit of the layer requests nothing).
     {
         unsigned T, X; unit_TX(0, 0, T, X);
 #pragma unroll
-        for (int f = 0; f < BN2_NF2; f++) af[0][f] = bn_lds_read<half8_t>(ldsb, (int)((atab[f][0] + T) ^ X));
+        for (int f = 0; f < BN2_NF2; f++) { half8_t& d = af[0][f]; const unsigned ad = (atab[f][0] + T) ^ X; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad)); }
     }
 #pragma unroll 1
     for (int sb = 0; sb < 2; sb++) {
+        const bool last_sb = sb == 1;
         sm_static_for<0, 18>([&](auto uc) {
             constexpr int U = decltype(uc)::value;
             {   // weights LA units ahead (beyond the last unit: a harmless reload)
@@ -207,21 +213,34 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
                 const int sb2 = U + LA >= 18 ? (sb + 1 < 2 ? sb + 1 : sb) : sb;
                 load_w2(std::integral_constant<int, (U + LA) % (LA + 1)>(), sb2, U2);
             }
-            {   // pixel fragments one unit ahead
-                constexpr int U1 = (U + 1) % 18;
-                const int sb1 = U + 1 >= 18 ? (sb + 1 < 2 ? sb + 1 : sb) : sb;
-                unsigned T, X; unit_TX(sb1, U1, T, X);
-#pragma unroll
-                for (int f = 0; f < BN2_NF2; f++) af[(U + 1) & 1][f] = bn_lds_read<half8_t>(ldsb, (int)((atab[f][(U1 >> 1) % 3] + T) ^ X));
-            }
-#pragma unroll
-            for (int f = 0; f < BN2_NF2; f++) {
-                acc2[f][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[U % (LA + 1)][0], af[U & 1][f], acc2[f][0], 0, 0, 0);
-                acc2[f][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[U % (LA + 1)][1], af[U & 1][f], acc2[f][1], 0, 0, 0);
-            }
+            constexpr int U1 = (U + 1) % 18;
+            const int sb1 = U + 1 >= 18 ? (sb + 1 < 2 ? sb + 1 : sb) : sb;
+            unsigned T, X; unit_TX(sb1, U1, T, X);
+            const bool fetch = !(U == 17 && last_sb);                  // (wave-uniform)
+            __builtin_amdgcn_sched_barrier(0);
+            sm_static_for<0, BN2_NF2>([&](auto fc) {
+                constexpr int F = decltype(fc)::value;
+#ifndef BN2_ABL_NO_READS
+                if (fetch) asm volatile("s_waitcnt lgkmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(12 - F) : "memory");
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef BN2_ABL_NO_MFMA
+                acc2[F][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[U % (LA + 1)][0], af[U & 1][F], acc2[F][0], 0, 0, 0);
+                acc2[F][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[U % (LA + 1)][1], af[U & 1][F], acc2[F][1], 0, 0, 0);
+#else
+                asm volatile("" :: "v"(wb[U % (LA + 1)][0]), "v"(wb[U % (LA + 1)][1]), "v"(af[U & 1][F]));
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+#ifndef BN2_ABL_NO_READS
+                if (fetch) { half8_t& d = af[(U + 1) & 1][F]; const unsigned ad = (atab[F][(U1 >> 1) % 3] + T) ^ X; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad)); }
+#else
+                if (fetch) { asm volatile("s_nop 0" ::: "memory"); }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+            });
         });
     }
-
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     BN2_STAMP(5);
     // ---- phase 3: T2 = act2(acc2 + b2), rounded, -> LDS [pixel t][128 channels] (256-byte rows; chunk c16 of pixel t at position c16 ^ (t & 15)); then the expand --------
     const unsigned t2_0 = xr_0;                                        // (over the x stages: dead since the barrier that closed phase 1)
