@@ -523,6 +523,7 @@ extern "C" int sm_bottleneck_fwd(const sm_bneck_desc* d, const void* x, const vo
         auto sl2 = [](int act, float s) { return act == SM_ACT_NONE ? 1.f : act == SM_ACT_RELU ? 0.f : s; };
         q.sl1 = sl2(d->act1, d->slope1); q.sl2 = sl2(d->act2, d->slope2); q.sl3 = sl2(d->act3, d->slope3);
         bn2_geometry(d, &q);
+        q.cap = (res == x && d->res_ld == d->x_ld && d->C3 == d->C0 && (d->C3 % 512) == 0) ? 1 : 0;      // identity block: the first residual passes ride in registers from phase 1 (C3 % 512: a wave's pass p is x stage (C3 / 128) wave + p, in ring slot p)
         const size_t lds = bn2_lds_bytes(q);
         static size_t attr_lds = 0;
         if (lds > attr_lds) { SM_HIP_CHECK(hipFuncSetAttribute((const void*)bneck128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_lds = lds; }

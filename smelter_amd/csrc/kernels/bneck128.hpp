@@ -21,6 +21,10 @@
 // Numerics: every layer accumulates in fp32 over k ascending (MFMA steps of 32) from zero, + bias in fp32, activation, ONE rounding to fp16 of both hidden tensors (they stay
 // in the parity oracle's rounding list).
 #pragma once
+// (output stores: sc1 — write through; same-box A/B of the four policies: 56.0 / 56.4 us against 61 (default), 57 (sc0 sc1), 58 (nt))
+#ifndef BN2_ST_AUX
+#define BN2_ST_AUX 16
+#endif
 
 struct Bn2Params {
     const half_t* x; const half_t* w1; const float* b1; const half_t* w2; const float* b2; const half_t* w3; const float* b3; const half_t* res; half_t* y;
@@ -28,9 +32,11 @@ struct Bn2Params {
     float sl1, sl2, sl3;             // f(v) = v < 0 ? v * sl : v   (1 = no activation, 0 = ReLU)
     int TH, bands, RS, PR, NP1;      // tile rows, bands per image, slots per patch row, patch rows (TH + 2), patch pixels inside image columns (PR * W)
     int slice_bytes, xc_bytes;       // one T1 slice (64 channels of the patch, 2 KB aligned), one x stage (NP1 rounded up to 16 pixels x 128 bytes)
+    int cap;                         // 1: the residual IS the block input (res == x, same stride, n3 == C0): its first passes are kept from the x stages of phase 1 instead of re-read
     int ka, kb;                      // swizzle of the T1 patch: chunk c of slot (row r, column cc) at position c ^ ((ka (cc / 2) + kb r) & 7)   (conv3x3_kq.hpp)
     unsigned w_mul, w_sh, bands_mul, bands_sh;
 };
+constexpr int BN2_NCAP = 2;                                           // expand passes whose residual rows are kept from phase 1
 constexpr int BN2_XRING = 4 * 16384;                                  // the x ring of phase 1: four stages of 256 pixels x 64 bytes
 constexpr int BN2_CM = 128, BN2_NF1 = 16, BN2_NF2 = 13;                // middle channels; pixel fragments (16 pixels each) of the patch / of the tile
 
@@ -59,6 +65,12 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
     auto key = [&](int r, int cc) -> unsigned { return (unsigned)((p.ka * (cc >> 1) + p.kb * r) & 7); };
 
     BN2_STAMP(0);
+#ifdef BN2_STAGGER
+    {   // experiment: the blocks of an XCD (b % 8 equal) start BN2_STAGGER clk apart in eight groups, so that they do not ask the L2 for the same weight rows at the same time
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime(), wait = (unsigned long long)((blockIdx.x >> 3) & 7) * BN2_STAGGER;
+        while (__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     // ---- phase 0: the patch is cleared (halo columns, rows outside the image) -------------------------------------------------------------------------------------
     {
         const u32x4 z = {0, 0, 0, 0};
@@ -104,11 +116,23 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
     unsigned xba[BN2_NF1];
 #pragma unroll
     for (int f = 0; f < BN2_NF1; f++) { const int i = f * 16 + l15; xba[f] = xr_0 + (unsigned)(i * 64 + ((g ^ ((i >> 2) & 3)) << 4)); }
+    u32x4 rrc[BN2_NCAP][BN2_NF2];                                     // residual rows kept from phase 1 (p.cap)
     floatx4 acc1[BN2_NF1][2];
 #pragma unroll
     for (int f = 0; f < BN2_NF1; f++) { acc1[f][0] = floatx4{0.f, 0.f, 0.f, 0.f}; acc1[f][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
     BN2_STAMP(1);
     issue_stage(std::integral_constant<int, 0>(), 0); issue_stage(std::integral_constant<int, 1>(), 1); issue_stage(std::integral_constant<int, 2>(), 2);
+    // (for the epilogue of this phase, computed here where the wave would otherwise wait for its first stages: the patch slot of my pixel of fragment f — 0xffffffff outside the
+    //  image — and the bias rows of my couts)
+    unsigned t1w[BN2_NF1];
+#pragma unroll
+    for (int f = 0; f < BN2_NF1; f++) {
+        const int i = f * 16 + l15, r = (int)sm_fastdiv((unsigned)i, p.w_mul, p.w_sh), xx = i - r * W, iy = y0 - 1 + r, cc = xx + 1;
+        t1w[f] = (i < p.NP1 && (unsigned)iy < (unsigned)H) ? (unsigned)((r * RS + cc) * 128) | (key(r, cc) << 28) : 0xffffffffu;      // (slot offset < 2^17; the key rides in the top bits)
+    }
+    floatx4 bq1v[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) bq1v[j] = p.b1 ? *(const floatx4*)(p.b1 + 32 * wave + 16 * j + 4 * g) : floatx4{0.f, 0.f, 0.f, 0.f};
     const int nf1 = (p.NP1 + 15) >> 4;                                 // fragments that hold patch pixels (wave-uniform)
     auto stage = [&](auto slotc, int s) __attribute__((always_inline)) {
         constexpr int SL = decltype(slotc)::value;
@@ -116,6 +140,17 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
         __builtin_amdgcn_s_barrier();                                 // everybody's; everybody has left the slot stage s + 3 goes to (it held stage s - 1)
         __builtin_amdgcn_sched_barrier(0);
         issue_stage(std::integral_constant<int, (SL + XD) % XS>(), s + XD);
+        if constexpr (SL < BN2_NCAP) {
+            // the residual of my expand pass SL — couts [n3 / 4 * wave + 32 SL, + 32) of the tile's pixels — is channels 32 s .. of this very stage when s = (n3 / 128) wave + SL
+            // (identity block: n3 = C0, n3 % 512 == 0 so that the stage sits in ring slot SL): 13 fragment reads keep it in registers; the fabric carries those rows once instead of twice
+            if (p.cap && s == (p.n3 >> 7) * wave + SL) {
+#pragma unroll
+                for (int f = 0; f < BN2_NF2; f++) {
+                    const int t = f * 16 + l15, i = (t < PTe ? t : 0) + W;                 // tile pixel t = patch pixel t + W (one row down)
+                    rrc[SL][f] = __builtin_bit_cast(u32x4, bn_lds_read<half8_t>(ldsb, (int)(xr_0 + (unsigned)SL * 16384u + (unsigned)(i * 64 + ((g ^ ((i >> 2) & 3)) << 4)))));
+                }
+            }
+        }
 #pragma unroll
         for (int f = 0; f < BN2_NF1; f++) {
             if (f < nf1) {
@@ -139,19 +174,24 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
     // epilogue 1: lane (pixel l15 of fragment f, g) holds couts 32 wave + 16 j + 4 g .. + 3 -> 8 bytes of the pixel's slot in slice (couts / 64), chunk (couts % 64) / 8
     {
         const unsigned t1s = t1_0 + (unsigned)(wave >> 1) * (unsigned)p.slice_bytes;
+        const bool relu1 = p.sl1 == 0.f;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const floatx4 bq = p.b1 ? *(const floatx4*)(p.b1 + 32 * wave + 16 * j + 4 * g) : floatx4{0.f, 0.f, 0.f, 0.f};
-            const int chunk = (wave & 1) * 4 + 2 * j + (g >> 1);
+            const floatx4 bq = bq1v[j];
+            const unsigned chunk = (unsigned)((wave & 1) * 4 + 2 * j + (g >> 1));
 #pragma unroll
             for (int f = 0; f < BN2_NF1; f++) {
-                const int i = f * 16 + l15, r = (int)sm_fastdiv((unsigned)i, p.w_mul, p.w_sh), xx = i - r * W, iy = y0 - 1 + r;
-                if (i < p.NP1 && (unsigned)iy < (unsigned)H) {
+                if (t1w[f] != 0xffffffffu) {
                     half4_t o;
+                    if (relu1) {                                       // plain ReLU (wave-uniform): round, then one packed maximum per pair (the same values: rounding is monotone)
 #pragma unroll
-                    for (int e = 0; e < 4; e++) { const float v = acc1[f][j][e] + bq[e]; o[e] = (half_t)(v < 0.f ? v * p.sl1 : v); }
-                    const int cc = xx + 1;
-                    *(__attribute__((address_space(3))) half4_t*)(size_t)(t1s + (unsigned)((r * RS + cc) * 128) + (((unsigned)chunk ^ key(r, cc)) << 4) + (unsigned)((g & 1) * 8)) = o;
+                        for (int e = 0; e < 4; e++) o[e] = (half_t)(acc1[f][j][e] + bq[e]);
+                        o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { const float v = acc1[f][j][e] + bq[e]; o[e] = (half_t)(v < 0.f ? v * p.sl1 : v); }
+                    }
+                    *(__attribute__((address_space(3))) half4_t*)(size_t)(t1s + (t1w[f] & 0x0fffffffu) + ((chunk ^ (t1w[f] >> 28)) << 4) + (unsigned)((g & 1) * 8)) = o;
                 }
             }
         }
@@ -193,6 +233,9 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
         T = (unsigned)(sb * p.slice_bytes + kh * RS * 128); X = (unsigned)(hh * 64);
         asm volatile("" : "+s"(T), "+s"(X));
     };
+    floatx4 bq2v[2];                                                  // (for the T2 epilogue: requested here, a whole loop ahead)
+#pragma unroll
+    for (int j = 0; j < 2; j++) bq2v[j] = p.b2 ? *(const floatx4*)(p.b2 + 32 * wave + 16 * j + 4 * g) : floatx4{0.f, 0.f, 0.f, 0.f};
     sm_static_for<0, LA>([&](auto uc) { load_w2(uc, 0, decltype(uc)::value); });
     // Fragment reads are asm statements with a HAND-COUNTED wait (conv3x3_kq.hpp's order): written as plain loads "one unit ahead", hipcc sank every read next to its MFMAs and
     // waited for it there — one exposed LDS latency per fragment, 32 k clk for 15 k of MFMAs.  Pinned by sched_barriers: fragment F of unit U + 1 is requested right behind the
@@ -244,17 +287,24 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
     BN2_STAMP(5);
     // ---- phase 3: T2 = act2(acc2 + b2), rounded, -> LDS [pixel t][128 channels] (256-byte rows; chunk c16 of pixel t at position c16 ^ (t & 15)); then the expand --------
     const unsigned t2_0 = xr_0;                                        // (over the x stages: dead since the barrier that closed phase 1)
+    const bool relu2 = p.sl2 == 0.f;
     {
 #pragma unroll
         for (int j = 0; j < 2; j++) {
-            const floatx4 bq = p.b2 ? *(const floatx4*)(p.b2 + 32 * wave + 16 * j + 4 * g) : floatx4{0.f, 0.f, 0.f, 0.f};
+            const floatx4 bq = bq2v[j];
             const int c16 = 4 * wave + 2 * j + (g >> 1);
 #pragma unroll
             for (int f = 0; f < BN2_NF2; f++) {
                 const int t = f * 16 + l15;
                 half4_t o;
+                if (relu2) {
 #pragma unroll
-                for (int e = 0; e < 4; e++) { const float v = acc2[f][j][e] + bq[e]; o[e] = (half_t)(v < 0.f ? v * p.sl2 : v); }
+                    for (int e = 0; e < 4; e++) o[e] = (half_t)(acc2[f][j][e] + bq[e]);
+                    o = __builtin_elementwise_max(o, half4_t{0, 0, 0, 0});
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { const float v = acc2[f][j][e] + bq[e]; o[e] = (half_t)(v < 0.f ? v * p.sl2 : v); }
+                }
                 *(__attribute__((address_space(3))) half4_t*)(size_t)(t2_0 + (unsigned)(t * 256) + (unsigned)((c16 ^ (t & 15)) << 4) + (unsigned)((g & 1) * 8)) = o;
             }
         }
@@ -292,41 +342,72 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) { w3a[ks][0] = *w3_ptr(0, ks, 0); w3a[ks][1] = *w3_ptr(0, ks, 1); }
+        const bool cap = p.cap != 0, relu3 = p.sl3 == 0.f;
+        floatx4 bqn0 = {0.f, 0.f, 0.f, 0.f}, bqn1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.b3) { bqn0 = *(const floatx4*)(p.b3 + cpw * wave + 8 * g); bqn1 = *(const floatx4*)(p.b3 + cpw * wave + 8 * g + 4); }
 #pragma unroll
-        for (int f = 0; f < BN2_NF2; f++) rr[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)rb[f], 0, 0);
+        for (int f = 0; f < BN2_NF2; f++) rr[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(cap ? BN_DEAD : rb[f]), 0, 0);
 #pragma unroll 1
         for (int ps = 0; ps < npass; ps++) {
             const int cb = cpw * wave + 32 * ps;                       // first cout of the pass
-            const unsigned pso = (unsigned)(64 * ps), psn = ps + 1 < npass ? (unsigned)(64 * (ps + 1)) : 0x80000000u;      // byte offset of this / the next pass's couts
-            const floatx4 bq0 = p.b3 ? *(const floatx4*)(p.b3 + cb + 8 * g) : floatx4{0.f, 0.f, 0.f, 0.f}, bq1 = p.b3 ? *(const floatx4*)(p.b3 + cb + 8 * g + 4) : floatx4{0.f, 0.f, 0.f, 0.f};
+            // (kept rows: passes 0 .. BN2_NCAP - 1 take theirs from phase 1's registers; the rolling re-fill asks memory only for passes that have none)
+            if (cap && ps < BN2_NCAP) {
+                if (ps == 0) {
+#pragma unroll
+                    for (int f = 0; f < BN2_NF2; f++) rr[f] = rrc[0][f];
+                } else {
+#pragma unroll
+                    for (int f = 0; f < BN2_NF2; f++) rr[f] = rrc[BN2_NCAP - 1][f];
+                }
+            }
+            const bool nload = ps + 1 < npass && !(cap && ps + 1 < BN2_NCAP);
+            const unsigned pso = (unsigned)(64 * ps), psn = nload ? (unsigned)(64 * (ps + 1)) : 0x80000000u;      // byte offset of this / the next pass's couts
+            const floatx4 bq0 = bqn0, bq1 = bqn1;
+            { const int cn = cpw * wave + 32 * (ps + 1 < npass ? ps + 1 : ps) + 8 * g; if (p.b3) { bqn0 = *(const floatx4*)(p.b3 + cn); bqn1 = *(const floatx4*)(p.b3 + cn + 4); } }      // (the next pass's bias rows: a pass of flight time)
             // the 13 fragments in two halves (7 + 6): 56 accumulator registers live instead of 104 — the epilogue's conversions want them in the vector file
             sm_static_for<0, 2>([&](auto hc) {
                 constexpr int HF = decltype(hc)::value, F0 = HF ? 7 : 0, F1 = HF ? BN2_NF2 : 7;
                 floatx4 acc3[7][2];
 #pragma unroll
                 for (int f = F0; f < F1; f++) { acc3[f - F0][0] = floatx4{0.f, 0.f, 0.f, 0.f}; acc3[f - F0][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+                // fragment reads TWO ahead of their MFMAs, the order pinned (left to itself hipcc requests all of a k step's fragments at once — 28 registers more than the
+                // vector file has room for here: the first build spilled to scratch inside this loop — or none ahead at all)
+                constexpr int NFH = F1 - F0, NST = 4 * NFH;           // steps (ks, f) of this half
+                constexpr int RA = 5;                                  // read-ahead in steps (a step = 2 MFMAs = 32 clk; an LDS read takes > 100)
+                half8_t bf[RA + 1];
+                auto rd = [&](int st) -> half8_t { const int ks = st / NFH, f = F0 + st % NFH; return bn_lds_read<half8_t>(ldsb, (int)(t2a[f] + (unsigned)(((4 * ks + g) ^ tsw) << 4))); };
 #pragma unroll
-                for (int ks = 0; ks < 4; ks++) {
-#pragma unroll
-                    for (int f = F0; f < F1; f++) {
-                        const half8_t bf = bn_lds_read<half8_t>(ldsb, (int)(t2a[f] + (unsigned)(((4 * ks + g) ^ tsw) << 4)));
-                        acc3[f - F0][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3a[ks][0], bf, acc3[f - F0][0], 0, 0, 0);
-                        acc3[f - F0][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3a[ks][1], bf, acc3[f - F0][1], 0, 0, 0);
-                    }
-                    if constexpr (HF == 1) { w3a[ks][0] = *w3_ptr(ps + 1, ks, 0); w3a[ks][1] = *w3_ptr(ps + 1, ks, 1); }     // (consumed by both halves: the next pass's)
-                }
+                for (int q = 0; q < RA; q++) bf[q] = rd(q);
+                sm_static_for<0, NST>([&](auto sc) {
+                    constexpr int ST = decltype(sc)::value, KS = ST / NFH, FI = ST % NFH;
+                    if constexpr (ST + RA < NST) bf[(ST + RA) % (RA + 1)] = rd(ST + RA);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc3[FI][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3a[KS][0], bf[ST % (RA + 1)], acc3[FI][0], 0, 0, 0);
+                    acc3[FI][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(w3a[KS][1], bf[ST % (RA + 1)], acc3[FI][1], 0, 0, 0);
+                    if constexpr (HF == 1 && FI == NFH - 1) { w3a[KS][0] = *w3_ptr(ps + 1, KS, 0); w3a[KS][1] = *w3_ptr(ps + 1, KS, 1); }     // (consumed by both halves: the next pass's)
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if (ps == 1) BN2_STAMP(16 + 2 * HF);
 #pragma unroll
                 for (int f = F0; f < F1; f++) {
                     const half8_t rh = __builtin_bit_cast(half8_t, rr[f]);
                     half8_t ov;
+                    if (relu3) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        const float v0 = acc3[f - F0][0][e] + bq0[e] + (float)rh[e], v1 = acc3[f - F0][1][e] + bq1[e] + (float)rh[4 + e];
-                        ov[e] = (half_t)(v0 < 0.f ? v0 * p.sl3 : v0); ov[4 + e] = (half_t)(v1 < 0.f ? v1 * p.sl3 : v1);
+                        for (int e = 0; e < 4; e++) { ov[e] = (half_t)(acc3[f - F0][0][e] + bq0[e] + (float)rh[e]); ov[4 + e] = (half_t)(acc3[f - F0][1][e] + bq1[e] + (float)rh[4 + e]); }
+                        ov = __builtin_elementwise_max(ov, half8_t{0, 0, 0, 0, 0, 0, 0, 0});
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const float v0 = acc3[f - F0][0][e] + bq0[e] + (float)rh[e], v1 = acc3[f - F0][1][e] + bq1[e] + (float)rh[4 + e];
+                            ov[e] = (half_t)(v0 < 0.f ? v0 * p.sl3 : v0); ov[4 + e] = (half_t)(v1 < 0.f ? v1 * p.sl3 : v1);
+                        }
                     }
                     rr[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(rb[f] + psn), 0, 0);              // the next pass's row of this fragment
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs_y, (int)(yb[f] + pso), 0, BN_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs_y, (int)(yb[f] + pso), 0, BN2_ST_AUX);
+                    if (((f - F0) & 1) == 1) __builtin_amdgcn_sched_barrier(0);        // (two fragments per scheduling region: their chains interleave; more and the conversions of all seven are in flight at once)
                 }
+                if (ps == 1) BN2_STAMP(17 + 2 * HF);
             });
             BN2_STAMP(8 + ps);
         }

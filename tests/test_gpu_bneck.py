@@ -203,7 +203,7 @@ def test_bottleneck_refusals():
     L = ops.lib()
     ok = BneckDesc(1, 8, 8, 256, 64, 256, 256, 256, 256, 1, 0.0, 1, 0.0, 1, 0.0)
     assert L.sm_bottleneck_supported(ctypes.byref(ok))
-    for field, val in (("Cm", 128), ("C0", 512), ("C0", 96), ("C3", 288), ("C3", 40), ("act2", 3), ("x_ld", 128), ("y_ld", 250)):
+    for field, val in (("Cm", 96), ("C0", 512), ("C0", 96), ("C3", 288), ("C3", 40), ("act2", 3), ("x_ld", 128), ("y_ld", 250)):
         bad = BneckDesc(1, 8, 8, 256, 64, 256, 256, 256, 256, 1, 0.0, 1, 0.0, 1, 0.0)
         setattr(bad, field, val)
         assert not L.sm_bottleneck_supported(ctypes.byref(bad)), field

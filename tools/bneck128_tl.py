@@ -22,7 +22,7 @@ assert L.sm_bneck_timeline_read(tl.ctypes.data_as(C.c_void_p)) == 0
 tl = tl.reshape(256, 2, 2, 32).astype(np.int64)       # [block][wave & 1][wave >> 1][slot]
 t0 = np.where(tl > 0, tl, np.iinfo(np.int64).max).min(axis=(1, 2, 3), keepdims=True)
 rel = np.where(tl > 0, tl - t0, -1)
-names = ["start", "set-up done (patch cleared, DMA table)", "reduce stages done", "T1 written", "patch barrier passed", "3x3 loop done", "T2 written", "T2 barrier passed"] + ["expand pass %d done" % i for i in range(8)]
+names = ["start", "set-up done (patch cleared, DMA table)", "reduce stages done", "T1 written", "patch barrier passed", "3x3 loop done", "T2 written", "T2 barrier passed"] + ["expand pass %d done" % i for i in range(8)] + ["pass 1: MFMAs of half 0 done", "pass 1: epilogue of half 0 done", "pass 1: MFMAs of half 1 done", "pass 1: epilogue of half 1 done"]
 for k, nm in enumerate(names):
     v = rel[:, :, :, k]; v = v[v >= 0]
     if v.size: print("%-42s median %6d  min %6d  max %6d" % (nm, np.median(v), v.min(), v.max()))
