@@ -565,7 +565,9 @@ int Executor::plan(ONNXGraph& g, int batch) {
             sm_bneck_desc bd{}; bd.N = batch; bd.H = ov.h; bd.W = ov.w; bd.C0 = o1.cin; bd.Cm = 128; bd.C3 = oh.cout;
             bd.x_ld = std::max(place_[o1.inputs[0]].ld, o1.cin); bd.y_ld = std::max(place_[oh.output].ld, oh.cout); bd.res_ld = oh.residual >= 0 ? std::max(place_[oh.residual].ld, oh.cout) : 0;
             bd.act1 = o1.act; bd.slope1 = o1.slope; bd.act2 = o3.act; bd.slope2 = o3.slope; bd.act3 = oh.act; bd.slope3 = oh.slope;
-            if (iv.h != ov.h || iv.w != ov.w || !sm_bottleneck_supported(&bd)) continue;
+            // (images of <= 208 pixels are the persistent runs' domain, pass 3k: a stage of such blocks leaves in ONE launch there; the block kernel is for the larger ones, where a
+            //  tile is a band of an image and the layers are memory-bound — ResNet-50's 28 x 28 stage)
+            if (iv.h != ov.h || iv.w != ov.w || ov.h * ov.w <= 208 || !sm_bottleneck_supported(&bd)) continue;
             c.has_head = true; c.head = std::move(h.op);
             steps_.erase(steps_.begin() + u);
         }

@@ -62,7 +62,6 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
     const long pix0 = ((long)n0 * H + y0) * W;
     const unsigned t1_0 = lds0, xr_0 = lds0 + 2u * (unsigned)p.slice_bytes;
     const bn_lds_cptr ldsb = bn_lds_base(0u);                           // (addresses below are absolute LDS byte addresses)
-    auto key = [&](int r, int cc) -> unsigned { return (unsigned)((p.ka * (cc >> 1) + p.kb * r) & 7); };
 
     BN2_STAMP(0);
 #ifdef BN2_STAGGER
@@ -128,7 +127,7 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
 #pragma unroll
     for (int f = 0; f < BN2_NF1; f++) {
         const int i = f * 16 + l15, r = (int)sm_fastdiv((unsigned)i, p.w_mul, p.w_sh), xx = i - r * W, iy = y0 - 1 + r, cc = xx + 1;
-        t1w[f] = (i < p.NP1 && (unsigned)iy < (unsigned)H) ? (unsigned)((r * RS + cc) * 128) | (key(r, cc) << 28) : 0xffffffffu;      // (slot offset < 2^17; the key rides in the top bits)
+        t1w[f] = (i < p.NP1 && (unsigned)iy < (unsigned)H) ? (unsigned)((r * RS + cc) * 16) : 0xffffffffu;      // (outside the image: the epilogue sends the lane's 8 bytes to a sink in the dead x ring — no branch per store)
     }
     floatx4 bq1v[2];
 #pragma unroll
@@ -173,15 +172,15 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
     BN2_STAMP(2);
     // epilogue 1: lane (pixel l15 of fragment f, g) holds couts 32 wave + 16 j + 4 g .. + 3 -> 8 bytes of the pixel's slot in slice (couts / 64), chunk (couts % 64) / 8
     {
-        const unsigned t1s = t1_0 + (unsigned)(wave >> 1) * (unsigned)p.slice_bytes;
+        const unsigned plane_b = (unsigned)p.slice_bytes >> 3, sink = xr_0 + (unsigned)tid * 8u;      // (the x ring is dead: every stage has been multiplied, the dead operations behind the last one have landed)
         const bool relu1 = p.sl1 == 0.f;
 #pragma unroll
         for (int j = 0; j < 2; j++) {
             const floatx4 bq = bq1v[j];
-            const unsigned chunk = (unsigned)((wave & 1) * 4 + 2 * j + (g >> 1));
+            const unsigned t1p = t1_0 + (unsigned)(4 * wave + 2 * j + (g >> 1)) * plane_b + (unsigned)((g & 1) * 8);      // my couts 32 wave + 16 j + 4 g .. + 3: half of plane 4 wave + 2 j + g / 2
 #pragma unroll
             for (int f = 0; f < BN2_NF1; f++) {
-                if (t1w[f] != 0xffffffffu) {
+                {
                     half4_t o;
                     if (relu1) {                                       // plain ReLU (wave-uniform): round, then one packed maximum per pair (the same values: rounding is monotone)
 #pragma unroll
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) { const float v = acc1[f][j][e] + bq[e]; o[e] = (half_t)(v < 0.f ? v * p.sl1 : v); }
                     }
-                    *(__attribute__((address_space(3))) half4_t*)(size_t)(t1s + (t1w[f] & 0x0fffffffu) + ((chunk ^ (t1w[f] >> 28)) << 4) + (unsigned)((g & 1) * 8)) = o;
+                    *(__attribute__((address_space(3))) half4_t*)(size_t)(t1w[f] != 0xffffffffu ? t1p + t1w[f] : sink) = o;
                 }
             }
         }
@@ -203,13 +202,15 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
     BN2_STAMP(4);
 
     // ---- phase 2: the 3x3 over the patch.  Unit U = (tap U / 2, 32-channel half U % 2) of super-block sb (64 channels = one slice): 13 x 2 MFMAs ------------------------
-    const int kflip = (p.kb >> 2) & 1;                                // (kb = 4: one patch row down flips bit 2 of the key, i.e. swaps the slot's two 64-byte planes)
-    unsigned atab[BN2_NF2][3];                                        // address of fragment f's slot under tap (0, kw), channel quarter g, half 0, in slice 0
+    // T1 lies in LDS as sixteen PLANES [8 channels][patch slot] x 16 bytes (slot = row * RS + column; planes 256-byte aligned): the fragment of unit (tap, half hh) of slice
+    // sb is plane 8 sb + 4 hh + g at slot (fragment's slot) + kh RS + kw — "lane base + one scalar per unit", and sixteen consecutive pixels of one plane are sixteen
+    // consecutive 16-byte slots whatever the row length (conv3x3_kq.hpp's swizzled 128-byte slots measured ~12 clk per read here: 22 k clk of LDS time in this loop)
+    const unsigned plane_b2 = (unsigned)p.slice_bytes >> 3;
+    unsigned pfa[BN2_NF2];                                            // address of my pixel's slot of fragment f under tap (0, 0), plane g
 #pragma unroll
     for (int f = 0; f < BN2_NF2; f++) {
         const int t = f * 16 + l15, tc = t < PTe ? t : 0, vrow = (int)sm_fastdiv((unsigned)tc, p.w_mul, p.w_sh), xx = tc - vrow * W;
-#pragma unroll
-        for (int kw = 0; kw < 3; kw++) atab[f][kw] = t1_0 + (unsigned)((vrow * RS + xx + kw) * 128) + (((unsigned)g ^ key(vrow, xx + kw)) << 4);
+        pfa[f] = t1_0 + (unsigned)g * plane_b2 + (unsigned)((vrow * RS + xx) * 16);
     }
     const half_t* w2p[2];
 #pragma unroll
@@ -226,12 +227,12 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
         const int off = (u >> 1) * BN2_CM + sb * 64 + (u & 1) * 32;
         wb[SL][0] = *(const half8_t*)(w2p[0] + off); wb[SL][1] = *(const half8_t*)(w2p[1] + off);
     };
-    // fragment f under unit u of super-block sb = (atab[f][kw] + T) ^ X with two per-unit scalars, opaque to the optimiser (18 x 13 addresses are NOT loop invariants to keep
-    // in registers: the first build spilled over them)
-    auto unit_TX = [&](int sb, int u, unsigned& T, unsigned& X) {
-        const int tap = u >> 1, kh = tap / 3, hh = (u & 1) ^ (kflip & kh & 1);
-        T = (unsigned)(sb * p.slice_bytes + kh * RS * 128); X = (unsigned)(hh * 64);
-        asm volatile("" : "+s"(T), "+s"(X));
+    // fragment f under unit u of slice sb = pfa[f] + T with one per-unit scalar, opaque to the optimiser (18 x 13 addresses are NOT loop invariants to keep in registers)
+    auto unit_T = [&](int sb, int u) -> unsigned {
+        const int tap = u >> 1, kh = tap / 3, kw = tap - 3 * kh;
+        unsigned T = (unsigned)(8 * sb + 4 * (u & 1)) * plane_b2 + (unsigned)((kh * RS + kw) * 16);
+        asm volatile("" : "+s"(T));
+        return T;
     };
     floatx4 bq2v[2];                                                  // (for the T2 epilogue: requested here, a whole loop ahead)
 #pragma unroll
@@ -242,9 +243,9 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
     // MFMAs of fragment F of unit U; in front of those MFMAs the younger reads are the 12 - F left of this unit and the F already requested for the next: lgkmcnt(12) throughout
     // (the last unit of the layer requests nothing).
     {
-        unsigned T, X; unit_TX(0, 0, T, X);
+        const unsigned T = unit_T(0, 0);
 #pragma unroll
-        for (int f = 0; f < BN2_NF2; f++) { half8_t& d = af[0][f]; const unsigned ad = (atab[f][0] + T) ^ X; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad)); }
+        for (int f = 0; f < BN2_NF2; f++) { half8_t& d = af[0][f]; const unsigned ad = pfa[f] + T; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad)); }
     }
 #pragma unroll 1
     for (int sb = 0; sb < 2; sb++) {
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
             }
             constexpr int U1 = (U + 1) % 18;
             const int sb1 = U + 1 >= 18 ? (sb + 1 < 2 ? sb + 1 : sb) : sb;
-            unsigned T, X; unit_TX(sb1, U1, T, X);
+            const unsigned T = unit_T(sb1, U1);
             const bool fetch = !(U == 17 && last_sb);                  // (wave-uniform)
             __builtin_amdgcn_sched_barrier(0);
             sm_static_for<0, BN2_NF2>([&](auto fc) {
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
 #endif
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef BN2_ABL_NO_READS
-                if (fetch) { half8_t& d = af[(U + 1) & 1][F]; const unsigned ad = (atab[F][(U1 >> 1) % 3] + T) ^ X; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad)); }
+                if (fetch) { half8_t& d = af[(U + 1) & 1][F]; const unsigned ad = pfa[F] + T; asm volatile("ds_read_b128 %0, %1" : "=v"(d) : "v"(ad)); }
 #else
                 if (fetch) { asm volatile("s_nop 0" ::: "memory"); }
 #endif
@@ -421,7 +422,7 @@ static bool bn2_geometry(const sm_bneck_desc* d, Bn2Params* p) {
     int TH = std::min(H, std::min(208 / W, 256 / W - 2));
     if (TH < 1) return false;
     const int RS = (W + 1 + 7) / 8 * 8, PR = TH + 2;
-    const int slice = (PR * RS * 128 + 2047) / 2048 * 2048, np1 = PR * W, xc = ((np1 + 15) & ~15) * 128;
+    const int plane = (PR * RS * 16 + 255) / 256 * 256, slice = 8 * plane, np1 = PR * W, xc = ((np1 + 15) & ~15) * 128;      // (T1: sixteen 8-channel PLANES [slot] x 16 bytes, 256-byte aligned: see the kernel)
     const int t2 = 13 * 16 * 256;
     if ((size_t)2 * slice + (size_t)std::max(BN2_XRING, t2) + 2048 > 160 * 1024) return false;
     if (p) {

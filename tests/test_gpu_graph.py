@@ -177,16 +177,18 @@ def test_resnet50_runs_whole_bottleneck_blocks_as_one_launch(hw, batch, monkeypa
     w64 = [d for d in whole if "N=64 K=256 k=1x1 +act" in d.split(">>")[0]]
     w128 = [d for d in whole if "N=128 K=512 k=1x1 +act" in d.split(">>")[0]]       # the 28 x 28 stage's blocks 2 - 4 (bneck128.hpp): reduce, 3x3 AND expand in one launch
     assert len(w64) == 2 and all("k=3x3" in d.split(">>")[1] and "N=256 K=64 k=1x1 +res +act" in d.split(">>")[2] for d in w64)
-    assert len(w128) == 3 and all("K=1152 k=3x3" in d.split(">>")[1] and "N=512 K=128 k=1x1 +res +act" in d.split(">>")[2] for d in w128) and len(whole) == 5
+    big = (hw[0] // 8) * (hw[1] // 8) > 208                               # the 128-channel block kernel takes images beyond the persistent runs' domain (28 x 28 at 224 x 224 input)
+    n128 = 3 if big else 0
+    assert len(w128) == n128 and all("K=1152 k=3x3" in d.split(">>")[1] and "N=512 K=128 k=1x1 +res +act" in d.split(">>")[2] for d in w128) and len(whole) == 2 + n128
     hidden = set(ex.valueNames) - set(ex.storedValueNames)
     monkeypatch.setenv("SMELTER_BNECK", "0")
     ex0, plain = run_hip(model, x)
     # (+2: the reduce layers of stage 1; +6: reduce and expand layers of stage 2's three identity blocks)
-    assert ex0.numOps == ex.numOps + 8 and not any("whole bottleneck block" in ex0.opDesc(i) for i in range(ex0.numOps))
+    assert ex0.numOps == ex.numOps + 2 + 2 * n128 and not any("whole bottleneck block" in ex0.opDesc(i) for i in range(ex0.numOps))
     assert abs(ex0.flops - ex.flops) <= 1e-9 * ex.flops and abs(ex0.algorithmicBytes - ex.algorithmicBytes) <= 1e-6 * ex.algorithmicBytes      # accounted as the layers the graph holds
     assert ex.launchBytes < ex0.launchBytes                              # two hidden tensors fewer to move
     assert set(ex.valueNames) == set(ex0.valueNames)                     # the rounding list is the same ...
-    assert len(hidden - (set(ex0.valueNames) - set(ex0.storedValueNames))) == 2 + 6  # ... eight more of its tensors have no storage (T1 of five blocks, T2 of the three 128-channel ones)
+    assert len(hidden - (set(ex0.valueNames) - set(ex0.storedValueNames))) == 2 + 2 * n128  # ... eight more of its tensors have no storage (T1 of five blocks, T2 of the three 128-channel ones)
     assert nerr(got, plain) <= 1e-3
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3
 
