@@ -101,7 +101,9 @@ FC_CASES = [
     (64, 2048, 1000, 0),    # ResNet-50's classifier at bs 64: 63 x 4 blocks, the last output tile holds 8 outputs
     (70, 2048, 1000, 1),    # ragged rows (five row tiles, the last holds 6), ReLU
     (1, 2048, 1000, 0),     # one row
-    (256, 1280, 1000, 0),   # MobileNet-v2's classifier at bs 256 (40 k steps)
+    (256, 1280, 1000, 0),   # MobileNet-v2's classifier at bs 256 (40 k steps): four row groups per block
+    (150, 512, 1000, 1),    # two row groups per block, the last block's second group holds 6 rows
+    (250, 320, 1000, 2),    # four row groups per block, the last group ragged (10 rows)
     (17, 288, 36, 2),       # 9 k steps over four waves (2 + 2 + 2 + 3), N % 16 != 0, leaky
     (33, 256, 8, 0),        # the smallest K the kernel takes, one output tile of 8
 ]
