@@ -46,6 +46,7 @@ __device__ unsigned long long g_kq_tl[1024 * 4 * 16];
 struct KqParams {
     const half_t* x; const half_t* w; const float* bias; half_t* y;
     int N, H, W, Cin, Cout, K, x_ld, y_ld, act; float slope;
+    int Ho, Wo;                                                        // output size (the stride-2 instantiations; H, W else)
     int nt, RS, NI, slice_bytes, TH, TI, mt, bands, mpx, nsb;
     unsigned nt_mul, nt_sh, dhw_mul, dhw_sh, dw_mul, dw_sh, h1_mul, h1_sh, bands_mul, bands_sh, rs_mul, rs_sh;
     int ka, kb;                                                        // LDS swizzle: chunk c of patch slot (row r, column cc) sits at position c ^ ((ka (cc / 2) + kb r) & 7), kb in {0, 4};
@@ -68,11 +69,17 @@ __device__ __forceinline__ void kq_bdma16(unsigned voff, kq_u32x4 rsrc, unsigned
 constexpr int kq_dma_units(int U, int LA) { int n = 0; for (int d = 1; d <= LA; d++) n += ((U - d + 18) % 18) != 17; return n; }
 __device__ __forceinline__ void kq_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int KG, int NG, int NF, int NB>
+// S2 — 3x3 / STRIDE 2 / pad 1 (ONNXConvolutionPadding.swift:91-113: the first 3x3 of ResNet-50's stages 2-4), same kernel: the stride lives in the patch layout.  A patch
+// row holds its columns DE-INTERLEAVED — column cc = input column + 1 sits in slot cc / 2 when cc is even, in slot RS / 2 + cc / 2 when it is odd — so that the taps of
+// output pixel ox are the slots ox (kw = 0), RS / 2 + ox (kw = 1) and ox + 1 (kw = 2): the 16 lanes of a fragment read CONSECUTIVE slots as at stride 1 (a stride of two
+// slots would put them on half the banks), the tap offsets stay wave-uniform constants, and the rows of output row oy are the patch rows 2 oy + kh.  Output tiles of
+// NFR fragments (13 | 7): a band of 16 NFR / Wo output rows or 16 NFR / (Ho Wo) images.
+template <int KG, int NG, int NF, int NB, int NFR = 13, bool S2 = false>
 __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
-    static_assert(18 % ((NF == 4 ? 2 : 5) + 1) == 0 && KG * NG == 4 && (NF == 1 || NF == 2 || NF == 4) && (NB == 1 || NB == 2), "four waves");
-    constexpr int NFR = 13, WN = NF * 16, BN = NG * WN;               // pixel fragments per tile, couts per wave / per block
-    constexpr int ROUNDS = NF == 4 ? 2 : 1, RFR = ROUNDS == 2 ? 7 : NFR;   // the partial sums pass the LDS in ROUNDS rounds of <= RFR fragments
+    static_assert(18 % ((NF == 4 ? 2 : 5) + 1) == 0 && KG * NG == 4 && (NF == 1 || NF == 2 || NF == 4) && (NB == 1 || NB == 2) && (NFR == 13 || NFR == 7), "four waves");
+    constexpr int WN = NF * 16, BN = NG * WN;                         // couts per wave / per block (NFR pixel fragments per tile)
+    constexpr int HF = (NFR + 1) / 2;                                 // fragments the first of two K slices keeps in the exchange epilogue
+    constexpr int ROUNDS = NF == 4 && NFR > 7 ? 2 : 1, RFR = ROUNDS == 2 ? 7 : NFR;   // the partial sums pass the LDS in ROUNDS rounds of <= RFR fragments
     constexpr int RLD = WN + 4, RROWS = RFR * 16;                     // reduce region: floats per pixel row, pixel rows per round
     constexpr int OCT = WN / 8, PPS = 64 / OCT;                       // 8-cout groups per pixel, pixels per wave step of the summing pass
     constexpr bool TAB = NF <= 2;                                     // fragment addresses from a per-lane table (13 x 3 x 2 registers) instead of 4 VALU per read: with <= 2 MFMAs per read the wave's issue slots are the limit
@@ -90,17 +97,18 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
     const int bid = blockIdx.x, xcd = bid & (SM_NUM_XCD - 1), bslot = bid >> 3;
     const int mq = (int)sm_fastdiv((unsigned)bslot, p.nt_mul, p.nt_sh), ntile = bslot - mq * p.nt, mtile = xcd * p.mpx + mq;
     if (mq >= p.mpx || mtile >= p.mt) return;
-    const int H = p.H, W = p.W, RS = p.RS, HW = H * W;
+    const int H = p.H, W = p.W, RS = p.RS, HW = H * W, HR = RS >> 1;
+    const int Ho = S2 ? p.Ho : H, Wo = S2 ? p.Wo : W, HWo = Ho * Wo;  // output image
     const bool band = p.TH > 0;
-    int n0, y0 = 0, imgs = 1, PTe;
+    int n0, y0 = 0, imgs = 1, PTe;                                    // (y0: first OUTPUT row of a band)
     if (band) {
         n0 = (int)sm_fastdiv((unsigned)mtile, p.bands_mul, p.bands_sh);
         y0 = (mtile - n0 * p.bands) * p.TH;
-        PTe = min(p.TH, H - y0) * W;
+        PTe = min(p.TH, Ho - y0) * Wo;
     } else {
-        n0 = mtile * p.TI; imgs = min(p.TI, p.N - n0); PTe = imgs * HW;
+        n0 = mtile * p.TI; imgs = min(p.TI, p.N - n0); PTe = imgs * HWo;
     }
-    const long pix0 = ((long)n0 * H + y0) * W;                        // the tile's output pixels are pix0 .. pix0 + PTe - 1
+    const long pix0 = ((long)n0 * Ho + y0) * Wo;                      // the tile's output pixels are pix0 .. pix0 + PTe - 1
 
     // ---- weight fragment offsets: lane (l15, g) of fragment j holds cout co0 + 16 j + l15, channels 8 g .. 8 g + 7 of the unit's 32 ----
     const int co0 = ntile * BN + ng * WN;
@@ -133,15 +141,15 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
     const int KPR = RS >> 3, c8 = lane & 7, l8 = lane >> 3;
     auto dma_off = [&](int r, int k) -> unsigned {                    // byte offset (channel base excluded) of this lane's piece of instruction (r, k); dead lanes: beyond the buffer
         // row r: band mode = image row y0 - 1 + r of image n0; whole-image mode = row (r - 1) % (H + 1) of image n0 + (r - 1) / (H + 1), row H being the zero row between images
-        int n = n0, y = y0 - 1 + r; bool rok;
+        int n = n0, y = (S2 ? 2 * y0 : y0) - 1 + r; bool rok;
         if (band) rok = (unsigned)y < (unsigned)H;
         else {
             const int vr = r - 1, im = vr < 0 ? 0 : (int)sm_fastdiv((unsigned)vr, p.h1_mul, p.h1_sh);
             y = vr - im * (H + 1); n = n0 + im; rok = vr >= 0 && y < H && im < imgs;
         }
         const unsigned rowbase = (unsigned)(((n * H + y) * W - 1)) * ld2;                  // + cc * ld2: pixel (y, cc - 1)
-        const int cc = 8 * k + l8;
-        const unsigned key = (unsigned)((p.ka * (cc >> 1) + p.kb * r) & 7);                 // swizzle key of slot (r, cc)
+        const int sl = 8 * k + l8, cc = S2 ? (sl < HR ? 2 * sl : 2 * (sl - HR) + 1) : sl;   // slot of the row -> column
+        const unsigned key = (unsigned)((p.ka * (sl >> 1) + p.kb * r) & 7);                 // swizzle key of slot (r, sl)
         const bool ok = rok && (unsigned)(cc - 1) < (unsigned)W;
         return ok ? rowbase + (unsigned)cc * ld2 + (((unsigned)c8 ^ key) << 4) : 0x80000000u;
     };
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
     half8_t af[2][NFR];
     unsigned ad[NFR];                                                 // fragment addresses of the unit being fetched
     auto tap_off = [&](int tap) {                                     // byte offset of a tap's slots (opaque to the optimiser: 18 x 13 addresses are NOT loop invariants to keep in registers)
-        unsigned t = (unsigned)(((tap / 3) * RS + tap % 3) << 7);
+        unsigned t = (unsigned)(((tap / 3) * RS + (S2 ? (tap % 3 == 1 ? HR : tap % 3 >> 1) : tap % 3)) << 7);
         asm volatile("" : "+s"(t));
         return t;
     };
@@ -195,18 +203,19 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
 #pragma unroll
             for (int f = 0; f < NFR; f++) {
                 const int t = f * 16 + l15, tc = t < PTe ? t : 0;
-                int vrow, xx;
-                if (band) { vrow = (int)sm_fastdiv((unsigned)tc, p.dw_mul, p.dw_sh); xx = tc - vrow * W; }
+                int vrow, xx;                                        // patch row of tap row 0, output column
+                if (band) { vrow = (int)sm_fastdiv((unsigned)tc, p.dw_mul, p.dw_sh); xx = tc - vrow * Wo; if (S2) vrow *= 2; }
                 else {
-                    const int im = (int)sm_fastdiv((unsigned)tc, p.dhw_mul, p.dhw_sh), rr = tc - im * HW, yy = (int)sm_fastdiv((unsigned)rr, p.dw_mul, p.dw_sh);
-                    xx = rr - yy * W; vrow = im * (H + 1) + yy;
+                    const int im = (int)sm_fastdiv((unsigned)tc, p.dhw_mul, p.dhw_sh), rr = tc - im * HWo, yy = (int)sm_fastdiv((unsigned)rr, p.dw_mul, p.dw_sh);
+                    xx = rr - yy * Wo; vrow = im * (H + 1) + (S2 ? 2 * yy : yy);
                 }
                 pf[f] = lds0 + slice_o + (unsigned)((vrow * RS + xx) << 7);   // centre = slot (vrow + 1) RS + xx + 1; tap (kh, kw) = this slot + kh RS + kw
                 if constexpr (TAB) {
 #pragma unroll
                     for (int kw = 0; kw < 3; kw++) {
-                        const int slot = vrow * RS + xx + kw, r = (int)sm_fastdiv((unsigned)slot, p.rs_mul, p.rs_sh), cc = slot - r * RS;
-                        const unsigned a0 = pf[f] + (unsigned)(kw << 7) + (((unsigned)g ^ (unsigned)((p.ka * (cc >> 1) + p.kb * r) & 7)) << 4);
+                        const int ko = S2 ? (kw == 1 ? HR : kw >> 1) : kw;
+                        const int slot = vrow * RS + xx + ko, r = (int)sm_fastdiv((unsigned)slot, p.rs_mul, p.rs_sh), cc = slot - r * RS;
+                        const unsigned a0 = pf[f] + (unsigned)(ko << 7) + (((unsigned)g ^ (unsigned)((p.ka * (cc >> 1) + p.kb * r) & 7)) << 4);
                         atab[f][kw][0] = a0; atab[f][kw][1] = a0 ^ 64u;
                     }
                 }
@@ -259,7 +268,7 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
             __builtin_amdgcn_sched_barrier(0);
             sm_static_for<0, NFR>([&](auto fc) {
                 constexpr int F = decltype(fc)::value;
-                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(U == 17 ? 12 - F : 12) : "memory");   // (the last unit fetches nothing)
+                asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(U == 17 ? NFR - 1 - F : NFR - 1) : "memory");   // (the last unit fetches nothing)
                 __builtin_amdgcn_sched_barrier(0);
                 unsigned pt = 0, ky = 0;
 #pragma unroll
@@ -288,7 +297,7 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
                         }
                     }
                 }
-                if constexpr (NB == 2 && U < 17 && F == 6) {
+                if constexpr (NB == 2 && U < 17 && F == NFR / 2) {
                     const bool real = more && ng + U * NG < p.NI;
                     kq_bdma16(real ? dmo[U < DMX ? U : 0] : 0x80000000u, rs_x,
                               (unsigned)__builtin_amdgcn_readfirstlane((int)(real ? nbuf + (unsigned)(ng + U * NG) * 1024u : sink)), nch0b);
@@ -316,24 +325,24 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
     if constexpr (XCH) {
         // KG = 2: wave kg keeps fragments [F0, F1) = kg ? [7, 13) : [0, 7) and hands the others to its partner (same ng, other kg) through the LDS in accumulator
         // layout (lane-linear 1 KB per fragment: conflict-free, half the bytes of the all-to-all pass); sum = slice 0 + slice 1 on both sides.  KG = 1: nothing to add.
-        const int F0 = KG == 2 && kg ? 7 : 0, F1 = KG == 2 && !kg ? 7 : NFR;
+        const int F0 = KG == 2 && kg ? HF : 0, F1 = KG == 2 && !kg ? HF : NFR;
         if constexpr (KG == 2) {
             float* const xb = (float*)(kq_smem + (lds0 - ws_lds_addr(kq_smem)));
             const int pw = (kg ^ 1) * NG + ng;                        // partner wave
             sm_static_for<0, NFR>([&](auto fc) {
                 constexpr int F = decltype(fc)::value;
-                if ((F < 7) != (kg == 0)) {                           // (wave-uniform) a fragment I give away: slot F % 7 of MY region
+                if ((F < HF) != (kg == 0)) {                          // (wave-uniform) a fragment I give away: slot F % HF of MY region
 #pragma unroll
-                    for (int j = 0; j < NF; j++) *(floatx4*)&xb[((wave * 7 + F % 7) * NF + j) * 256 + lane * 4] = acc[F][j];
+                    for (int j = 0; j < NF; j++) *(floatx4*)&xb[((wave * HF + F % HF) * NF + j) * 256 + lane * 4] = acc[F][j];
                 }
             });
             kq_lds_barrier();
             sm_static_for<0, NFR>([&](auto fc) {
                 constexpr int F = decltype(fc)::value;
-                if ((F < 7) == (kg == 0)) {
+                if ((F < HF) == (kg == 0)) {
 #pragma unroll
                     for (int j = 0; j < NF; j++) {
-                        const floatx4 o4 = *(const floatx4*)&xb[((pw * 7 + F % 7) * NF + j) * 256 + lane * 4];
+                        const floatx4 o4 = *(const floatx4*)&xb[((pw * HF + F % HF) * NF + j) * 256 + lane * 4];
                         acc[F][j] = kg == 0 ? acc[F][j] + o4 : o4 + acc[F][j];
                     }
                 }
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(256) void conv3x3_kq_kernel(KqParams p) {
         KQ_TL(10);
         // stores: descriptor on y, scalar offset = the fragment's first pixel, per-lane offset = (pixel in fragment, cout group) — no address arithmetic per store;
         // lanes without a cout group (partial last cout tile) or, in the tile's last fragments, without a pixel sit beyond num_records
-        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)((unsigned)p.N * (unsigned)HW * (unsigned)p.y_ld * 2u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)((unsigned)p.N * (unsigned)HWo * (unsigned)p.y_ld * 2u), 0x00020000);
         const unsigned ybase = (unsigned)pix0 * (unsigned)p.y_ld * 2u, yfrag = 16u * (unsigned)p.y_ld * 2u;
         unsigned yoff[NF / 2];
 #pragma unroll

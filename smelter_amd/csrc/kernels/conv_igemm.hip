@@ -568,10 +568,10 @@ __global__ __launch_bounds__(256) void dwconv3x3_lds_kernel(ConvParams p, int cb
 //   kind 4: p0 = Cin of the instantiation; CF_HEAD / CF_XHEAD / CF_W44 (two-role kernel: 4 of the 8 waves issue the patch DMA) / CF_SIDE
 //   kind 6: p0 = taps (kH' of the row-pair form), p1 = KB between the two patch buffers (0 = as large as the weights allow), p2 = loader waves
 //   kinds 5, 7: p0 = ring stages
-//   kind 9: flags = patch buffers (1 | 2), p0 = KG, p1 = NG, p2 = NF
+//   kind 9: flags = patch buffers (1 | 2) | CF_KQ_S2 (the stride-2 instantiations), p0 = KG, p1 = NG, p2 = NF, BM / 16 = NFR
 //   kind 8: BM = pixels per step (32 FS), BN = channels per block, p0 = Cin of the instantiation; CF_RES = the instantiation that stages a residual tile;
 //           ring form: p1 = stages, p2 = parts the weight slice passes the LDS in (0 = 1); CF_DUAL = takes (only) launches with a second source
-enum { CF_HEAD = 1, CF_XHEAD = 2, CF_W44 = 4, CF_SIDE = 8, CF_RES = 16, CF_DUAL = 32, CF_POOL = 64 };
+enum { CF_HEAD = 1, CF_XHEAD = 2, CF_W44 = 4, CF_SIDE = 8, CF_RES = 16, CF_DUAL = 32, CF_POOL = 64, CF_KQ_S2 = 128 };
 struct TileCfg { int BM, BN, kind, threads; void (*fn)(ConvParams); const char* name; int flags = 0, p0 = 0, p1 = 0, p2 = 0; };
 const TileCfg kCfgs[] = {
     {128, 128, 0, 256, conv_igemm_kernel<128, 128, 2, 2>, "128x128"},
@@ -711,6 +711,11 @@ const TileCfg kCfgs[] = {
     // kind 5 with the 2x2 / stride-2 max-pool of the output as a second output of the launch (conv3x3_p9.hpp POOL: the U-Net's 128-channel level; the weight-stationary kernel has it for Cin, Cout <= 64)
     {256, 128, 5, 512, conv3x3_p9_kernel<256, 128, 4, 2, 3, true>, "p9:256x128 s3 pool", CF_POOL, 3},
     // ---- build-conditional entries stay BEHIND the product pool so that product indices do not depend on the build ----
+    // kind 9, flags & CF_KQ_S2: 3x3 / STRIDE 2 / pad 1 (the first 3x3 of a ResNet stage), the stride in the patch layout; BM = 16 x the tile's fragments (13 | 7)
+    {208, 128, 9, 256, nullptr, "kq/2:k1n4 196x128", 1 | CF_KQ_S2, 1, 4, 2},
+    {112, 128, 9, 256, nullptr, "kq/2:k2n2 112x128", 1 | CF_KQ_S2, 2, 2, 4},
+    {112, 64, 9, 256, nullptr, "kq/2:k2n2 112x64", 1 | CF_KQ_S2, 2, 2, 2},
+    {112, 128, 9, 256, nullptr, "kq/2:k1n4 112x128", 1 | CF_KQ_S2, 1, 4, 2},
 #ifdef SM_ABLATION   // the single-role expand head (conv3x3_ws.hpp HX): 16 of 55 us added to the 3x3; the two-role kernel replaced it
     {128, 64, 4, 256, conv3x3_ws_kernel<64, 64, 4, 1, 12, 0, 0, 0, false, true>, "ws:64->64 w4x1 xhead", CF_XHEAD, 64},
 #endif
@@ -845,21 +850,29 @@ size_t p9_setup(ConvParams& p, const TileCfg& c) {
 // Geometry of the wave-split 3x3 kernel (conv3x3_kq.hpp) for tile config `c` (p0 = KG, p1 = NG, p2 = NF): whole images per tile when an image has
 // <= 208 pixels, else a band of TH full rows.  Returns the dynamic LDS size in bytes, 0 if the config does not fit the layer.
 size_t kq_setup(ConvParams& p, const TileCfg& c) {
-    const int KG = c.p0, NG = c.p1, NF = c.p2, NB = c.flags;
+    const int KG = c.p0, NG = c.p1, NF = c.p2, NB = c.flags & 3, PT = c.BM;   // (PT: output pixels a tile may hold, 16 per fragment)
+    const bool s2 = (c.flags & CF_KQ_S2) != 0;
     if (p.W < 7 || p.W > 208 || (p.Cin % (KG * 64)) != 0) return 0;
-    const int HW = p.H * p.W, RS = (p.W + 1 + 7) / 8 * 8;             // slots per patch row: W pixels + >= 1 zero column, a whole number of 8-slot DMA instructions
-    int vrows;
-    if (HW <= 208) { p.kq_TH = 0; p.kq_TI = 208 / HW; p.kq_bands = 1; p.kq_mt = sm_ceil_div(p.N, p.kq_TI); vrows = p.kq_TI * (p.H + 1) - 1; }
-    else { p.kq_TH = 208 / p.W; p.kq_TI = 1; p.kq_bands = sm_ceil_div(p.H, p.kq_TH); if ((long)p.N * p.kq_bands >= (1L << 30)) return 0; p.kq_mt = p.N * p.kq_bands; vrows = p.kq_TH; }
-    // rows 0 .. vrows + 1 (two halo rows); when the row has no spare zero column (RS == W + 1) the bottom-right tap of the last pixel is slot 0 of one more row
-    p.kq_RS = RS; p.kq_NI = (vrows + 2) * (RS / 8) + (RS == p.W + 1 ? 1 : 0); p.kq_slice_bytes = (p.kq_NI + 1) / 2 * 2048; p.kq_nsb = p.Cin / (KG * 64);
-    if ((long)p.N * HW * p.x_ld * 2 >= 0x7fff0000L || (long)p.N * HW * p.y_ld * 2 >= 0x7fff0000L) return 0;   // (32-bit buffer offsets on both sides)
+    const int HW = p.H * p.W, Ho = s2 ? p.Ho : p.H, Wo = s2 ? p.Wo : p.W, HWo = Ho * Wo;
+    if (Wo < 4 || Wo > PT) return 0;
+    // slots per patch row, a whole number of 8-slot DMA instructions.  Stride 1: W pixels + >= 1 zero column.  Stride 2: two halves of >= Wo + 1 slots (columns 0, 2, .. 2 Wo | 1, 3, .. 2 Wo - 1)
+    const int RS = s2 ? 2 * ((Wo + 1 + 3) / 4 * 4) : (p.W + 1 + 7) / 8 * 8;
+    int rows;                                                        // patch rows of a tile
+    if (HWo <= PT) { p.kq_TH = 0; p.kq_TI = PT / HWo; p.kq_bands = 1; p.kq_mt = sm_ceil_div(p.N, p.kq_TI); rows = p.kq_TI * (p.H + 1) + 1; }   // images H + 1 rows apart: the zero row between two of them is bottom halo of one, top halo of the next
+    else { p.kq_TH = PT / Wo; p.kq_TI = 1; p.kq_bands = sm_ceil_div(Ho, p.kq_TH); if ((long)p.N * p.kq_bands >= (1L << 30)) return 0; p.kq_mt = p.N * p.kq_bands; rows = s2 ? 2 * p.kq_TH + 1 : p.kq_TH + 2; }
+    // stride 1: when the row has no spare zero column (RS == W + 1) the bottom-right tap of the last pixel is slot 0 of one more row
+    p.kq_RS = RS; p.kq_NI = rows * (RS / 8) + (!s2 && RS == p.W + 1 ? 1 : 0); p.kq_slice_bytes = (p.kq_NI + 1) / 2 * 2048; p.kq_nsb = p.Cin / (KG * 64);
+    if ((long)p.N * HW * p.x_ld * 2 >= 0x7fff0000L || (long)p.N * HWo * p.y_ld * 2 >= 0x7fff0000L) return 0;   // (32-bit buffer offsets on both sides)
     p.nt = sm_ceil_div(p.Cout, NG * NF * 16); p.kq_mpx = sm_ceil_div(p.kq_mt, SM_NUM_XCD);
     if ((long)p.kq_mpx * SM_NUM_XCD * p.nt >= (1L << 31)) return 0;
     sm_fastdiv_make((unsigned)RS, &p.kq_rs_mul, &p.kq_rs_sh); sm_fastdiv_make((unsigned)(p.H + 1), &p.kq_h1_mul, &p.kq_h1_sh);
     sm_fastdiv_make((unsigned)p.kq_bands, &p.kq_bands_mul, &p.kq_bands_sh); sm_fastdiv_make((unsigned)p.nt, &p.nt_mul, &p.nt_sh);
     if (NB == 2 && (p.kq_nsb < 2 || sm_ceil_div(p.kq_NI, NG) > 17)) return 0;   // two buffers: something to prefetch, one patch instruction per unit and wave
-    const size_t patch = (size_t)KG * p.kq_slice_bytes * NB + (NB == 2 ? 1024 : 0), red = (size_t)4 * (NF == 4 ? 112 : 208) * (NF * 16 + 4) * 4;
+    // epilogue area: two K slices with >= 2 fragments per wave trade half of their sums in accumulator layout (1 KB per fragment); one such slice has nothing to add; else every partial sum passes the LDS
+    const bool xch = KG <= 2 && NF >= 2;
+    const int nfr = PT / 16;
+    const size_t patch = (size_t)KG * p.kq_slice_bytes * NB + (NB == 2 ? 1024 : 0);
+    const size_t red = xch ? (KG == 2 ? (size_t)4 * ((nfr + 1) / 2) * NF * 1024 : 0) : (size_t)4 * (NF == 4 ? 112 : 208) * (NF * 16 + 4) * 4;
     const size_t lds = std::max(patch, red) + 2048;                  // (+ 2 KB: the kernel aligns its slices to 2 KB)
     return lds <= 160 * 1024 ? lds : 0;
 }
@@ -916,7 +929,9 @@ bool cfg_eligible(const TileCfg& c, const ConvParams& p) {
                (long)p.N * p.H * p.W * p.x_ld * 2 < 0x7fff0000L && (long)p.N * p.H * p.W * p.y_ld * 2 < 0x7fff0000L && (long)p.N * ((p.H + 15) / 16) * ((p.W + 13) / 14) < (1L << 30);
     if (c.kind == 9) {   // wave-split 3x3: no residual, no upsampled input, dense 16-byte rows, ReLU family, 32-bit weight offsets
         ConvParams q = p;
-        return same3x3 && !p.ups && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 &&
+        // stride 2: pad 1 in front, any padding behind it that leaves the last tap at most one row / column beyond the image (the patch holds zeros there)
+        const bool half3x3 = p.kH == 3 && p.kW == 3 && p.sH == 2 && p.sW == 2 && p.dH == 1 && p.dW == 1 && p.pt == 1 && p.pl == 1 && 2 * p.Ho - 1 <= p.H && 2 * p.Wo - 1 <= p.W && p.Ho >= 1;
+        return ((c.flags & CF_KQ_S2) ? half3x3 : same3x3) && !p.ups && !p.yplace && !p.res && p.splitk <= 1 && p.act <= SM_ACT_PRELU && (p.Cout & 7) == 0 && (p.y_ld & 7) == 0 && (p.x_ld & 7) == 0 &&
                ((((uintptr_t)p.y) & 15) == 0) && ((((uintptr_t)p.x) & 15) == 0) && ((((uintptr_t)p.w) & 15) == 0) && ((((uintptr_t)p.bias) & 15) == 0) &&
                (long)p.Cout * p.K * 2 < 0x7fff0000L && kq_setup(q, c) > 0;
     }
@@ -1094,7 +1109,7 @@ int launch(const sm_conv_desc* d, ConvParams& p, int cfg, void* ws, size_t ws_by
     }
     if (c.kind == 9) {
         const size_t lds = kq_setup(p, c);
-        kq_launch(kq_variant(c.p0, c.p1, c.p2, c.flags), p, (unsigned)(p.kq_mpx * SM_NUM_XCD * p.nt), lds, s);
+        kq_launch(kq_variant(c.p0, c.p1, c.p2, c.flags & 3, c.BM / 16, (c.flags & CF_KQ_S2) ? 1 : 0), p, (unsigned)(p.kq_mpx * SM_NUM_XCD * p.nt), lds, s);
         SM_LAUNCH_CHECK(); return SM_OK;
     }
     if (c.kind == 5) {

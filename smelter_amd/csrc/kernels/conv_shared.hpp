@@ -61,8 +61,8 @@ __device__ __forceinline__ unsigned ws_lds_addr(const void* p) { return (unsigne
 
 template <int N> __device__ __forceinline__ void sm_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// conv_kq.hip: launches instantiation `variant` (kq_variant(KG, NG, NF, NB)) of conv3x3_kq_kernel
-int kq_variant(int KG, int NG, int NF, int NB);
+// conv_kq.hip: launches instantiation `variant` (kq_variant(KG, NG, NF, NB, NFR, S2)) of conv3x3_kq_kernel
+int kq_variant(int KG, int NG, int NF, int NB, int NFR, int S2);
 void kq_launch(int variant, const ConvParams& p, unsigned grid, size_t lds, hipStream_t s);
 // ... and conv3x3_kqp_kernel<KG, NG> (persistent, weights in registers); -1: no such instantiation
 int kqp_launch(int KG, int NG, const ConvParams& p, hipStream_t s);

@@ -642,6 +642,63 @@ def test_conv3x3_wave_split(case, cfg):
     assert_close(to_host(y), ref, cin * 9)
 
 
+KQ2_CASES = [
+    # n, h, w, cin, cout, act, pads   -- conv3x3_kq.hpp S2: 3x3 / stride 2, the stride in the patch layout (columns de-interleaved), 196- or 112-pixel output tiles
+    (3, 56, 56, 128, 128, 1, (1, 1, 1, 1)),    # ResNet-50 conv_101: bands of 7 (4) output rows, two super-blocks of 64 channels (one of 128)
+    (3, 28, 28, 256, 256, 1, (1, 1, 1, 1)),    # conv_208: one image (a band of 7 rows) per tile
+    (9, 14, 14, 512, 512, 1, (1, 1, 1, 1)),    # conv_365: four (two) images per tile, ragged last tile of one image
+    (2, 15, 13, 128, 72, 2, (1, 1, 1, 1)),     # odd sizes: the last tap row / column is the bottom / right padding; Cout % 16 != 0, PRelu
+    (2, 16, 20, 128, 64, 0, (1, 1, 0, 0)),     # no padding behind (ONNX pads [1, 1, 0, 0]): same output size at even sizes, no activation
+    (1, 37, 41, 256, 136, 1, (1, 1, 1, 1)),    # 19 x 21 outputs: bands of 9 (5) rows, ragged last band, three cout tiles (one partial)
+    (5, 9, 8, 128, 64, 1, (1, 1, 1, 1)),       # 5 x 4 outputs: ten (five) images per tile, narrowest width
+]
+
+
+@pytest.mark.parametrize("case", KQ2_CASES)
+@pytest.mark.parametrize("cfg", cfgs_named("kq/2:"))
+def test_conv3x3_stride2_wave_split(case, cfg):
+    """the first 3x3 of a ResNet stage (ONNXConvolutionPadding.swift:91-113: explicit pads, stride 2) on the wave-split kernel, against the oracle"""
+    n, hh, ww, cin, cout, act, pads = case
+    rng = np.random.default_rng(hash(case[:6]) % 2 ** 31)
+    x = h(rng.standard_normal((n, cin, hh, ww)))
+    w = h(rng.standard_normal((cout, 3, 3, cin)) * np.sqrt(2.0 / (cin * 9)))
+    b = rng.standard_normal(cout).astype(np.float32)
+    ref = O.conv2d(x, w, b, stride=(2, 2), pads=pads)
+    slope = 0.25 if act == 2 else 0.0
+    if act:
+        ref = np.where(ref >= 0, ref, ref * slope)
+    from smelter_amd._native import SmelterError
+    try:
+        y = ops.conv2d(to_dev(x), torch.from_numpy(w).cuda().half(), torch.from_numpy(b).cuda(), stride=(2, 2), pads=pads, act=act, slope=slope, cfg=cfg)
+    except SmelterError as e:
+        if "does not apply" in e.detail:                      # Cin is not a multiple of the config's super-block, or the patch of a tile does not fit the LDS
+            pytest.skip(e.detail)
+        raise
+    assert_close(to_host(y), ref, cin * 9)
+
+
+def test_conv3x3_stride2_takes_the_three_resnet_layers():
+    """every stride-2 3x3 of ResNet-50 at batch 64 has at least one wave-split configuration (the autotuner decides among them and the tiled kernels); full size: the
+    configurations against the default tiled kernel (same fp32 accumulation up to the order of the channel slices)"""
+    from smelter_amd._native import SmelterError
+    rng = np.random.default_rng(11)
+    for hw, c in ((56, 128), (28, 256), (14, 512)):
+        x = torch.from_numpy(rng.standard_normal((64, hw, hw, c)).astype(np.float16)).cuda()
+        w = torch.from_numpy((rng.standard_normal((c, 3, 3, c)) * np.sqrt(2.0 / (c * 9))).astype(np.float16)).cuda()
+        b = torch.from_numpy(rng.standard_normal(c).astype(np.float32)).cuda()
+        ref = ops.conv2d(x, w, b, stride=(2, 2), pads=(1, 1, 1, 1), act=1).float()
+        took = 0
+        for cfg in cfgs_named("kq/2:"):
+            try:
+                y = ops.conv2d(x, w, b, stride=(2, 2), pads=(1, 1, 1, 1), act=1, cfg=cfg).float()
+            except SmelterError as e:
+                assert "does not apply" in e.detail
+                continue
+            took += 1
+            assert y.shape == ref.shape and float((y - ref).abs().max()) <= float(ref.abs().max()) * 2.0 ** -9, (hw, c, ops.config_name(cfg))
+        assert took >= 1, (hw, c)
+
+
 KQP_CASES = [
     # n, h, w, cin, cout, act, ups   -- conv3x3_kqp.hpp: persistent, whole weight tensor in registers, 14 x 14 tiles (h, w = the OUTPUT size; ups: the input is half of it)
     (2, 28, 28, 128, 64, 1, False),    # exact tiles, two channel slices (the halves trade fragments through the released patch buffer)

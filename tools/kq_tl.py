@@ -10,6 +10,7 @@ from smelter_amd import _native
 ap = argparse.ArgumentParser()
 ap.add_argument("--shape", default="64,14,14,256,256")
 ap.add_argument("--cfg", default="kq:k4n1 196x64")
+ap.add_argument("--stride", type=int, default=1, help="2: the stride-2 instantiations (labels kq/2:...)")
 ap.add_argument("--flush", action="store_true", help="evict L2 / Infinity Cache (640 MB memset) before the measured launch")
 ap.add_argument("--lib", default="build/libsmelter_hip_kqtl.so")
 a = ap.parse_args()
@@ -20,12 +21,12 @@ cfg = [c for c in range(ops.num_conv_configs()) if ops.config_name(c) == a.cfg][
 x = torch.randn((n, h, w, cin), device="cuda").half()
 wt = (torch.randn((cout, 3, 3, cin), device="cuda") * (2.0 / (cin * 9)) ** 0.5).half()
 b = torch.randn(cout, device="cuda")
-y = torch.empty((n, h, w, cout), device="cuda", dtype=torch.float16)
+y = torch.empty((n, (h - 1) // a.stride + 1, (w - 1) // a.stride + 1, cout), device="cuda", dtype=torch.float16)
 junk = torch.empty(640 << 20, dtype=torch.uint8, device="cuda") if a.flush else None
 for it in range(3):
     if junk is not None:
         junk.fill_(it)
-    ops.conv2d(x, wt, b, stride=(1, 1), pads=(1, 1, 1, 1), act=1, cfg=cfg, out=y)
+    ops.conv2d(x, wt, b, stride=(a.stride, a.stride), pads=(1, 1, 1, 1), act=1, cfg=cfg, out=y)
 torch.cuda.synchronize()
 L = ops.lib()
 nb = 1024
