@@ -869,6 +869,7 @@ int Executor::plan(ONNXGraph& g, int batch) {
         size_t off = 0;
         for (auto& r : busy) { if (off + b.bytes <= r.first) break; off = std::max(off, r.second); }
         root_offset_[b.v] = off; placed.push_back(b); act_bytes_ = std::max(act_bytes_, off + b.bytes);
+        if (getenv("SMELTER_DEBUG_PLAN")) fprintf(stderr, "[plan] buffer %-28s %9.2f MB  alive steps %3d .. %3d  at %9.2f MB\n", values_[b.v].name.c_str(), b.bytes / 1e6, first[b.v], last[b.v], off / 1e6);
     }
 
     // ---- 5. weight arena layout + accounting ---------------------------------------------------------------

@@ -818,11 +818,14 @@ int stage_plan(const sm_stage_phase* ph, int n, StArgs& a, bool quiet) {
 
 }  // namespace
 
-// 1 if the current device runs a launch in its fast mode when nothing else occupies it: at least 256 compute units (one block each); the executor keeps its layers apart otherwise
+// 1 if the current device runs a launch in its fast mode when nothing else occupies it: a gfx950 / gfx942 part in its full configuration — 256 compute units in 8 XCDs, so that block b
+// lands on XCD b % 8 and the 32 blocks of a team share that XCD's L2 (the hand-off of mode 1 relies on exactly that; ADVICE r5: a partitioned or harvested device has the unit
+// count of a smaller multiple and another block -> XCD map).  The executor keeps its layers apart otherwise.
 extern "C" int sm_stage_device_fast(void) {
     int dev = 0; hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-    return prop.multiProcessorCount >= ST_GRID ? 1 : 0;
+    const bool arch = !strncmp(prop.gcnArchName, "gfx950", 6) || !strncmp(prop.gcnArchName, "gfx942", 6);
+    return arch && prop.multiProcessorCount == SM_NUM_XCD * 32 && prop.multiProcessorCount >= ST_GRID ? 1 : 0;
 }
 extern "C" int sm_stage_supported(const sm_stage_phase* ph, int32_t n) { StArgs a; return stage_plan(ph, n, a, true) == SM_OK ? 1 : 0; }
 extern "C" size_t sm_stage_ctl_bytes(const sm_stage_phase* ph, int32_t n) {

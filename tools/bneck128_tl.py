@@ -1,5 +1,5 @@
 """Timeline of ONE bneck128 launch (diagnostic build -DSM_BN_TL): s_memtime stamps of the four waves of every block; median over blocks relative to the block's first stamp.
-    SMELTER_LIB_PATH=build/diag/libsmelter_hip_bntl.so python tools/bneck128_tl.py"""
+    SMELTER_LIB_PATH=build/libsmelter_hip_bntl.so python tools/bneck128_tl.py"""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

@@ -1,6 +1,6 @@
-"""Timeline of ONE sm_bottleneck_fwd launch (diagnostic build with -DSM_BN_TL, see scratch/build_diag.sh): s_memtime stamps of wave 0 (3x3 + expand) and wave 4 (reducer)
+"""Timeline of ONE sm_bottleneck_fwd launch (diagnostic build with -DSM_BN_TL, tools/bneck_tl.sh builds it): s_memtime stamps of wave 0 (3x3 + expand) and wave 4 (reducer)
 of every block; prints the median over blocks of every stamp relative to the block's own first stamp, in clocks (s_memtime ticks at 100 MHz on gfx950: x 24 = core clocks).
-    SMELTER_LIB_PATH=build/diag/libsmelter_hip_bntl.so python tools/bneck_tl.py"""
+    SMELTER_LIB_PATH=build/libsmelter_hip_bntl.so python tools/bneck_tl.py"""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
