@@ -48,7 +48,7 @@ def ab_pairs(name, a_label, b_label):
 
 
 def block_state(tag):
-    rows = []
+    items = []
     names = {"": ("ResNet-50 bs=64", "r50"), "_mbv2": ("MobileNet-v2 bs=256", "mbv2"), "_unet": ("U-Net 512² bs=16", "unet")}
     ab = ab_pairs("%s_ab_same_box.txt" % tag, "", "")
     for suf, (label, key) in names.items():
@@ -56,21 +56,26 @@ def block_state(tag):
         if not b:
             continue
         r = b["roofline"]
-        abtxt = "—"
+        abtxt = "no same-box pair"
         if key in ab and len(ab[key]) == 2:
             (la, va), (lb, vb) = sorted(ab[key].items(), key=lambda kv: 0 if "round" in kv[0] or "binary" in kv[0] else 1)
             ma, mb = sum(va) / len(va), sum(vb) / len(vb)
             abtxt = "%s → %s ms (**%+.1f %%**)" % (" / ".join("%.3f" % v for v in va), " / ".join("%.3f" % v for v in vb), (mb / ma - 1) * 100)
         frac = "%.3f of the %s peak (%s %s)" % (r["frac"], "2.5 PFLOP/s MFMA" if r["bound"] == "mfma" else "8 TB/s HBM", r["achieved"], r["unit"])
-        rows.append("| %s | %s | **%.4f ms, %.1f k img/s**, %d launches, `roofline.frac` %s | " % (label, abtxt, b["ms_per_step"], b["value"] / 1e3, b["config"]["launches_per_step"], frac))
-    head = ("| BASELINE config | previous round's binary → this tree, same box (`profiles/%s_ab_same_box.txt`) | `bench.py`, driver form (`profiles/%s_bench*.json`) |\n|---|---|---|\n" % (tag, tag))
+        items.append("* **%s** — `bench.py`, driver form (`profiles/%s_bench%s.json`): **%.4f ms, %.1f k img/s**, %d launches, `roofline.frac` %s.  Previous round's binary → this tree, "
+                     "same box, three alternating runs (`profiles/%s_ab_same_box.txt`): %s." % (label, tag, suf, b["ms_per_step"], b["value"] / 1e3, b["config"]["launches_per_step"], frac, tag, abtxt))
     sec = last_json_line("%s_bench.json" % tag)
-    extra = ""
+    if sec:
+        runs = sec["config"].get("persistent_runs")
+        if runs is not None:
+            items.append("* Persistent runs of that ResNet-50 line (`config.persistent_runs`): " + ("; ".join(
+                "%d layers from step %d: one launch %.1f µs against %.1f µs layer by layer → %s" % (r["layers"], r["first_step"], r["t_run_us"], r["t_layers_us"], "on" if r["on"] else "off (" + ", ".join(r["why_off"]) + ")")
+                for r in runs) or "none") + ".")
     if sec and "secondary" in sec and "relu6_clip_export" in sec["secondary"].get("mbv2", {}):
         q = sec["secondary"]["mbv2"]["relu6_clip_export"]
-        extra = "\n\nMobileNet-v2 as a torchvision export holds it (every activation an ONNX `Clip(0, 6)`): %.4f ms, %.1f k img/s, %d launches (`secondary.mbv2.relu6_clip_export` of the same record)." % (
-            q["ms_per_step"], q["value"] / 1e3, q["launches_per_step"])
-    return head + "\n".join(r[:-3] + " |" for r in rows) + extra
+        items.append("* MobileNet-v2 as a torchvision export holds it (every activation an ONNX `Clip(0, 6)`): %.4f ms, %.1f k img/s, %d launches (`secondary.mbv2.relu6_clip_export` of the same record)." % (
+            q["ms_per_step"], q["value"] / 1e3, q["launches_per_step"]))
+    return "\n".join(items)
 
 
 def block_kernel(tag):
@@ -96,9 +101,11 @@ def block_pmc(tag):
             continue
         bm = b["roofline"]["byte_models"]
         rd, wr = p["hbm_read_bytes_per_step"] / 1e9, p["hbm_write_bytes_per_step"] / 1e9
-        rows.append("| %s | %.2f GB | %.2f GB | %.2f GB read + %.2f GB written = **%.2f GB** (%.2f× compulsory) |" % (
+        rows.append("| %s | %.2f GB | %.2f GB | %.2f + %.2f = **%.2f GB** | %.2f× |" % (
             label, bm["graph_per_layer_bytes_per_step"] / 1e9, bm["post_fusion_compulsory_bytes_per_step"] / 1e9, rd, wr, rd + wr, (rd + wr) * 1e9 / bm["post_fusion_compulsory_bytes_per_step"]))
-    return ("| per step | graph per-layer bytes (`smelter_exec_algorithmic_bytes`) | post-fusion compulsory bytes (`smelter_exec_launch_bytes`) | PMC, `profiles/%s_pmc_traffic*.json` (FETCH_SIZE ×2 KiB + WRITE_SIZE KiB, separate passes) |\n|---|---|---|---|\n" % tag) + "\n".join(rows)
+    return ("Bytes per step.  Per-layer: `smelter_exec_algorithmic_bytes` (every graph tensor written and read once).  Compulsory: `smelter_exec_launch_bytes` (what the launches must move "
+            "after fusion).  PMC: `profiles/%s_pmc_traffic*.json`, FETCH_SIZE ×2 KiB + WRITE_SIZE KiB in separate passes (L2 ↔ fabric traffic).\n\n"
+            "| model | per-layer | compulsory | PMC read + written | PMC ÷ compulsory |\n|---|---|---|---|---|\n" % tag) + "\n".join(rows)
 
 
 def block_t0(tag):
@@ -122,7 +129,8 @@ def block_parity(tag):
         e = d[k]; q = e["error_over_max_ref"]
         rows.append("| %s | %s | %.2e (%.2e) | %.2e (%.2e) | %d of %d |" % (label, e["checked_images"], e["rel_l2"], e["floor_rel_l2"], e["nerr_vs_fp16_storage_oracle"], e["floor_fp32_vs_fp64_accumulation"],
                                                                          q["count_above_1e-3_of_max_ref"], q["elements"]))
-    return ("| model (`profiles/%s_parity_full_size.json`) | images checked | rel-L2 vs the fp16-storage oracle (floor) | max-norm vs the same oracle (floor) | elements above 1e-3·max\\|ref\\| |\n|---|---|---|---|---|\n" % tag) + "\n".join(rows)
+    return ("`profiles/%s_parity_full_size.json` (final binary; both norms against the fp16-storage oracle, in brackets the floor = the oracle's own fp32-vs-fp64 accumulation difference):\n\n"
+            "| model | images checked | rel-L2 (floor) | max-norm (floor) | elements above 1e-3·max\\|ref\\| |\n|---|---|---|---|---|\n" % tag) + "\n".join(rows)
 
 
 def block_stage(tag):
@@ -171,7 +179,60 @@ def block_stage(tag):
     return "\n".join(out)
 
 
-BLOCKS = {"state": block_state, "kernel": block_kernel, "pmc": block_pmc, "t0": block_t0, "parity": block_parity, "stage": block_stage}
+def block_bneck(tag):
+    out = []
+    ab = P("%s_ab_bneck_same_box.txt" % tag)
+    if os.path.exists(ab):
+        vals = {}
+        for l in open(ab):
+            m = re.match(r"(blocks as reduce.*?|whole blocks.*?)\s+r50 bs=64: ([\d.]+) ms/iter.*launches (\d+)", l)
+            if m:
+                vals.setdefault(m.group(1).strip(), []).append((float(m.group(2)), int(m.group(3))))
+        for k, v in vals.items():
+            out.append("* %s: %s ms (%d launches)" % (k, " / ".join("%.3f" % t for t, _ in v), v[0][1]))
+        if len(vals) == 2:
+            (a, va), (b, vb) = list(vals.items())
+            out.append("  Same box, three alternating rounds (`profiles/%s_ab_bneck_same_box.txt`): **%+.1f %%**." % (tag, (sum(t for t, _ in vb) / len(vb)) / (sum(t for t, _ in va) / len(va)) * 100 - 100))
+    bb = P("%s_bneck_bench.txt" % tag)
+    if os.path.exists(bb):
+        cur = None
+        for l in open(bb):
+            if l.startswith("=="):
+                cur = l.strip("= \n")
+            m = re.match(r"chained: two launches ([\d.]+) us \((\d+) MB.*one launch ([\d.]+) us \((\d+) MB compulsory, ([\d.]+) TB/s, (\d+) TFLOP/s\)", l)
+            if m and cur:
+                out.append("* `%s` (`profiles/%s_bneck_bench.txt`; hipGraph of chained launches): the launches it replaces %s µs (%s MB), ONE launch **%s µs** (%s MB compulsory, %s TB/s, %s TFLOP/s)." % (
+                    cur, tag, m.group(1), m.group(2), m.group(3), m.group(4), m.group(5), m.group(6)))
+    adm = P("%s_run_admission.txt" % tag)
+    if os.path.exists(adm):
+        lines = [l.strip() for l in open(adm)]
+        vec = [re.search(r"on = (\[.*?\])", l).group(1) for l in lines if l.startswith("compile ")]
+        same = [l for l in lines if l.startswith("same `on` vector")]
+        runs = [l for l in lines if l.startswith("run at step")]
+        if vec:
+            out.append("* Admission of the persistent runs over %d compiles in one process (`profiles/%s_run_admission.txt`, `tools/run_admission.py`): `on` = %s — %s" % (
+                len(vec), tag, " ".join(vec), same[0] if same else ""))
+            ts = [re.search(r"one launch ([\d.]+) us \| layer by layer ([\d.]+) us", l) for l in runs]
+            ts = [(float(m.group(1)), float(m.group(2))) for m in ts if m]
+            if ts:
+                out.append("  The A/B medians behind them: one launch %s µs, layer by layer %s µs." % (" / ".join("%.1f" % a for a, _ in ts), " / ".join("%.1f" % b for _, b in ts)))
+    return "\n".join(out)
+
+
+BLOCKS = {"bneck": block_bneck, "state": block_state, "kernel": block_kernel, "pmc": block_pmc, "t0": block_t0, "parity": block_parity, "stage": block_stage}
+
+
+def wrap(text, width=150):
+    """generated prose in lines of at most `width` columns (list items with a hanging indent); table rows stay whole"""
+    import textwrap
+    out = []
+    for l in text.split("\n"):
+        if len(l) <= width or l.lstrip().startswith("|"):
+            out.append(l); continue
+        m = re.match(r"^(\s*)([*-]\s+)?", l)
+        first = m.group(0); rest = m.group(1) + " " * len(m.group(2) or "")
+        out.extend(textwrap.wrap(l[len(first):], width=width, initial_indent=first, subsequent_indent=rest, break_long_words=False, break_on_hyphens=False))
+    return "\n".join(out)
 
 
 def stamp(text, tag):
@@ -179,13 +240,13 @@ def stamp(text, tag):
         name = m.group(1)
         if name not in BLOCKS:
             return m.group(0)
-        return "<!-- numbers:%s -->\n%s\n<!-- /numbers:%s -->" % (name, BLOCKS[name](tag).rstrip(), name)
+        return "<!-- numbers:%s -->\n%s\n<!-- /numbers:%s -->" % (name, wrap(BLOCKS[name](tag).rstrip()), name)
     return re.sub(r"<!-- numbers:(\w+) -->.*?<!-- /numbers:\1 -->", rep, text, flags=re.S)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--tag", default="r05")
+    ap.add_argument("--tag", default="r06")
     ap.add_argument("--check", action="store_true")
     a = ap.parse_args()
     changed = []
