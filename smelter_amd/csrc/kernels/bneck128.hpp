@@ -422,7 +422,9 @@ static bool bn2_geometry(const sm_bneck_desc* d, Bn2Params* p) {
     int TH = std::min(H, std::min(208 / W, 256 / W - 2));
     if (TH < 1) return false;
     const int RS = (W + 1 + 7) / 8 * 8, PR = TH + 2;
-    const int plane = (PR * RS * 16 + 255) / 256 * 256, slice = 8 * plane, np1 = PR * W, xc = ((np1 + 15) & ~15) * 128;      // (T1: sixteen 8-channel PLANES [slot] x 16 bytes, 256-byte aligned: see the kernel)
+    // (+ 1 slot: when a row has no spare zero column — RS == W + 1 — the bottom-right tap of the band's last pixel is slot 0 of one more row; it must be a zero of THIS plane,
+    //  not the first slot of the next one / of the x ring: found by a shape fuzz against the separate launches at W = 31, 39, 55)
+    const int plane = ((PR * RS + 1) * 16 + 255) / 256 * 256, slice = 8 * plane, np1 = PR * W, xc = ((np1 + 15) & ~15) * 128;      // (T1: sixteen 8-channel PLANES [slot] x 16 bytes, 256-byte aligned: see the kernel)
     const int t2 = 13 * 16 * 256;
     if ((size_t)2 * slice + (size_t)std::max(BN2_XRING, t2) + 2048 > 160 * 1024) return false;
     if (p) {

@@ -101,6 +101,8 @@ CASES128 = [
     (1, 9, 30, 64, 128, False, (2, 2, 2), (0.1, 0.2, 0.3)),        # one x stage, leaky activations, 30-pixel rows (RS = 32), one pass of 32 couts per wave
     (5, 7, 7, 192, 256, True, (0, 1, 1), (0, 0, 0)),               # tiny images, an odd number of x stages, no activation behind the reduce (padding still ZERO)
     (1, 4, 56, 64, 128, False, (1, 0, 1), (0, 0, 0)),              # 56-pixel rows: three rows per tile (RS = 64), linear 3x3
+    (2, 13, 31, 64, 128, False, (1, 1, 1), (0, 0, 0)),             # RS == W + 1 (no spare zero column): the bottom-right tap of a band's last pixel is one slot BEHIND the patch rows
+    (2, 9, 55, 128, 256, True, (0, 2, 1), (0, 0.2, 0)),            # ... at 55-pixel rows (RS = 56, bands of 2 rows): every other row ends a band
 ]
 
 
@@ -213,3 +215,44 @@ def test_bottleneck_refusals():
     y = torch.zeros((1, 8, 8, 256), device="cuda").half()
     rc = L.sm_bottleneck_fwd(ctypes.byref(bad), x.data_ptr(), w.data_ptr(), None, w.data_ptr(), None, w.data_ptr(), None, None, y.data_ptr(), None)
     assert rc != 0
+
+
+def test_bottleneck_shape_sweep_against_the_separate_launches():
+    """Seeded sweep over the domain of both kernels — image sizes from 1 x 1 to 39 x 62, every C0 / C3 step, batch 1 - 5, all activation triples, with and without a residual,
+    operands that are channel slices of wider buffers (pixel strides above the channel count on all three tensors) — against the SAME block as three sm_conv2d_fwd launches.
+    Found in round 6: rows without a spare zero column (W + 1 a multiple of 8) read the bottom-right tap of a band's last pixel from the neighbouring LDS plane."""
+    rng = np.random.default_rng(20261001)
+    torch.manual_seed(7)
+    tested = 0
+    for it in range(160):
+        cm = int(rng.choice([64, 128]))
+        if cm == 64:
+            c0 = int(rng.choice([64, 128, 256])); c3 = 32 * int(rng.integers(1, 9)); hh = int(rng.integers(1, 40)); ww = int(rng.integers(1, 45))
+        else:
+            c0 = 64 * int(rng.integers(1, 9)); c3 = 128 * int(rng.integers(1, 5)); hh = int(rng.integers(1, 40)); ww = int(rng.integers(4, 63))
+        n = int(rng.integers(1, 6))
+        use_res = bool(rng.integers(0, 2))
+        acts = tuple(int(a) for a in rng.integers(0, 3, 3)); slopes = tuple(float(v) for v in rng.uniform(0.05, 0.4, 3))
+        xpad, ypad, rpad = (int(8 * rng.integers(0, 3)) for _ in range(3))
+        d = BneckDesc(n, hh, ww, c0, cm, c3, c0 + xpad, c3 + ypad, c3 + rpad if use_res else 0, acts[0], slopes[0], acts[1], slopes[1], acts[2], slopes[2])
+        if not ops.lib().sm_bottleneck_supported(ctypes.byref(d)):
+            continue                                                        # (a band of this width does not fit the LDS: the executor keeps the layers)
+        x = torch.randn((n, hh, ww, c0 + xpad), device="cuda").half()[..., :c0]
+        w1 = (torch.randn((cm, 1, 1, c0), device="cuda") * (2.0 / c0) ** 0.5).half(); b1 = torch.randn(cm, device="cuda") * 0.2
+        w2 = (torch.randn((cm, 3, 3, cm), device="cuda") * (2.0 / (9 * cm)) ** 0.5).half(); b2 = torch.randn(cm, device="cuda") * 0.2
+        w3 = (torch.randn((c3, 1, 1, cm), device="cuda") * (2.0 / cm) ** 0.5).half(); b3 = torch.randn(c3, device="cuda") * 0.2
+        res = torch.randn((n, hh, ww, c3 + rpad), device="cuda").half()[..., :c3] if use_res else None
+        yfull = torch.full((n, hh, ww, c3 + ypad), 7.0, device="cuda").half()
+        y = ops.bottleneck(x, w1.reshape(cm, c0), b1, w2, b2, w3.reshape(c3, cm), b3, residual=res, acts=acts, slopes=slopes, out=yfull[..., :c3])
+        t1 = ops.conv2d(x, w1, b1, act=acts[0], slope=slopes[0])
+        t2 = ops.conv2d(t1, w2, b2, pads=(1, 1, 1, 1), act=acts[1], slope=slopes[1])
+        ref = ops.conv2d(t2, w3, b3, residual=res, act=acts[2], slope=slopes[2]).float()
+        torch.cuda.synchronize()
+        tested += 1
+        what = (cm, c0, c3, n, hh, ww, use_res, acts, xpad, ypad, rpad)
+        # same roundings; the separate 3x3 may add its K slices in another order: two fp16 ulps of the value + an accumulation floor, and few elements may differ at all
+        tol = ref.abs() * 2.0 ** -8 + float(ref.abs().max()) * 2.0 ** -9
+        assert not bool(((y.float() - ref).abs() > tol).any()), what
+        assert float((y.float() != ref).float().mean()) < 0.05, what
+        assert ypad == 0 or (float(yfull[..., c3:].min()) == 7.0 and float(yfull[..., c3:].max()) == 7.0), what       # nothing written beside the output slice
+    assert tested >= 120
