@@ -164,7 +164,7 @@ def test_resnet50_expand_head_with_the_shortcut_listed_elsewhere(order, monkeypa
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3
 
 
-@pytest.mark.parametrize("hw,batch", [((64, 64), 3), ((224, 224), 2), ((96, 72), 2)])
+@pytest.mark.parametrize("hw,batch", [((64, 64), 3), ((224, 224), 2), ((96, 72), 2), ((120, 248), 1)])      # (120 x 248: 15 x 31 maps in stage 2 — rows without a spare zero column in the block kernel's patch)
 def test_resnet50_runs_whole_bottleneck_blocks_as_one_launch(hw, batch, monkeypatch):
     """executor pass 3l (round 6): blocks 2 and 3 of the first stage — 1x1 reduce 256 -> 64, 3x3 64 -> 64, 1x1 expand 64 -> 256 + block input + ReLU — are ONE sm_bottleneck_fwd
     step each (csrc/kernels/bneck.hip: both hidden tensors on chip).  Flip-and-compare: with SMELTER_BNECK=0 the reduce layers are launches of their own again (+2); the two
