@@ -511,7 +511,8 @@ extern "C" int sm_bottleneck_supported(const sm_bneck_desc* d) {
 extern "C" int sm_bottleneck_fwd(const sm_bneck_desc* d, const void* x, const void* w1, const float* b1, const void* w2, const float* b2, const void* w3, const float* b3,
                                  const void* res, void* y, sm_stream_t stream) {
     SM_REQUIRE(d && x && w1 && w2 && w3 && y, "sm_bottleneck_fwd: null argument");
-    SM_REQUIRE(sm_bottleneck_supported(d), "sm_bottleneck_fwd: no kernel takes this block (1x1 C0 in {64, 128, 256} -> 64, 3x3 / s1 / p1 64 -> 64, 1x1 64 -> C3 <= 256, C3 %% 32 == 0, ReLU-family activations, tensors < 2 GB)");
+    SM_REQUIRE(sm_bottleneck_supported(d), "sm_bottleneck_fwd: no kernel takes this block (Cm = 64: C0 in {64, 128, 256}, C3 <= 256, C3 %% 32 == 0; Cm = 128: C0 %% 64 == 0, C3 %% 128 == 0, 4 <= W <= 62 and a band of rows that fits the LDS; "
+               "3x3 / s1 / p1 in the middle, ReLU-family activations, tensors < 2 GB)");
     SM_REQUIRE(!res || d->res_ld >= d->C3, "sm_bottleneck_fwd: residual pixel stride %d < C3 %d", d->res_ld, d->C3);
     SM_REQUIRE(((((uintptr_t)x) | ((uintptr_t)w1) | ((uintptr_t)w2) | ((uintptr_t)w3) | ((uintptr_t)y) | ((uintptr_t)res)) & 15) == 0, "sm_bottleneck_fwd: operands must be 16-byte aligned");
     if (d->Cm == BN2_CM) {
