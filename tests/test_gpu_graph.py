@@ -653,3 +653,23 @@ def test_inverted_residual_blocks_run_on_the_block_kernels():
     assert kind(112, 16, 96, 24, 2) == 3 and kind(56, 24, 144, 24, 1) == 3
     assert kind(28, 32, 192, 32, 1) == 4 and kind(14, 64, 384, 64, 1) == 4 and kind(14, 96, 576, 160, 2) == 4 and kind(7, 160, 960, 160, 1) == 4
     assert nerr(got, O.Graph(model).run(x)) <= 5e-3
+
+
+def test_fused_and_unfused_executors_agree_on_random_input_sizes():
+    """Seeded sweep over input sizes and batches of the three model families: the default executor (every fusion pass, persistent runs where they apply, hipGraph) against the
+    layer-by-layer one (fuse = False).  Bound: the fp16-storage noise of test_fusion_pass_switches_keep_the_function, loosened for the U-Net as there."""
+    rng = np.random.default_rng(3)
+    for it in range(18):
+        kind = ["r50", "mbv2", "unet"][it % 3]
+        if kind == "r50":
+            hw = (32 * int(rng.integers(1, 9)) + 8 * int(rng.integers(0, 4)), 32 * int(rng.integers(1, 9)) + 8 * int(rng.integers(0, 4))); model = zoo.resnet50(hw=hw)
+        elif kind == "mbv2":
+            hw = (32 * int(rng.integers(1, 8)) + 2 * int(rng.integers(0, 16)), 32 * int(rng.integers(1, 8)) + 2 * int(rng.integers(0, 16))); model = zoo.mobilenet_v2(hw=hw)
+        else:
+            hw = (16 * int(rng.integers(2, 14)), 16 * int(rng.integers(2, 14))); model = zoo.unet(hw=hw)
+        bs = int(rng.choice([1, 2, 3, 8]))
+        x = zoo.synthetic_images(bs, 3, hw)
+        ex, got = run_hip(model, x)
+        ex0, plain = run_hip(model, x, fuse=False, useHipGraph=False)
+        assert ex.numLaunches < ex0.numLaunches and np.isfinite(got).all()
+        assert nerr(got, plain) <= 3e-3, (kind, hw, bs, nerr(got, plain))

@@ -1396,3 +1396,34 @@ def test_zz_every_tile_configuration_ran_unskipped():
     never = [(c, ops.config_name(c)) for c in ALL_CFGS if c not in CFGS_RUN]
     assert not never, "tile configurations no test ran: %s" % never
 
+
+def test_kernel_families_shape_sweeps_against_the_default_kernels():
+    """Seeded sweeps (round 6; the same method found the missing zero slot of the 128-channel block kernel): the classifier kernel against an fp32 matrix product over
+    M = 1 .. 256 rows, every K / N step; every stride-2 and stride-1 wave-split configuration against the launcher's default kernel on random image sizes (rows with
+    and without a spare zero column, bands and whole images, one-sided padding), channel counts and activations"""
+    from smelter_amd._native import SmelterError
+    rng = np.random.default_rng(5); torch.manual_seed(5)
+    for it in range(100):
+        m = int(rng.integers(1, 257)); k = 32 * int(rng.integers(8, 80)); n = 4 * int(rng.integers(1, 300)); act = int(rng.integers(0, 3))
+        x = torch.randn((m, 1, 1, k), device="cuda").half(); w = (torch.randn((n, 1, 1, k), device="cuda") * (2.0 / k) ** 0.5).half(); b = torch.randn(n, device="cuda")
+        y = ops.conv2d(x, w, b, act=act, slope=0.25).float().reshape(m, n)
+        ref = x.reshape(m, k).float() @ w.reshape(n, k).float().t() + b
+        ref = torch.relu(ref) if act == 1 else torch.where(ref < 0, ref * 0.25, ref) if act == 2 else ref
+        assert not bool(((y - ref).abs() > ref.abs() * 2.0 ** -9 + float(ref.abs().max()) * 2.0 ** -10).any()), ("fc", m, k, n, act)
+    for label, stride, sizes in (("kq/2:", 2, (3, 60)), ("kq:", 1, (1, 40))):
+        cfgs = cfgs_named(label)
+        took = 0
+        for it in range(60):
+            n = int(rng.integers(1, 7)); hh = int(rng.integers(*sizes)); ww = int(rng.integers(7, 60)); cin = 64 * int(rng.integers(1, 7)); cout = 8 * int(rng.integers(1, 40))
+            act = int(rng.integers(0, 3)); pads = (1, 1, int(rng.integers(0, 2)) if stride == 2 else 1, int(rng.integers(0, 2)) if stride == 2 else 1)
+            x = torch.randn((n, hh, ww, cin), device="cuda").half(); w = (torch.randn((cout, 3, 3, cin), device="cuda") * (2.0 / (9 * cin)) ** 0.5).half(); b = torch.randn(cout, device="cuda")
+            ref = ops.conv2d(x, w, b, stride=(stride, stride), pads=pads, act=act, slope=0.25).float()
+            for c in cfgs:
+                try:
+                    y = ops.conv2d(x, w, b, stride=(stride, stride), pads=pads, act=act, slope=0.25, cfg=c).float()
+                except SmelterError as e:
+                    assert "does not apply" in e.detail
+                    continue
+                took += 1
+                assert y.shape == ref.shape and not bool(((y - ref).abs() > ref.abs() * 2.0 ** -9 + float(ref.abs().max()) * 2.0 ** -10).any()), (ops.config_name(c), n, hh, ww, cin, cout, act, pads)
+        assert took >= 60, label
