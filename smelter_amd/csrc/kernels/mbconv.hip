@@ -1596,7 +1596,9 @@ static size_t mb_v3_lds_nw(const sm_mbconv_desc* d, int nw, bool wg = false) {
 // K = Cin + 2 <= 80 | 112 (5 | 7 k steps) and Cout <= 64 | 96 | 160 — MobileNet-v2's 14 x 14 blocks
 // v5 (hidden patch in registers): the expand form with W1 / W2 in the LDS, Cout <= 64
 static size_t mb_v5_lds_nw(const sm_mbconv_desc* d, int nw) {
-    const int ChP = (d->Ch + 31) & ~31, KP1 = (d->Cin + 2 + 15) & ~15, CoP = (d->Cout + 31) & ~31;
+    // KP1 = the INSTANTIATION's K (two k steps up to Cin = 30, three beyond: the launcher's MB5_PICK) — not Cin + 2 rounded up: with Cin = 8 the kernel's W1 rows are 32 halfs
+    // where this function counted 16, and the last wave's depthwise buffer lay behind the allocation (round-6 shape sweep: wave 15's tile wrong from its second row on)
+    const int ChP = (d->Ch + 31) & ~31, KP1 = d->Cin <= 30 ? 32 : 48, CoP = (d->Cout + 31) & ~31;
     return (size_t)ChP * KP1 * 2 + (size_t)ChP * 24 * 2 + (size_t)CoP * (ChP * 2 + 16) + (size_t)(ChP + CoP) * 4 + (size_t)nw * 32 * 80;
 }
 static bool mb_v5_ok(const sm_mbconv_desc* d) {
@@ -1626,7 +1628,9 @@ static bool mb_common_ok(const sm_mbconv_desc* d) {
 }
 // (kernels 1-3 hold no instantiation for bounded activations: SM_ACT_CLIP blocks go to the register-window kernels — template RELU = 2 — or to kernel 4's CLIP instantiations)
 static bool mb_clip(const sm_mbconv_desc* d) { return d->act1 == SM_ACT_CLIP || d->act2 == SM_ACT_CLIP || d->act3 == SM_ACT_CLIP; }
-static bool mb_v1_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && !mb_clip(d) && d->Cin <= 32 && d->Ch <= 192 && d->Cout <= 64 && mb_v1_lds(d) <= 160 * 1024; }
+// (v1 adds the residual from its X patch, which only the expand form fills: a depthwise-first block WITH a residual — MnasNet / EfficientNet's repeated MBConv1 — is no kernel's;
+//  found by the round-6 shape sweep: the launch returned the block without its residual)
+static bool mb_v1_ok(const sm_mbconv_desc* d) { return mb_common_ok(d) && !mb_clip(d) && d->Cin <= 32 && d->Ch <= 192 && d->Cout <= 64 && (!d->residual || d->expand) && mb_v1_lds(d) <= 160 * 1024; }
 // v2 (chunked): any Ch; Cin <= 64 when there is an expand layer (X patch in LDS, <= 4 k steps); Cout <= 64 (stride 1) / 128 (stride 2): one
 // (row block, cout block) pair per wave; the residual is read from the X patch, i.e. needs the expand form
 static bool mb_v2_ok(const sm_mbconv_desc* d) {
@@ -1656,6 +1660,7 @@ static bool mb_v4_ok(const sm_mbconv_desc* d) {
 }
 static int mb_pick(const sm_mbconv_desc* d, int force = 0) {          // 4, 3, 1 or 2; force = 1 | 2 | 3 | 4: that kernel where it applies (sm_mbconv_fwd_kind: tests, tuning)
     const bool ok1 = d && mb_v1_ok(d), ok2 = d && mb_v2_ok(d), ok3 = d && mb_v3_ok(d), ok4 = d && mb_v4_ok(d);
+    if (force && !(force == 1 ? ok1 : force == 2 ? ok2 : force == 3 ? ok3 : ok4)) force = 0;      // a kernel that does not take the block: the launcher's own choice (NOT the rest of the list below)
     if (force == 1 && ok1) return 1;
     if (force == 2 && ok2) return 2;
     if (force == 3 && ok3) return 3;

@@ -1427,3 +1427,49 @@ def test_kernel_families_shape_sweeps_against_the_default_kernels():
                 took += 1
                 assert y.shape == ref.shape and not bool(((y - ref).abs() > ref.abs() * 2.0 ** -9 + float(ref.abs().max()) * 2.0 ** -10).any()), (ops.config_name(c), n, hh, ww, cin, cout, act, pads)
         assert took >= 60, label
+
+
+def test_fused_inverted_residual_shape_sweep_against_the_three_launches():
+    """Seeded sweep over sm_mbconv_fwd_kind's domain (round 6) — image sizes 2 .. 59, Cin 8 .. 192, hidden widths 8 .. 960, Cout 8 .. 320, both strides, with and without the
+    expand layer and the residual, every kernel by name and the launcher's choice — against the same block as three sm_conv2d_fwd launches.  What it found: the
+    register-window kernel's LDS size was computed with K = Cin + 2 rounded up where its instantiations use two or three whole k steps (Cin = 8: the last wave's
+    buffer lay behind the allocation); kernel 1 took a depthwise-first block WITH a residual and dropped the residual; naming a kernel that does not take the block fell
+    through to the older kernels instead of the launcher's choice."""
+    from smelter_amd._native import SmelterError
+    rng = np.random.default_rng(7); torch.manual_seed(2)
+    took, kinds = 0, set()
+    for it in range(260):
+        n = int(rng.integers(1, 6)); hh = int(rng.integers(2, 60)); ww = int(rng.integers(2, 60)); stride = int(rng.choice([1, 2]))
+        cin = 8 * int(rng.integers(1, 25)); ch = cin * int(rng.choice([1, 3, 6])) if rng.integers(0, 4) else 32 * int(rng.integers(1, 31)); cout = 8 * int(rng.integers(1, 41))
+        ch = min(ch, 960)
+        expand = bool(rng.integers(0, 5))
+        if not expand:
+            ch = cin
+        residual = bool(rng.integers(0, 2)) and stride == 1 and cin == cout
+        if rng.integers(0, 3) == 0 and stride == 1:
+            cout = cin; residual = True
+        acts = (int(rng.choice([1, 2])), int(rng.choice([1, 2])), int(rng.choice([0, 1]))); slopes = (0.2, 0.3, 0.0)
+        x = torch.randn((n, hh, ww, cin), device="cuda").half()
+        w1 = (torch.randn((ch, 1, 1, cin), device="cuda") * (2.0 / cin) ** 0.5).half() if expand else None; b1 = torch.randn(ch, device="cuda") * 0.2 if expand else None
+        wd = (torch.randn((ch, 3, 3), device="cuda") * (2.0 / 9) ** 0.5).half(); bd = torch.randn(ch, device="cuda") * 0.2
+        w2 = (torch.randn((cout, 1, 1, ch), device="cuda") * (2.0 / ch) ** 0.5).half(); b2 = torch.randn(cout, device="cuda") * 0.2
+        ref = None
+        for kern in (0, 1, 2, 3, 4):
+            try:
+                y = ops.mbconv(x, w1.reshape(ch, cin) if expand else None, b1, wd, bd, w2.reshape(cout, ch), b2, stride=stride, residual=residual, acts=acts, slopes=slopes, kernel=kern).float()
+            except SmelterError as e:
+                assert "unsupported block geometry" in e.detail, e.detail
+                break                                                       # (no kernel takes the block: the executor keeps its layers)
+            if ref is None:
+                t = ops.conv2d(x, w1, b1, act=acts[0], slope=slopes[0]) if expand else x
+                t = ops.conv2d(t, wd.reshape(ch, 3, 3, 1), bd, stride=(stride, stride), pads=(1, 1, 1, 1), groups=ch, act=acts[1], slope=slopes[1])
+                ref = ops.conv2d(t, w2, b2, residual=x if residual else None, act=acts[2], slope=slopes[2]).float()
+            took += 1; kinds.add(kern)
+            what = (kern, n, hh, ww, cin, ch, cout, stride, expand, residual, acts)
+            assert y.shape == ref.shape and not bool(torch.isnan(y).any()), what
+            assert not bool(((y - ref).abs() > ref.abs() * 2.0 ** -7 + float(ref.abs().max()) * 2.0 ** -8).any()), what
+    assert took >= 300 and kinds == {0, 1, 2, 3, 4}
+    # the three defects by name
+    from smelter_amd._native import MbConvDesc
+    d = MbConvDesc(2, 18, 30, 18, 30, 1, 24, 24, 24, 0, 1, 1, 0.0, 1, 0.0, 0, 0.0, 24, 24)
+    assert not ops.lib().sm_mbconv_supported(ctypes.byref(d))              # depthwise-first block with a residual: no kernel's
