@@ -56,13 +56,13 @@ __device__ unsigned long long g_bn_tl[256 * 2 * 64];
 // (stores: sc1 = write through, the line is not kept — the output is never re-read through this launch's L2; same box, two repetitions: 58.3 / 58.7 -> 57.3 / 55.9 us.
 //  nt on the stores or on either load stream measured 14 .. 28 us WORSE: profiles/r06_bneck_policy.txt)
 #ifndef BN_ST_AUX
-#define BN_ST_AUX 16
+#define BN_ST_AUX 0
 #endif
 #ifndef BN_LDX_AUX
-#define BN_LDX_AUX 0
+#define BN_LDX_AUX 2
 #endif
 #ifndef BN_LDR_AUX
-#define BN_LDR_AUX 0
+#define BN_LDR_AUX 2
 #endif
 constexpr int BN_TW = 14, BN_PW = 16, BN_THMAX = 8, BN_NPX = (BN_THMAX + 2) * BN_PW;       // 160 patch pixels = 5 fragments
 constexpr int BN_PLANE = BN_NPX * 16, BN_PATCH = 8 * BN_PLANE;                              // 2560-byte channel planes, 20 KB per patch

@@ -25,6 +25,12 @@
 #ifndef BN2_ST_AUX
 #define BN2_ST_AUX 16
 #endif
+#ifndef BN2_LDX_AUX                                                    // cache policy of the x stream (LDS-DMA: an assembler suffix, "" | " nt" | " sc1") and of the residual rows (aux operand: 0 | 2 = nt | 16 = sc1)
+#define BN2_LDX_AUX ""
+#endif
+#ifndef BN2_LDR_AUX
+#define BN2_LDR_AUX 0
+#endif
 
 struct Bn2Params {
     const half_t* x; const half_t* w1; const float* b1; const half_t* w2; const float* b2; const half_t* w3; const float* b3; const half_t* res; half_t* y;
@@ -42,7 +48,7 @@ constexpr int BN2_CM = 128, BN2_NF1 = 16, BN2_NF2 = 13;                // middle
 
 __device__ __forceinline__ void bn2_bdma16(unsigned voff, u32x4 rsrc, unsigned lds_dst, unsigned soff) {   // LDS-DMA through a buffer descriptor (conv3x3_kq.hpp kq_bdma16): dead lanes -> zeros
     unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen" BN2_LDX_AUX " lds\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(lds_dst), "s"(soff) : "memory");
 }
 
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
         floatx4 bqn0 = {0.f, 0.f, 0.f, 0.f}, bqn1 = {0.f, 0.f, 0.f, 0.f};
         if (p.b3) { bqn0 = *(const floatx4*)(p.b3 + cpw * wave + 8 * g); bqn1 = *(const floatx4*)(p.b3 + cpw * wave + 8 * g + 4); }
 #pragma unroll
-        for (int f = 0; f < BN2_NF2; f++) rr[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(cap ? BN_DEAD : rb[f]), 0, 0);
+        for (int f = 0; f < BN2_NF2; f++) rr[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(cap ? BN_DEAD : rb[f]), 0, BN2_LDR_AUX);
 #pragma unroll 1
         for (int ps = 0; ps < npass; ps++) {
             const int cb = cpw * wave + 32 * ps;                       // first cout of the pass
@@ -404,7 +410,7 @@ __global__ __launch_bounds__(256) void bneck128_kernel(Bn2Params p) {
                             ov[e] = (half_t)(v0 < 0.f ? v0 * p.sl3 : v0); ov[4 + e] = (half_t)(v1 < 0.f ? v1 * p.sl3 : v1);
                         }
                     }
-                    rr[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(rb[f] + psn), 0, 0);              // the next pass's row of this fragment
+                    rr[f] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(rb[f] + psn), 0, BN2_LDR_AUX);              // the next pass's row of this fragment
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs_y, (int)(yb[f] + pso), 0, BN2_ST_AUX);
                     if (((f - F0) & 1) == 1) __builtin_amdgcn_sched_barrier(0);        // (two fragments per scheduling region: their chains interleave; more and the conversions of all seven are in flight at once)
                 }
