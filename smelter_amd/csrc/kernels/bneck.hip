@@ -53,8 +53,9 @@ __device__ unsigned long long g_bn_tl[256 * 2 * 64];
 #define BN_STAMP(slot) do { } while (0)
 #endif
 // cache policy of the output stores / of the x and residual loads (aux operand of the raw buffer builtins: 0 default, 2 = nt, 16 = sc1, 17 = sc0 sc1) — build-time knobs for the A/B
-// (stores: sc1 = write through, the line is not kept — the output is never re-read through this launch's L2; same box, two repetitions: 58.3 / 58.7 -> 57.3 / 55.9 us.
-//  nt on the stores or on either load stream measured 14 .. 28 us WORSE: profiles/r06_bneck_policy.txt)
+// Ranked IN THE NETWORK (bench.py --steps 300, same box, alternating): plain stores -1.1 .. -1.4 % of the ResNet-50 step against sc1, nt loads of both streams another -0.5 .. -2 %.
+// (The chained microbenchmark — two tensors ping-ponging inside the Infinity Cache — ranks them the other way round: sc1 stores best, nt anything 14 .. 28 us worse,
+//  profiles/r06_bneck_policy.txt; a block costs 54 us there and 62 .. 77 us between its real neighbours.)
 #ifndef BN_ST_AUX
 #define BN_ST_AUX 0
 #endif

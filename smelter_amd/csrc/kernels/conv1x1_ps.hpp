@@ -96,10 +96,10 @@ __global__ __launch_bounds__((WGM * WGN + 4) * 64) void conv1x1_ps_kernel(ConvPa
             if (dual && ld_kt >= p.kt_sw) {                             // (wave-uniform)
                 const int koff2 = (ld_kt - p.kt_sw) * 64;
 #pragma unroll
-                for (int i = 0; i < A_IT; i++) SM_GLDS16(arow2[i] + koff2, sa + i * NLT * 16);
+                for (int i = 0; i < A_IT; i++) SM_GLDS16_AUX(arow2[i] + koff2, sa + i * NLT * 16, SM_PS_X_NT);
             } else {
 #pragma unroll
-                for (int i = 0; i < A_IT; i++) SM_GLDS16(arow[i] + koff, sa + i * NLT * 16);
+                for (int i = 0; i < A_IT; i++) SM_GLDS16_AUX(arow[i] + koff, sa + i * NLT * 16, SM_PS_X_NT);
             }
 #pragma unroll
             for (int i = 0; i < B_IT; i++) SM_GLDS16(brow[i] + koff, sa + A_BYTES + i * NLT * 16);

@@ -91,13 +91,13 @@ __global__ __launch_bounds__(512) void conv1x1_rw_kernel(ConvParams p) {
         for (int i = 0; i < NPX; i++) {
             const int slab = i / RB, rb = i % RB;
             const bool in = m0 + rb * 64 + drow < p.M;
-            SM_GLDS16(in ? p.x + (m0 + rb * 64) * p.x_ld + relx + slab * 64 : zero, xt0 + (i * 512 + wave * 64) * 16);
+            SM_GLDS16_AUX(in ? p.x + (m0 + rb * 64) * p.x_ld + relx + slab * 64 : zero, xt0 + (i * 512 + wave * 64) * 16, SM_RW_X_NT);
         }
 #pragma unroll
         for (int i = 0; i < NPR; i++) {
             const int slab = i / RB, rb = i % RB;
             const bool in = m0 + rb * 64 + drow < p.M;
-            SM_GLDS16(in ? p.res + (m0 + rb * 64) * p.res_ld + relr + slab * 64 : zero, rt0 + (i * 512 + wave * 64) * 16);
+            SM_GLDS16_AUX(in ? p.res + (m0 + rb * 64) * p.res_ld + relr + slab * 64 : zero, rt0 + (i * 512 + wave * 64) * 16, SM_RW_X_NT);
         }
     }
 
@@ -321,7 +321,7 @@ __global__ __launch_bounds__((NCONS + 4) * 64) void conv1x1_rwl_kernel(ConvParam
                 const half_t* src = slab < NSLAB ? p.x + (m0 + row) * p.x_ld + slab * 64 + sw
                                                  : p.res + (m0 + row) * p.res_ld + slice * BN + (slab - NSLAB) * 64 + sw;
                 if constexpr (DUAL) { if (slab >= p.kt_sw) src = row2 + (slab - p.kt_sw) * 64 + sw; }      // (slab = i: compile time; kt_sw uniform)
-                SM_GLDS16(in ? src : zero, sa + i * NLT * 16);
+                SM_GLDS16_AUX(in ? src : zero, sa + i * NLT * 16, SM_RW_X_NT);
             }
             ++issued;
         };

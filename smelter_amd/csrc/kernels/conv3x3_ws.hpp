@@ -220,7 +220,7 @@ __global__ __launch_bounds__((NW + NLW) * 64) void conv3x3_ws_kernel(ConvParams 
             if (i < NI && i * NT + wave * 64 < patch_slots) {         // wave-uniform
                 const int pr = (int)(prpc[i] >> 16), pc = (int)(prpc[i] & 0xffff);
                 const bool in = (unsigned)(iy0 + pr) < (unsigned)p.H && (unsigned)(ix0 + pc) < (unsigned)p.W;
-                SM_GLDS16(in ? xb + rel[i] : zero, dst + i * NT * 16);
+                SM_GLDS16_AUX(in ? xb + rel[i] : zero, dst + i * NT * 16, SM_WS_X_NT);
             }
         }
     };

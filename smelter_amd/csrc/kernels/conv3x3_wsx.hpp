@@ -94,7 +94,7 @@ __global__ __launch_bounds__(512) void conv3x3_wsx_kernel(ConvParams p) {
                 if (i < NI && i * NTP + wave * 64 < patch_slots) {
                     const int pr = (int)(prpc[i] >> 16), pc = (int)(prpc[i] & 0xffff);
                     const bool in = (unsigned)(iy0 + pr) < (unsigned)p.H && (unsigned)(ix0 + pc) < (unsigned)p.W;
-                    SM_GLDS16(in ? xb + rel[i] : zero, dst + i * NTP * 16);
+                    SM_GLDS16_AUX(in ? xb + rel[i] : zero, dst + i * NTP * 16, SM_WS_X_NT);
                 }
             }
         };

@@ -36,6 +36,17 @@ __device__ __attribute__((aligned(64))) unsigned int g_zero_page[64];   // zero-
 #ifndef SM_B_NT
 #define SM_B_NT 0
 #endif
+// ... per kernel family, for the ACTIVATION streams only (round 6: policies are ranked IN THE NETWORK — a microbenchmark that loops one layer keeps its tensors in the Infinity Cache and
+// ranks them differently): SM_RW_X_NT (conv1x1_rw.hpp: x and residual tiles), SM_PS_X_NT (conv1x1_ps.hpp: A rows), SM_WS_X_NT (conv3x3_ws.hpp / conv3x3_wsx.hpp: patches)
+#ifndef SM_RW_X_NT
+#define SM_RW_X_NT 0
+#endif
+#ifndef SM_PS_X_NT
+#define SM_PS_X_NT 0
+#endif
+#ifndef SM_WS_X_NT
+#define SM_WS_X_NT 0
+#endif
 #define SM_GLDS16_AUX(gptr, ldsptr, AUX)                                                                    \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gptr),                \
                                      (__attribute__((address_space(3))) void*)(ldsptr), 16, 0, AUX)
