@@ -53,14 +53,16 @@ __device__ unsigned long long g_bn_tl[256 * 2 * 64];
 #define BN_STAMP(slot) do { } while (0)
 #endif
 // cache policy of the output stores / of the x and residual loads (aux operand of the raw buffer builtins: 0 default, 2 = nt, 16 = sc1, 17 = sc0 sc1) — build-time knobs for the A/B
-// Ranked IN THE NETWORK (bench.py --steps 300, same box, alternating): plain stores -1.1 .. -1.4 % of the ResNet-50 step against sc1, nt loads of both streams another -0.5 .. -2 %.
+// Ranked IN THE NETWORK (bench.py --steps 300, same box, alternating): plain stores -1.1 .. -1.4 % of the ResNet-50 step against sc1; nt on the RESIDUAL rows (read for the last time)
+// another -1.1 % (five rounds: 1.0902 -> 1.0786 ms); nt on the x stream as well: faster on one box, slower on another (1.0860), and the residual rows then miss the L2 the x loads
+// would have filled (216 instead of 132 MB read per launch, 76 instead of 58 us in the loop) — x stays plain.
 // (The chained microbenchmark — two tensors ping-ponging inside the Infinity Cache — ranks them the other way round: sc1 stores best, nt anything 14 .. 28 us worse,
 //  profiles/r06_bneck_policy.txt; a block costs 54 us there and 62 .. 77 us between its real neighbours.)
 #ifndef BN_ST_AUX
 #define BN_ST_AUX 0
 #endif
 #ifndef BN_LDX_AUX
-#define BN_LDX_AUX 2
+#define BN_LDX_AUX 0
 #endif
 #ifndef BN_LDR_AUX
 #define BN_LDR_AUX 2

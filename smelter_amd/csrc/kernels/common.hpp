@@ -22,6 +22,11 @@ template <int I, int N, class F> __device__ __forceinline__ void sm_static_for(F
 // A layer's output is never re-read through this launch's L2 — the next launch invalidates it — but with the default policy the last <= 32 MB of it sit DIRTY in the
 // L2s when the kernel ends, and the kernel boundary then waits for their write-back (MI355X_MICROARCH.md, boundary row: + B / 6 TB/s for B dirty bytes).  sc1 stores
 // write through and drop the line.  Build-time switch for the A/B (make EXTRA=-DSM_ST_AUX=16).
+// Cache policy of the kernels that read the fp32 IMAGE BATCH (stem_pool.hpp, stem3.hip, mbconv5s_kernel): 2 = nt.  The batch is read once per step and is 38 - 154 MB; loaded with
+// the default policy it takes that much of the 256 MB Infinity Cache away from the activation arena and the weights (round 6, ranked in the network: ResNet-50 1.000 -> 0.971 ms).
+#ifndef SM_STEM_IN_AUX
+#define SM_STEM_IN_AUX 2
+#endif
 #ifndef SM_ST_AUX
 #define SM_ST_AUX 0
 #endif

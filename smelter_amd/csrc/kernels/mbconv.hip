@@ -1086,7 +1086,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                     const int sg = wave + i * NW, c = sg >= 2 * IR ? 2 : sg >= IR ? 1 : 0, rr = sg - c * IR, gy = iry0 + rr;
                     const bool ok = colok && sg < nseg && (unsigned)gy < (unsigned)p.in_H;
                     const unsigned off = ok ? ((((unsigned)n * 3u + (unsigned)c) * (unsigned)p.in_H + (unsigned)gy) * (unsigned)p.in_W + (unsigned)gx) * 4u : 0x80000000u;
-                    g[ps][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+                    g[ps][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, SM_STEM_IN_AUX));
                 }
             }
 #pragma unroll

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                 const int gy = iry0 + (int)rr, gx = irx0 + (int)x;
                 const bool ok = e < (unsigned)p.nelem && (unsigned)gy < (unsigned)p.in_H && (unsigned)gx < (unsigned)p.in_W;
                 const unsigned off = ok ? ((((unsigned)n * (unsigned)p.C + c) * (unsigned)p.in_H + (unsigned)gy) * (unsigned)p.in_W + (unsigned)gx) * 4u : 0x80000000u;
-                g[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, 0));
+                g[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)off, 0, SM_STEM_IN_AUX));
                 dst[i] = ((rr * (unsigned)pitch + x) * 4u + c) * 2u;
             }
 #pragma unroll

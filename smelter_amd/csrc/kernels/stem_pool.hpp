@@ -79,7 +79,7 @@ __global__ __launch_bounds__(512) void conv_stem_pool_kernel(ConvParams p) {
                     const unsigned voff = (okc && (unsigned)(r + h) < (unsigned)IH) ? (unsigned)(base + lrel[i] + h * IW) << 2 : DEAD;
 #pragma unroll
                     for (int ch = 0; ch < 4; ch++) {
-                        if (ch < C) v[i][h][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)((unsigned)ch * plane * 4u), 0));   // (wave-uniform branch)
+                        if (ch < C) v[i][h][ch] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)voff, (int)((unsigned)ch * plane * 4u), SM_STEM_IN_AUX));   // (wave-uniform branch)
                         else v[i][h][ch] = 0.f;
                     }
                 }
