@@ -26,6 +26,15 @@
 #include <algorithm>
 
 #include "common.hpp"
+// the block kernels' reads of their input image (X fragments kept in registers per tile): MB_X_NT = 1 makes them non-temporal — build-time knob, ranked in the network
+#ifndef MB_X_NT
+#define MB_X_NT 0
+#endif
+#if MB_X_NT
+#define MB_X_LOAD(ptr) __builtin_nontemporal_load((const half8_t*)(ptr))
+#else
+#define MB_X_LOAD(ptr) (*(const half8_t*)(ptr))
+#endif
 
 #ifdef SM_TIMELINE   // diagnostic build: clock64() spent per phase by thread 0 of block 0, summed over its tiles (sm_mbconv_debug_timeline)
 __device__ unsigned long long g_mb_tl[8];   // (v4: slot 7 = the wait for the weight DMA at the top of phase B)
@@ -597,7 +606,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv3_kernel(MbParams p) {
             for (int ks = 0; ks < KS1; ks++) {
                 const int k = ks * 16 + hi * 8;
                 half8_t v = hz;
-                if (inimg) { if (k < p.Cin) v = *(const half8_t*)(src + k); else if (k == p.Cin) v = ones; }
+                if (inimg) { if (k < p.Cin) v = MB_X_LOAD(src + k); else if (k == p.Cin) v = ones; }
                 fx[mf][ks] = v;
             }
         }
@@ -873,7 +882,7 @@ __global__ __launch_bounds__(NW * 64) void mbconv5_kernel(MbParams p) {
             for (int ks = 0; ks < KS1; ks++) {
                 const int k = ks * 16 + hi * 8;
                 half8_t v = hz;
-                if (inimg) { if (k < p.Cin) v = *(const half8_t*)(src + k); else if (k == p.Cin) v = ones; }
+                if (inimg) { if (k < p.Cin) v = MB_X_LOAD(src + k); else if (k == p.Cin) v = ones; }
                 fx[mf][ks] = v;
             }
         }
@@ -1303,7 +1312,7 @@ __global__ __launch_bounds__(512) void mbconv4_kernel(MbParams p) {
         inimg = t < p.ntiles && pp < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
         const half_t* const src = p.x + (((long)n * p.H + iy) * p.W + ix) * p.x_ld;
 #pragma unroll
-        for (int ks = 0; ks < KSX; ks++) { const int k = ks * 16 + hi * 8; fx[ks] = (inimg && k < p.Cin) ? *(const half8_t*)(src + k) : hz; }
+        for (int ks = 0; ks < KSX; ks++) { const int k = ks * 16 + hi * 8; fx[ks] = (inimg && k < p.Cin) ? MB_X_LOAD(src + k) : hz; }
     };
     load_x(blockIdx.x);
     {   // depthwise weights [Ch][9] -> [9][ChP]: the loads of a batch are independent (one round trip per batch, not per element)
